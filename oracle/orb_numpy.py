@@ -1,0 +1,315 @@
+"""Second, independently written restatement of the tinyslam ORB front-end, in NumPy.
+
+TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED (same caveat as oracle/orb_oracle.h: the reference
+has no tests or golden vectors and cannot run here).  Its only job is to cross-check
+oracle/orb_oracle.c so that one misreading of the shaders does not become both the oracle and
+the implementation.  Written array-at-a-time from the WGSL text, sharing
+no code with the C restatement; binary32 arithmetic is NumPy float32 (one rounding per ufunc).
+
+Reference text followed: src/shaders/grayscale.wgsl:12-38, blit.wgsl:17-36,
+gaussian_blur_x.wgsl:14-60, fast.wgsl:25-159, brief.wgsl:20-68 (+ table 70-327), and the stage
+order of src/orb.rs:469-557.
+"""
+import hashlib
+import os
+import re
+
+import numpy as np
+
+F = np.float32
+
+RING4 = [(3, 0), (-3, 0), (0, 3), (0, -3)]
+RING16 = [(-3, 0), (-3, -1), (-2, -2), (-1, -3), (0, -3), (1, -3), (2, -2), (3, -1),
+          (3, 0), (3, 1), (2, 2), (1, 3), (0, 3), (-1, 3), (-2, 2), (-3, 1)]
+BLUR_OFF = [F(-2.2273038885157046), F(-0.4391873198428642), F(1.3243948342247673), F(3.0)]
+BLUR_WGT = [F(0.13748623236806098), F(0.5037756553768409), F(0.32748695702046415), F(0.031251155234634016)]
+
+
+def _pattern():
+    """BRIEF pattern parsed from the generated header (data, pinned by SHA-256 in SURVEY.md 8a)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    text = open(os.path.join(here, "orb_pattern.h")).read()
+    body = text[text.index("{") + 1:text.rindex("}")]
+    vals = np.array([int(v) for v in re.findall(r"-?\d+", body)], dtype=np.int8)
+    assert vals.size == 1024
+    assert hashlib.sha256(vals.tobytes()).hexdigest() == \
+        "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+    return vals.reshape(256, 4).astype(np.int32)
+
+
+PATTERN = _pattern()
+
+
+def to_f16_bits(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float16).view(np.uint16)
+
+
+def from_f16_bits(a):
+    return np.asarray(a, dtype=np.uint16).view(np.float16).astype(np.float32)
+
+
+def level_sizes(W, H, depth):
+    return [(max(1, W >> m), max(1, H >> m)) for m in range(depth)]
+
+
+# ------------------------------------------------------------------ stages
+def grayscale(rgba):
+    """grayscale.wgsl: luminance of the vertically mirrored texel, stored as R16Float."""
+    img = np.asarray(rgba, dtype=np.uint8)[::-1, :, :]
+    chan = img.astype(np.float32) / F(255.0)
+    lum = (F(0.229) * chan[..., 0] + F(0.587) * chan[..., 1]) + F(0.114) * chan[..., 2]
+    return to_f16_bits(lum)
+
+
+def _lerp_axis_coords(n_dst, n_src):
+    s = (np.arange(n_dst, dtype=np.float32) + F(0.5)) * (F(n_src) / F(n_dst)) - F(0.5)
+    s0 = np.floor(s)
+    frac = (s - s0).astype(np.float32)
+    i0 = np.clip(s0.astype(np.int64), 0, n_src - 1)
+    i1 = np.clip(s0.astype(np.int64) + 1, 0, n_src - 1)
+    return i0, i1, frac
+
+
+def mip(src_bits):
+    """blit.wgsl: bilinear sample of the previous level at each target texel centre."""
+    src = from_f16_bits(src_bits)
+    hs, ws = src.shape
+    wd, hd = max(1, ws >> 1), max(1, hs >> 1)
+    if ws == 2 * wd and hs == 2 * hd:
+        top = src[0::2, 0::2] + src[0::2, 1::2]
+        bot = src[1::2, 0::2] + src[1::2, 1::2]
+        return to_f16_bits((top + bot) * F(0.25))
+    x0, x1, fx = _lerp_axis_coords(wd, ws)
+    y0, y1, fy = _lerp_axis_coords(hd, hs)
+    a, b = src[np.ix_(y0, x0)], src[np.ix_(y0, x1)]
+    c, d = src[np.ix_(y1, x0)], src[np.ix_(y1, x1)]
+    top = a + fx[None, :] * (b - a)
+    bot = c + fx[None, :] * (d - c)
+    return to_f16_bits(top + fy[:, None] * (bot - top))
+
+
+def blur_pass(src_bits):
+    """gaussian_blur_x.wgsl used for BOTH passes (orb.rs:399-402); offsets in UV units; flipped v."""
+    src = from_f16_bits(src_bits)[::-1, :]
+    h, w = src.shape
+    fw = F(w)
+    u = (np.arange(w, dtype=np.float32) + F(0.5)) / fw
+    acc = np.zeros((h, w), dtype=np.float32)
+    for off, wgt in zip(BLUR_OFF, BLUR_WGT):
+        coord = (u + off) * fw - F(0.5)
+        c0 = np.floor(coord)
+        frac = (coord - c0).astype(np.float32)
+        i0 = np.clip(c0.astype(np.int64), 0, w - 1)
+        i1 = np.clip(c0.astype(np.int64) + 1, 0, w - 1)
+        t0, t1 = src[:, i0], src[:, i1]
+        sample = t0 + frac[None, :] * (t1 - t0)
+        acc = acc + sample * wgt
+    return to_f16_bits(acc)
+
+
+def _streak12(mask):
+    """fast.wgsl:51-60 on uint32 arrays."""
+    def rot(v, k):
+        return (v >> np.uint32(k)) | ((v << np.uint32(16 - k)) & np.uint32(0xFFFF))
+    o6 = mask & rot(mask, 6)
+    o3 = o6 & rot(o6, 3)
+    return o3 & rot(o3, 2) & rot(o3, 1)
+
+
+def atan2f(y, x):
+    """CRD-9 canonical atan2 (same definition as orc_atan2f, re-derived here on arrays)."""
+    y = np.asarray(y, dtype=np.float32)
+    x = np.asarray(x, dtype=np.float32)
+    ax, ay = np.abs(x), np.abs(y)
+    mx = np.maximum(ax, ay)
+    mn = np.minimum(ax, ay)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a = np.where(mx > 0, mn / np.where(mx > 0, mx, F(1)), F(0)).astype(np.float32)
+    big = a > F(0.41421356)
+    t = np.where(big, (a - F(1.0)) / (a + F(1.0)), a).astype(np.float32)
+    base = np.where(big, F(0.78539816), F(0.0)).astype(np.float32)
+    z = t * t
+    p = np.full_like(z, F(8.05374449538e-2))
+    p = p * z - F(1.38776856032e-1)
+    p = p * z + F(1.99777106478e-1)
+    p = p * z - F(3.33329491539e-1)
+    r = (p * z) * t + t
+    r = base + r
+    r = np.where(ay > ax, F(1.57079632679) - r, r)
+    r = np.where(x < 0, F(3.14159265) - r, r)
+    r = np.where(y < 0, -r, r)
+    r = np.where((ax == 0) & (ay == 0), F(0), r)
+    return r.astype(np.float32)
+
+
+def _load(level, xs, ys):
+    """textureLoad with out-of-level coordinates returning 0 (CRD-6)."""
+    h, w = level.shape
+    ok = (xs >= 0) & (ys >= 0) & (xs < w) & (ys < h)
+    out = np.zeros(np.broadcast(xs, ys).shape, dtype=np.float32)
+    xs_b, ys_b = np.broadcast_arrays(xs, ys)
+    out[ok] = level[ys_b[ok], xs_b[ok]]
+    return out
+
+
+def fast(gray_levels_bits, threshold):
+    """fast.wgsl compute_fast over all octaves; returns (x, y, angle, octave) rows in raster order."""
+    thr = F(threshold)
+    H0, W0 = gray_levels_bits[0].shape
+    lim_x = (W0 - 16) & 0xFFFFFFFF
+    lim_y = (H0 - 16) & 0xFFFFFFFF
+    rows = []
+    width, height = W0, H0
+    for octv, bits in enumerate(gray_levels_bits):
+        lvl = from_f16_bits(bits)
+        gw, gh = (width + 7) // 8 * 8, (height + 7) // 8 * 8
+        width //= 2
+        height //= 2
+        if gw == 0 or gh == 0:
+            continue
+        gx, gy = np.meshgrid(np.arange(gw, dtype=np.int64), np.arange(gh, dtype=np.int64))
+        guard = (gx > 16) & (gy > 16) & (gx < lim_x) & (gy < lim_y)
+        if not guard.any():
+            continue
+        gx, gy = gx[guard], gy[guard]
+        c = _load(lvl, gx, gy)
+        over = np.zeros(gx.shape, dtype=np.int32)
+        under = np.zeros(gx.shape, dtype=np.int32)
+        for dx, dy in RING4:
+            diff = _load(lvl, gx + dx, gy + dy) - c
+            over += diff > thr
+            under += (~(diff > thr)) & (diff < -thr)
+        cand = (over >= 3) | (under >= 3)
+        gx, gy, c = gx[cand], gy[cand], c[cand]
+        m_over = np.zeros(gx.shape, dtype=np.uint32)
+        m_under = np.zeros(gx.shape, dtype=np.uint32)
+        cx = np.zeros(gx.shape, dtype=np.float32)
+        cy = np.zeros(gx.shape, dtype=np.float32)
+        for i, (dx, dy) in enumerate(RING16):
+            v = _load(lvl, gx + dx, gy + dy)
+            diff = v - c
+            cx = cx + v * F(dx)
+            cy = cy + v * F(dy)
+            is_o = diff > thr
+            is_u = (~is_o) & (diff < -thr)
+            m_over |= (is_o.astype(np.uint32) << np.uint32(i))
+            m_under |= (is_u.astype(np.uint32) << np.uint32(i))
+        corner = (_streak12(m_over) | _streak12(m_under)) > 0
+        gx, gy, cx, cy = gx[corner], gy[corner], cx[corner], cy[corner]
+        ang = atan2f(cy, cx)
+        code = np.where((cy < 0) | (ang < 0), F(0), np.trunc(ang * F(1000.0))).astype(np.uint32)
+        for k in range(gx.size):
+            rows.append((int(gx[k]), int(gy[k]), int(code[k]), octv))
+    return np.array(rows, dtype=np.uint32).reshape(-1, 4)
+
+
+def brief(blur_levels_bits, corners):
+    """brief.wgsl: rotated BRIEF-256; returns uint32 (n, 8)."""
+    corners = np.asarray(corners, dtype=np.uint32).reshape(-1, 4)
+    n = corners.shape[0]
+    out = np.zeros((n, 8), dtype=np.uint32)
+    levels = [from_f16_bits(b) for b in blur_levels_bits]
+    theta = corners[:, 2].astype(np.float32) / F(1000.0)
+    ct = np.cos(theta.astype(np.float64)).astype(np.float32)
+    st = np.sin(theta.astype(np.float64)).astype(np.float32)
+    px = corners[:, 0].astype(np.int64)
+    py = corners[:, 1].astype(np.int64)
+    for j in range(256):
+        ax, ay, bx, by = (F(v) for v in PATTERN[j])
+        rax = ct * ax + st * ay
+        ray = (-st) * ax + ct * ay
+        rbx = ct * bx + st * by
+        rby = (-st) * bx + ct * by
+        tax, tay = np.trunc(rax).astype(np.int64) + px, np.trunc(ray).astype(np.int64) + py
+        tbx, tby = np.trunc(rbx).astype(np.int64) + px, np.trunc(rby).astype(np.int64) + py
+        va = np.zeros(n, dtype=np.float32)
+        vb = np.zeros(n, dtype=np.float32)
+        for octv, lvl in enumerate(levels):
+            sel = corners[:, 3] == octv
+            if sel.any():
+                va[sel] = _load(lvl, tax[sel], tay[sel])
+                vb[sel] = _load(lvl, tbx[sel], tby[sel])
+        out[:, j >> 5] |= ((va > vb).astype(np.uint32) << np.uint32(j & 31))
+    return out
+
+
+def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192):
+    """orb.rs:469-557 stage order."""
+    gray = [grayscale(rgba)]
+    for _ in range(1, depth):
+        gray.append(mip(gray[-1]))
+    tmp = [blur_pass(g) for g in gray]
+    blur = [blur_pass(t) for t in tmp]
+    kps = fast(gray, threshold)
+    total = kps.shape[0]
+    kps = kps[:max_features]
+    desc = brief(blur, kps)
+    return dict(total=total, corners=kps, descriptors=desc, gray=gray, blur=blur)
+
+
+# ------------------------------------------------------------------ synthetic frames
+def _mix32(a):
+    a = np.asarray(a, dtype=np.uint32).copy()
+    a ^= a >> np.uint32(16)
+    a *= np.uint32(0x7FEB352D)
+    a ^= a >> np.uint32(15)
+    a *= np.uint32(0x846CA68B)
+    a ^= a >> np.uint32(16)
+    return a
+
+
+def _rnd(seed, stream, idx):
+    with np.errstate(over="ignore"):
+        s = _mix32(np.uint32((seed + 0x85EBCA6B) & 0xFFFFFFFF))
+        t = _mix32(np.uint32((int(stream) + 0x9E3779B9 + int(s)) & 0xFFFFFFFF))
+        return _mix32(np.asarray(idx, dtype=np.uint32) ^ t)
+
+
+def synth_frame(W, H, seed, flags=15):
+    """Same recipe as orc_synth_frame, written with whole-image integer arrays."""
+    seed = int(seed) & 0xFFFFFFFF
+    x = np.arange(W, dtype=np.int64)[None, :].repeat(H, 0)
+    y = np.arange(H, dtype=np.int64)[:, None].repeat(W, 1)
+    chans = [np.zeros((H, W), dtype=np.int64) for _ in range(3)]
+    if flags & 1:
+        chans[0] = 255 * x // (W - 1) if W > 1 else chans[0]
+        chans[1] = 255 * y // (H - 1) if H > 1 else chans[1]
+        chans[2] = 255 * (x + y) // (W + H - 2) if W + H > 2 else chans[2]
+    if flags & 4:
+        ncx = (W + 127) // 128
+        cx, cy = x // 128, y // 64
+        h = _rnd(seed, 2, (cy * ncx + cx).astype(np.uint32)).astype(np.int64)
+        rise = 4 + ((h >> 1) & 15) % 13
+        run = 2 * rise
+        ox = ((h >> 8) & 255) % (128 - run)
+        oy = ((h >> 16) & 255) % (64 - rise)
+        level = (h >> 24) & 255
+        u = x - (cx * 128 + ox)
+        v = y - (cy * 64 + oy)
+        inside = ((h & 1) == 1) & (u >= 0) & (v >= 0) & (u < run) & (v < rise)
+        uu = np.where((h & 32) != 0, run - 1 - u, u)
+        vv = np.where((h & 64) != 0, rise - 1 - v, v)
+        inside &= vv * run <= uu * rise
+        for k in range(3):
+            chans[k] = np.where(inside, level, chans[k])
+    if flags & 2:
+        ncx = (W + 31) // 32
+        cx, cy = x // 32, y // 32
+        h = _rnd(seed, 1, (cy * ncx + cx).astype(np.uint32)).astype(np.int64)
+        s = 1 + ((h >> 1) & 3)
+        ox = 1 + ((h >> 4) & 255) % (31 - s)
+        oy = 1 + ((h >> 12) & 255) % (31 - s)
+        level = 128 + ((h >> 20) & 127)
+        bx, by = cx * 32 + ox, cy * 32 + oy
+        inside = ((h & 1) == 1) & (x >= bx) & (x < bx + s) & (y >= by) & (y < by + s)
+        for k in range(3):
+            chans[k] = np.where(inside, level, chans[k])
+    if flags & 8:
+        n = _rnd(seed, 3, (y * W + x).astype(np.uint32)).astype(np.int64)
+        for k in range(3):
+            chans[k] = (3 * chans[k] + ((n >> (8 * k)) & 255)) // 4
+    out = np.empty((H, W, 4), dtype=np.uint8)
+    for k in range(3):
+        out[..., k] = chans[k].astype(np.uint8)
+    out[..., 3] = 255
+    return out

@@ -1,0 +1,480 @@
+/*
+ * orb_oracle.c -- CPU restatement of the tinyslam ORB front-end.  TEST INFRASTRUCTURE ONLY;
+ * PARITY UNPINNED (see orb_oracle.h for what that means and who may use this file).
+ *
+ * Every function cites the reference text it follows (paths relative to ccaven/tinyslam).
+ * Build with -O2 -ffp-contract=off: every product and sum below is meant to be rounded to
+ * binary32 on its own, and the HIP kernels are built the same way.
+ */
+#include "orb_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "orb_pattern.h"
+
+/* ------------------------------------------------------------------------------------------
+ * scalar helpers
+ * ---------------------------------------------------------------------------------------- */
+
+static uint32_t f32_bits(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    return u;
+}
+
+static float bits_f32(uint32_t u) {
+    float v;
+    memcpy(&v, &u, 4);
+    return v;
+}
+
+/* CRD-3: binary32 -> binary16, round to nearest even, subnormal results kept.  Render-target
+ * stores of an R16Float attachment (orb.rs:151, 285, 393, 404). */
+uint16_t orc_f32_to_f16(float v) {
+    uint32_t u = f32_bits(v);
+    uint32_t sign = (u >> 16) & 0x8000u;
+    uint32_t mag = u & 0x7fffffffu;
+    if (mag >= 0x7f800000u) { /* inf / nan */
+        return (uint16_t)(sign | 0x7c00u | ((mag > 0x7f800000u) ? 0x200u : 0u));
+    }
+    if (mag >= 0x47800000u) { /* >= 65536 -> rounds to inf (65520 and up round to inf below) */
+        return (uint16_t)(sign | 0x7c00u);
+    }
+    if (mag < 0x33000000u) { /* < 2^-25: rounds to zero (2^-25 itself ties to even = 0) */
+        return (uint16_t)sign;
+    }
+    int32_t e = (int32_t)(mag >> 23) - 127; /* unbiased */
+    uint32_t m = (mag & 0x7fffffu) | 0x800000u; /* 24-bit significand */
+    uint32_t shift;
+    uint32_t half_exp;
+    if (e < -14) { /* subnormal half: value = m * 2^(e-23), unit = 2^-24 */
+        shift = (uint32_t)(-1 - e); /* 13 + (-14 - e) */
+        half_exp = 0;
+    } else {
+        shift = 13;
+        half_exp = (uint32_t)(e + 15);
+    }
+    uint32_t q = m >> shift;
+    uint32_t rem = m & ((1u << shift) - 1u);
+    uint32_t halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (q & 1u))) q++;
+    /* normal: q carries the hidden bit (0x400); adding lets a mantissa overflow bump the exponent */
+    uint32_t h = (half_exp == 0) ? q : (((half_exp - 1) << 10) + q);
+    return (uint16_t)(sign | h);
+}
+
+float orc_f16_to_f32(uint16_t h) {
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu;
+    uint32_t m = h & 0x3ffu;
+    if (e == 0) {
+        /* zero or subnormal: m * 2^-24, exact in binary32 */
+        float v = (float)m * 5.9604644775390625e-08f;
+        return sign ? -v : v;
+    }
+    if (e == 31) return bits_f32(sign | 0x7f800000u | (m << 13));
+    return bits_f32(sign | ((e + 112u) << 23) | (m << 13));
+}
+
+/* CRD-1: Rgba8Unorm texel -> float (input texture orb.rs:116-121). */
+float orc_unorm8(uint8_t b) { return (float)b / 255.0f; }
+
+/* fast.wgsl:51-54.  WGSL precedence makes this (num >> count) | ((num << (16-count)) & 0xffff). */
+static uint32_t rotate_bits_16(uint32_t num, uint32_t count) {
+    return (num >> count) | ((num << (16u - count)) & 0x0000ffffu);
+}
+
+/* fast.wgsl:56-60 */
+uint32_t orc_detect_streak_16(uint32_t x) {
+    uint32_t o_6 = x & rotate_bits_16(x, 6u);
+    uint32_t o_3 = o_6 & rotate_bits_16(o_6, 3u);
+    return o_3 & rotate_bits_16(o_3, 2u) & rotate_bits_16(o_3, 1u);
+}
+
+/* CRD-9: the canonical atan2 used for fast.wgsl:115.  Only + - * / on binary32, each rounded on
+ * its own; octant reduction, then a degree-4 odd polynomial in the reduced argument (the
+ * classic Cephes atanf coefficients).  atan2(0,0) = 0. */
+float orc_atan2f(float y, float x) {
+    float ax = fabsf(x), ay = fabsf(y);
+    if (ax == 0.0f && ay == 0.0f) return 0.0f;
+    float mx = ax > ay ? ax : ay;
+    float mn = ax > ay ? ay : ax;
+    float a = mn / mx;
+    float t = a, base = 0.0f;
+    if (a > 0.41421356f) {
+        t = (a - 1.0f) / (a + 1.0f);
+        base = 0.78539816f;
+    }
+    float z = t * t;
+    float p = 8.05374449538e-2f;
+    p = p * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    float r = (p * z) * t + t;
+    r = base + r;
+    if (ay > ax) r = 1.57079632679f - r;
+    if (x < 0.0f) r = 3.14159265f - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+/* fast.wgsl:153 `u32(angle * 1000.0)`: negative angles saturate to 0. */
+uint32_t orc_angle_code(float cy, float cx) {
+    float r = orc_atan2f(cy, cx);
+    if (cy < 0.0f || r < 0.0f) return 0u;
+    return (uint32_t)truncf(r * 1000.0f);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * pyramid geometry
+ * ---------------------------------------------------------------------------------------- */
+
+void orc_pyramid_layout(uint32_t W, uint32_t H, uint32_t depth, orc_pyramid_t *p) {
+    memset(p, 0, sizeof(*p));
+    p->depth = depth;
+    size_t off = 0;
+    for (uint32_t m = 0; m < depth && m < ORC_MAX_LEVELS; m++) {
+        uint32_t w = W >> m, h = H >> m;
+        p->w[m] = w ? w : 1;
+        p->h[m] = h ? h : 1;
+        p->offset[m] = off;
+        off += (size_t)p->w[m] * p->h[m];
+    }
+    p->total = off;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K1 grayscale.wgsl:12-38 (pass at orb.rs:478-496)
+ *   texcoord = position*0.5+0.5 maps framebuffer row 0 to v = 1: output row y samples input row
+ *   H-1-y at its texel centre (bilinear weight exactly 1, CRD-1); luminance per CRD-2.
+ * ---------------------------------------------------------------------------------------- */
+void orc_grayscale(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray) {
+    for (uint32_t y = 0; y < H; y++) {
+        const uint8_t *src = rgba + (size_t)(H - 1 - y) * W * 4;
+        for (uint32_t x = 0; x < W; x++) {
+            float r = orc_unorm8(src[4 * x + 0]);
+            float g = orc_unorm8(src[4 * x + 1]);
+            float b = orc_unorm8(src[4 * x + 2]);
+            float pr = 0.229f * r; /* grayscale.wgsl:36: 0.229, not 0.299 */
+            float pg = 0.587f * g;
+            float pb = 0.114f * b;
+            float lum = (pr + pg) + pb;
+            gray[(size_t)y * W + x] = orc_f32_to_f16(lum);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K2 blit.wgsl:17-36 (passes at orb.rs:413-429): bilinear sample of mip m-1 at the centre of
+ * each target texel, no flip.  CRD-4.
+ * ---------------------------------------------------------------------------------------- */
+static uint32_t clamp_idx(int64_t i, uint32_t n) {
+    if (i < 0) return 0;
+    if (i > (int64_t)n - 1) return n - 1;
+    return (uint32_t)i;
+}
+
+void orc_mip(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint32_t wd, uint32_t hd) {
+    if (ws == 2 * wd && hs == 2 * hd) {
+        for (uint32_t y = 0; y < hd; y++)
+            for (uint32_t x = 0; x < wd; x++) {
+                float a = orc_f16_to_f32(src[(size_t)(2 * y) * ws + 2 * x]);
+                float b = orc_f16_to_f32(src[(size_t)(2 * y) * ws + 2 * x + 1]);
+                float c = orc_f16_to_f32(src[(size_t)(2 * y + 1) * ws + 2 * x]);
+                float d = orc_f16_to_f32(src[(size_t)(2 * y + 1) * ws + 2 * x + 1]);
+                float top = a + b;
+                float bot = c + d;
+                float v = (top + bot) * 0.25f;
+                dst[(size_t)y * wd + x] = orc_f32_to_f16(v);
+            }
+        return;
+    }
+    float rx = (float)ws / (float)wd;
+    float ry = (float)hs / (float)hd;
+    for (uint32_t y = 0; y < hd; y++) {
+        float sy = ((float)y + 0.5f) * ry - 0.5f;
+        float fy0 = floorf(sy);
+        float fy = sy - fy0;
+        uint32_t y0 = clamp_idx((int64_t)fy0, hs), y1 = clamp_idx((int64_t)fy0 + 1, hs);
+        for (uint32_t x = 0; x < wd; x++) {
+            float sx = ((float)x + 0.5f) * rx - 0.5f;
+            float fx0 = floorf(sx);
+            float fx = sx - fx0;
+            uint32_t x0 = clamp_idx((int64_t)fx0, ws), x1 = clamp_idx((int64_t)fx0 + 1, ws);
+            float a = orc_f16_to_f32(src[(size_t)y0 * ws + x0]);
+            float b = orc_f16_to_f32(src[(size_t)y0 * ws + x1]);
+            float c = orc_f16_to_f32(src[(size_t)y1 * ws + x0]);
+            float d = orc_f16_to_f32(src[(size_t)y1 * ws + x1]);
+            float dab = b - a;
+            float top = a + fx * dab;
+            float dcd = d - c;
+            float bot = c + fx * dcd;
+            float dtb = bot - top;
+            float v = top + fy * dtb;
+            dst[(size_t)y * wd + x] = orc_f32_to_f16(v);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K3/K4 gaussian_blur_x.wgsl:14-26, 32-41, 53-60.  The SAME shader is used for both blur passes
+ * (orb.rs:399-402 builds the "gaussian_blur_y" pipeline from module "gaussian_blur_x").
+ * Offsets are added to the normalised u coordinate (not scaled by 1/w), sampler is bilinear
+ * clamp-to-edge (orb.rs:123-139), and the vertex shader flips v like grayscale does.  CRD-5.
+ * ---------------------------------------------------------------------------------------- */
+static const float BLUR_OFFSETS[4] = {-2.2273038885157046f, -0.4391873198428642f, 1.3243948342247673f, 3.0f};
+static const float BLUR_WEIGHTS[4] = {0.13748623236806098f, 0.5037756553768409f, 0.32748695702046415f,
+                                      0.031251155234634016f};
+
+void orc_blur_pass(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst) {
+    float fw = (float)w;
+    for (uint32_t y = 0; y < h; y++) {
+        const uint16_t *row = src + (size_t)(h - 1 - y) * w; /* flipped v, sampled at the row centre */
+        for (uint32_t x = 0; x < w; x++) {
+            float u = ((float)x + 0.5f) / fw;
+            float acc = 0.0f;
+            for (int i = 0; i < 4; i++) {
+                float uo = u + BLUR_OFFSETS[i];
+                float coord = uo * fw - 0.5f;
+                float c0 = floorf(coord);
+                float f = coord - c0;
+                uint32_t i0 = clamp_idx((int64_t)c0, w), i1 = clamp_idx((int64_t)c0 + 1, w);
+                float t0 = orc_f16_to_f32(row[i0]);
+                float t1 = orc_f16_to_f32(row[i1]);
+                float d = t1 - t0;
+                float s = t0 + f * d;
+                float ws = s * BLUR_WEIGHTS[i];
+                acc = acc + ws;
+            }
+            dst[(size_t)y * w + x] = orc_f32_to_f16(acc);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K5 fast.wgsl:62-159, dispatched once per octave (orb.rs:504-520).
+ * ---------------------------------------------------------------------------------------- */
+static const int RING4[4][2] = {{3, 0}, {-3, 0}, {0, 3}, {0, -3}}; /* fast.wgsl:25-30 */
+static const int RING16[16][2] = {{-3, 0}, {-3, -1}, {-2, -2}, {-1, -3}, {0, -3}, {1, -3}, {2, -2}, {3, -1},
+                                  {3, 0},  {3, 1},   {2, 2},   {1, 3},   {0, 3},  {-1, 3}, {-2, 2}, {-3, 1}};
+
+/* textureLoad of one mip level; outside the level -> 0 (CRD-6). */
+static float level_load(const uint16_t *pyr, const orc_pyramid_t *lay, uint32_t lvl, int64_t x, int64_t y) {
+    if (x < 0 || y < 0 || x >= (int64_t)lay->w[lvl] || y >= (int64_t)lay->h[lvl]) return 0.0f;
+    return orc_f16_to_f32(pyr[lay->offset[lvl] + (size_t)y * lay->w[lvl] + (size_t)x]);
+}
+
+void orc_fast(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, orc_corner_t *out, uint32_t cap,
+              uint32_t *total) {
+    uint32_t count = 0;
+    uint32_t W0 = lay->w[0], H0 = lay->h[0];
+    uint32_t lim_x = W0 - 16u, lim_y = H0 - 16u; /* textureDimensions(texture) is the level-0 size; u32 wrap kept */
+    uint32_t width = W0, height = H0;             /* orb.rs:501-502 */
+    for (uint32_t oct = 0; oct < lay->depth; oct++) {
+        uint32_t gw = ((width + 7) / 8) * 8, gh = ((height + 7) / 8) * 8; /* orb.rs:511-515, 8x8 groups */
+        for (uint32_t gy = 0; gy < gh; gy++)
+            for (uint32_t gx = 0; gx < gw; gx++) {
+                if (!(gx > 16u && gy > 16u && gx < lim_x && gy < lim_y)) continue; /* fast.wgsl:77 */
+                float c = level_load(pyr, lay, oct, gx, gy);
+                uint32_t num_over = 0, num_under = 0;
+                for (int i = 0; i < 4; i++) { /* fast.wgsl:85-93 */
+                    float v = level_load(pyr, lay, oct, (int64_t)gx + RING4[i][0], (int64_t)gy + RING4[i][1]);
+                    float diff = v - c;
+                    if (diff > threshold)
+                        num_over++;
+                    else if (diff < -threshold)
+                        num_under++;
+                }
+                if (!(num_over >= 3 || num_under >= 3)) continue; /* fast.wgsl:95 */
+                uint32_t is_over = 0, is_under = 0;
+                float cx = 0.0f, cy = 0.0f;
+                for (int i = 0; i < 16; i++) { /* fast.wgsl:102-113 */
+                    float v = level_load(pyr, lay, oct, (int64_t)gx + RING16[i][0], (int64_t)gy + RING16[i][1]);
+                    float diff = v - c;
+                    float px = v * (float)RING16[i][0];
+                    float py = v * (float)RING16[i][1];
+                    cx = cx + px;
+                    cy = cy + py;
+                    if (diff > threshold)
+                        is_over |= 1u << i;
+                    else if (diff < -threshold)
+                        is_under |= 1u << i;
+                }
+                uint32_t streak = orc_detect_streak_16(is_over) | orc_detect_streak_16(is_under);
+                if (streak > 0u) { /* fast.wgsl:121-157 */
+                    if (count < cap) {
+                        out[count].x = gx;
+                        out[count].y = gy;
+                        out[count].angle = orc_angle_code(cy, cx);
+                        out[count].octave = oct;
+                    }
+                    count++;
+                }
+            }
+        width /= 2; /* orb.rs:517-518 */
+        height /= 2;
+    }
+    *total = count;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K6 brief.wgsl:20-68.  One u32 word per (feature, global_id.x); bit i of word k <-> pattern
+ * row 32k+i (brief.wgsl:47).  cos/sin per CRD-10 (double libm rounded to binary32; a test
+ * checks all 3142 codes against the product's committed table).
+ * ---------------------------------------------------------------------------------------- */
+void orc_brief(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
+               orc_descriptor_t *out) {
+    for (uint32_t fidx = 0; fidx < n; fidx++) {
+        const orc_corner_t *k = &corners[fidx];
+        uint32_t oct = k->octave;
+        float theta = (float)k->angle / 1000.0f; /* brief.wgsl:35 */
+        float ct = (float)cos((double)theta);
+        float st = (float)sin((double)theta);
+        float nst = -st;
+        for (uint32_t word = 0; word < 8; word++) {
+            uint32_t bits = 0;
+            for (uint32_t i = 0; i < 32; i++) {
+                const int8_t *row = &ORC_BRIEF_PATTERN[4 * ((word << 5) | i)];
+                float ax = (float)row[0], ay = (float)row[1], bx = (float)row[2], by = (float)row[3];
+                /* mat2x2f(ct,-st, st,ct) * p, column-major: (ct*x + st*y, -st*x + ct*y)  brief.wgsl:38-54 */
+                float a0 = ct * ax, a1 = st * ay, a2 = nst * ax, a3 = ct * ay;
+                float b0 = ct * bx, b1 = st * by, b2 = nst * bx, b3 = ct * by;
+                float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+                int64_t tax = (int64_t)(int32_t)rax + (int64_t)(int32_t)k->x; /* vec2i() truncates */
+                int64_t tay = (int64_t)(int32_t)ray + (int64_t)(int32_t)k->y;
+                int64_t tbx = (int64_t)(int32_t)rbx + (int64_t)(int32_t)k->x;
+                int64_t tby = (int64_t)(int32_t)rby + (int64_t)(int32_t)k->y;
+                float va = 0.0f, vb = 0.0f;
+                if (oct < lay->depth) {
+                    va = level_load(blur_pyr, lay, oct, tax, tay);
+                    vb = level_load(blur_pyr, lay, oct, tbx, tby);
+                }
+                if (va > vb) bits |= 1u << i; /* brief.wgsl:62-64 */
+            }
+            out[fidx].word[word] = bits;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * whole frame, orb.rs:469-557: grayscale -> mips -> blur A (all levels) -> blur B (all levels)
+ * -> FAST per octave -> BRIEF.
+ * ---------------------------------------------------------------------------------------- */
+int orc_extract(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, float threshold, uint32_t max_features,
+                orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total, uint16_t *gray_pyr,
+                uint16_t *blur_pyr) {
+    if (!rgba || !W || !H || depth < 1 || depth > ORC_MAX_LEVELS || !total) return -1;
+    orc_pyramid_t lay;
+    orc_pyramid_layout(W, H, depth, &lay);
+    uint16_t *gray = (uint16_t *)malloc(lay.total * sizeof(uint16_t));
+    uint16_t *tmp = (uint16_t *)malloc(lay.total * sizeof(uint16_t));
+    uint16_t *blur = (uint16_t *)malloc(lay.total * sizeof(uint16_t));
+    if (!gray || !tmp || !blur) {
+        free(gray);
+        free(tmp);
+        free(blur);
+        return -1;
+    }
+    orc_grayscale(rgba, W, H, gray);
+    for (uint32_t m = 1; m < depth; m++)
+        orc_mip(gray + lay.offset[m - 1], lay.w[m - 1], lay.h[m - 1], gray + lay.offset[m], lay.w[m], lay.h[m]);
+    for (uint32_t m = 0; m < depth; m++) orc_blur_pass(gray + lay.offset[m], lay.w[m], lay.h[m], tmp + lay.offset[m]);
+    for (uint32_t m = 0; m < depth; m++) orc_blur_pass(tmp + lay.offset[m], lay.w[m], lay.h[m], blur + lay.offset[m]);
+    uint32_t count = 0;
+    orc_fast(gray, &lay, threshold, corners, max_features, &count);
+    uint32_t stored = count < max_features ? count : max_features;
+    if (descriptors) orc_brief(blur, &lay, corners, stored, descriptors);
+    *total = count;
+    if (gray_pyr) memcpy(gray_pyr, gray, lay.total * sizeof(uint16_t));
+    if (blur_pyr) memcpy(blur_pyr, blur, lay.total * sizeof(uint16_t));
+    free(gray);
+    free(tmp);
+    free(blur);
+    return 0;
+}
+
+int orc_extract_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth, float threshold,
+                      uint32_t max_features, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *totals,
+                      int n_threads) {
+    int rc = 0;
+    size_t frame_bytes = (size_t)W * H * 4;
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int64_t f = 0; f < (int64_t)n_frames; f++) {
+        int r = orc_extract(rgba + (size_t)f * frame_bytes, W, H, depth, threshold, max_features,
+                            corners + (size_t)f * max_features,
+                            descriptors ? descriptors + (size_t)f * max_features : NULL, &totals[f], NULL, NULL);
+        if (r) {
+#pragma omp critical
+            rc = r;
+        }
+    }
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic frames.  Counter-based so that C, NumPy and a GPU generator
+ * produce identical bytes without sharing a sequential random stream.
+ * ---------------------------------------------------------------------------------------- */
+static uint32_t mix32(uint32_t a) {
+    a ^= a >> 16;
+    a *= 0x7feb352dU;
+    a ^= a >> 15;
+    a *= 0x846ca68bU;
+    a ^= a >> 16;
+    return a;
+}
+
+static uint32_t syn_rnd(uint32_t seed, uint32_t stream, uint32_t idx) {
+    return mix32(idx ^ mix32(stream + 0x9E3779B9U + mix32(seed + 0x85EBCA6BU)));
+}
+
+void orc_synth_frame(uint8_t *rgba, uint32_t W, uint32_t H, uint32_t seed, uint32_t flags) {
+    uint32_t ncx_w = (W + 127) / 128, ncx_b = (W + 31) / 32;
+    for (uint32_t y = 0; y < H; y++)
+        for (uint32_t x = 0; x < W; x++) {
+            uint32_t c[3] = {0, 0, 0};
+            if (flags & ORC_SYN_GRADIENT) {
+                c[0] = W > 1 ? 255u * x / (W - 1) : 0;
+                c[1] = H > 1 ? 255u * y / (H - 1) : 0;
+                c[2] = (W + H > 2) ? 255u * (x + y) / (W + H - 2) : 0;
+            }
+            if (flags & ORC_SYN_WEDGES) { /* one acute right triangle per 128x64 cell */
+                uint32_t cx = x / 128, cy = y / 64;
+                uint32_t hsh = syn_rnd(seed, 2, cy * ncx_w + cx);
+                if (hsh & 1u) {
+                    uint32_t rise = 4 + ((hsh >> 1) & 15u) % 13u, run = 2 * rise;
+                    uint32_t ox = ((hsh >> 8) & 255u) % (128 - run), oy = ((hsh >> 16) & 255u) % (64 - rise);
+                    uint32_t level = (hsh >> 24) & 255u;
+                    int32_t u = (int32_t)x - (int32_t)(cx * 128 + ox), v = (int32_t)y - (int32_t)(cy * 64 + oy);
+                    if (u >= 0 && v >= 0 && u < (int32_t)run && v < (int32_t)rise) {
+                        uint32_t uu = (hsh & 32u) ? run - 1 - (uint32_t)u : (uint32_t)u;
+                        uint32_t vv = (hsh & 64u) ? rise - 1 - (uint32_t)v : (uint32_t)v;
+                        if (vv * run <= uu * rise) c[0] = c[1] = c[2] = level;
+                    }
+                }
+            }
+            if (flags & ORC_SYN_BLOBS) { /* at most one bright square (side 1..4) per 32x32 cell */
+                uint32_t cx = x / 32, cy = y / 32;
+                uint32_t hsh = syn_rnd(seed, 1, cy * ncx_b + cx);
+                if (hsh & 1u) {
+                    uint32_t s = 1 + ((hsh >> 1) & 3u);
+                    uint32_t ox = 1 + ((hsh >> 4) & 255u) % (31 - s), oy = 1 + ((hsh >> 12) & 255u) % (31 - s);
+                    uint32_t level = 128 + ((hsh >> 20) & 127u);
+                    uint32_t bx = cx * 32 + ox, by = cy * 32 + oy;
+                    if (x >= bx && x < bx + s && y >= by && y < by + s) c[0] = c[1] = c[2] = level;
+                }
+            }
+            if (flags & ORC_SYN_NOISE) {
+                uint32_t n = syn_rnd(seed, 3, y * W + x);
+                for (int k = 0; k < 3; k++) c[k] = (3 * c[k] + ((n >> (8 * k)) & 255u)) / 4;
+            }
+            uint8_t *p = rgba + ((size_t)y * W + x) * 4;
+            p[0] = (uint8_t)c[0];
+            p[1] = (uint8_t)c[1];
+            p[2] = (uint8_t)c[2];
+            p[3] = 255;
+        }
+}

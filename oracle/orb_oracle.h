@@ -1,0 +1,93 @@
+/*
+ * orb_oracle.h -- CPU restatement of the tinyslam ORB front-end (TEST INFRASTRUCTURE ONLY).
+ *
+ * PARITY UNPINNED: the reference (ccaven/tinyslam @ v2) ships no tests, golden vectors or
+ * fixtures for this path and cannot be built or run in this environment (Rust + wgpu/Vulkan,
+ * no cargo/rustc/Vulkan ICD).  This file restates the reference's WGSL
+ * shaders and the stage order of src/orb.rs in plain C, with the implementation-defined
+ * points fixed by SURVEY.md's canonical restatement decisions CRD-1..CRD-12.  It is pinned
+ * only by known-answer tests derived from the reference text and by a second, independently
+ * written NumPy restatement (oracle/orb_numpy.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything
+ * under oracle/.  The product (tinyslam_amd/, include/) never includes, links or calls it.
+ *
+ * All images are planes of IEEE binary16 bit patterns (uint16_t), row-major, tightly packed:
+ * the reference keeps every image after the input as R16Float (src/orb.rs:151,228,296,311).
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LEVELS 10 /* src/orb.rs:67 MAX_HIERARCHY_DEPTH */
+
+/* src/orb.rs:10-17 CornerData == fast.wgsl:1-6 Feature */
+typedef struct {
+    uint32_t x, y, angle, octave;
+} orc_corner_t;
+
+/* src/orb.rs:19-23 CornerDescriptor (8 little-endian u32 words, brief.wgsl:15) */
+typedef struct {
+    uint32_t word[8];
+} orc_descriptor_t;
+
+/* Level geometry: mip m is (max(1,W>>m), max(1,H>>m)) texels (wgpu mip chain, orb.rs:224-233).
+ * offset[] are texel offsets of each level inside one packed pyramid buffer. */
+typedef struct {
+    uint32_t depth;
+    uint32_t w[ORC_MAX_LEVELS], h[ORC_MAX_LEVELS];
+    size_t offset[ORC_MAX_LEVELS];
+    size_t total; /* texels in the packed pyramid */
+} orc_pyramid_t;
+
+void orc_pyramid_layout(uint32_t W, uint32_t H, uint32_t depth, orc_pyramid_t *p);
+
+/* scalar helpers (exposed for known-answer tests) */
+uint16_t orc_f32_to_f16(float v);  /* CRD-3: round-to-nearest-even, subnormals kept */
+float orc_f16_to_f32(uint16_t h);  /* exact */
+float orc_atan2f(float y, float x); /* CRD-9 */
+uint32_t orc_angle_code(float cy, float cx); /* fast.wgsl:115,153 + CRD-9 */
+uint32_t orc_detect_streak_16(uint32_t mask); /* fast.wgsl:51-60 */
+float orc_unorm8(uint8_t b); /* CRD-1 */
+
+/* stages */
+void orc_grayscale(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray); /* grayscale.wgsl:12-38 */
+void orc_mip(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint32_t wd, uint32_t hd); /* blit.wgsl:17-36 */
+void orc_blur_pass(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst); /* gaussian_blur_x.wgsl:32-60 */
+/* fast.wgsl:62-159 over every octave in dispatch order (orb.rs:504-520).  Appends in raster
+ * order, octave-major.  Stores at most cap records, returns the raw counter in *total. */
+void orc_fast(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, orc_corner_t *out, uint32_t cap,
+              uint32_t *total);
+/* brief.wgsl:20-68 for n corners */
+void orc_brief(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
+               orc_descriptor_t *out);
+
+/* Whole frame: orb.rs:469-557 extract_corners.  gray_pyr / blur_pyr (may be NULL) receive the
+ * packed pyramids (lay.total texels each).  Returns 0, or -1 on invalid arguments. */
+int orc_extract(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, float threshold, uint32_t max_features,
+                orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total, uint16_t *gray_pyr,
+                uint16_t *blur_pyr);
+
+/* Frame-parallel batch for the CPU baseline leg of bench.py: n_frames contiguous RGBA frames,
+ * outputs strided by max_features.  n_threads <= 1 runs serially. */
+int orc_extract_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth, float threshold,
+                      uint32_t max_features, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *totals,
+                      int n_threads);
+
+/* Synthetic frames: counter-based, integer only. */
+#define ORC_SYN_GRADIENT 1u
+#define ORC_SYN_BLOBS 2u
+#define ORC_SYN_WEDGES 4u
+#define ORC_SYN_NOISE 8u
+void orc_synth_frame(uint8_t *rgba, uint32_t W, uint32_t H, uint32_t seed, uint32_t flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

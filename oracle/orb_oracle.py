@@ -1,0 +1,189 @@
+"""ctypes front-end of the CPU restatement (oracle/orb_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: see oracle/orb_oracle.h.  Only tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py may import this module; the product never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liborb_oracle.so")
+
+MAX_LEVELS = 10
+SYN_GRADIENT, SYN_BLOBS, SYN_WEDGES, SYN_NOISE = 1, 2, 4, 8
+SYN_ALL = 15
+
+CORNER_DTYPE = np.dtype([("x", "<u4"), ("y", "<u4"), ("angle", "<u4"), ("octave", "<u4")])
+
+
+class _Pyramid(ctypes.Structure):
+    _fields_ = [
+        ("depth", ctypes.c_uint32),
+        ("w", ctypes.c_uint32 * MAX_LEVELS),
+        ("h", ctypes.c_uint32 * MAX_LEVELS),
+        ("offset", ctypes.c_size_t * MAX_LEVELS),
+        ("total", ctypes.c_size_t),
+    ]
+
+
+def build(force=False):
+    """Compile the restatement with gcc (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, n) for n in ("orb_oracle.c", "orb_oracle.h", "orb_pattern.h", "Makefile")]
+    if not force and os.path.exists(_LIB_PATH):
+        if all(os.path.getmtime(s) <= os.path.getmtime(_LIB_PATH) for s in srcs):
+            return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        u8p, u16p, u32p, vp = (ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint16),
+                               ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p)
+        u32, f32 = ctypes.c_uint32, ctypes.c_float
+        L.orc_pyramid_layout.argtypes = [u32, u32, u32, ctypes.POINTER(_Pyramid)]
+        L.orc_f32_to_f16.argtypes = [f32]
+        L.orc_f32_to_f16.restype = ctypes.c_uint16
+        L.orc_f16_to_f32.argtypes = [ctypes.c_uint16]
+        L.orc_f16_to_f32.restype = f32
+        L.orc_atan2f.argtypes = [f32, f32]
+        L.orc_atan2f.restype = f32
+        L.orc_angle_code.argtypes = [f32, f32]
+        L.orc_angle_code.restype = u32
+        L.orc_detect_streak_16.argtypes = [u32]
+        L.orc_detect_streak_16.restype = u32
+        L.orc_unorm8.argtypes = [ctypes.c_uint8]
+        L.orc_unorm8.restype = f32
+        L.orc_grayscale.argtypes = [vp, u32, u32, vp]
+        L.orc_mip.argtypes = [vp, u32, u32, vp, u32, u32]
+        L.orc_blur_pass.argtypes = [vp, u32, u32, vp]
+        L.orc_fast.argtypes = [vp, ctypes.POINTER(_Pyramid), f32, vp, u32, u32p]
+        L.orc_brief.argtypes = [vp, ctypes.POINTER(_Pyramid), vp, u32, vp]
+        L.orc_extract.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, u32p, vp, vp]
+        L.orc_extract.restype = ctypes.c_int
+        L.orc_extract_batch.argtypes = [vp, u32, u32, u32, u32, f32, u32, vp, vp, vp, ctypes.c_int]
+        L.orc_extract_batch.restype = ctypes.c_int
+        L.orc_synth_frame.argtypes = [vp, u32, u32, u32, u32]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def pyramid_layout(W, H, depth):
+    p = _Pyramid()
+    lib().orc_pyramid_layout(W, H, depth, ctypes.byref(p))
+    return p
+
+
+def level_dims(W, H, depth):
+    p = pyramid_layout(W, H, depth)
+    return [(int(p.w[m]), int(p.h[m]), int(p.offset[m])) for m in range(depth)], int(p.total)
+
+
+def f32_to_f16(v):
+    return int(lib().orc_f32_to_f16(float(np.float32(v))))
+
+
+def f16_to_f32(h):
+    return float(lib().orc_f16_to_f32(int(h)))
+
+
+def atan2f(y, x):
+    return np.float32(lib().orc_atan2f(float(np.float32(y)), float(np.float32(x))))
+
+
+def angle_code(cy, cx):
+    return int(lib().orc_angle_code(float(np.float32(cy)), float(np.float32(cx))))
+
+
+def detect_streak_16(mask):
+    return int(lib().orc_detect_streak_16(int(mask)))
+
+
+def unorm8(b):
+    return np.float32(lib().orc_unorm8(int(b)))
+
+
+def synth_frame(W, H, seed, flags=SYN_ALL):
+    out = np.empty((H, W, 4), dtype=np.uint8)
+    lib().orc_synth_frame(_ptr(out), W, H, int(seed) & 0xFFFFFFFF, flags)
+    return out
+
+
+def grayscale(rgba):
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    H, W = rgba.shape[:2]
+    out = np.empty((H, W), dtype=np.uint16)
+    lib().orc_grayscale(_ptr(rgba), W, H, _ptr(out))
+    return out
+
+
+def mip(src, wd=None, hd=None):
+    src = np.ascontiguousarray(src, dtype=np.uint16)
+    hs, ws = src.shape
+    wd = max(1, ws >> 1) if wd is None else wd
+    hd = max(1, hs >> 1) if hd is None else hd
+    out = np.empty((hd, wd), dtype=np.uint16)
+    lib().orc_mip(_ptr(src), ws, hs, _ptr(out), wd, hd)
+    return out
+
+
+def blur_pass(src):
+    src = np.ascontiguousarray(src, dtype=np.uint16)
+    h, w = src.shape
+    out = np.empty((h, w), dtype=np.uint16)
+    lib().orc_blur_pass(_ptr(src), w, h, _ptr(out))
+    return out
+
+
+def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=False):
+    """Whole frame.  Returns dict(total, corners[structured], descriptors[u32 (n,8)], gray, blur)."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    H, W = rgba.shape[:2]
+    corners = np.zeros(max_features, dtype=CORNER_DTYPE)
+    desc = np.zeros((max_features, 8), dtype=np.uint32)
+    total = ctypes.c_uint32(0)
+    _, ntex = level_dims(W, H, depth)
+    gray = np.zeros(ntex, dtype=np.uint16) if planes else None
+    blur = np.zeros(ntex, dtype=np.uint16) if planes else None
+    rc = lib().orc_extract(_ptr(rgba), W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
+                           _ptr(corners), _ptr(desc), ctypes.byref(total),
+                           _ptr(gray) if planes else None, _ptr(blur) if planes else None)
+    if rc != 0:
+        raise ValueError("orc_extract: invalid arguments")
+    n = min(total.value, max_features)
+    return dict(total=total.value, corners=corners[:n], descriptors=desc[:n], gray=gray, blur=blur)
+
+
+def extract_batch(frames, depth=2, threshold=20.0 / 255.0, max_features=8192, n_threads=1):
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    F, H, W = frames.shape[:3]
+    corners = np.zeros((F, max_features), dtype=CORNER_DTYPE)
+    desc = np.zeros((F, max_features, 8), dtype=np.uint32)
+    totals = np.zeros(F, dtype=np.uint32)
+    rc = lib().orc_extract_batch(_ptr(frames), F, W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
+                                 _ptr(corners), _ptr(desc), _ptr(totals), int(n_threads))
+    if rc != 0:
+        raise ValueError("orc_extract_batch failed")
+    return totals, corners, desc
+
+
+def sort_keypoints(corners, descriptors=None):
+    """Canonical comparison order: by (octave, y, x)."""
+    order = np.lexsort((corners["x"], corners["y"], corners["octave"]))
+    if descriptors is None:
+        return corners[order]
+    return corners[order], descriptors[order]
