@@ -1,0 +1,156 @@
+/*
+ * tinyorb.h -- C ABI of the MI355X-native ORB feature-extraction front-end.
+ *
+ * This is the drop-in boundary for the `tinyslam::orb` module of ccaven/tinyslam
+ * (src/lib.rs:1, src/orb.rs).  Each entry point names the reference item it replaces;
+ * INTEGRATION.md shows the Rust `extern "C"` shim a maintainer would add on the reference
+ * side.  Plain pointers and sizes only: no C++, HIP or torch types cross this boundary.
+ *
+ * Semantics follow the reference's literal behaviour:
+ * keypoints are FAST-12 corners on an R16Float luminance pyramid (vertically flipped frame),
+ * orientation is the 16-pixel ring centroid in milliradians (negative angles stored as 0),
+ * descriptors are 256-bit rotated BRIEF on the reference's (x-only, UV-offset) blur.
+ *
+ * Threading: calls on one OrbProgram must be serialised by the caller; distinct programs are
+ * independent (one program = one device + its streams), like one wgpu Device/Queue per
+ * OrbProgram in the reference (orb.rs:47-51).
+ */
+#ifndef TINYORB_H
+#define TINYORB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TINYORB_ABI_VERSION 1
+
+/* status codes (the reference panics instead: orb.rs:553 unwrap, label look-ups) */
+#define ORB_OK 0
+#define ORB_EINVAL 1    /* bad argument / configuration (reference: wgpu validation panic) */
+#define ORB_EHIP 2      /* HIP runtime failure; text in orb_last_error() */
+#define ORB_ECAPACITY 3 /* more corners detected than max_features; first max_features kept */
+#define ORB_ESTATE 4    /* call out of order (e.g. read before extract) */
+
+#define ORB_MAX_HIERARCHY_DEPTH 10 /* orb.rs:67 MAX_HIERARCHY_DEPTH */
+
+/* wgpu::Extent3d as used by OrbConfig.image_size (orb.rs:41, 120, 227) */
+typedef struct OrbExtent3d {
+    uint32_t width;
+    uint32_t height;
+    uint32_t depth_or_array_layers; /* must be 1 */
+} OrbExtent3d;
+
+/* orb.rs:40-45 `pub struct OrbConfig` -- same field order */
+typedef struct OrbConfig {
+    OrbExtent3d image_size;
+    uint32_t max_features;
+    uint32_t hierarchy_depth; /* 1..=10; the reference needs >= 2 */
+    float initial_threshold;  /* intensity units, [0,1] */
+} OrbConfig;
+
+/* orb.rs:10-17 `#[repr(C)] CornerData` == WGSL `Feature` (fast.wgsl:1-6); 16 bytes.
+ * x,y are in the octave's own pixel grid of the vertically flipped image (Q2);
+ * angle is milliradians 0..3141 (Q7). */
+typedef struct CornerData {
+    uint32_t x;
+    uint32_t y;
+    uint32_t angle;
+    uint32_t octave;
+} CornerData;
+
+/* orb.rs:19-23 `#[repr(C)] CornerDescriptor`; 32 bytes = 8 little-endian u32 words
+ * (brief.wgsl:15); bit i of word k is BRIEF test 32k+i (brief.wgsl:47,63). */
+typedef struct CornerDescriptor {
+    uint8_t bits[32];
+} CornerDescriptor;
+
+/* Build-side options with no counterpart in the reference. Zero-initialise for defaults. */
+typedef struct OrbOptions {
+    int32_t device;       /* HIP device ordinal */
+    uint32_t max_batch;   /* frames per batched call; 0 -> 1 */
+    uint32_t flags;       /* ORB_FLAG_* */
+    uint32_t reserved[5];
+} OrbOptions;
+
+#define ORB_FLAG_STAGED 1u  /* force the one-kernel-per-stage pipeline (cross-check of the fused path) */
+
+typedef struct OrbProgram OrbProgram; /* opaque; replaces orb.rs:47-51 `OrbProgram` */
+
+/* ---- lifetime: replaces the struct literal + OrbProgram::init (orb.rs:107-219) ---- */
+int orb_program_create(const OrbConfig *config, const OrbOptions *options, OrbProgram **out);
+void orb_program_destroy(OrbProgram *p);
+/* last error text of this program (or of the failed create when p == NULL) */
+const char *orb_last_error(const OrbProgram *p);
+uint32_t orb_abi_version(void);
+
+/* ---- single-frame API, one call per reference method ---- */
+/* orb.rs:567-583 write_input_image: tightly packed RGBA8, rows of 4*width bytes. */
+int orb_write_input_image(OrbProgram *p, const uint8_t *bytes, size_t len);
+/* orb.rs:585-589 set_threshold */
+int orb_set_threshold(OrbProgram *p, float threshold);
+/* orb.rs:469-557 extract_corners: runs the whole pipeline, blocks until the results are in
+ * host staging, returns the RAW detection counter (may exceed max_features, Q9/Q19; then the
+ * status is ORB_ECAPACITY and the first max_features records are valid). */
+int orb_extract_corners(OrbProgram *p, uint32_t *corner_count);
+/* orb.rs:559-561 read_corners: copies min(n, max_features) records from staging. */
+int orb_read_corners(OrbProgram *p, CornerData *dst, size_t n);
+/* orb.rs:563-565 read_descriptors */
+int orb_read_descriptors(OrbProgram *p, CornerDescriptor *dst, size_t n);
+
+/* ---- batched mode (BASELINE.json configs[3], [4]): independent frames, one call ---- */
+/* frames_dev: n_frames contiguous RGBA8 frames in DEVICE memory.  stream: a hipStream_t (or
+ * NULL for the program's own stream).  Asynchronous: results stay device-resident in the
+ * program's output slabs until the next batched call. */
+int orb_extract_batch_device(OrbProgram *p, const uint8_t *frames_dev, uint32_t n_frames, void *stream);
+/* Same with host frames: pinned double-buffered upload overlapped with compute. */
+int orb_extract_batch_host(OrbProgram *p, const uint8_t *frames_host, uint32_t n_frames);
+/* Wait for the last batched call to finish. */
+int orb_batch_sync(OrbProgram *p);
+/* Raw per-frame counters of the last batch (synchronises). */
+int orb_batch_counts(OrbProgram *p, uint32_t *totals, uint32_t n_frames);
+/* Copy up to n records of one frame of the last batch to the host (synchronises). */
+int orb_batch_read(OrbProgram *p, uint32_t frame, CornerData *corners, CornerDescriptor *descriptors, size_t n);
+/* Device pointers of the output slabs, for a device-side collate (RCCL gather):
+ * counts[max_batch] u32, corners[max_batch][max_features], descriptors[max_batch][max_features]. */
+int orb_batch_device_buffers(OrbProgram *p, void **counts, void **corners, void **descriptors);
+
+/* ---- inspection (parity tests) ---- */
+#define ORB_PLANE_GRAY 0
+#define ORB_PLANE_BLUR 1
+/* Copies one pyramid level (binary16 bit patterns, row-major) of a frame of the last call.
+ * The fused pipeline does not materialise every plane; it returns ORB_ESTATE for those. */
+int orb_debug_read_plane(OrbProgram *p, uint32_t frame, int kind, uint32_t level, uint16_t *dst, size_t n_texels);
+/* Level geometry: width/height of mip `level` (max(1, W>>level), wgpu mip chain orb.rs:224-233). */
+int orb_level_size(const OrbProgram *p, uint32_t level, uint32_t *width, uint32_t *height);
+/* Device scalar helpers, so the tests can pin CRD-3 / CRD-9 on the GPU itself (host arrays). */
+int orb_debug_f32_to_f16(OrbProgram *p, const float *src, uint16_t *dst, size_t n);
+int orb_debug_angle_code(OrbProgram *p, const float *cy, const float *cx, uint32_t *dst, size_t n);
+
+/* ---- measurement ---- */
+#define ORB_KERNEL_COUNT 8
+/* When enabled every kernel launch is bracketed by hipEvents on its stream. */
+int orb_profile_enable(OrbProgram *p, int enable);
+int orb_profile_reset(OrbProgram *p);
+/* Accumulated device time and number of launches of kernel `id` (synchronises). */
+int orb_profile_get(OrbProgram *p, int id, double *total_ms, uint64_t *launches);
+const char *orb_kernel_name(int id);
+
+/* ---- synthetic frames, generated on the device ---- */
+#define ORB_SYN_GRADIENT 1u
+#define ORB_SYN_BLOBS 2u
+#define ORB_SYN_WEDGES 4u
+#define ORB_SYN_NOISE 8u
+/* Frame i gets seed seed0+i.  frames_dev == NULL allocates/uses the program's own input slab
+ * (max_batch frames) and returns its address in *out_dev. */
+int orb_synth_frames_device(OrbProgram *p, uint8_t *frames_dev, uint32_t n_frames, uint32_t seed0, uint32_t flags,
+                            uint8_t **out_dev);
+/* Device-to-host copy helper for tests that have no other HIP binding. */
+int orb_copy_to_host(OrbProgram *p, void *dst_host, const void *src_dev, size_t nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYORB_H */

@@ -1,0 +1,129 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Integer/index work (keypoint x, y, angle code, octave) and descriptor bits must be identical
+(Hamming distance 0); intermediate binary16 planes are compared as bit patterns.  Output order
+is unspecified in the reference (atomic append), so lists are compared after
+sorting by (octave, y, x) (CRD-11).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THR = 20.0 / 255.0
+
+
+def _program(tinyorb, W, H, depth=2, max_features=8192, max_batch=1, flags=0, thr=THR):
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=max_features, hierarchy_depth=depth,
+                            initial_threshold=thr, max_batch=max_batch, flags=flags)
+    return tinyorb.OrbProgram(cfg).init()
+
+
+def _sorted(corners, desc):
+    order = np.lexsort((corners["x"], corners["y"], corners["octave"]))
+    return corners[order], desc[order]
+
+
+def _assert_frame_equal(oracle, ref, total, corners, desc):
+    assert total == ref["total"]
+    c, d = _sorted(corners, desc)
+    rc, rd = oracle.sort_keypoints(ref["corners"], ref["descriptors"])
+    assert len(c) == len(rc)
+    for k in ("octave", "y", "x", "angle"):
+        assert np.array_equal(c[k], rc[k]), k
+    ham = np.unpackbits((d ^ rd).view(np.uint8), axis=1).sum(axis=1)
+    assert int(ham.max(initial=0)) == 0, "descriptor Hamming distance %d" % int(ham.max())
+    # compaction sanity: no duplicate (octave, x, y)
+    keys = np.stack([c["octave"], c["y"], c["x"]], 1)
+    assert len(np.unique(keys, axis=0)) == len(keys)
+
+
+@pytest.mark.parametrize("W,H,depth,seed", [(64, 48, 2, 3), (160, 120, 3, 1), (200, 97, 3, 7), (640, 480, 2, 1)])
+@pytest.mark.parametrize("flags", [1, 0])
+def test_single_frame_matches_oracle(tinyorb, oracle, W, H, depth, seed, flags):
+    rgba = oracle.synth_frame(W, H, seed)
+    ref = oracle.extract(rgba, depth=depth, threshold=THR, planes=True)
+    with _program(tinyorb, W, H, depth, flags=flags) as prog:
+        total, corners, desc = prog.extract(rgba)
+        _assert_frame_equal(oracle, ref, total, corners, desc)
+        if flags & tinyorb.ORB_FLAG_STAGED:
+            dims, _ = oracle.level_dims(W, H, depth)
+            for m, (w, h, off) in enumerate(dims):
+                assert prog.level_size(m) == (w, h)
+                g = prog.read_plane(tinyorb.ORB_PLANE_GRAY, m)
+                b = prog.read_plane(tinyorb.ORB_PLANE_BLUR, m)
+                assert np.array_equal(g.ravel(), ref["gray"][off:off + w * h]), "gray level %d" % m
+                assert np.array_equal(b.ravel(), ref["blur"][off:off + w * h]), "blur level %d" % m
+
+
+def test_config2_config3_720p(tinyorb, oracle):
+    """BASELINE.json configs[1] and [2]: one 1280x720 frame, keypoints then descriptors."""
+    rgba = oracle.synth_frame(1280, 720, 2)
+    ref = oracle.extract(rgba, depth=2, threshold=THR)
+    assert ref["total"] > 1000
+    with _program(tinyorb, 1280, 720, 2) as prog:
+        total, corners, desc = prog.extract(rgba)
+        _assert_frame_equal(oracle, ref, total, corners, desc)
+
+
+def test_device_scalar_math_matches_oracle(tinyorb, oracle):
+    """CRD-3 (f32->f16 RNE, subnormals) and CRD-9 (canonical atan2 -> milliradian code) on the GPU."""
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2**32, size=1 << 20, dtype=np.uint64).astype(np.uint32)
+    special = np.array([0x00000000, 0x80000000, 0x33000000, 0x33000001, 0x337fffff, 0x33800000, 0x387fc000,
+                        0x38800000, 0x477fe000, 0x477ff000, 0x47800000, 0x7f800000, 0x3f800000, 0x3f801000,
+                        0x3f803000, 0x38000000, 0x37ffffff, 0x00000001, 0x007fffff], dtype=np.uint32)
+    unit = rng.random(1 << 20, dtype=np.float32)
+    tiny = (rng.random(1 << 18, dtype=np.float32) * np.float32(2.0 ** -14)).astype(np.float32)
+    src = np.concatenate([bits.view(np.float32), special.view(np.float32), unit, tiny])
+    src = src[~np.isnan(src)]
+    with _program(tinyorb, 64, 48) as prog:
+        got = prog.device_f32_to_f16(src)
+        want = src.astype(np.float16).view(np.uint16)
+        assert np.array_equal(got, want)
+        sample = src[:4096]
+        assert [oracle.f32_to_f16(v) for v in sample] == got[:4096].tolist()
+
+        n = 1 << 18
+        cy = (rng.random(n, dtype=np.float32) * 40 - 8).astype(np.float32)
+        cx = (rng.random(n, dtype=np.float32) * 40 - 20).astype(np.float32)
+        cy[:64] = 0
+        cx[:32] = 0
+        cy[64:128] = np.abs(cx[64:128])
+        got = prog.device_angle_code(cy, cx)
+        from oracle import orb_numpy
+        ang = orb_numpy.atan2f(cy, cx)
+        want = np.where((cy < 0) | (ang < 0), np.float32(0), np.trunc(ang * np.float32(1000.0))).astype(np.uint32)
+        assert np.array_equal(got, want)
+        idx = rng.integers(0, n, 2048)
+        assert [oracle.angle_code(cy[i], cx[i]) for i in idx] == got[idx].tolist()
+
+
+def test_batch_equals_singles(tinyorb, oracle):
+    """batch(N frames) == [single(frame)], frames generated on the device."""
+    W, H, B = 320, 240, 6
+    with _program(tinyorb, W, H, 2, max_batch=B) as prog:
+        dev = prog.synth_frames_device(B, 100)
+        frames = prog.copy_to_host(dev, B * W * H * 4).reshape(B, H, W, 4)
+        for i in range(B):
+            assert np.array_equal(frames[i], oracle.synth_frame(W, H, 100 + i)), "device generator frame %d" % i
+        prog.extract_batch_device(dev, B)
+        counts = prog.batch_counts(B)
+        for i in range(B):
+            ref = oracle.extract(frames[i], depth=2, threshold=THR)
+            corners, desc = prog.batch_read(i, int(counts[i]))
+            _assert_frame_equal(oracle, ref, int(counts[i]), corners, desc)
+
+
+def test_capacity_overflow_reports_raw_count(tinyorb, oracle):
+    rgba = oracle.synth_frame(320, 240, 9)
+    ref = oracle.extract(rgba, depth=2, threshold=THR)
+    cap = ref["total"] // 2
+    with _program(tinyorb, 320, 240, 2, max_features=cap) as prog:
+        total, corners, desc = prog.extract(rgba)
+        assert total == ref["total"] and len(corners) == cap
+        # every stored record is a genuine detection with the right descriptor
+        full = {(int(c["octave"]), int(c["y"]), int(c["x"])): (int(c["angle"]), d.tobytes())
+                for c, d in zip(ref["corners"], ref["descriptors"])}
+        for c, d in zip(corners, desc):
+            assert full[(int(c["octave"]), int(c["y"]), int(c["x"]))] == (int(c["angle"]), d.tobytes())

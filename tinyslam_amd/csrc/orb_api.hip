@@ -1,0 +1,553 @@
+// orb_api.hip -- libtinyorb: the C ABI of include/tinyorb.h over the HIP kernels.
+//
+// Host-side counterpart of src/orb.rs in the reference: OrbProgram::init (orb.rs:107-219) becomes
+// orb_program_create (device allocations instead of wgpu textures/buffers/pipelines), and
+// extract_corners (orb.rs:469-557) becomes a short sequence of kernel launches on one HIP stream
+// instead of 3*D render passes + D+1 compute dispatches + 3 staging copies.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/tinyorb.h"
+#include "orb_kernels_staged.h"
+
+using namespace orb;
+
+namespace {
+
+enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH };
+const char* const kKernelNames[ORB_KERNEL_COUNT] = {"k_grayscale", "k_mip",      "k_blur_rows", "k_fast",
+                                                    "k_brief",     "k_front_l0", "k_front_ln",  "k_synth"};
+
+thread_local std::string g_create_error;
+
+struct ProfSpan {
+    int kid;
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct OrbProgram {
+    OrbConfig cfg{};
+    OrbOptions opt{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Pyramid pyr{};
+    size_t frame_bytes = 0;
+    uint32_t max_batch = 1;
+    float threshold = 0.f;
+
+    uint8_t* d_input = nullptr;  // max_batch frames (single-frame API, host batches, synth)
+    uint16_t* d_gray = nullptr;  // max_batch x pyr.stride
+    uint16_t* d_blur = nullptr;
+    uint32_t* d_counts = nullptr;
+    CornerData* d_corners = nullptr;
+    CornerDescriptor* d_desc = nullptr;
+    uint32_t* d_pattern = nullptr;
+    float* d_cos = nullptr;
+    float* d_sin = nullptr;
+
+    // host staging of the single-frame API (orb.rs:216-218 staging buffers)
+    uint32_t* h_count = nullptr;
+    CornerData* h_corners = nullptr;
+    CornerDescriptor* h_desc = nullptr;
+    bool single_valid = false;
+
+    uint32_t last_batch = 0;  // frames of the last batched call
+    hipStream_t last_stream = nullptr;
+    bool planes_valid = false;
+
+    bool profiling = false;
+    std::vector<ProfSpan> pending;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[ORB_KERNEL_COUNT] = {0};
+    uint64_t prof_n[ORB_KERNEL_COUNT] = {0};
+
+    std::string err;
+};
+
+namespace {
+
+int fail(OrbProgram* p, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (p)
+        p->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(p, expr)                                                                                  \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return fail((p), ORB_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// Bracket one kernel launch with events when profiling is on.
+struct LaunchScope {
+    OrbProgram* p;
+    hipStream_t s;
+    int kid;
+    hipEvent_t start = nullptr, stop = nullptr;
+    LaunchScope(OrbProgram* p_, hipStream_t s_, int kid_) : p(p_), s(s_), kid(kid_) {
+        if (!p->profiling) return;
+        auto get = [&]() -> hipEvent_t {
+            if (!p->event_pool.empty()) {
+                hipEvent_t e = p->event_pool.back();
+                p->event_pool.pop_back();
+                return e;
+            }
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            return e;
+        };
+        start = get();
+        stop = get();
+        if (start && stop) (void)hipEventRecord(start, s);
+    }
+    ~LaunchScope() {
+        if (start && stop) {
+            (void)hipEventRecord(stop, s);
+            p->pending.push_back({kid, start, stop});
+        }
+    }
+};
+
+int drain_profile(OrbProgram* p) {
+    for (auto& sp : p->pending) {
+        HIP_TRY(p, hipEventSynchronize(sp.stop));
+        float ms = 0.f;
+        HIP_TRY(p, hipEventElapsedTime(&ms, sp.start, sp.stop));
+        p->prof_ms[sp.kid] += ms;
+        p->prof_n[sp.kid] += 1;
+        p->event_pool.push_back(sp.start);
+        p->event_pool.push_back(sp.stop);
+    }
+    p->pending.clear();
+    return ORB_OK;
+}
+
+void layout_pyramid(uint32_t W, uint32_t H, uint32_t depth, Pyramid* pyr) {
+    memset(pyr, 0, sizeof *pyr);
+    pyr->depth = depth;
+    uint32_t off = 0;
+    for (uint32_t m = 0; m < depth; m++) {
+        uint32_t w = W >> m, h = H >> m;  // wgpu mip chain: max(1, dim >> m)
+        pyr->w[m] = w ? w : 1u;
+        pyr->h[m] = h ? h : 1u;
+        pyr->off[m] = off;
+        off += pyr->w[m] * pyr->h[m];
+        off = (off + 7u) & ~7u;  // keep every level 16-byte aligned
+    }
+    pyr->stride = (off + 63u) & ~63u;
+}
+
+// The staged pipeline for `n` frames starting at device pointer `frames` (orb.rs:469-534).
+int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
+    const Pyramid& pyr = p->pyr;
+    const uint32_t W = pyr.w[0], H = pyr.h[0], D = pyr.depth, cap = p->cfg.max_features;
+    HIP_TRY(p, hipMemsetAsync(p->d_counts, 0, sizeof(uint32_t) * n, s));  // orb.rs:475 clear_buffer(counter)
+    {
+        LaunchScope ls(p, s, KID_GRAY);
+        dim3 grid((W + 1023u) / 1024u, H, n);
+        hipLaunchKernelGGL(k_grayscale, grid, dim3(256), 0, s, frames, p->frame_bytes, p->d_gray, pyr);
+    }
+    for (uint32_t m = 1; m < D; m++) {  // orb.rs:413-429
+        LaunchScope ls(p, s, KID_MIP);
+        dim3 grid((pyr.w[m] + 63u) / 64u, (pyr.h[m] + 3u) / 4u, n);
+        hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, p->d_gray, pyr, m);
+    }
+    for (uint32_t m = 0; m < D; m++) {  // orb.rs:432-466 (both passes)
+        LaunchScope ls(p, s, KID_BLUR);
+        dim3 grid(pyr.h[m], 1, n);
+        size_t lds = (size_t)pyr.w[m] * 2u * sizeof(uint16_t);
+        hipLaunchKernelGGL(k_blur_rows, grid, dim3(256), lds, s, p->d_gray, p->d_blur, pyr, m);
+    }
+    uint32_t width = W, height = H;  // orb.rs:501-519
+    for (uint32_t oct = 0; oct < D; oct++) {
+        const uint32_t gw = ((width + 7u) / 8u) * 8u, gh = ((height + 7u) / 8u) * 8u;
+        if (gw && gh) {
+            LaunchScope ls(p, s, KID_FAST);
+            dim3 grid((gw + 15u) / 16u, (gh + 15u) / 16u, n);
+            hipLaunchKernelGGL(k_fast, grid, dim3(16, 16), 0, s, p->d_gray, pyr, oct, gw, gh, p->threshold, p->d_counts,
+                               p->d_corners, cap);
+        }
+        width /= 2u;
+        height /= 2u;
+    }
+    {  // orb.rs:523-534
+        LaunchScope ls(p, s, KID_BRIEF);
+        BriefTables tab{p->d_pattern, p->d_cos, p->d_sin};
+        uint32_t bx = (cap + 127u) / 128u;  // ~32 keypoints per wave at a full frame
+        if (bx > 64u) bx = 64u;
+        if (bx < 1u) bx = 1u;
+        hipLaunchKernelGGL(k_brief, dim3(bx, 1, n), dim3(256), 0, s, p->d_blur, pyr, p->d_counts, p->d_corners, cap,
+                           p->d_desc, tab);
+    }
+    HIP_TRY(p, hipGetLastError());
+    p->planes_valid = true;
+    return ORB_OK;
+}
+
+int run_pipeline(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) { return run_staged(p, frames, n, s); }
+
+int ensure_input(OrbProgram* p) {
+    if (!p->d_input) HIP_TRY(p, hipMalloc(&p->d_input, p->frame_bytes * p->max_batch));
+    return ORB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t orb_abi_version(void) { return TINYORB_ABI_VERSION; }
+
+const char* orb_last_error(const OrbProgram* p) { return p ? p->err.c_str() : g_create_error.c_str(); }
+
+const char* orb_kernel_name(int id) { return (id >= 0 && id < ORB_KERNEL_COUNT) ? kKernelNames[id] : ""; }
+
+int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbProgram** out) {
+    if (!out) return fail(nullptr, ORB_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!config) return fail(nullptr, ORB_EINVAL, "config is NULL");
+    const uint32_t W = config->image_size.width, H = config->image_size.height;
+    if (W == 0 || H == 0 || config->image_size.depth_or_array_layers != 1)
+        return fail(nullptr, ORB_EINVAL, "image_size must be WxHx1 with W,H > 0");
+    if ((uint64_t)W * H > (1ull << 28)) return fail(nullptr, ORB_EINVAL, "image too large");
+    if (config->hierarchy_depth < 1 || config->hierarchy_depth > ORB_MAX_HIERARCHY_DEPTH)
+        return fail(nullptr, ORB_EINVAL, "hierarchy_depth must be 1..=10 (orb.rs:66-67)");
+    if (config->max_features == 0 || config->max_features > (1u << 24))
+        return fail(nullptr, ORB_EINVAL, "max_features must be 1..=2^24");
+    if (!(config->initial_threshold >= 0.f)) return fail(nullptr, ORB_EINVAL, "initial_threshold must be >= 0");
+
+    OrbProgram* p = new (std::nothrow) OrbProgram();
+    if (!p) return fail(nullptr, ORB_EINVAL, "out of host memory");
+    p->cfg = *config;
+    if (options) p->opt = *options;
+    p->device = p->opt.device;
+    p->max_batch = p->opt.max_batch ? p->opt.max_batch : 1u;
+    p->threshold = config->initial_threshold;  // orb.rs:178
+    p->frame_bytes = (size_t)W * H * 4u;
+    layout_pyramid(W, H, config->hierarchy_depth, &p->pyr);
+
+    auto bail = [&](int code) {
+        g_create_error = p->err;
+        orb_program_destroy(p);
+        return code;
+    };
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        fail(p, ORB_EHIP, "no HIP device available (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+        return bail(ORB_EHIP);
+    }
+    if (p->device < 0 || p->device >= n_dev) {
+        fail(p, ORB_EINVAL, "device %d out of range (0..%d)", p->device, n_dev - 1);
+        return bail(ORB_EINVAL);
+    }
+#define CREATE_TRY(expr)                                                            \
+    do {                                                                            \
+        hipError_t e2_ = (expr);                                                    \
+        if (e2_ != hipSuccess) {                                                    \
+            fail(p, ORB_EHIP, "%s failed: %s", #expr, hipGetErrorString(e2_));      \
+            return bail(ORB_EHIP);                                                  \
+        }                                                                           \
+    } while (0)
+    CREATE_TRY(hipSetDevice(p->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    const size_t B = p->max_batch, cap = config->max_features;
+    CREATE_TRY(hipMalloc(&p->d_gray, B * p->pyr.stride * sizeof(uint16_t)));
+    CREATE_TRY(hipMalloc(&p->d_blur, B * p->pyr.stride * sizeof(uint16_t)));
+    CREATE_TRY(hipMalloc(&p->d_counts, B * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&p->d_corners, B * cap * sizeof(CornerData)));
+    CREATE_TRY(hipMalloc(&p->d_desc, B * cap * sizeof(CornerDescriptor)));
+    CREATE_TRY(hipMemset(p->d_counts, 0, B * sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(p->d_corners, 0, B * cap * sizeof(CornerData)));
+    CREATE_TRY(hipMemset(p->d_desc, 0, B * cap * sizeof(CornerDescriptor)));
+    CREATE_TRY(hipMalloc(&p->d_pattern, 256 * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&p->d_cos, ORB_ANGLE_STEPS * sizeof(float)));
+    CREATE_TRY(hipMalloc(&p->d_sin, ORB_ANGLE_STEPS * sizeof(float)));
+    CREATE_TRY(hipMemcpy(p->d_pattern, ORB_BRIEF_PATTERN, 1024, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(p->d_cos, ORB_COS_BITS, ORB_ANGLE_STEPS * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(p->d_sin, ORB_SIN_BITS, ORB_ANGLE_STEPS * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipHostMalloc(&p->h_count, sizeof(uint32_t), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(&p->h_corners, cap * sizeof(CornerData), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(&p->h_desc, cap * sizeof(CornerDescriptor), hipHostMallocDefault));
+#undef CREATE_TRY
+    *out = p;
+    return ORB_OK;
+}
+
+void orb_program_destroy(OrbProgram* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    for (auto& sp : p->pending) {
+        (void)hipEventDestroy(sp.start);
+        (void)hipEventDestroy(sp.stop);
+    }
+    for (auto e : p->event_pool) (void)hipEventDestroy(e);
+    (void)hipFree(p->d_input);
+    (void)hipFree(p->d_gray);
+    (void)hipFree(p->d_blur);
+    (void)hipFree(p->d_counts);
+    (void)hipFree(p->d_corners);
+    (void)hipFree(p->d_desc);
+    (void)hipFree(p->d_pattern);
+    (void)hipFree(p->d_cos);
+    (void)hipFree(p->d_sin);
+    if (p->h_count) (void)hipHostFree(p->h_count);
+    if (p->h_corners) (void)hipHostFree(p->h_corners);
+    if (p->h_desc) (void)hipHostFree(p->h_desc);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int orb_write_input_image(OrbProgram* p, const uint8_t* bytes, size_t len) {
+    if (!p) return ORB_EINVAL;
+    if (!bytes || len != p->frame_bytes)
+        return fail(p, ORB_EINVAL, "write_input_image: expected %zu bytes (4*W*H), got %zu", p->frame_bytes, len);
+    HIP_TRY(p, hipSetDevice(p->device));
+    if (int rc = ensure_input(p)) return rc;
+    HIP_TRY(p, hipMemcpyAsync(p->d_input, bytes, len, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(p, hipStreamSynchronize(p->stream));  // the caller's slice may be reused right away
+    return ORB_OK;
+}
+
+int orb_set_threshold(OrbProgram* p, float threshold) {
+    if (!p) return ORB_EINVAL;
+    if (!(threshold >= 0.f)) return fail(p, ORB_EINVAL, "threshold must be >= 0");
+    p->threshold = threshold;
+    return ORB_OK;
+}
+
+int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
+    if (!p) return ORB_EINVAL;
+    if (!corner_count) return fail(p, ORB_EINVAL, "corner_count is NULL");
+    HIP_TRY(p, hipSetDevice(p->device));
+    if (int rc = ensure_input(p)) return rc;
+    hipStream_t s = p->stream;
+    if (int rc = run_pipeline(p, p->d_input, 1, s)) return rc;
+    const size_t cap = p->cfg.max_features;
+    // orb.rs:537-547: counter, corners and descriptors go to host staging, then block.
+    HIP_TRY(p, hipMemcpyAsync(p->h_count, p->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(p, hipMemcpyAsync(p->h_corners, p->d_corners, cap * sizeof(CornerData), hipMemcpyDeviceToHost, s));
+    HIP_TRY(p, hipMemcpyAsync(p->h_desc, p->d_desc, cap * sizeof(CornerDescriptor), hipMemcpyDeviceToHost, s));
+    HIP_TRY(p, hipStreamSynchronize(s));
+    p->single_valid = true;
+    p->last_batch = 1;
+    p->last_stream = s;
+    *corner_count = *p->h_count;  // raw counter, orb.rs:550-556
+    if (*corner_count > cap) return fail(p, ORB_ECAPACITY, "%u corners detected, max_features is %zu", *corner_count, cap);
+    return ORB_OK;
+}
+
+int orb_read_corners(OrbProgram* p, CornerData* dst, size_t n) {
+    if (!p) return ORB_EINVAL;
+    if (!dst && n) return fail(p, ORB_EINVAL, "dst is NULL");
+    if (!p->single_valid) return fail(p, ORB_ESTATE, "read_corners before extract_corners");
+    const size_t cap = p->cfg.max_features;
+    memcpy(dst, p->h_corners, (n < cap ? n : cap) * sizeof(CornerData));
+    return ORB_OK;
+}
+
+int orb_read_descriptors(OrbProgram* p, CornerDescriptor* dst, size_t n) {
+    if (!p) return ORB_EINVAL;
+    if (!dst && n) return fail(p, ORB_EINVAL, "dst is NULL");
+    if (!p->single_valid) return fail(p, ORB_ESTATE, "read_descriptors before extract_corners");
+    const size_t cap = p->cfg.max_features;
+    memcpy(dst, p->h_desc, (n < cap ? n : cap) * sizeof(CornerDescriptor));
+    return ORB_OK;
+}
+
+int orb_extract_batch_device(OrbProgram* p, const uint8_t* frames_dev, uint32_t n_frames, void* stream) {
+    if (!p) return ORB_EINVAL;
+    if (!frames_dev) return fail(p, ORB_EINVAL, "frames_dev is NULL");
+    if (n_frames == 0 || n_frames > p->max_batch)
+        return fail(p, ORB_EINVAL, "n_frames %u outside 1..=max_batch (%u)", n_frames, p->max_batch);
+    HIP_TRY(p, hipSetDevice(p->device));
+    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+    if (int rc = run_pipeline(p, frames_dev, n_frames, s)) return rc;
+    p->last_batch = n_frames;
+    p->last_stream = s;
+    p->single_valid = false;
+    return ORB_OK;
+}
+
+int orb_extract_batch_host(OrbProgram* p, const uint8_t* frames_host, uint32_t n_frames) {
+    if (!p) return ORB_EINVAL;
+    if (!frames_host) return fail(p, ORB_EINVAL, "frames_host is NULL");
+    if (n_frames == 0 || n_frames > p->max_batch)
+        return fail(p, ORB_EINVAL, "n_frames %u outside 1..=max_batch (%u)", n_frames, p->max_batch);
+    HIP_TRY(p, hipSetDevice(p->device));
+    if (int rc = ensure_input(p)) return rc;
+    HIP_TRY(p, hipMemcpyAsync(p->d_input, frames_host, p->frame_bytes * n_frames, hipMemcpyHostToDevice, p->stream));
+    return orb_extract_batch_device(p, p->d_input, n_frames, nullptr);
+}
+
+int orb_batch_sync(OrbProgram* p) {
+    if (!p) return ORB_EINVAL;
+    HIP_TRY(p, hipSetDevice(p->device));
+    HIP_TRY(p, hipStreamSynchronize(p->last_stream ? p->last_stream : p->stream));
+    return ORB_OK;
+}
+
+int orb_batch_counts(OrbProgram* p, uint32_t* totals, uint32_t n_frames) {
+    if (!p) return ORB_EINVAL;
+    if (!totals || n_frames > p->last_batch) return fail(p, ORB_EINVAL, "batch_counts: bad arguments");
+    if (int rc = orb_batch_sync(p)) return rc;
+    HIP_TRY(p, hipMemcpy(totals, p->d_counts, sizeof(uint32_t) * n_frames, hipMemcpyDeviceToHost));
+    return ORB_OK;
+}
+
+int orb_batch_read(OrbProgram* p, uint32_t frame, CornerData* corners, CornerDescriptor* descriptors, size_t n) {
+    if (!p) return ORB_EINVAL;
+    if (frame >= p->last_batch) return fail(p, ORB_EINVAL, "batch_read: frame %u not in the last batch", frame);
+    if (int rc = orb_batch_sync(p)) return rc;
+    const size_t cap = p->cfg.max_features;
+    if (n > cap) n = cap;
+    if (corners)
+        HIP_TRY(p, hipMemcpy(corners, p->d_corners + (size_t)frame * cap, n * sizeof(CornerData), hipMemcpyDeviceToHost));
+    if (descriptors)
+        HIP_TRY(p, hipMemcpy(descriptors, p->d_desc + (size_t)frame * cap, n * sizeof(CornerDescriptor),
+                             hipMemcpyDeviceToHost));
+    return ORB_OK;
+}
+
+int orb_batch_device_buffers(OrbProgram* p, void** counts, void** corners, void** descriptors) {
+    if (!p) return ORB_EINVAL;
+    if (counts) *counts = p->d_counts;
+    if (corners) *corners = p->d_corners;
+    if (descriptors) *descriptors = p->d_desc;
+    return ORB_OK;
+}
+
+int orb_level_size(const OrbProgram* p, uint32_t level, uint32_t* width, uint32_t* height) {
+    if (!p || level >= p->pyr.depth) return ORB_EINVAL;
+    if (width) *width = p->pyr.w[level];
+    if (height) *height = p->pyr.h[level];
+    return ORB_OK;
+}
+
+int orb_debug_read_plane(OrbProgram* p, uint32_t frame, int kind, uint32_t level, uint16_t* dst, size_t n_texels) {
+    if (!p) return ORB_EINVAL;
+    if (!dst || level >= p->pyr.depth || frame >= p->last_batch || (kind != ORB_PLANE_GRAY && kind != ORB_PLANE_BLUR))
+        return fail(p, ORB_EINVAL, "debug_read_plane: bad arguments");
+    if (!p->planes_valid) return fail(p, ORB_ESTATE, "plane not materialised by the last call");
+    const size_t texels = (size_t)p->pyr.w[level] * p->pyr.h[level];
+    if (n_texels != texels) return fail(p, ORB_EINVAL, "debug_read_plane: expected %zu texels", texels);
+    if (int rc = orb_batch_sync(p)) return rc;
+    const uint16_t* base = (kind == ORB_PLANE_GRAY ? p->d_gray : p->d_blur) + (size_t)frame * p->pyr.stride + p->pyr.off[level];
+    HIP_TRY(p, hipMemcpy(dst, base, texels * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    return ORB_OK;
+}
+
+int orb_debug_f32_to_f16(OrbProgram* p, const float* src, uint16_t* dst, size_t n) {
+    if (!p || !src || !dst) return ORB_EINVAL;
+    if (n == 0) return ORB_OK;
+    HIP_TRY(p, hipSetDevice(p->device));
+    float* d_src = nullptr;
+    uint16_t* d_dst = nullptr;
+    HIP_TRY(p, hipMalloc(&d_src, n * sizeof(float)));
+    hipError_t e = hipMalloc(&d_dst, n * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMemcpy(d_src, src, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_f16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, d_src, d_dst, n);
+        e = hipStreamSynchronize(p->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(dst, d_dst, n * sizeof(uint16_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d_src);
+    (void)hipFree(d_dst);
+    if (e != hipSuccess) return fail(p, ORB_EHIP, "debug_f32_to_f16: %s", hipGetErrorString(e));
+    return ORB_OK;
+}
+
+int orb_debug_angle_code(OrbProgram* p, const float* cy, const float* cx, uint32_t* dst, size_t n) {
+    if (!p || !cy || !cx || !dst) return ORB_EINVAL;
+    if (n == 0) return ORB_OK;
+    HIP_TRY(p, hipSetDevice(p->device));
+    float *d_cy = nullptr, *d_cx = nullptr;
+    uint32_t* d_dst = nullptr;
+    HIP_TRY(p, hipMalloc(&d_cy, n * sizeof(float)));
+    hipError_t e = hipMalloc(&d_cx, n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&d_dst, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(d_cy, cy, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_cx, cx, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_angle, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, d_cy, d_cx, d_dst, n);
+        e = hipStreamSynchronize(p->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(dst, d_dst, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d_cy);
+    (void)hipFree(d_cx);
+    (void)hipFree(d_dst);
+    if (e != hipSuccess) return fail(p, ORB_EHIP, "debug_angle_code: %s", hipGetErrorString(e));
+    return ORB_OK;
+}
+
+int orb_profile_enable(OrbProgram* p, int enable) {
+    if (!p) return ORB_EINVAL;
+    p->profiling = enable != 0;
+    return ORB_OK;
+}
+
+int orb_profile_reset(OrbProgram* p) {
+    if (!p) return ORB_EINVAL;
+    HIP_TRY(p, hipSetDevice(p->device));
+    if (int rc = drain_profile(p)) return rc;
+    for (int i = 0; i < ORB_KERNEL_COUNT; i++) {
+        p->prof_ms[i] = 0;
+        p->prof_n[i] = 0;
+    }
+    return ORB_OK;
+}
+
+int orb_profile_get(OrbProgram* p, int id, double* total_ms, uint64_t* launches) {
+    if (!p || id < 0 || id >= ORB_KERNEL_COUNT) return ORB_EINVAL;
+    HIP_TRY(p, hipSetDevice(p->device));
+    if (int rc = drain_profile(p)) return rc;
+    if (total_ms) *total_ms = p->prof_ms[id];
+    if (launches) *launches = p->prof_n[id];
+    return ORB_OK;
+}
+
+int orb_synth_frames_device(OrbProgram* p, uint8_t* frames_dev, uint32_t n_frames, uint32_t seed0, uint32_t flags,
+                            uint8_t** out_dev) {
+    if (!p) return ORB_EINVAL;
+    if (n_frames == 0) return fail(p, ORB_EINVAL, "n_frames is 0");
+    HIP_TRY(p, hipSetDevice(p->device));
+    if (!frames_dev) {
+        if (n_frames > p->max_batch) return fail(p, ORB_EINVAL, "n_frames %u > max_batch %u", n_frames, p->max_batch);
+        if (int rc = ensure_input(p)) return rc;
+        frames_dev = p->d_input;
+    }
+    const uint32_t W = p->pyr.w[0], H = p->pyr.h[0];
+    {
+        LaunchScope ls(p, p->stream, KID_SYNTH);
+        hipLaunchKernelGGL(k_synth, dim3((W + 255u) / 256u, H, n_frames), dim3(256), 0, p->stream, frames_dev,
+                           p->frame_bytes, W, H, seed0, flags);
+    }
+    HIP_TRY(p, hipGetLastError());
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    if (out_dev) *out_dev = frames_dev;
+    return ORB_OK;
+}
+
+int orb_copy_to_host(OrbProgram* p, void* dst_host, const void* src_dev, size_t nbytes) {
+    if (!p || !dst_host || !src_dev) return ORB_EINVAL;
+    HIP_TRY(p, hipSetDevice(p->device));
+    HIP_TRY(p, hipMemcpy(dst_host, src_dev, nbytes, hipMemcpyDeviceToHost));
+    return ORB_OK;
+}
+
+}  // extern "C"

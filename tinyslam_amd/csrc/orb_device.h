@@ -1,0 +1,128 @@
+// orb_device.h -- device-side scalar building blocks of the ORB path (gfx950).
+//
+// Everything here is compiled with -ffp-contract=off: each binary32 product and sum is rounded
+// on its own, which is what SURVEY.md's canonical decisions CRD-2/-5/-8/-9/-10 fix for the
+// points the reference's WGSL leaves implementation-defined.  Division is hipcc's default
+// correctly rounded f32 divide.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace orb {
+
+constexpr int kMaxLevels = 10;  // orb.rs:67
+
+// Geometry of the packed binary16 pyramid of one frame (levels back to back).
+struct Pyramid {
+    uint32_t depth;
+    uint32_t w[kMaxLevels];
+    uint32_t h[kMaxLevels];
+    uint32_t off[kMaxLevels];  // texel offset of each level
+    uint32_t stride;           // texels per frame (sum of levels, rounded up to 64)
+};
+
+typedef _Float16 half_t;
+
+// CRD-3: f32 -> f16 round-to-nearest-even, subnormals kept (v_cvt_f16_f32).
+__device__ __forceinline__ half_t to_half(float v) { return (half_t)v; }
+__device__ __forceinline__ float from_half(half_t h) { return (float)h; }
+__device__ __forceinline__ uint16_t half_bits(half_t h) { return __builtin_bit_cast(uint16_t, h); }
+__device__ __forceinline__ half_t bits_half(uint16_t b) { return __builtin_bit_cast(half_t, b); }
+
+// CRD-1 + CRD-2: grayscale.wgsl:31-38 for one RGBA8 texel (little-endian packed word).
+__device__ __forceinline__ float luminance(uint32_t rgba) {
+    float r = (float)(rgba & 255u) / 255.0f;
+    float g = (float)((rgba >> 8) & 255u) / 255.0f;
+    float b = (float)((rgba >> 16) & 255u) / 255.0f;
+    float pr = 0.229f * r;  // grayscale.wgsl:36 (0.229, sic)
+    float pg = 0.587f * g;
+    float pb = 0.114f * b;
+    return (pr + pg) + pb;
+}
+
+// fast.wgsl:51-60 detect_streak_16: non-zero iff the 16-bit circular mask holds a run of >= 12.
+__device__ __forceinline__ uint32_t rotate_bits_16(uint32_t v, uint32_t c) {
+    return (v >> c) | ((v << (16u - c)) & 0xffffu);
+}
+__device__ __forceinline__ uint32_t detect_streak_16(uint32_t x) {
+    uint32_t o6 = x & rotate_bits_16(x, 6u);
+    uint32_t o3 = o6 & rotate_bits_16(o6, 3u);
+    return o3 & rotate_bits_16(o3, 2u) & rotate_bits_16(o3, 1u);
+}
+
+// CRD-9: canonical atan2 (octant reduction + odd polynomial, only + - * / on binary32).
+__device__ __forceinline__ float atan2_canonical(float y, float x) {
+    float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    if (ax == 0.0f && ay == 0.0f) return 0.0f;
+    float mx = ax > ay ? ax : ay;
+    float mn = ax > ay ? ay : ax;
+    float a = mn / mx;
+    float t = a, base = 0.0f;
+    if (a > 0.41421356f) {
+        t = (a - 1.0f) / (a + 1.0f);
+        base = 0.78539816f;
+    }
+    float z = t * t;
+    float p = 8.05374449538e-2f;
+    p = p * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    float r = (p * z) * t + t;
+    r = base + r;
+    if (ay > ax) r = 1.57079632679f - r;
+    if (x < 0.0f) r = 3.14159265f - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+// fast.wgsl:115 + 153: milliradian code, negative angles saturate to 0 (Q7).
+__device__ __forceinline__ uint32_t angle_code(float cy, float cx) {
+    float r = atan2_canonical(cy, cx);
+    if (cy < 0.0f || r < 0.0f) return 0u;
+    return (uint32_t)__builtin_truncf(r * 1000.0f);
+}
+
+// FAST ring, fast.wgsl:32-49 (index order matters for the centroid sum, CRD-8).
+__device__ constexpr int kRingDx[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+__device__ constexpr int kRingDy[16] = {0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1};
+
+// gaussian_blur_x.wgsl:14-26 (binary32 roundings of the literals)
+__device__ constexpr float kBlurOff[4] = {-2.2273038885157046f, -0.4391873198428642f, 1.3243948342247673f, 3.0f};
+__device__ constexpr float kBlurWgt[4] = {0.13748623236806098f, 0.5037756553768409f, 0.32748695702046415f,
+                                          0.031251155234634016f};
+
+// One literal blur tap position (CRD-5): indices of the two texels and the lerp fraction.
+struct BlurTap {
+    int i0, i1;
+    float f;
+};
+__device__ __forceinline__ BlurTap blur_tap(uint32_t x, uint32_t w, float off) {
+    float fw = (float)w;
+    float u = ((float)x + 0.5f) / fw;
+    float uo = u + off;
+    float coord = uo * fw - 0.5f;
+    float c0 = __builtin_floorf(coord);
+    BlurTap t;
+    t.f = coord - c0;
+    int i = (int)c0;
+    int hi = (int)w - 1;
+    t.i0 = i < 0 ? 0 : (i > hi ? hi : i);
+    int j = i + 1;
+    t.i1 = j < 0 ? 0 : (j > hi ? hi : j);
+    return t;
+}
+
+// Synthetic-frame hash; must match the recipe in the oracle byte for byte.
+__device__ __forceinline__ uint32_t mix32(uint32_t a) {
+    a ^= a >> 16;
+    a *= 0x7feb352dU;
+    a ^= a >> 15;
+    a *= 0x846ca68bU;
+    a ^= a >> 16;
+    return a;
+}
+__device__ __forceinline__ uint32_t syn_rnd(uint32_t seed, uint32_t stream, uint32_t idx) {
+    return mix32(idx ^ mix32(stream + 0x9E3779B9U + mix32(seed + 0x85EBCA6BU)));
+}
+
+}  // namespace orb

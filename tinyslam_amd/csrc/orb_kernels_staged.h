@@ -1,0 +1,331 @@
+// orb_kernels_staged.h -- one kernel per reference stage, batched over frames (blockIdx.z).
+//
+// This is the straightforward pipeline: every R16Float plane the reference materialises
+// (orb.rs:221-409: image_hierarchy, blur_tmp_hierarchy, blur_hierarchy) exists in HBM here
+// too, except blur_tmp which lives in LDS.  It is the cross-check for the fused pipeline
+// (orb_kernels_fused.h) and the path taken for shapes the fused kernels do not cover.
+#pragma once
+#include "orb_device.h"
+#include "orb_tables.h"
+
+namespace orb {
+
+// ---------------------------------------------------------------------------------------------
+// K1  grayscale.wgsl:12-38 -- RGBA8 -> luminance f16 of the vertically mirrored row.
+// One thread = 4 horizontally adjacent pixels: one 16-byte load, one 8-byte store.
+// grid: (ceil(W/4/256), H, frames)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grayscale(const uint8_t* __restrict__ frames, size_t frame_bytes,
+                                                   uint16_t* __restrict__ gray, Pyramid pyr) {
+    const uint32_t W = pyr.w[0], H = pyr.h[0];
+    const uint32_t y = blockIdx.y, f = blockIdx.z;
+    const uint32_t x0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (x0 >= W) return;
+    const uint8_t* src_row = frames + (size_t)f * frame_bytes + (size_t)(H - 1u - y) * W * 4u;
+    uint16_t* dst_row = gray + (size_t)f * pyr.stride + pyr.off[0] + (size_t)y * W;
+    if (x0 + 4u <= W && (W & 3u) == 0u) {
+        const uint4 px = *reinterpret_cast<const uint4*>(src_row + (size_t)x0 * 4u);
+        ushort4 out;
+        out.x = half_bits(to_half(luminance(px.x)));
+        out.y = half_bits(to_half(luminance(px.y)));
+        out.z = half_bits(to_half(luminance(px.z)));
+        out.w = half_bits(to_half(luminance(px.w)));
+        *reinterpret_cast<ushort4*>(dst_row + x0) = out;
+    } else {
+        for (uint32_t x = x0; x < W && x < x0 + 4u; x++) {
+            uint32_t v = *reinterpret_cast<const uint32_t*>(src_row + (size_t)x * 4u);
+            dst_row[x] = half_bits(to_half(luminance(v)));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2  blit.wgsl:17-36 -- mip m from mip m-1 (CRD-4).  One thread per target texel.
+// grid: (ceil(wd/64), ceil(hd/4), frames), block (64,4)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mip(uint16_t* __restrict__ gray, Pyramid pyr, uint32_t m) {
+    const uint32_t wd = pyr.w[m], hd = pyr.h[m], ws = pyr.w[m - 1], hs = pyr.h[m - 1];
+    const uint32_t x = blockIdx.x * 64u + threadIdx.x, y = blockIdx.y * 4u + threadIdx.y;
+    if (x >= wd || y >= hd) return;
+    const uint16_t* src = gray + (size_t)blockIdx.z * pyr.stride + pyr.off[m - 1];
+    uint16_t* dst = gray + (size_t)blockIdx.z * pyr.stride + pyr.off[m];
+    float v;
+    if (ws == 2u * wd && hs == 2u * hd) {
+        const uint32_t two = *reinterpret_cast<const uint32_t*>(src + (size_t)(2u * y) * ws + 2u * x);
+        const uint32_t two2 = *reinterpret_cast<const uint32_t*>(src + (size_t)(2u * y + 1u) * ws + 2u * x);
+        float a = from_half(bits_half((uint16_t)(two & 0xffffu))), b = from_half(bits_half((uint16_t)(two >> 16)));
+        float c = from_half(bits_half((uint16_t)(two2 & 0xffffu))), d = from_half(bits_half((uint16_t)(two2 >> 16)));
+        float top = a + b;
+        float bot = c + d;
+        v = (top + bot) * 0.25f;
+    } else {
+        float rx = (float)ws / (float)wd, ry = (float)hs / (float)hd;
+        float sx = ((float)x + 0.5f) * rx - 0.5f, sy = ((float)y + 0.5f) * ry - 0.5f;
+        float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+        float fx = sx - fx0, fy = sy - fy0;
+        int ix = (int)fx0, iy = (int)fy0;
+        int x0 = min(max(ix, 0), (int)ws - 1), x1 = min(max(ix + 1, 0), (int)ws - 1);
+        int y0 = min(max(iy, 0), (int)hs - 1), y1 = min(max(iy + 1, 0), (int)hs - 1);
+        float a = from_half(bits_half(src[(size_t)y0 * ws + x0])), b = from_half(bits_half(src[(size_t)y0 * ws + x1]));
+        float c = from_half(bits_half(src[(size_t)y1 * ws + x0])), d = from_half(bits_half(src[(size_t)y1 * ws + x1]));
+        float dab = b - a;
+        float top = a + fx * dab;
+        float dcd = d - c;
+        float bot = c + fx * dcd;
+        float dtb = bot - top;
+        v = top + fy * dtb;
+    }
+    dst[(size_t)y * wd + x] = half_bits(to_half(v));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3+K4  gaussian_blur_x.wgsl:45-61 twice (orb.rs:432-466; both pipelines use the X shader,
+// orb.rs:399-402).  Each pass mirrors v (gaussian_blur_x.wgsl:32-41), so after two passes the
+// rows line up with the grey image again and blur(.,y) depends on grey row y alone: pass(pass(row)).
+// One block = one row of one level of one frame; row and the f16-rounded intermediate in LDS.
+// grid: (h_level, 1, frames), dynamic LDS = 2 * w * 2 bytes.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float blur_point(const half_t* row, uint32_t x, uint32_t w) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        BlurTap t = blur_tap(x, w, kBlurOff[i]);
+        float t0 = from_half(row[t.i0]), t1 = from_half(row[t.i1]);
+        float d = t1 - t0;
+        float s = t0 + t.f * d;
+        float ws = s * kBlurWgt[i];
+        acc = acc + ws;
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_blur_rows(const uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
+                                                   Pyramid pyr, uint32_t m) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const uint32_t w = pyr.w[m];
+    half_t* row = reinterpret_cast<half_t*>(lds_raw);
+    half_t* tmp = row + w;
+    const uint32_t y = blockIdx.x;
+    const size_t base = (size_t)blockIdx.z * pyr.stride + pyr.off[m] + (size_t)y * w;
+    for (uint32_t x = threadIdx.x; x < w; x += 256u) row[x] = bits_half(gray[base + x]);
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < w; x += 256u) tmp[x] = to_half(blur_point(row, x, w));
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < w; x += 256u) blur[base + x] = half_bits(to_half(blur_point(tmp, x, w)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5  fast.wgsl:62-159 for one octave (one dispatch of orb.rs:509-519).
+// 16x16 pixels per block, tile + 3-pixel halo staged in LDS as f32; out-of-level texels are 0
+// (CRD-6).  The reference's per-thread LDS atomic + one global atomic per workgroup
+// (fast.wgsl:123-141) becomes a wave64 ballot/prefix and one global atomic per wave.
+// grid: (ceil(gw/16), ceil(gh/16), frames) with gw,gh the reference's 8-rounded dispatch size.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void append_corners(bool is_corner, uint32_t x, uint32_t y, uint32_t angle, uint32_t oct,
+                                               uint32_t* counter, CornerData* out, uint32_t cap) {
+    const uint64_t mask = __ballot(is_corner);
+    if (mask == 0ull) return;
+    const uint32_t lane = __lane_id();
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(mask));
+    base = __shfl(base, __builtin_ctzll(mask));
+    if (is_corner) {
+        const uint32_t idx = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (idx < cap) {
+            uint4 rec = make_uint4(x, y, angle, oct);
+            *reinterpret_cast<uint4*>(&out[idx]) = rec;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fast(const uint16_t* __restrict__ gray, Pyramid pyr, uint32_t oct,
+                                              uint32_t gw, uint32_t gh, float threshold, uint32_t* __restrict__ counts,
+                                              CornerData* __restrict__ corners, uint32_t cap) {
+    constexpr int T = 16, R = 3, S = T + 2 * R;
+    __shared__ float tile[S][S + 1];
+    const uint32_t w = pyr.w[oct], h = pyr.h[oct];
+    const uint32_t f = blockIdx.z;
+    const uint16_t* lvl = gray + (size_t)f * pyr.stride + pyr.off[oct];
+    const int bx = (int)blockIdx.x * T, by = (int)blockIdx.y * T;
+    const int tid = (int)(threadIdx.y * T + threadIdx.x);
+    for (int i = tid; i < S * S; i += T * T) {
+        int ty = i / S, tx = i - ty * S;
+        int gx = bx + tx - R, gy = by + ty - R;
+        float v = 0.0f;
+        if (gx >= 0 && gy >= 0 && gx < (int)w && gy < (int)h) v = from_half(bits_half(lvl[(size_t)gy * w + gx]));
+        tile[ty][tx] = v;
+    }
+    __syncthreads();
+    const uint32_t gx = (uint32_t)bx + threadIdx.x, gy = (uint32_t)by + threadIdx.y;
+    const int lx = (int)threadIdx.x + R, ly = (int)threadIdx.y + R;
+    bool is_corner = false;
+    uint32_t angle = 0;
+    // fast.wgsl:77 -- textureDimensions() is the level-0 size for every octave (Q8); u32 wrap kept.
+    const uint32_t lim_x = pyr.w[0] - 16u, lim_y = pyr.h[0] - 16u;
+    if (gx < gw && gy < gh && gx > 16u && gy > 16u && gx < lim_x && gy < lim_y) {
+        const float c = tile[ly][lx];
+        uint32_t n_over = 0, n_under = 0;
+        const float v4[4] = {tile[ly][lx + 3], tile[ly][lx - 3], tile[ly + 3][lx], tile[ly - 3][lx]};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float diff = v4[i] - c;
+            if (diff > threshold)
+                n_over++;
+            else if (diff < -threshold)
+                n_under++;
+        }
+        if (n_over >= 3u || n_under >= 3u) {
+            uint32_t m_over = 0, m_under = 0;
+            float cx = 0.0f, cy = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                float v = tile[ly + kRingDy[i]][lx + kRingDx[i]];
+                float diff = v - c;
+                float px = v * (float)kRingDx[i];
+                float py = v * (float)kRingDy[i];
+                cx = cx + px;
+                cy = cy + py;
+                if (diff > threshold)
+                    m_over |= 1u << i;
+                else if (diff < -threshold)
+                    m_under |= 1u << i;
+            }
+            if ((detect_streak_16(m_over) | detect_streak_16(m_under)) > 0u) {
+                is_corner = true;
+                angle = angle_code(cy, cx);
+            }
+        }
+    }
+    append_corners(is_corner, gx, gy, angle, oct, counts + f, corners + (size_t)f * cap, cap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6  brief.wgsl:20-68.  One wave64 per keypoint: lane l evaluates tests l, 64+l, 128+l, 192+l;
+// each ballot yields two of the eight u32 words (bit i of word k = test 32k+i, brief.wgsl:47,63).
+// cos/sin come from the 3142-entry table of CRD-10 (the angle code is an integer 0..3141).
+// grid: (waves_x, 1, frames); each wave strides over the frame's keypoints.
+// ---------------------------------------------------------------------------------------------
+struct BriefTables {
+    const uint32_t* pattern;  // 256 x packed (ax, ay, bx, by) int8
+    const float* cos_tab;     // ORB_ANGLE_STEPS entries
+    const float* sin_tab;
+};
+
+__device__ __forceinline__ float level_load(const uint16_t* lvl, uint32_t w, uint32_t h, int x, int y) {
+    if (x < 0 || y < 0 || x >= (int)w || y >= (int)h) return 0.0f;  // CRD-6
+    return from_half(bits_half(lvl[(size_t)y * w + x]));
+}
+
+__device__ __forceinline__ bool brief_test(uint32_t packed, float ct, float st, float nst, int px, int py,
+                                           const uint16_t* lvl, uint32_t w, uint32_t h) {
+    const float ax = (float)(int8_t)(packed & 255u), ay = (float)(int8_t)((packed >> 8) & 255u);
+    const float bx = (float)(int8_t)((packed >> 16) & 255u), by = (float)(int8_t)(packed >> 24);
+    // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y)   brief.wgsl:38-54
+    float a0 = ct * ax, a1 = st * ay, a2 = nst * ax, a3 = ct * ay;
+    float b0 = ct * bx, b1 = st * by, b2 = nst * bx, b3 = ct * by;
+    float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+    const float va = level_load(lvl, w, h, (int)rax + px, (int)ray + py);  // vec2i() truncates, brief.wgsl:56-57
+    const float vb = level_load(lvl, w, h, (int)rbx + px, (int)rby + py);
+    return va > vb;  // brief.wgsl:62
+}
+
+__global__ __launch_bounds__(256) void k_brief(const uint16_t* __restrict__ blur, Pyramid pyr,
+                                               const uint32_t* __restrict__ counts,
+                                               const CornerData* __restrict__ corners, uint32_t cap,
+                                               CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
+    const uint32_t f = blockIdx.z;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t n = min(counts[f], cap);
+    const CornerData* kp = corners + (size_t)f * cap;
+    uint32_t* out = reinterpret_cast<uint32_t*>(descriptors + (size_t)f * cap);
+    const uint32_t p0 = tab.pattern[lane], p1 = tab.pattern[64u + lane], p2 = tab.pattern[128u + lane],
+                   p3 = tab.pattern[192u + lane];
+    for (uint32_t k = wave; k < n; k += n_waves) {
+        const uint4 rec = *reinterpret_cast<const uint4*>(&kp[k]);  // x, y, angle, octave
+        const uint32_t oct = rec.w;
+        uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+        if (oct < pyr.depth) {
+            const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
+            const float ct = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
+            const uint32_t w = pyr.w[oct], h = pyr.h[oct];
+            const uint16_t* lvl = blur + (size_t)f * pyr.stride + pyr.off[oct];
+            const int px = (int)rec.x, py = (int)rec.y;
+            b0 = __ballot(brief_test(p0, ct, st, nst, px, py, lvl, w, h));
+            b1 = __ballot(brief_test(p1, ct, st, nst, px, py, lvl, w, h));
+            b2 = __ballot(brief_test(p2, ct, st, nst, px, py, lvl, w, h));
+            b3 = __ballot(brief_test(p3, ct, st, nst, px, py, lvl, w, h));
+        }
+        if (lane < 8u) {
+            const uint64_t src = lane < 2u ? b0 : (lane < 4u ? b1 : (lane < 6u ? b2 : b3));
+            out[(size_t)k * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic frames: frame i of the launch uses seed0 + i.  One thread = 4 pixels.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t synth_pixel(uint32_t x, uint32_t y, uint32_t W, uint32_t H, uint32_t seed,
+                                                uint32_t flags) {
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    if (flags & 1u) {
+        c0 = W > 1u ? 255u * x / (W - 1u) : 0u;
+        c1 = H > 1u ? 255u * y / (H - 1u) : 0u;
+        c2 = (W + H > 2u) ? 255u * (x + y) / (W + H - 2u) : 0u;
+    }
+    if (flags & 4u) {
+        const uint32_t cx = x / 128u, cy = y / 64u;
+        const uint32_t hsh = syn_rnd(seed, 2u, cy * ((W + 127u) / 128u) + cx);
+        if (hsh & 1u) {
+            const uint32_t rise = 4u + ((hsh >> 1) & 15u) % 13u, run = 2u * rise;
+            const uint32_t ox = ((hsh >> 8) & 255u) % (128u - run), oy = ((hsh >> 16) & 255u) % (64u - rise);
+            const int u = (int)x - (int)(cx * 128u + ox), v = (int)y - (int)(cy * 64u + oy);
+            if (u >= 0 && v >= 0 && u < (int)run && v < (int)rise) {
+                const uint32_t uu = (hsh & 32u) ? run - 1u - (uint32_t)u : (uint32_t)u;
+                const uint32_t vv = (hsh & 64u) ? rise - 1u - (uint32_t)v : (uint32_t)v;
+                if (vv * run <= uu * rise) c0 = c1 = c2 = (hsh >> 24) & 255u;
+            }
+        }
+    }
+    if (flags & 2u) {
+        const uint32_t cx = x / 32u, cy = y / 32u;
+        const uint32_t hsh = syn_rnd(seed, 1u, cy * ((W + 31u) / 32u) + cx);
+        if (hsh & 1u) {
+            const uint32_t s = 1u + ((hsh >> 1) & 3u);
+            const uint32_t bx = cx * 32u + 1u + ((hsh >> 4) & 255u) % (31u - s);
+            const uint32_t by = cy * 32u + 1u + ((hsh >> 12) & 255u) % (31u - s);
+            if (x >= bx && x < bx + s && y >= by && y < by + s) c0 = c1 = c2 = 128u + ((hsh >> 20) & 127u);
+        }
+    }
+    if (flags & 8u) {
+        const uint32_t n = syn_rnd(seed, 3u, y * W + x);
+        c0 = (3u * c0 + (n & 255u)) / 4u;
+        c1 = (3u * c1 + ((n >> 8) & 255u)) / 4u;
+        c2 = (3u * c2 + ((n >> 16) & 255u)) / 4u;
+    }
+    return c0 | (c1 << 8) | (c2 << 16) | 0xff000000u;
+}
+
+__global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ frames, size_t frame_bytes, uint32_t W,
+                                               uint32_t H, uint32_t seed0, uint32_t flags) {
+    const uint32_t y = blockIdx.y, f = blockIdx.z;
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= W) return;
+    uint32_t* row = reinterpret_cast<uint32_t*>(frames + (size_t)f * frame_bytes + (size_t)y * W * 4u);
+    row[x] = synth_pixel(x, y, W, H, seed0 + f, flags);
+}
+
+// scalar probes for the tests (CRD-3, CRD-9 on the device)
+__global__ void k_probe_f16(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = half_bits(to_half(src[i]));
+}
+__global__ void k_probe_angle(const float* __restrict__ cy, const float* __restrict__ cx, uint32_t* __restrict__ dst,
+                              size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = angle_code(cy[i], cx[i]);
+}
+
+}  // namespace orb

@@ -1,0 +1,323 @@
+"""Host-side mirror of the reference's `tinyslam::orb` module over the C ABI (include/tinyorb.h).
+
+Same names and argument meaning as src/orb.rs: `OrbConfig` (orb.rs:40-45), `OrbProgram` with
+`init` (107), `write_input_image` (567), `set_threshold` (585), `extract_corners` (469),
+`read_corners` (559), `read_descriptors` (563), and the POD records `CornerData` (10-17) /
+`CornerDescriptor` (19-23).  Where the reference panics this raises `OrbError`.
+
+There is no CPU fallback: if libtinyorb.so is missing or no HIP device is present, loading
+or `init()` raises.
+"""
+import ctypes
+import importlib.util
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libtinyorb.so")
+
+ORB_OK, ORB_EINVAL, ORB_EHIP, ORB_ECAPACITY, ORB_ESTATE = 0, 1, 2, 3, 4
+ORB_PLANE_GRAY, ORB_PLANE_BLUR = 0, 1
+ORB_KERNEL_COUNT = 8
+ORB_FLAG_STAGED = 1
+SYN_GRADIENT, SYN_BLOBS, SYN_WEDGES, SYN_NOISE = 1, 2, 4, 8
+SYN_ALL = 15
+
+# orb.rs:10-17 / orb.rs:19-23 as numpy record layouts (16 B / 32 B)
+CORNER_DTYPE = np.dtype([("x", "<u4"), ("y", "<u4"), ("angle", "<u4"), ("octave", "<u4")])
+DESCRIPTOR_DTYPE = np.dtype([("bits", "u1", (32,))])
+
+# Names every build of libtinyorb.so must export (checked by tests against include/tinyorb.h).
+EXPORTS = [
+    "orb_abi_version", "orb_last_error", "orb_kernel_name", "orb_program_create", "orb_program_destroy",
+    "orb_write_input_image", "orb_set_threshold", "orb_extract_corners", "orb_read_corners",
+    "orb_read_descriptors", "orb_extract_batch_device", "orb_extract_batch_host", "orb_batch_sync",
+    "orb_batch_counts", "orb_batch_read", "orb_batch_device_buffers", "orb_level_size",
+    "orb_debug_read_plane", "orb_debug_f32_to_f16", "orb_debug_angle_code", "orb_profile_enable",
+    "orb_profile_reset", "orb_profile_get", "orb_synth_frames_device", "orb_copy_to_host",
+]
+
+
+class OrbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("tinyorb error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Extent3d(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("depth_or_array_layers", ctypes.c_uint32)]
+
+
+class _Config(ctypes.Structure):
+    _fields_ = [("image_size", _Extent3d), ("max_features", ctypes.c_uint32), ("hierarchy_depth", ctypes.c_uint32),
+                ("initial_threshold", ctypes.c_float)]
+
+
+class _Options(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("max_batch", ctypes.c_uint32), ("flags", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32 * 5)]
+
+
+_lib = None
+
+
+def _preload_hip_runtime():
+    """If PyTorch is installed, bind to ITS bundled libamdhip64 so that a later `import torch`
+    (bench.py, torch.distributed) shares one HIP runtime with libtinyorb instead of loading a
+    second copy next to the system one."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def load_library(path=None):
+    """Loads libtinyorb.so.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise OrbError(ORB_EHIP, "%s not found: run `python -m tinyslam_amd.build` (hipcc, gfx950)" % path)
+    _preload_hip_runtime()
+    L = ctypes.CDLL(path)
+    vp, u32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t
+    L.orb_abi_version.restype = u32
+    L.orb_last_error.restype = ctypes.c_char_p
+    L.orb_last_error.argtypes = [vp]
+    L.orb_kernel_name.restype = ctypes.c_char_p
+    L.orb_kernel_name.argtypes = [ctypes.c_int]
+    L.orb_program_create.argtypes = [ctypes.POINTER(_Config), ctypes.POINTER(_Options), ctypes.POINTER(vp)]
+    L.orb_program_destroy.argtypes = [vp]
+    L.orb_program_destroy.restype = None
+    L.orb_write_input_image.argtypes = [vp, vp, sz]
+    L.orb_set_threshold.argtypes = [vp, ctypes.c_float]
+    L.orb_extract_corners.argtypes = [vp, ctypes.POINTER(u32)]
+    L.orb_read_corners.argtypes = [vp, vp, sz]
+    L.orb_read_descriptors.argtypes = [vp, vp, sz]
+    L.orb_extract_batch_device.argtypes = [vp, vp, u32, vp]
+    L.orb_extract_batch_host.argtypes = [vp, vp, u32]
+    L.orb_batch_sync.argtypes = [vp]
+    L.orb_batch_counts.argtypes = [vp, vp, u32]
+    L.orb_batch_read.argtypes = [vp, u32, vp, vp, sz]
+    L.orb_batch_device_buffers.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.orb_level_size.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.orb_debug_read_plane.argtypes = [vp, u32, ctypes.c_int, u32, vp, sz]
+    L.orb_debug_f32_to_f16.argtypes = [vp, vp, vp, sz]
+    L.orb_debug_angle_code.argtypes = [vp, vp, vp, vp, sz]
+    L.orb_profile_enable.argtypes = [vp, ctypes.c_int]
+    L.orb_profile_reset.argtypes = [vp]
+    L.orb_profile_get.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
+    L.orb_synth_frames_device.argtypes = [vp, vp, u32, u32, u32, ctypes.POINTER(vp)]
+    L.orb_copy_to_host.argtypes = [vp, vp, vp, sz]
+    if L.orb_abi_version() != 1:
+        raise OrbError(ORB_EINVAL, "libtinyorb ABI version mismatch")
+    if path == LIB_PATH:
+        _lib = L
+    return L
+
+
+@dataclass
+class Extent3d:
+    """wgpu::Extent3d as used by OrbConfig.image_size."""
+    width: int
+    height: int
+    depth_or_array_layers: int = 1
+
+
+@dataclass
+class OrbConfig:
+    """orb.rs:40-45."""
+    image_size: Extent3d
+    max_features: int = 8192
+    hierarchy_depth: int = 2
+    initial_threshold: float = 20.0 / 255.0
+    # build-side options (no counterpart in the reference)
+    device: int = 0
+    max_batch: int = 1
+    flags: int = 0
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class OrbProgram:
+    """orb.rs:47-51 + impl 106-590.  Construct, then `init()` (the reference builds the struct
+    by literal and calls `init`, orb.rs:107)."""
+
+    def __init__(self, config: OrbConfig):
+        self.config = config
+        self._h = None
+        self._lib = None
+
+    # ---- lifetime -------------------------------------------------------------------------
+    def init(self):
+        L = load_library()
+        c = self.config
+        cfg = _Config(_Extent3d(c.image_size.width, c.image_size.height, c.image_size.depth_or_array_layers),
+                      c.max_features, c.hierarchy_depth, float(np.float32(c.initial_threshold)))
+        opt = _Options(c.device, c.max_batch, c.flags)
+        h = ctypes.c_void_p()
+        rc = L.orb_program_create(ctypes.byref(cfg), ctypes.byref(opt), ctypes.byref(h))
+        if rc != ORB_OK:
+            raise OrbError(rc, (L.orb_last_error(None) or b"").decode())
+        self._h, self._lib = h, L
+        return self
+
+    def close(self):
+        if self._h is not None:
+            self._lib.orb_program_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self if self._h is not None else self.init()
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow=()):
+        if rc != ORB_OK and rc not in allow:
+            raise OrbError(rc, (self._lib.orb_last_error(self._h) or b"").decode())
+        return rc
+
+    def _handle(self):
+        if self._h is None:
+            raise OrbError(ORB_ESTATE, "OrbProgram.init() has not been called")
+        return self._h
+
+    # ---- the reference's six methods --------------------------------------------------------
+    def write_input_image(self, data):
+        """orb.rs:567: tightly packed RGBA8 bytes (any buffer / uint8 array of 4*W*H bytes)."""
+        a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray, memoryview))
+                                 else np.asarray(data, dtype=np.uint8))
+        self._check(self._lib.orb_write_input_image(self._handle(), _ptr(a), a.size))
+
+    def set_threshold(self, threshold):
+        """orb.rs:585"""
+        self._check(self._lib.orb_set_threshold(self._handle(), float(np.float32(threshold))))
+
+    def extract_corners(self):
+        """orb.rs:469: returns the RAW counter (may exceed max_features, like the reference)."""
+        n = ctypes.c_uint32(0)
+        self._check(self._lib.orb_extract_corners(self._handle(), ctypes.byref(n)), allow=(ORB_ECAPACITY,))
+        return n.value
+
+    def read_corners(self, dst):
+        """orb.rs:559: fills a CORNER_DTYPE array (the reference's &mut [CornerData])."""
+        assert dst.dtype == CORNER_DTYPE and dst.flags.c_contiguous
+        self._check(self._lib.orb_read_corners(self._handle(), _ptr(dst), dst.size))
+        return dst
+
+    def read_descriptors(self, dst):
+        """orb.rs:563: fills a DESCRIPTOR_DTYPE (or uint8 (n,32) / uint32 (n,8)) array."""
+        assert dst.flags.c_contiguous and dst.nbytes % 32 == 0
+        self._check(self._lib.orb_read_descriptors(self._handle(), _ptr(dst), dst.nbytes // 32))
+        return dst
+
+    # ---- conveniences over the six methods -------------------------------------------------
+    def extract(self, rgba):
+        """One frame in -> (total, corners[stored], descriptors u32 (stored, 8))."""
+        self.write_input_image(rgba)
+        total = self.extract_corners()
+        n = min(total, self.config.max_features)
+        corners = self.read_corners(np.zeros(n, dtype=CORNER_DTYPE))
+        desc = self.read_descriptors(np.zeros((n, 8), dtype=np.uint32))
+        return total, corners, desc
+
+    # ---- batched mode -----------------------------------------------------------------------
+    def extract_batch_device(self, frames_dev_ptr, n_frames, stream=None):
+        self._check(self._lib.orb_extract_batch_device(self._handle(), ctypes.c_void_p(frames_dev_ptr), n_frames,
+                                                       ctypes.c_void_p(stream) if stream else None))
+
+    def extract_batch_host(self, frames):
+        a = np.ascontiguousarray(frames, dtype=np.uint8)
+        self._check(self._lib.orb_extract_batch_host(self._handle(), _ptr(a), a.shape[0]))
+
+    def batch_sync(self):
+        self._check(self._lib.orb_batch_sync(self._handle()))
+
+    def batch_counts(self, n_frames):
+        out = np.zeros(n_frames, dtype=np.uint32)
+        self._check(self._lib.orb_batch_counts(self._handle(), _ptr(out), n_frames))
+        return out
+
+    def batch_read(self, frame, n):
+        corners = np.zeros(n, dtype=CORNER_DTYPE)
+        desc = np.zeros((n, 8), dtype=np.uint32)
+        self._check(self._lib.orb_batch_read(self._handle(), frame, _ptr(corners), _ptr(desc), n))
+        return corners, desc
+
+    def batch_device_buffers(self):
+        a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self._lib.orb_batch_device_buffers(self._handle(), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    # ---- inspection / measurement -------------------------------------------------------------
+    def level_size(self, level):
+        w, h = ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self._lib.orb_level_size(self._handle(), level, ctypes.byref(w), ctypes.byref(h)))
+        return w.value, h.value
+
+    def read_plane(self, kind, level, frame=0):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), dtype=np.uint16)
+        self._check(self._lib.orb_debug_read_plane(self._handle(), frame, kind, level, _ptr(out), out.size))
+        return out
+
+    def device_f32_to_f16(self, src):
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        out = np.zeros(src.shape, dtype=np.uint16)
+        self._check(self._lib.orb_debug_f32_to_f16(self._handle(), _ptr(src), _ptr(out), src.size))
+        return out
+
+    def device_angle_code(self, cy, cx):
+        cy = np.ascontiguousarray(cy, dtype=np.float32)
+        cx = np.ascontiguousarray(cx, dtype=np.float32)
+        out = np.zeros(cy.shape, dtype=np.uint32)
+        self._check(self._lib.orb_debug_angle_code(self._handle(), _ptr(cy), _ptr(cx), _ptr(out), cy.size))
+        return out
+
+    def profile_enable(self, on=True):
+        self._check(self._lib.orb_profile_enable(self._handle(), 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self._lib.orb_profile_reset(self._handle()))
+
+    def profile(self):
+        """{kernel name: (total_ms, launches)} for kernels launched since the last reset."""
+        out = {}
+        for i in range(ORB_KERNEL_COUNT):
+            ms, n = ctypes.c_double(), ctypes.c_uint64()
+            self._check(self._lib.orb_profile_get(self._handle(), i, ctypes.byref(ms), ctypes.byref(n)))
+            if n.value:
+                out[self._lib.orb_kernel_name(i).decode()] = (ms.value, n.value)
+        return out
+
+    def synth_frames_device(self, n_frames, seed0, flags=SYN_ALL, frames_dev_ptr=None):
+        """Generates synthetic frames on the device; returns the device address."""
+        out = ctypes.c_void_p()
+        self._check(self._lib.orb_synth_frames_device(self._handle(), ctypes.c_void_p(frames_dev_ptr) if frames_dev_ptr else None,
+                                                      n_frames, seed0 & 0xFFFFFFFF, flags, ctypes.byref(out)))
+        return out.value
+
+    def copy_to_host(self, dev_ptr, nbytes):
+        out = np.zeros(nbytes, dtype=np.uint8)
+        self._check(self._lib.orb_copy_to_host(self._handle(), _ptr(out), ctypes.c_void_p(dev_ptr), nbytes))
+        return out
