@@ -85,6 +85,10 @@ void orb_program_destroy(OrbProgram *p);
 /* last error text of this program (or of the failed create when p == NULL) */
 const char *orb_last_error(const OrbProgram *p);
 uint32_t orb_abi_version(void);
+/* "fused" (one kernel per pyramid level + BRIEF) or "staged" (one kernel per reference stage;
+ * taken with ORB_FLAG_STAGED or for shapes the fused kernels do not cover: width not a multiple
+ * of 4, width > 2048, odd level-0 size with depth > 1). */
+const char *orb_pipeline(const OrbProgram *p);
 
 /* ---- single-frame API, one call per reference method ---- */
 /* orb.rs:567-583 write_input_image: tightly packed RGBA8, rows of 4*width bytes. */

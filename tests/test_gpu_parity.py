@@ -38,22 +38,26 @@ def _assert_frame_equal(oracle, ref, total, corners, desc):
     assert len(np.unique(keys, axis=0)) == len(keys)
 
 
-@pytest.mark.parametrize("W,H,depth,seed", [(64, 48, 2, 3), (160, 120, 3, 1), (200, 97, 3, 7), (640, 480, 2, 1)])
+@pytest.mark.parametrize("W,H,depth,seed", [(64, 48, 2, 3), (160, 120, 3, 1), (200, 97, 3, 7), (640, 480, 2, 1),
+                                            (1284, 250, 4, 5), (332, 202, 5, 11), (2048, 64, 2, 4), (2052, 40, 1, 6)])
 @pytest.mark.parametrize("flags", [1, 0])
 def test_single_frame_matches_oracle(tinyorb, oracle, W, H, depth, seed, flags):
     rgba = oracle.synth_frame(W, H, seed)
     ref = oracle.extract(rgba, depth=depth, threshold=THR, planes=True)
     with _program(tinyorb, W, H, depth, flags=flags) as prog:
+        staged = bool(flags & tinyorb.ORB_FLAG_STAGED)
+        fused_ok = W % 4 == 0 and W <= 2048 and (depth == 1 or (W % 2 == 0 and H % 2 == 0))
+        assert prog.pipeline() == ("fused" if fused_ok and not staged else "staged")
         total, corners, desc = prog.extract(rgba)
-        _assert_frame_equal(oracle, ref, total, corners, desc)
-        if flags & tinyorb.ORB_FLAG_STAGED:
-            dims, _ = oracle.level_dims(W, H, depth)
-            for m, (w, h, off) in enumerate(dims):
-                assert prog.level_size(m) == (w, h)
+        dims, _ = oracle.level_dims(W, H, depth)
+        for m, (w, h, off) in enumerate(dims):
+            assert prog.level_size(m) == (w, h)
+            if m > 0 or prog.pipeline() == "staged":  # the fused path keeps the level-0 grey plane in LDS only
                 g = prog.read_plane(tinyorb.ORB_PLANE_GRAY, m)
-                b = prog.read_plane(tinyorb.ORB_PLANE_BLUR, m)
                 assert np.array_equal(g.ravel(), ref["gray"][off:off + w * h]), "gray level %d" % m
-                assert np.array_equal(b.ravel(), ref["blur"][off:off + w * h]), "blur level %d" % m
+            b = prog.read_plane(tinyorb.ORB_PLANE_BLUR, m)
+            assert np.array_equal(b.ravel(), ref["blur"][off:off + w * h]), "blur level %d" % m
+        _assert_frame_equal(oracle, ref, total, corners, desc)
 
 
 def test_config2_config3_720p(tinyorb, oracle):

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/tinyorb.h"
+#include "orb_kernels_fused.h"
 #include "orb_kernels_staged.h"
 
 using namespace orb;
@@ -62,6 +63,8 @@ struct OrbProgram {
     uint32_t last_batch = 0;  // frames of the last batched call
     hipStream_t last_stream = nullptr;
     bool planes_valid = false;
+    bool fused = false;
+    uint32_t max_lds = 0;
 
     bool profiling = false;
     std::vector<ProfSpan> pending;
@@ -199,7 +202,79 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
     return ORB_OK;
 }
 
-int run_pipeline(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) { return run_staged(p, frames, n, s); }
+// Can the fused per-level kernels handle this configuration?  (Otherwise: staged pipeline.)
+bool fused_eligible(const OrbProgram* p) {
+    if (p->opt.flags & ORB_FLAG_STAGED) return false;
+    const Pyramid& pyr = p->pyr;
+    if ((pyr.w[0] & 3u) != 0u || pyr.w[0] > (uint32_t)(kFrontMaxCols * kFrontThreads) || pyr.w[0] < 8u) return false;
+    if (pyr.depth > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) return false;
+    return true;
+}
+
+FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t gh, uint32_t n_frames) {
+    FrontGeom g{};
+    g.lvl = lvl;
+    g.gw = gw;
+    g.gh = gh;
+    const uint32_t w = pyr.w[lvl], h = pyr.h[lvl];
+    const uint32_t rows = h > gh ? h : gh;
+    g.n_bands = (rows + kFrontRows - 1) / kFrontRows;
+    g.n_frames = n_frames;
+    const uint32_t cols = (w > gw ? w : gw) + 4u;
+    g.ls = kLdsPad + ((cols + 7u) & ~7u);
+    g.ts = (w + 7u) & ~7u;
+    g.write_mip = (lvl + 1 < pyr.depth && w == 2u * pyr.w[lvl + 1] && h == 2u * pyr.h[lvl + 1]) ? 1u : 0u;
+    g.xcd_swizzle = (n_frames % 8u == 0u) ? 1u : 0u;
+    return g;
+}
+
+// The fused pipeline: one k_front launch per level + BRIEF.
+int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
+    const Pyramid& pyr = p->pyr;
+    const uint32_t D = pyr.depth, cap = p->cfg.max_features;
+    HIP_TRY(p, hipMemsetAsync(p->d_counts, 0, sizeof(uint32_t) * n, s));  // orb.rs:475
+    uint32_t width = pyr.w[0], height = pyr.h[0];                          // orb.rs:501-519
+    for (uint32_t lvl = 0; lvl < D; lvl++) {
+        const uint32_t gw = ((width + 7u) / 8u) * 8u, gh = ((height + 7u) / 8u) * 8u;
+        width /= 2u;
+        height /= 2u;
+        if (lvl > 0 && !(pyr.w[lvl - 1] == 2u * pyr.w[lvl] && pyr.h[lvl - 1] == 2u * pyr.h[lvl])) {
+            LaunchScope ls(p, s, KID_MIP);  // inexact reduction (odd source size): generic bilinear blit
+            dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 3u) / 4u, n);
+            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, p->d_gray, pyr, lvl);
+        }
+        FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n);
+        if (gw == 0) g.gh = 0;  // no FAST dispatch at this octave (orb.rs:511-515 with width 0)
+        const uint32_t lds = front_lds_bytes(g);
+        if (lds > p->max_lds) return fail(p, ORB_EINVAL, "level %u needs %u bytes of LDS", lvl, lds);
+        const dim3 grid(g.n_bands * n);
+        if (lvl == 0) {
+            LaunchScope ls(p, s, KID_FUSED_L0);
+            hipLaunchKernelGGL(k_front<true>, grid, dim3(kFrontThreads), lds, s, frames, p->frame_bytes, p->d_gray,
+                               p->d_blur, pyr, g, p->threshold, p->d_counts, p->d_corners, cap);
+        } else {
+            LaunchScope ls(p, s, KID_FUSED_LN);
+            hipLaunchKernelGGL(k_front<false>, grid, dim3(kFrontThreads), lds, s, frames, p->frame_bytes, p->d_gray,
+                               p->d_blur, pyr, g, p->threshold, p->d_counts, p->d_corners, cap);
+        }
+    }
+    {  // orb.rs:523-534
+        LaunchScope ls(p, s, KID_BRIEF);
+        BriefTables tab{p->d_pattern, p->d_cos, p->d_sin};
+        uint32_t bx = (cap + 127u) / 128u;
+        if (bx > 64u) bx = 64u;
+        if (bx < 1u) bx = 1u;
+        hipLaunchKernelGGL(k_brief, dim3(bx, 1, n), dim3(256), 0, s, p->d_blur, pyr, p->d_counts, p->d_corners, cap,
+                           p->d_desc, tab);
+    }
+    HIP_TRY(p, hipGetLastError());
+    p->planes_valid = true;  // except the level-0 grey plane, which the fused path keeps in LDS only
+    return ORB_OK;
+}
+
+int run_pipeline(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
+    return p->fused ? run_fused(p, frames, n, s) : run_staged(p, frames, n, s);
+}
 
 int ensure_input(OrbProgram* p) {
     if (!p->d_input) HIP_TRY(p, hipMalloc(&p->d_input, p->frame_bytes * p->max_batch));
@@ -213,6 +288,8 @@ extern "C" {
 uint32_t orb_abi_version(void) { return TINYORB_ABI_VERSION; }
 
 const char* orb_last_error(const OrbProgram* p) { return p ? p->err.c_str() : g_create_error.c_str(); }
+
+const char* orb_pipeline(const OrbProgram* p) { return p ? (p->fused ? "fused" : "staged") : ""; }
 
 const char* orb_kernel_name(int id) { return (id >= 0 && id < ORB_KERNEL_COUNT) ? kKernelNames[id] : ""; }
 
@@ -265,6 +342,30 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     } while (0)
     CREATE_TRY(hipSetDevice(p->device));
     CREATE_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    {
+        int lds_max = 0;
+        CREATE_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, p->device));
+        p->max_lds = (uint32_t)lds_max;
+        p->fused = fused_eligible(p);
+        if (p->fused) {
+            uint32_t need = 0, width = W, height = H;
+            for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
+                FrontGeom g = front_geometry(p->pyr, lvl, ((width + 7u) / 8u) * 8u, ((height + 7u) / 8u) * 8u, 1);
+                width /= 2u;
+                height /= 2u;
+                const uint32_t b = front_lds_bytes(g);
+                if (b > need) need = b;
+            }
+            if (need > p->max_lds) {
+                p->fused = false;
+            } else {
+                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            }
+        }
+    }
     const size_t B = p->max_batch, cap = config->max_features;
     CREATE_TRY(hipMalloc(&p->d_gray, B * p->pyr.stride * sizeof(uint16_t)));
     CREATE_TRY(hipMalloc(&p->d_blur, B * p->pyr.stride * sizeof(uint16_t)));
@@ -443,7 +544,8 @@ int orb_debug_read_plane(OrbProgram* p, uint32_t frame, int kind, uint32_t level
     if (!p) return ORB_EINVAL;
     if (!dst || level >= p->pyr.depth || frame >= p->last_batch || (kind != ORB_PLANE_GRAY && kind != ORB_PLANE_BLUR))
         return fail(p, ORB_EINVAL, "debug_read_plane: bad arguments");
-    if (!p->planes_valid) return fail(p, ORB_ESTATE, "plane not materialised by the last call");
+    if (!p->planes_valid || (p->fused && kind == ORB_PLANE_GRAY && level == 0))
+        return fail(p, ORB_ESTATE, "plane not materialised by the last call");
     const size_t texels = (size_t)p->pyr.w[level] * p->pyr.h[level];
     if (n_texels != texels) return fail(p, ORB_EINVAL, "debug_read_plane: expected %zu texels", texels);
     if (int rc = orb_batch_sync(p)) return rc;

@@ -1,0 +1,63 @@
+"""Batched-frame sharding over the GPUs of one node and the final collate.
+
+The reference has no multi-device code (single wgpu device, orb.rs:47-51).  Frames are
+independent, so the path shards with NO data-path collective: rank g extracts the contiguous
+frame range `shard_range(F, G, g)` on its own GPU.  The only exchange is the collate of the
+results to rank 0: per-frame counts (all_gather, 4 B/frame) and the keypoint/descriptor slabs
+trimmed to the largest per-frame count (gather).  With backend "nccl" this is RCCL over xGMI;
+the CPU tests run the same code over gloo.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_frames: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous range [lo, hi) of frame indices owned by `rank` (collated output is in frame order)."""
+    lo = (n_frames * rank) // world
+    hi = (n_frames * (rank + 1)) // world
+    return lo, hi
+
+
+class DeviceArray:
+    """Zero-copy view of a raw device allocation for torch (`torch.as_tensor(DeviceArray(...))`)."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": tuple(shape), "typestr": typestr,
+                                         "version": 2, "strides": None}
+
+
+def as_tensor(ptr: int, shape, typestr: str, device) -> torch.Tensor:
+    return torch.as_tensor(DeviceArray(ptr, shape, typestr), device=device)
+
+
+def collate_to_root(counts: torch.Tensor, corners: torch.Tensor, descriptors: torch.Tensor, cap: int,
+                    dst: int = 0, group: Optional[dist.ProcessGroup] = None):
+    """Gathers every rank's results on `dst`.
+
+    counts       (B,)        int32   raw per-frame counters of this rank's frames
+    corners      (B, cap, 4) int32   CornerData slabs (x, y, angle, octave)
+    descriptors  (B, cap, 8) int32   CornerDescriptor slabs
+    Every rank must pass the same B (pad the last shard).  Returns on dst a tuple
+    (counts_all (G*B,), corners_all (G*B, mx, 4), descriptors_all (G*B, mx, 8)) in frame order,
+    where mx = the largest stored count of any frame on any rank; other ranks get None.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        mx = int(torch.clamp(counts, max=cap).max().item()) if counts.numel() else 0
+        return counts, corners[:, :mx].contiguous(), descriptors[:, :mx].contiguous()
+    all_counts = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)
+    counts_all = torch.cat(all_counts)
+    mx = int(torch.clamp(counts_all, max=cap).max().item()) if counts_all.numel() else 0
+    mx = max(mx, 1)
+    # one payload per rank: corners and descriptors of a frame side by side -> a single gather
+    payload = torch.cat([corners[:, :mx], descriptors[:, :mx]], dim=2).contiguous()  # (B, mx, 12)
+    bufs = [torch.empty_like(payload) for _ in range(world)] if rank == dst else None
+    dist.gather(payload, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    merged = torch.cat(bufs, dim=0)
+    return counts_all, merged[:, :, :4].contiguous(), merged[:, :, 4:].contiguous()

@@ -31,7 +31,7 @@ DESCRIPTOR_DTYPE = np.dtype([("bits", "u1", (32,))])
 
 # Names every build of libtinyorb.so must export (checked by tests against include/tinyorb.h).
 EXPORTS = [
-    "orb_abi_version", "orb_last_error", "orb_kernel_name", "orb_program_create", "orb_program_destroy",
+    "orb_abi_version", "orb_pipeline", "orb_last_error", "orb_kernel_name", "orb_program_create", "orb_program_destroy",
     "orb_write_input_image", "orb_set_threshold", "orb_extract_corners", "orb_read_corners",
     "orb_read_descriptors", "orb_extract_batch_device", "orb_extract_batch_host", "orb_batch_sync",
     "orb_batch_counts", "orb_batch_read", "orb_batch_device_buffers", "orb_level_size",
@@ -96,6 +96,8 @@ def load_library(path=None):
     L.orb_last_error.restype = ctypes.c_char_p
     L.orb_last_error.argtypes = [vp]
     L.orb_kernel_name.restype = ctypes.c_char_p
+    L.orb_pipeline.restype = ctypes.c_char_p
+    L.orb_pipeline.argtypes = [vp]
     L.orb_kernel_name.argtypes = [ctypes.c_int]
     L.orb_program_create.argtypes = [ctypes.POINTER(_Config), ctypes.POINTER(_Options), ctypes.POINTER(vp)]
     L.orb_program_destroy.argtypes = [vp]
@@ -270,6 +272,9 @@ class OrbProgram:
         return a.value, b.value, c.value
 
     # ---- inspection / measurement -------------------------------------------------------------
+    def pipeline(self):
+        return self._lib.orb_pipeline(self._handle()).decode()
+
     def level_size(self, level):
         w, h = ctypes.c_uint32(), ctypes.c_uint32()
         self._check(self._lib.orb_level_size(self._handle(), level, ctypes.byref(w), ctypes.byref(h)))
