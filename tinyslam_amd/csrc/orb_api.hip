@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -50,6 +51,10 @@ struct OrbProgram {
     uint32_t* d_counts = nullptr;
     CornerData* d_corners = nullptr;
     CornerDescriptor* d_desc = nullptr;
+    CornerData* d_seg = nullptr;     // fused path: [max_batch][n_slots][seg_cap] band segments
+    uint32_t* d_seg_counts = nullptr;  // [max_batch][n_slots]
+    BandGeom bands{};
+    TileGeom tiles{};
     uint32_t* d_pattern = nullptr;
     float* d_cos = nullptr;
     float* d_sin = nullptr;
@@ -211,6 +216,12 @@ bool fused_eligible(const OrbProgram* p) {
     return true;
 }
 
+uint32_t front_bands(const Pyramid& pyr, uint32_t lvl) {
+    const uint32_t gh = (((pyr.h[0] >> lvl) + 7u) / 8u) * 8u;  // orb.rs:513, 518
+    const uint32_t rows = pyr.h[lvl] > gh ? pyr.h[lvl] : gh;
+    return (rows + kFrontRows - 1) / kFrontRows;
+}
+
 FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t gh, uint32_t n_frames) {
     FrontGeom g{};
     g.lvl = lvl;
@@ -225,6 +236,9 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
     g.ts = (w + 7u) & ~7u;
     g.write_mip = (lvl + 1 < pyr.depth && w == 2u * pyr.w[lvl + 1] && h == 2u * pyr.h[lvl + 1]) ? 1u : 0u;
     g.xcd_swizzle = (n_frames % 8u == 0u) ? 1u : 0u;
+    g.phase_mask = 15u;
+    if (const char* e = getenv("TINYORB_PHASE_MASK")) g.phase_mask = (uint32_t)atoi(e);
+    if (const char* e = getenv("TINYORB_NO_SWIZZLE")) g.xcd_swizzle = atoi(e) ? 0u : g.xcd_swizzle;
     return g;
 }
 
@@ -232,8 +246,9 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
 int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
     const Pyramid& pyr = p->pyr;
     const uint32_t D = pyr.depth, cap = p->cfg.max_features;
-    HIP_TRY(p, hipMemsetAsync(p->d_counts, 0, sizeof(uint32_t) * n, s));  // orb.rs:475
-    uint32_t width = pyr.w[0], height = pyr.h[0];                          // orb.rs:501-519
+    // orb.rs:475 clear_buffer(counter): every band slot's count is rewritten by its k_front block and
+    // counts[] by k_brief_bands, so nothing needs clearing here.
+    uint32_t width = pyr.w[0], height = pyr.h[0];  // orb.rs:501-519
     for (uint32_t lvl = 0; lvl < D; lvl++) {
         const uint32_t gw = ((width + 7u) / 8u) * 8u, gh = ((height + 7u) / 8u) * 8u;
         width /= 2u;
@@ -245,27 +260,40 @@ int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
         }
         FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n);
         if (gw == 0) g.gh = 0;  // no FAST dispatch at this octave (orb.rs:511-515 with width 0)
+        g.slot_base = p->bands.slot_base[lvl];
+        g.n_slots = p->bands.n_slots;
+        g.seg_cap = p->bands.seg_cap;
+        if (g.n_bands != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
+            return fail(p, ORB_EINVAL, "internal: band count mismatch at level %u", lvl);
         const uint32_t lds = front_lds_bytes(g);
         if (lds > p->max_lds) return fail(p, ORB_EINVAL, "level %u needs %u bytes of LDS", lvl, lds);
         const dim3 grid(g.n_bands * n);
         if (lvl == 0) {
             LaunchScope ls(p, s, KID_FUSED_L0);
             hipLaunchKernelGGL(k_front<true>, grid, dim3(kFrontThreads), lds, s, frames, p->frame_bytes, p->d_gray,
-                               p->d_blur, pyr, g, p->threshold, p->d_counts, p->d_corners, cap);
+                               p->d_blur, pyr, g, p->threshold, p->d_seg_counts, p->d_seg);
         } else {
             LaunchScope ls(p, s, KID_FUSED_LN);
             hipLaunchKernelGGL(k_front<false>, grid, dim3(kFrontThreads), lds, s, frames, p->frame_bytes, p->d_gray,
-                               p->d_blur, pyr, g, p->threshold, p->d_counts, p->d_corners, cap);
+                               p->d_blur, pyr, g, p->threshold, p->d_seg_counts, p->d_seg);
         }
     }
-    {  // orb.rs:523-534
+    {  // orb.rs:523-534, plus the compaction of the band segments into the final lists
         LaunchScope ls(p, s, KID_BRIEF);
         BriefTables tab{p->d_pattern, p->d_cos, p->d_sin};
-        uint32_t bx = (cap + 127u) / 128u;
-        if (bx > 64u) bx = 64u;
-        if (bx < 1u) bx = 1u;
-        hipLaunchKernelGGL(k_brief, dim3(bx, 1, n), dim3(256), 0, s, p->d_blur, pyr, p->d_counts, p->d_corners, cap,
-                           p->d_desc, tab);
+        if (getenv("TINYORB_BRIEF_BANDS")) {
+            BandGeom bg = p->bands;
+            bg.n_frames = n;
+            bg.xcd_swizzle = (n % 8u == 0u) ? 1u : 0u;
+            hipLaunchKernelGGL(k_brief_bands, dim3(bg.n_slots * n), dim3(256), 0, s, p->d_blur, pyr, bg,
+                               p->d_seg_counts, p->d_seg, p->d_counts, p->d_corners, cap, p->d_desc, tab);
+        } else {
+            TileGeom tg = p->tiles;
+            tg.n_frames = n;
+            tg.xcd_swizzle = (n % 8u == 0u) ? 1u : 0u;
+            hipLaunchKernelGGL(k_brief_tiles, dim3(tg.tile_base[pyr.depth] * n), dim3(256), 0, s, p->d_blur, pyr, tg,
+                               p->d_seg_counts, p->d_seg, p->d_counts, p->d_corners, cap, p->d_desc, tab);
+        }
     }
     HIP_TRY(p, hipGetLastError());
     p->planes_valid = true;  // except the level-0 grey plane, which the fused path keeps in LDS only
@@ -359,6 +387,30 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
             if (need > p->max_lds) {
                 p->fused = false;
             } else {
+                BandGeom& bg = p->bands;
+                uint32_t slots = 0;
+                for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
+                    bg.slot_base[lvl] = slots;
+                    slots += front_bands(p->pyr, lvl);
+                }
+                bg.slot_base[p->pyr.depth] = slots;
+                bg.n_slots = slots;
+                const uint64_t band_px = (uint64_t)kFrontRows * (((uint64_t)W + 7u) / 8u * 8u);
+                bg.seg_cap = (uint32_t)(band_px < config->max_features ? band_px : config->max_features);
+                TileGeom& tg = p->tiles;
+                tg.n_slots = bg.n_slots;
+                tg.seg_cap = bg.seg_cap;
+                uint32_t tiles = 0;
+                for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
+                    tg.slot_base[lvl] = bg.slot_base[lvl];
+                    tg.tile_base[lvl] = tiles;
+                    const uint32_t gw = (((W >> lvl) + 7u) / 8u) * 8u;
+                    const uint32_t cols = p->pyr.w[lvl] > gw ? p->pyr.w[lvl] : gw;
+                    tg.tile_cols[lvl] = (cols + kBriefTileW - 1) / kBriefTileW;
+                    tiles += ((front_bands(p->pyr, lvl) + 1u) / 2u) * tg.tile_cols[lvl];
+                }
+                tg.slot_base[p->pyr.depth] = bg.n_slots;
+                tg.tile_base[p->pyr.depth] = tiles;
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<false>),
@@ -375,6 +427,11 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     CREATE_TRY(hipMemset(p->d_counts, 0, B * sizeof(uint32_t)));
     CREATE_TRY(hipMemset(p->d_corners, 0, B * cap * sizeof(CornerData)));
     CREATE_TRY(hipMemset(p->d_desc, 0, B * cap * sizeof(CornerDescriptor)));
+    if (p->fused) {
+        CREATE_TRY(hipMalloc(&p->d_seg, B * p->bands.n_slots * (size_t)p->bands.seg_cap * sizeof(CornerData)));
+        CREATE_TRY(hipMalloc(&p->d_seg_counts, B * p->bands.n_slots * sizeof(uint32_t)));
+        CREATE_TRY(hipMemset(p->d_seg_counts, 0, B * p->bands.n_slots * sizeof(uint32_t)));
+    }
     CREATE_TRY(hipMalloc(&p->d_pattern, 256 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&p->d_cos, ORB_ANGLE_STEPS * sizeof(float)));
     CREATE_TRY(hipMalloc(&p->d_sin, ORB_ANGLE_STEPS * sizeof(float)));
@@ -404,6 +461,8 @@ void orb_program_destroy(OrbProgram* p) {
     (void)hipFree(p->d_counts);
     (void)hipFree(p->d_corners);
     (void)hipFree(p->d_desc);
+    (void)hipFree(p->d_seg);
+    (void)hipFree(p->d_seg_counts);
     (void)hipFree(p->d_pattern);
     (void)hipFree(p->d_cos);
     (void)hipFree(p->d_sin);

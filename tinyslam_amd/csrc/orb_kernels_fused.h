@@ -40,10 +40,14 @@ struct FrontGeom {
     uint32_t ts;        // LDS row stride of the blur intermediate, in halfs
     uint32_t write_mip; // 1: level lvl+1 exists and is an exact 2x2 reduction
     uint32_t xcd_swizzle;
+    uint32_t phase_mask;  // debug: bit0 B1, bit1 B2, bit2 C0, bit3 C (timing experiments only)
+    uint32_t slot_base;   // index of this level's band 0 among the frame's band slots
+    uint32_t n_slots;     // band slots per frame (all levels)
+    uint32_t seg_cap;     // CornerData records per band segment
 };
 
 __host__ __device__ inline uint32_t front_lds_bytes(const FrontGeom& g) {
-    return ((kFrontRows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + (kFrontQueue + 4) * 4u;
+    return ((kFrontRows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + (kFrontQueue + 4) * 4u;  // queue + q_count + c_count
 }
 
 __device__ __forceinline__ float h2f(uint32_t packed, int hi) {
@@ -84,28 +88,32 @@ __device__ __forceinline__ bool fast_full_test(const half_t* ctr, int ls, float 
         const float py = v * (float)kRingDy[i];
         cx = cx + px;  // CRD-8: ring order, unfused
         cy = cy + py;
-        if (diff > thr)
-            m_over |= 1u << i;
-        else if (diff < -thr)
-            m_under |= 1u << i;
+        // thr >= 0, so `diff > thr` and `diff < -thr` exclude each other (fast.wgsl:108-112's else-if)
+        m_over |= (diff > thr) ? (1u << i) : 0u;
+        m_under |= (diff < -thr) ? (1u << i) : 0u;
     }
     if ((detect_streak_16(m_over) | detect_streak_16(m_under)) == 0u) return false;
     *angle = angle_code(cy, cx);
     return true;
 }
 
-__device__ __forceinline__ void append_one(uint32_t x, uint32_t y, uint32_t angle, uint32_t oct, uint32_t* counter,
-                                           CornerData* out, uint32_t cap) {
-    const uint32_t idx = atomicAdd(counter, 1u);
-    if (idx < cap) *reinterpret_cast<uint4*>(&out[idx]) = make_uint4(x, y, angle, oct);
+// Block-local stream compaction: a band's corners go to its own segment of the scratch list, the
+// slot comes from an LDS counter.  No global atomic is involved: 180 waves per frame bumping one
+// per-frame counter serialise at the memory side and cost more than the rest of the kernel.
+__device__ __forceinline__ void segment_append(bool is_corner, uint32_t x, uint32_t y, uint32_t angle, uint32_t oct,
+                                               uint32_t* lds_counter, CornerData* seg, uint32_t seg_cap) {
+    if (is_corner) {
+        const uint32_t idx = atomicAdd(lds_counter, 1u);  // hipcc turns this into one ds_add per wave
+        if (idx < seg_cap) *reinterpret_cast<uint4*>(&seg[idx]) = make_uint4(x, y, angle, oct);
+    }
 }
 
 template <bool L0>
 __global__ __launch_bounds__(kFrontThreads) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                          uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                                          Pyramid pyr, FrontGeom geo, float thr,
-                                                         uint32_t* __restrict__ counts,
-                                                         CornerData* __restrict__ corners, uint32_t cap) {
+                                                         uint32_t* __restrict__ seg_counts,
+                                                         CornerData* __restrict__ segments) {
     constexpr int NT = kFrontThreads, R = kFrontRows, TC = kFrontTmpRows;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int LS = (int)geo.ls, TS = (int)geo.ts;
@@ -113,6 +121,7 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const uint8_t* __restri
     half_t* const tmp = grey + (R + 6) * LS;                              // 2 x TC rows x TS
     uint32_t* const queue = reinterpret_cast<uint32_t*>(tmp + 2 * TC * TS);
     uint32_t* const q_count = queue + kFrontQueue;
+    uint32_t* const c_count = q_count + 1;  // corners found by this band
 
     // ---- which band of which frame: keep all bands of a frame on one XCD so halo rows hit its L2
     uint32_t frame, band;
@@ -133,59 +142,91 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const uint8_t* __restri
     const int tid = (int)threadIdx.x;
     uint16_t* const gray_f = gray + (size_t)frame * pyr.stride;
     uint16_t* const blur_lvl = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
+    const size_t slot = (size_t)frame * geo.n_slots + geo.slot_base + band;
+    CornerData* const seg = segments + slot * geo.seg_cap;
 
-    if (tid == 0) *q_count = 0u;
+    if (tid == 0) {
+        *q_count = 0u;
+        *c_count = 0u;
+    }
 
     // =========================== A: stage grey rows [y0-3, y0+R+3) ===========================
     if (L0) {
         // RGBA8 -> luminance of the vertically mirrored row (grayscale.wgsl:16-38), 4 px per item.
+        // Loads are issued kLoadBatch at a time before any is consumed, so a thread has that many
+        // 16-byte HBM requests in flight instead of one.
+        constexpr int U = 8;
         const int w4 = w >> 2;
         const float inv_w4 = 1.0f / (float)w4;
         const uint8_t* src = frames + (size_t)frame * frame_bytes;
         const int n_items = (R + 6) * w4;
-        for (int i = tid; i < n_items; i += NT) {
-            const int ly = (int)(((float)i + 0.5f) * inv_w4);
-            const int xi = i - ly * w4;
-            const int gy = y0 - 3 + ly;
-            if (gy < 0 || gy >= h) continue;  // never read by a pixel that passes the guard (fast.wgsl:77)
-            const uint4 px = *reinterpret_cast<const uint4*>(src + ((size_t)(h - 1 - gy) * w + (size_t)xi * 4) * 4);
-            uint2 out;
-            out.x = pack_half2(luminance_fast(px.x), luminance_fast(px.y));
-            out.y = pack_half2(luminance_fast(px.z), luminance_fast(px.w));
-            *reinterpret_cast<uint2*>(grey + ly * LS + kLdsPad + xi * 4) = out;
+        for (int ib = tid; ib < n_items; ib += NT * U) {
+            uint4 px[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = ib + u * NT;
+                const int ly = (int)(((float)i + 0.5f) * inv_w4);
+                const int xi = i - ly * w4;
+                const int gy = y0 - 3 + ly;
+                // rows outside the image are never read by a pixel that passes the guard (fast.wgsl:77)
+                const bool ok = i < n_items && gy >= 0 && gy < h;
+                dst[u] = ok ? ly * LS + kLdsPad + xi * 4 : -1;
+                px[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) px[u] = *reinterpret_cast<const uint4*>(src + ((size_t)(h - 1 - gy) * w + (size_t)xi * 4) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (dst[u] >= 0) {
+                    uint2 out;
+                    out.x = pack_half2(luminance_fast(px[u].x), luminance_fast(px[u].y));
+                    out.y = pack_half2(luminance_fast(px[u].z), luminance_fast(px[u].w));
+                    *reinterpret_cast<uint2*>(grey + dst[u]) = out;
+                }
+            }
         }
     } else {
         // f16 mip from HBM; texels outside the level read as 0 (CRD-6) because at octaves >= 1 the
         // reference's guard and dispatch size let pixels near/over the level edge through (Q8).
+        constexpr int U = 4;
         const uint16_t* src = gray_f + pyr.off[lvl];
         const int w8 = (LS - kLdsPad) >> 3;  // 8-texel groups per LDS row
         const float inv_w8 = 1.0f / (float)w8;
         const int n_items = (R + 6) * w8;
         const bool vec_ok = (w & 7) == 0;
-        for (int i = tid; i < n_items; i += NT) {
-            const int ly = (int)(((float)i + 0.5f) * inv_w8);
-            const int xg = i - ly * w8;
-            const int gy = y0 - 3 + ly;
-            const int x = xg * 8;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (gy >= 0 && gy < h) {
-                const uint16_t* row = src + (size_t)gy * w;
-                if (vec_ok && x + 8 <= w) {
-                    v = *reinterpret_cast<const uint4*>(row + x);
-                } else {
-                    uint32_t e[8];
+        for (int ib = tid; ib < n_items; ib += NT * U) {
+            uint4 v[U];
+            int dst[U];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) e[k] = (x + k < w) ? (uint32_t)row[x + k] : 0u;
-                    v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+            for (int u = 0; u < U; u++) {
+                const int i = ib + u * NT;
+                const int ly = (int)(((float)i + 0.5f) * inv_w8);
+                const int xg = i - ly * w8;
+                const int gy = y0 - 3 + ly;
+                const int x = xg * 8;
+                dst[u] = i < n_items ? ly * LS + kLdsPad + x : -1;
+                v[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (i < n_items && gy >= 0 && gy < h) {
+                    const uint16_t* row = src + (size_t)gy * w;
+                    if (vec_ok && x + 8 <= w) {
+                        v[u] = *reinterpret_cast<const uint4*>(row + x);
+                    } else {
+                        uint32_t e[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) e[k] = (x + k < w) ? (uint32_t)row[x + k] : 0u;
+                        v[u] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+                    }
                 }
             }
-            *reinterpret_cast<uint4*>(grey + ly * LS + kLdsPad + x) = v;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (dst[u] >= 0) *reinterpret_cast<uint4*>(grey + dst[u]) = v[u];
         }
     }
     __syncthreads();
 
     // =========================== B1: 4-point pre-test, 8 px per item ===========================
-    {
+    if (geo.phase_mask & 1u) {
         const int g8 = (int)geo.gw >> 3;
         const float inv_g8 = 1.0f / (float)g8;
         const int n_items = R * g8;
@@ -229,8 +270,8 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const uint8_t* __restri
                     queue[slot] = ((uint32_t)lyc << 16) | (uint32_t)(x + k);
                 } else {  // queue full (pathological frame): test in place
                     uint32_t angle;
-                    if (fast_full_test(rowc + k, LS, thr, &angle))
-                        append_one((uint32_t)(x + k), gy, angle, lvl, counts + frame, corners + (size_t)frame * cap, cap);
+                    const bool hit = fast_full_test(rowc + k, LS, thr, &angle);
+                    segment_append(hit, (uint32_t)(x + k), gy, angle, lvl, c_count, seg, geo.seg_cap);
                 }
             }
         }
@@ -238,7 +279,7 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const uint8_t* __restri
     __syncthreads();
 
     // =========================== B2: drain the candidate queue densely ===========================
-    {
+    if (geo.phase_mask & 2u) {
         const uint32_t n_q = min(*q_count, (uint32_t)kFrontQueue);
         for (uint32_t base = (uint32_t)(tid & ~63); base < n_q; base += NT) {  // wave-uniform trip count
             const uint32_t i = base + (uint32_t)(tid & 63);
@@ -251,12 +292,15 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const uint8_t* __restri
                 gy = (uint32_t)(y0 + lyc);
                 is_corner = fast_full_test(grey + (lyc + 3) * LS + kLdsPad + (int)x, LS, thr, &angle);
             }
-            append_corners(is_corner, x, gy, angle, lvl, counts + frame, corners + (size_t)frame * cap, cap);
+            segment_append(is_corner, x, gy, angle, lvl, c_count, seg, geo.seg_cap);
         }
     }
 
+    __syncthreads();
+    if (tid == 0) seg_counts[slot] = *c_count;  // raw count of the band (may exceed seg_cap)
+
     // =========================== C0: next mip level (blit.wgsl, exact 2x2 case) ===========================
-    if (geo.write_mip) {
+    if (geo.write_mip && (geo.phase_mask & 4u)) {
         const int wd = (int)pyr.w[lvl + 1], hd = (int)pyr.h[lvl + 1];
         uint16_t* dst = gray_f + pyr.off[lvl + 1];
         const int g4 = (wd + 3) >> 2;
@@ -292,7 +336,7 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const uint8_t* __restri
     }
 
     // =========================== C: literal blur, both passes ===========================
-    {
+    if (geo.phase_mask & 8u) {
         const int rows = min(R, h - y0);  // band rows that exist in this level
         if (rows > 0) {                   // uniform per block
             // tap 1 (offset -0.4392 in UV units) per column, kept in registers for every row
@@ -365,6 +409,269 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const uint8_t* __restri
                 pass2(k);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6 for the fused pipeline: brief.wgsl:20-68 over the band segments written by k_front.
+// One workgroup = one band slot of one frame, so the keypoints a CU works on share a window of
+// R + 36 blur rows (L1/L2 hits instead of one HBM line per sample), and the final compact lists
+// (orb.rs:159-164 `corners`, 195-199 `descriptors`) are produced here: slot s starts at the sum of
+// the stored counts of the slots before it.  One wave64 per keypoint, lane l owns tests l, 64+l,
+// 128+l, 192+l; four ballots give the eight u32 words (brief.wgsl:47,63,67).
+// ---------------------------------------------------------------------------------------------
+struct BandGeom {
+    uint32_t n_slots, seg_cap, n_frames, xcd_swizzle;
+    uint32_t slot_base[kMaxLevels + 1];  // first slot of each level; [depth] = n_slots
+};
+
+__global__ __launch_bounds__(256) void k_brief_bands(const uint16_t* __restrict__ blur, Pyramid pyr, BandGeom bg,
+                                                     const uint32_t* __restrict__ seg_counts,
+                                                     const CornerData* __restrict__ segments,
+                                                     uint32_t* __restrict__ counts, CornerData* __restrict__ corners,
+                                                     uint32_t cap, CornerDescriptor* __restrict__ descriptors,
+                                                     BriefTables tab) {
+    uint32_t frame, slot;
+    {
+        const uint32_t L = blockIdx.x;
+        if (bg.xcd_swizzle) {
+            const uint32_t xcd = L & 7u, q = L >> 3;
+            frame = (q / bg.n_slots) * 8u + xcd;
+            slot = q % bg.n_slots;
+        } else {
+            frame = L / bg.n_slots;
+            slot = L % bg.n_slots;
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t* sc = seg_counts + (size_t)frame * bg.n_slots;
+
+    // stored keypoints in the slots before this one, and the frame's raw total (orb.rs:550-556)
+    uint32_t before = 0, total = 0;
+    for (uint32_t s0 = 0; s0 < bg.n_slots; s0 += 64u) {
+        const uint32_t s = s0 + lane;
+        const uint32_t raw = s < bg.n_slots ? sc[s] : 0u;
+        total += raw;
+        before += s < slot ? min(raw, bg.seg_cap) : 0u;
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        before += __shfl_xor(before, sh);
+        total += __shfl_xor(total, sh);
+    }
+    if (slot == 0u && threadIdx.x == 0u) counts[frame] = total;
+
+    uint32_t lvl = 0;
+    for (uint32_t m = 1; m < pyr.depth; m++)
+        if (slot >= bg.slot_base[m]) lvl = m;
+    const uint32_t w = pyr.w[lvl], h = pyr.h[lvl];
+    const uint16_t* plane = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
+    const uint32_t n_here = min(sc[slot], bg.seg_cap);
+    const CornerData* seg = segments + ((size_t)frame * bg.n_slots + slot) * bg.seg_cap;
+    CornerData* out_kp = corners + (size_t)frame * cap;
+    uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)frame * cap);
+
+    const uint32_t p0 = tab.pattern[lane], p1 = tab.pattern[64u + lane], p2 = tab.pattern[128u + lane],
+                   p3 = tab.pattern[192u + lane];
+    uint4 next = make_uint4(0u, 0u, 0u, 0u);
+    if (wave < n_here) next = *reinterpret_cast<const uint4*>(&seg[wave]);
+    for (uint32_t j = wave; j < n_here; j += 4u) {
+        const uint32_t k = before + j;
+        if (k >= cap) break;  // frame is full (wave-uniform)
+        const uint4 rec = next;  // x, y, angle, octave
+        if (j + 4u < n_here) next = *reinterpret_cast<const uint4*>(&seg[j + 4u]);
+        const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
+        const float ct = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
+        const int px = (int)rec.x, py = (int)rec.y;
+        const uint64_t b0 = __ballot(brief_test(p0, ct, st, nst, px, py, plane, w, h));
+        const uint64_t b1 = __ballot(brief_test(p1, ct, st, nst, px, py, plane, w, h));
+        const uint64_t b2 = __ballot(brief_test(p2, ct, st, nst, px, py, plane, w, h));
+        const uint64_t b3 = __ballot(brief_test(p3, ct, st, nst, px, py, plane, w, h));
+        if (lane < 8u) {
+            const uint64_t src = lane < 2u ? b0 : (lane < 4u ? b1 : (lane < 6u ? b2 : b3));
+            out_desc[(size_t)k * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
+        } else if (lane == 8u) {
+            *reinterpret_cast<uint4*>(&out_kp[k]) = rec;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6, tiled: brief.wgsl:20-68 with the sampling window staged in LDS.
+//
+// A 64-lane gather of 2-byte texels through the vector memory path costs about one address per
+// cycle, and BRIEF needs 512 of them per keypoint; the same gather from LDS runs at bank speed.
+// So a workgroup owns a tile of kBriefTileH x kBriefTileW keypoint positions of one level of one
+// frame (two k_front bands high), copies the blurred window tile + 18 px halo into LDS once with
+// 16-byte loads (texels outside the level become 0, CRD-6, so the sampling loop needs no bounds
+// checks), picks the tile's keypoints out of the two band segments, and then runs one wave64 per
+// keypoint.  |trunc(R(-theta) p)| <= 18 for every pattern point (max radius 18.38).
+// Output index of a keypoint = stored keypoints in earlier band slots + its index in its band
+// segment, i.e. the final lists are the band segments back to back.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBriefTileH = 2 * kFrontRows;  // 32 rows = two band slots
+constexpr int kBriefTileW = 256;
+constexpr int kBriefHalo = 18;
+constexpr int kBriefPadX = 24;  // halo rounded up to a multiple of 8 texels (16-byte loads)
+constexpr int kBriefWinW = kBriefTileW + 2 * kBriefPadX;  // 304
+constexpr int kBriefWinH = kBriefTileH + 2 * kBriefHalo;  // 68
+constexpr int kBriefList = 256;
+
+struct TileGeom {
+    uint32_t n_slots, seg_cap, n_frames, xcd_swizzle;
+    uint32_t slot_base[kMaxLevels + 1];
+    uint32_t tile_base[kMaxLevels + 1];  // first tile of each level; [depth] = tiles per frame
+    uint32_t tile_cols[kMaxLevels];      // column tiles of each level
+};
+
+__global__ __launch_bounds__(256) void k_brief_tiles(const uint16_t* __restrict__ blur, Pyramid pyr, TileGeom tg,
+                                                     const uint32_t* __restrict__ seg_counts,
+                                                     const CornerData* __restrict__ segments,
+                                                     uint32_t* __restrict__ counts, CornerData* __restrict__ corners,
+                                                     uint32_t cap, CornerDescriptor* __restrict__ descriptors,
+                                                     BriefTables tab) {
+    __shared__ __attribute__((aligned(16))) uint16_t win[kBriefWinH * kBriefWinW];
+    __shared__ uint4 list_rec[kBriefList];   // x, y, angle, octave
+    __shared__ uint32_t list_k[kBriefList];  // output index
+    __shared__ uint32_t list_n;
+
+    const uint32_t tiles_per_frame = tg.tile_base[pyr.depth];
+    uint32_t frame, tile;
+    {
+        const uint32_t L = blockIdx.x;
+        if (tg.xcd_swizzle) {
+            const uint32_t xcd = L & 7u, q = L >> 3;
+            frame = (q / tiles_per_frame) * 8u + xcd;
+            tile = q % tiles_per_frame;
+        } else {
+            frame = L / tiles_per_frame;
+            tile = L % tiles_per_frame;
+        }
+    }
+    uint32_t lvl = 0;
+    for (uint32_t m = 1; m < pyr.depth; m++)
+        if (tile >= tg.tile_base[m]) lvl = m;
+    const uint32_t t_in = tile - tg.tile_base[lvl];
+    const uint32_t ty = t_in / tg.tile_cols[lvl], tx = t_in % tg.tile_cols[lvl];
+    const uint32_t n_bands = tg.slot_base[lvl + 1] - tg.slot_base[lvl];
+    const uint32_t slot_a = tg.slot_base[lvl] + 2u * ty;
+    const bool has_b = 2u * ty + 1u < n_bands;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t* sc = seg_counts + (size_t)frame * tg.n_slots;
+
+    // ---- stored keypoints before slot_a, and the frame's raw total (orb.rs:550-556)
+    uint32_t before = 0, total = 0;
+    for (uint32_t s0 = 0; s0 < tg.n_slots; s0 += 64u) {
+        const uint32_t s = s0 + lane;
+        const uint32_t raw = s < tg.n_slots ? sc[s] : 0u;
+        total += raw;
+        before += s < slot_a ? min(raw, tg.seg_cap) : 0u;
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        before += __shfl_xor(before, sh);
+        total += __shfl_xor(total, sh);
+    }
+    if (tile == 0u && tid == 0u) counts[frame] = total;
+    const uint32_t n_a = min(sc[slot_a], tg.seg_cap);
+    const uint32_t n_b = has_b ? min(sc[slot_a + 1u], tg.seg_cap) : 0u;
+    if (tid == 0u) list_n = 0u;
+    if (n_a + n_b == 0u) return;  // uniform: nothing detected in these two bands
+
+    // ---- stage the window: rows [y0-18, y0+32+18), columns [x0-24, x0+256+24), zero outside the level
+    const int w = (int)pyr.w[lvl], h = (int)pyr.h[lvl];
+    const int x0 = (int)tx * kBriefTileW, y0 = (int)ty * kBriefTileH;
+    const uint16_t* plane = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
+    {
+        constexpr int G = kBriefWinW / 8;  // 16-byte groups per window row
+        constexpr int N = kBriefWinH * G;
+        constexpr int U = 6;
+        const bool vec_ok = (w & 7) == 0;
+        for (int ib = (int)tid; ib < N; ib += 256 * U) {
+            uint4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = ib + u * 256;
+                const int r = i / G, g = i - r * G;
+                const int gy = y0 - kBriefHalo + r, gx = x0 - kBriefPadX + g * 8;
+                v[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (i < N && gy >= 0 && gy < h && gx + 8 > 0 && gx < w) {
+                    const uint16_t* row = plane + (size_t)gy * w;
+                    if (vec_ok && gx >= 0 && gx + 8 <= w) {
+                        v[u] = *reinterpret_cast<const uint4*>(row + gx);
+                    } else {
+                        uint32_t e[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) e[k] = (gx + k >= 0 && gx + k < w) ? (uint32_t)row[gx + k] : 0u;
+                        v[u] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = ib + u * 256;
+                if (i < N) *reinterpret_cast<uint4*>(&win[i * 8]) = v[u];
+            }
+        }
+    }
+
+    const CornerData* seg_a = segments + ((size_t)frame * tg.n_slots + slot_a) * tg.seg_cap;
+    const CornerData* seg_b = seg_a + tg.seg_cap;
+    CornerData* out_kp = corners + (size_t)frame * cap;
+    uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)frame * cap);
+    const uint32_t p0 = tab.pattern[lane], p1 = tab.pattern[64u + lane], p2 = tab.pattern[128u + lane],
+                   p3 = tab.pattern[192u + lane];
+    const uint32_t pats[4] = {p0, p1, p2, p3};
+
+    // ---- rounds of up to 256 segment records: pick this tile's keypoints, then one wave per keypoint
+    const uint32_t n_ab = n_a + n_b;
+    for (uint32_t c0 = 0; c0 < n_ab; c0 += 256u) {
+        __syncthreads();  // window staged / previous round drained
+        const uint32_t j = c0 + tid;
+        if (j < n_ab) {
+            const uint4 rec = *reinterpret_cast<const uint4*>(j < n_a ? &seg_a[j] : &seg_b[j - n_a]);
+            const uint32_t k = before + j;  // segments back to back
+            if (k < cap && rec.x >= (uint32_t)x0 && rec.x < (uint32_t)(x0 + kBriefTileW)) {
+                const uint32_t idx = atomicAdd(&list_n, 1u);
+                list_rec[idx] = rec;
+                list_k[idx] = k;
+            }
+        }
+        __syncthreads();
+        const uint32_t n_l = list_n;
+        for (uint32_t i = wave; i < n_l; i += 4u) {
+            const uint4 rec = list_rec[i];
+            const uint32_t k = list_k[i];
+            const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
+            const float ct = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
+            // keypoint position inside the window
+            const int cx = (int)rec.x - x0 + kBriefPadX, cy = (int)rec.y - y0 + kBriefHalo;
+            const uint16_t* ctr = win + cy * kBriefWinW + cx;
+            uint64_t bal[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t packed = pats[t];
+                const float ax = (float)(int8_t)(packed & 255u), ay = (float)(int8_t)((packed >> 8) & 255u);
+                const float bx = (float)(int8_t)((packed >> 16) & 255u), by = (float)(int8_t)(packed >> 24);
+                // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y)   brief.wgsl:38-54
+                const float a0 = ct * ax, a1 = st * ay, a2 = nst * ax, a3 = ct * ay;
+                const float b0 = ct * bx, b1 = st * by, b2 = nst * bx, b3 = ct * by;
+                const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+                const float va = from_half(bits_half(ctr[(int)ray * kBriefWinW + (int)rax]));  // vec2i() truncates
+                const float vb = from_half(bits_half(ctr[(int)rby * kBriefWinW + (int)rbx]));
+                bal[t] = __ballot(va > vb);  // brief.wgsl:62
+            }
+            if (lane < 8u) {
+                const uint64_t src = lane < 2u ? bal[0] : (lane < 4u ? bal[1] : (lane < 6u ? bal[2] : bal[3]));
+                out_desc[(size_t)k * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
+            } else if (lane == 8u) {
+                *reinterpret_cast<uint4*>(&out_kp[k]) = rec;
+            }
+        }
+        __syncthreads();
+        if (tid == 0u) list_n = 0u;
     }
 }
 
