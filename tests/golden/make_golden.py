@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ from the CPU restatement (oracle/orb_oracle.c),
+cross-checked here against the independent NumPy restatement (oracle/orb_numpy.py).
+
+PARITY UNPINNED: the reference ships no vectors and cannot run in this environment, so these are
+outputs of the BUILD's own oracle (BASELINE.json configs[0] "ground-truth dump through
+the reference wgpu/CPU-adapter path" is replaced by this).  A fixture is data only: generator
+parameters, SHA-256 of the generated RGBA frame and of the intermediate planes, the sorted keypoints
+and their descriptors.
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import orb_numpy, orb_oracle  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+THR = np.float32(20.0 / 255.0)
+# name, W, H, depth, seed, flags
+CASES = [
+    ("g64x48_d2", 64, 48, 2, 3, 15),
+    ("g160x120_d3", 160, 120, 3, 1, 15),
+    ("g200x97_d3_odd", 200, 97, 3, 7, 15),
+    ("g640x480_d2_config1", 640, 480, 2, 1, 7),   # BASELINE.json configs[0]: 640x480 gradient frame (+blobs+wedges)
+    ("g332x202_d5", 332, 202, 5, 11, 15),
+]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    for name, W, H, depth, seed, flags in CASES:
+        rgba = orb_oracle.synth_frame(W, H, seed, flags)
+        assert np.array_equal(rgba, orb_numpy.synth_frame(W, H, seed, flags))
+        ref = orb_oracle.extract(rgba, depth=depth, threshold=THR, max_features=8192, planes=True)
+        alt = orb_numpy.extract(rgba, depth=depth, threshold=THR, max_features=8192)
+        kc = np.stack([ref["corners"][k] for k in ("x", "y", "angle", "octave")], 1)
+        assert ref["total"] == alt["total"] and np.array_equal(kc, alt["corners"])
+        assert np.array_equal(ref["descriptors"], alt["descriptors"])
+        dims, _ = orb_oracle.level_dims(W, H, depth)
+        gray_sha, blur_sha = [], []
+        for m, (w, h, off) in enumerate(dims):
+            g, b = ref["gray"][off:off + w * h], ref["blur"][off:off + w * h]
+            assert np.array_equal(g, alt["gray"][m].ravel()) and np.array_equal(b, alt["blur"][m].ravel())
+            gray_sha.append(sha(g))
+            blur_sha.append(sha(b))
+        corners, desc = orb_oracle.sort_keypoints(ref["corners"], ref["descriptors"])
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            params=np.array([W, H, depth, seed, flags, 8192], dtype=np.int64), threshold=THR,
+            rgba_sha256=sha(rgba), gray_sha256=np.array(gray_sha), blur_sha256=np.array(blur_sha),
+            total=np.int64(ref["total"]),
+            corners=np.stack([corners[k] for k in ("x", "y", "angle", "octave")], 1).astype(np.uint32),
+            descriptors=desc.astype(np.uint32))
+        print(name, "total", ref["total"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+"""N > 1 host logic on CPU: frame sharding and the collate to rank 0, world_size 2 over gloo.
+
+The compute of each rank is stood in for by the oracle (tests may use it); the code under test is
+tinyslam_amd.node -- the same functions bench.py runs over RCCL on the GPUs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, CAP, THR = 96, 64, 256, 20.0 / 255.0
+N_FRAMES, SEED0 = 6, 300
+
+
+def test_shard_range_partitions_contiguously():
+    from tinyslam_amd import node
+    for n, g in [(2048, 8), (256, 1), (10, 4), (3, 8), (7, 2)]:
+        ranges = [node.shard_range(n, g, r) for r in range(g)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        for (a, b), (c, d) in zip(ranges, ranges[1:]):
+            assert b == c and a <= b
+        assert max(b - a for a, b in ranges) - min(b - a for a, b in ranges) <= 1
+    assert [node.shard_range(2048, 8, r) for r in (0, 7)] == [(0, 256), (1792, 2048)]
+
+
+def _frame_result(oracle, seed):
+    r = oracle.extract(oracle.synth_frame(W, H, seed), depth=2, threshold=THR, max_features=CAP)
+    n = len(r["corners"])
+    kp = np.zeros((CAP, 4), dtype=np.int32)
+    ds = np.zeros((CAP, 8), dtype=np.int32)
+    kp[:n] = np.stack([r["corners"][k] for k in ("x", "y", "angle", "octave")], 1).astype(np.int32)
+    ds[:n] = r["descriptors"].view(np.int32)
+    return r["total"], kp, ds
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import orb_oracle
+    from tinyslam_amd import node
+    lo, hi = node.shard_range(N_FRAMES, world, rank)
+    res = [_frame_result(orb_oracle, SEED0 + i) for i in range(lo, hi)]
+    counts = torch.tensor([r[0] for r in res], dtype=torch.int32)
+    corners = torch.from_numpy(np.stack([r[1] for r in res]))
+    desc = torch.from_numpy(np.stack([r[2] for r in res]))
+    out = node.collate_to_root(counts, corners, desc, CAP)
+    if rank == 0:
+        c, k, d = out
+        np.savez(out_path, counts=c.numpy(), corners=k.numpy(), desc=d.numpy())
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collate_world2_equals_single_process(oracle, tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / "collated.npz")
+    mp.spawn(_worker, args=(2, port, out_path), nprocs=2, join=True)
+    got = np.load(out_path)
+    assert got["counts"].shape == (N_FRAMES,)
+    mx = got["corners"].shape[1]
+    for i in range(N_FRAMES):
+        total, kp, ds = _frame_result(oracle, SEED0 + i)
+        assert got["counts"][i] == total
+        n = min(total, CAP)
+        assert n <= mx
+        assert np.array_equal(got["corners"][i, :n], kp[:n])
+        assert np.array_equal(got["desc"][i, :n], ds[:n])
+    assert mx == min(int(got["counts"].max()), CAP)
+
+
+def test_collate_world1_is_a_trim():
+    from tinyslam_amd import node
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    try:
+        counts = torch.tensor([3, 5], dtype=torch.int32)
+        corners = torch.arange(2 * 8 * 4, dtype=torch.int32).reshape(2, 8, 4)
+        desc = torch.arange(2 * 8 * 8, dtype=torch.int32).reshape(2, 8, 8)
+        c, k, d = node.collate_to_root(counts, corners, desc, 8)
+        assert k.shape == (2, 5, 4) and d.shape == (2, 5, 8) and torch.equal(c, counts)
+        assert torch.equal(k, corners[:, :5])
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

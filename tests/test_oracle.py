@@ -1,0 +1,260 @@
+"""CPU tests of the oracle itself (oracle/ is test infrastructure; PARITY UNPINNED).
+
+The reference ships no tests or vectors, so the oracle is pinned by (1) known-answer tests that
+follow from the reference's shader text alone, (2) an independently written NumPy
+restatement, and (3) the committed golden fixtures (regression pins of the build's own oracle).
+"""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orb_numpy
+
+THR = np.float32(20.0 / 255.0)
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _frame_with_squares(W, H, squares, bg=0, fg=255):
+    img = np.full((H, W, 4), bg, dtype=np.uint8)
+    img[..., 3] = 255
+    for (x, y, s) in squares:
+        img[y:y + s, x:x + s, :3] = fg
+    return img
+
+
+# ---------------------------------------------------------------- scalar known answers
+def test_detect_streak_is_fast12(oracle):
+    """fast.wgsl:51-60 == 'exists a circular run of >= 12 set bits' for all 65536 masks (Q4)."""
+    assert oracle.detect_streak_16(0x0FFF) == 0x0001
+    assert oracle.detect_streak_16(0x07FF) == 0
+    assert oracle.detect_streak_16(0xF0FF) == 0x1000
+    assert oracle.detect_streak_16(0xFFFF) == 0xFFFF
+    masks = np.arange(65536, dtype=np.uint32)
+    got = np.array([oracle.detect_streak_16(int(m)) for m in masks]) != 0
+    run12 = np.zeros(65536, dtype=bool)
+    run9 = np.zeros(65536, dtype=bool)
+    dbl = masks | (masks << np.uint32(16))
+    for start in range(16):
+        run12 |= ((dbl >> np.uint32(start)) & np.uint32(0xFFF)) == 0xFFF
+        run9 |= ((dbl >> np.uint32(start)) & np.uint32(0x1FF)) == 0x1FF
+    assert np.array_equal(got, run12)
+    assert int((got != run9).sum()) == 896  # it is NOT FAST-9
+    assert np.array_equal(orb_numpy._streak12(masks) != 0, run12)
+
+
+def test_pattern_fingerprint():
+    """BRIEF pattern == the reference table (brief.wgsl:70-327), pinned by SURVEY.md 8a."""
+    p = orb_numpy.PATTERN
+    assert p.shape == (256, 4)
+    assert p[0].tolist() == [8, -3, 9, 5] and p[-1].tolist() == [-1, -6, 0, -11]
+    assert p.min() == -13 and p.max() == 12 and int(p.sum()) == -406
+    assert _sha(p.astype(np.int8)) == "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+    # the product's copy of the table is the same data
+    import re
+    text = open(os.path.join(os.path.dirname(__file__), "..", "tinyslam_amd", "csrc", "orb_tables.h")).read()
+    body = text[text.index("ORB_BRIEF_PATTERN[1024]"):]
+    body = body[body.index("{") + 1:body.index("}")]
+    vals = np.array([int(v) for v in re.findall(r"-?\d+", body)], dtype=np.int8)
+    assert np.array_equal(vals.reshape(256, 4), p)
+
+
+def test_trig_table_matches_libm_and_numpy(oracle):
+    """CRD-10: the committed cos/sin table == double libm rounded to binary32, for all 3142 codes."""
+    import re
+    text = open(os.path.join(os.path.dirname(__file__), "..", "tinyslam_amd", "csrc", "orb_tables.h")).read()
+
+    def table(name):
+        body = text[text.index(name + "["):]
+        body = body[body.index("{") + 1:body.index("}")]
+        return np.array([int(v, 16) for v in re.findall(r"0x[0-9a-f]{8}", body)], dtype=np.uint32).view(np.float32)
+    cos_t, sin_t = table("ORB_COS_BITS"), table("ORB_SIN_BITS")
+    assert cos_t.size == 3142 and sin_t.size == 3142
+    theta = np.arange(3142, dtype=np.float32) / np.float32(1000.0)
+    assert np.array_equal(cos_t, np.cos(theta.astype(np.float64)).astype(np.float32))
+    assert np.array_equal(sin_t, np.sin(theta.astype(np.float64)).astype(np.float32))
+
+
+def test_f16_conversion_matches_numpy(oracle):
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([
+        rng.integers(0, 2**32, 20000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+        rng.random(20000, dtype=np.float32),
+        (rng.random(5000, dtype=np.float32) * np.float32(2.0**-14)),
+        np.array([0x33000000, 0x33000001, 0x387fc000, 0x38800000, 0x477fe000, 0x477ff000, 0x3f801000, 0x3f803000],
+                 dtype=np.uint32).view(np.float32)])
+    vals = vals[~np.isnan(vals)]
+    with np.errstate(over="ignore"):
+        want = vals.astype(np.float16).view(np.uint16)
+    got = np.array([oracle.f32_to_f16(v) for v in vals], dtype=np.uint16)
+    assert np.array_equal(got, want)
+    halves = np.arange(0, 0x7c00, 7, dtype=np.uint16)
+    back = np.array([oracle.f16_to_f32(int(h)) for h in halves], dtype=np.float32)
+    assert np.array_equal(back, halves.view(np.float16).astype(np.float32))
+
+
+def test_unorm8_is_ieee_division(oracle):
+    for b in range(256):
+        assert oracle.unorm8(b) == np.float32(b) / np.float32(255.0)
+
+
+def test_atan2_against_libm(oracle):
+    """CRD-9: canonical atan2 vs libm: milliradian code differs by at most 1, and only next to an integer."""
+    rng = np.random.default_rng(2)
+    cy = (rng.random(20000, dtype=np.float32) * 30).astype(np.float32)
+    cx = (rng.random(20000, dtype=np.float32) * 60 - 30).astype(np.float32)
+    mine = orb_numpy.atan2f(cy, cx)
+    libm = np.arctan2(cy.astype(np.float64), cx.astype(np.float64))
+    assert np.abs(mine.astype(np.float64) - libm).max() < 5e-7
+    code = np.trunc(mine * np.float32(1000.0)).astype(np.int64)
+    code_libm = np.trunc(libm * 1000.0).astype(np.int64)
+    diff = np.abs(code - code_libm)
+    assert diff.max() <= 1
+    near = np.abs(libm * 1000.0 - np.round(libm * 1000.0)) < 1e-3
+    assert np.all(near[diff == 1])
+    # C and NumPy restatements agree exactly
+    idx = rng.integers(0, cy.size, 3000)
+    assert [oracle.angle_code(cy[i], cx[i]) for i in idx] == \
+        np.where((cy[idx] < 0) | (mine[idx] < 0), 0, code[idx]).tolist()
+    assert oracle.angle_code(0.0, 0.0) == 0            # atan2(0,0) = 0
+    assert oracle.angle_code(-1.0, 1.0) == 0           # negative angles saturate to 0 (Q7)
+    assert oracle.angle_code(0.0, -1.0) == 3141        # pi -> 3141
+    assert oracle.angle_code(1.0, 0.0) == 1570
+
+
+# ---------------------------------------------------------------- whole-pipeline known answers
+def test_flat_image_has_no_corners(oracle):
+    img = np.full((96, 128, 4), 77, dtype=np.uint8)
+    r = oracle.extract(img, depth=2, threshold=THR)
+    assert r["total"] == 0 and len(r["corners"]) == 0
+
+
+@pytest.mark.parametrize("side,expected", [(1, 1), (2, 4), (3, 9), (4, 12), (5, 0), (6, 0)])
+def test_bright_square_corner_counts(oracle, side, expected):
+    """SURVEY.md 8c KAT 4: FAST-12 on an isolated bright s x s square (octave 0 only)."""
+    img = _frame_with_squares(128, 96, [(60, 40, side)])
+    r = oracle.extract(img, depth=1, threshold=THR)
+    assert r["total"] == expected
+    if side <= 3 and expected:
+        ys = 96 - 1 - r["corners"]["y"].astype(int)   # keypoints live in the flipped frame (Q2)
+        assert set(zip(r["corners"]["x"].tolist(), ys.tolist())) == \
+            {(60 + i, 40 + j) for i in range(side) for j in range(side)}
+
+
+def test_straight_edge_has_no_corners(oracle):
+    img = np.zeros((96, 128, 4), dtype=np.uint8)
+    img[:, 64:, :3] = 255
+    img[..., 3] = 255
+    assert oracle.extract(img, depth=1, threshold=THR)["total"] == 0
+
+
+def test_vertical_flip_of_input(oracle):
+    """KAT 6: flipping the input vertically maps keypoint rows y <-> H-1-y."""
+    rgba = oracle.synth_frame(160, 120, 5)
+    a = oracle.extract(rgba, depth=1, threshold=THR)
+    b = oracle.extract(rgba[::-1].copy(), depth=1, threshold=THR)
+    ka = {(int(c["x"]), int(c["y"])) for c in a["corners"]}
+    kb = {(int(c["x"]), 119 - int(c["y"])) for c in b["corners"]}
+    # the flipped frame sees the mirrored ring, so only the detection SET is compared (angles differ)
+    assert ka == kb and len(ka) > 10
+
+
+def test_depth1_is_octave0_subset(oracle):
+    """KAT 8: D = 1 output == the octave-0 records of the D = 2 output."""
+    rgba = oracle.synth_frame(200, 150, 8)
+    d1 = oracle.extract(rgba, depth=1, threshold=THR)
+    d2 = oracle.extract(rgba, depth=2, threshold=THR)
+    sel = d2["corners"]["octave"] == 0
+    assert np.array_equal(d1["corners"], d2["corners"][sel])
+    assert np.array_equal(d1["descriptors"], d2["descriptors"][sel])
+    assert (~sel).sum() > 0
+
+
+def test_angle_zero_descriptor_is_unrotated_pattern(oracle):
+    """KAT 5: a keypoint with angle code 0 samples the raw pattern offsets."""
+    rgba = oracle.synth_frame(160, 120, 4)
+    r = oracle.extract(rgba, depth=1, threshold=THR, planes=True)
+    blur = r["blur"][:160 * 120].reshape(120, 160).view(np.float16).astype(np.float32)
+    zero = np.nonzero(r["corners"]["angle"] == 0)[0]
+    assert zero.size > 0
+    p = orb_numpy.PATTERN
+    for i in zero[:20]:
+        x, y = int(r["corners"]["x"][i]), int(r["corners"]["y"][i])
+        bits = blur[y + p[:, 1], x + p[:, 0]] > blur[y + p[:, 3], x + p[:, 2]]
+        words = np.packbits(bits.reshape(8, 32), axis=1, bitorder="little").view(np.uint32).ravel()
+        assert np.array_equal(words, r["descriptors"][i])
+
+
+def test_blur_of_constant_and_row_locality(oracle):
+    """KAT 7 + Q11-Q13: blur is row-local; two passes = pass(pass(row)) with both flips cancelling."""
+    const = np.full((8, 64), oracle.f32_to_f16(0.5), dtype=np.uint16)
+    out = oracle.blur_pass(oracle.blur_pass(const))
+    assert np.all(np.abs(out.view(np.float16).astype(np.float32) - 0.5) < 2e-3)
+    rng = np.random.default_rng(3)
+    img = rng.random((10, 96), dtype=np.float32).astype(np.float16).view(np.uint16)
+    two = oracle.blur_pass(oracle.blur_pass(img))
+    for y in range(10):
+        solo = oracle.blur_pass(oracle.blur_pass(img[y:y + 1]))
+        assert np.array_equal(two[y], solo[0])
+    one = oracle.blur_pass(img)   # a single pass is vertically flipped w.r.t. its input
+    assert np.array_equal(one[0], oracle.blur_pass(img[9:10])[0])
+
+
+def test_mip_even_is_2x2_mean_and_odd_is_bilinear(oracle):
+    rng = np.random.default_rng(4)
+    src = rng.random((6, 10), dtype=np.float32).astype(np.float16)
+    got = oracle.mip(src.view(np.uint16)).view(np.float16).astype(np.float32)
+    s = src.astype(np.float32)
+    want = (((s[0::2, 0::2] + s[0::2, 1::2]) + (s[1::2, 0::2] + s[1::2, 1::2])) * np.float32(0.25)).astype(np.float16)
+    assert np.array_equal(got, want.astype(np.float32))
+    odd = rng.random((7, 11), dtype=np.float32).astype(np.float16).view(np.uint16)
+    assert np.array_equal(oracle.mip(odd), orb_numpy.mip(odd))
+    assert oracle.mip(odd).shape == (3, 5)
+
+
+# ---------------------------------------------------------------- cross-checks and fixtures
+@pytest.mark.parametrize("W,H,depth,seed", [(96, 80, 2, 21), (130, 75, 3, 22), (72, 200, 4, 23)])
+def test_c_and_numpy_restatements_agree(oracle, W, H, depth, seed):
+    rgba = oracle.synth_frame(W, H, seed)
+    assert np.array_equal(rgba, orb_numpy.synth_frame(W, H, seed))
+    a = oracle.extract(rgba, depth=depth, threshold=THR, planes=True)
+    b = orb_numpy.extract(rgba, depth=depth, threshold=THR)
+    dims, _ = oracle.level_dims(W, H, depth)
+    for m, (w, h, off) in enumerate(dims):
+        assert np.array_equal(a["gray"][off:off + w * h], b["gray"][m].ravel())
+        assert np.array_equal(a["blur"][off:off + w * h], b["blur"][m].ravel())
+    ka = np.stack([a["corners"][k] for k in ("x", "y", "angle", "octave")], 1)
+    assert a["total"] == b["total"] and np.array_equal(ka, b["corners"])
+    assert np.array_equal(a["descriptors"], b["descriptors"])
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_golden_fixture(oracle, path):
+    g = np.load(path)
+    W, H, depth, seed, flags, cap = (int(v) for v in g["params"])
+    rgba = oracle.synth_frame(W, H, seed, flags)
+    assert _sha(rgba) == str(g["rgba_sha256"])
+    r = oracle.extract(rgba, depth=depth, threshold=g["threshold"], max_features=cap, planes=True)
+    assert r["total"] == int(g["total"])
+    dims, _ = oracle.level_dims(W, H, depth)
+    for m, (w, h, off) in enumerate(dims):
+        assert _sha(r["gray"][off:off + w * h]) == str(g["gray_sha256"][m])
+        assert _sha(r["blur"][off:off + w * h]) == str(g["blur_sha256"][m])
+    c, d = oracle.sort_keypoints(r["corners"], r["descriptors"])
+    assert np.array_equal(np.stack([c[k] for k in ("x", "y", "angle", "octave")], 1), g["corners"])
+    assert np.array_equal(d, g["descriptors"])
+
+
+def test_batch_threads_equal_serial(oracle):
+    frames = np.stack([oracle.synth_frame(96, 64, 50 + i) for i in range(5)])
+    t1, c1, d1 = oracle.extract_batch(frames, depth=2, threshold=THR, max_features=512, n_threads=1)
+    t4, c4, d4 = oracle.extract_batch(frames, depth=2, threshold=THR, max_features=512, n_threads=4)
+    assert np.array_equal(t1, t4) and np.array_equal(c1, c4) and np.array_equal(d1, d4)
+    one = oracle.extract(frames[3], depth=2, threshold=THR, max_features=512)
+    assert one["total"] == t1[3] and np.array_equal(one["corners"], c1[3][:one["total"]])

@@ -3,7 +3,7 @@
     python -m tinyslam_amd.build [--force]
 
 -ffp-contract=off is part of the contract, not an optimisation choice: the kernels must round
-every binary32 product and sum on its own to stay bit-identical with the CPU oracle.
+every binary32 product and sum on its own to stay bit-identical with the CPU restatement the tests check against.
 """
 import os
 import shutil

@@ -112,7 +112,7 @@ __device__ __forceinline__ BlurTap blur_tap(uint32_t x, uint32_t w, float off) {
     return t;
 }
 
-// Synthetic-frame hash; must match the recipe in the oracle byte for byte.
+// Synthetic-frame hash; byte-identical to the recipe the tests hold (checked on the GPU).
 __device__ __forceinline__ uint32_t mix32(uint32_t a) {
     a ^= a >> 16;
     a *= 0x7feb352dU;

@@ -161,7 +161,13 @@ class OrbProgram:
     def __init__(self, config: OrbConfig):
         self.config = config
         self._h = None
-        self._lib = None
+        self._lib_obj = None
+
+    @property
+    def _lib(self):
+        if self._lib_obj is None:
+            raise OrbError(ORB_ESTATE, "OrbProgram.init() has not been called")
+        return self._lib_obj
 
     # ---- lifetime -------------------------------------------------------------------------
     def init(self):
@@ -174,7 +180,7 @@ class OrbProgram:
         rc = L.orb_program_create(ctypes.byref(cfg), ctypes.byref(opt), ctypes.byref(h))
         if rc != ORB_OK:
             raise OrbError(rc, (L.orb_last_error(None) or b"").decode())
-        self._h, self._lib = h, L
+        self._h, self._lib_obj = h, L
         return self
 
     def close(self):
