@@ -39,6 +39,7 @@ def cpu_baseline(n_sample):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
+    cores = min(cores, 16)  # the CPU share of a one-GPU box
     frames = np.stack([orb_oracle.synth_frame(W, H, SEED0 + i) for i in range(n_sample)])
     t0 = time.perf_counter()
     totals, _, _ = orb_oracle.extract_batch(frames, depth=DEPTH, threshold=THRESHOLD, max_features=MAX_FEATURES,

@@ -131,3 +131,131 @@ def test_capacity_overflow_reports_raw_count(tinyorb, oracle):
                 for c, d in zip(ref["corners"], ref["descriptors"])}
         for c, d in zip(corners, desc):
             assert full[(int(c["octave"]), int(c["y"]), int(c["x"]))] == (int(c["angle"]), d.tobytes())
+
+
+# ---------------------------------------------------------------------------------------------
+# committed golden fixtures, straight against the GPU (no oracle code runs in this test)
+# ---------------------------------------------------------------------------------------------
+import glob
+import hashlib
+import os
+
+_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", _GOLDEN, ids=[os.path.basename(p) for p in _GOLDEN])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_golden_fixture_on_gpu(tinyorb, path, flags):
+    g = np.load(path)
+    W, H, depth, seed, syn_flags, cap = (int(v) for v in g["params"])
+    with _program(tinyorb, W, H, depth, max_features=cap, flags=flags, thr=float(g["threshold"])) as prog:
+        dev = prog.synth_frames_device(1, seed, syn_flags)
+        rgba = prog.copy_to_host(dev, W * H * 4)
+        assert hashlib.sha256(rgba.tobytes()).hexdigest() == str(g["rgba_sha256"])
+        prog.extract_batch_device(dev, 1)
+        total = int(prog.batch_counts(1)[0])
+        assert total == int(g["total"])
+        corners, desc = prog.batch_read(0, total)
+        c, d = _sorted(corners, desc)
+        assert np.array_equal(np.stack([c[k] for k in ("x", "y", "angle", "octave")], 1), g["corners"])
+        assert np.array_equal(d, g["descriptors"])
+        for m in range(depth):
+            b = prog.read_plane(tinyorb.ORB_PLANE_BLUR, m)
+            assert hashlib.sha256(b.tobytes()).hexdigest() == str(g["blur_sha256"][m])
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full size (256 x 1280x720): size-independent properties + spot checks
+# ---------------------------------------------------------------------------------------------
+def test_full_size_batch_properties(tinyorb, oracle):
+    W, H, B, cap = 1280, 720, 256, 8192
+    with _program(tinyorb, W, H, 2, max_features=cap, max_batch=B) as fused, \
+            _program(tinyorb, W, H, 2, max_features=cap, max_batch=8, flags=tinyorb.ORB_FLAG_STAGED) as staged:
+        assert fused.pipeline() == "fused" and staged.pipeline() == "staged"
+        dev = fused.synth_frames_device(B // 2, 1000)
+        # second half of the batch = the same 128 frames again: duplicates must give identical results
+        fused.synth_frames_device(B // 2, 1000, frames_dev_ptr=dev + (B // 2) * W * H * 4)
+        fused.extract_batch_device(dev, B)
+        counts = fused.batch_counts(B)
+        assert np.array_equal(counts[:B // 2], counts[B // 2:])
+        assert counts.min() > 1000 and counts.max() <= cap
+        p = None
+        for i in (0, 1, 77, 127):
+            ca, da = _sorted(*fused.batch_read(i, int(counts[i])))
+            cb, db = _sorted(*fused.batch_read(i + B // 2, int(counts[i])))
+            assert np.array_equal(ca, cb) and np.array_equal(da, db)
+            # structural invariants of the reference's detector (fast.wgsl:77, orb.rs:509-519)
+            assert np.all(ca["octave"] < 2)
+            assert np.all((ca["x"] > 16) & (ca["y"] > 16) & (ca["x"] < W - 16) & (ca["y"] < H - 16))
+            lvl1 = ca["octave"] == 1
+            assert np.all(ca["x"][lvl1] < 640) and np.all(ca["y"][lvl1] < 360)
+            assert np.all(ca["angle"] <= 3141)
+            keys = np.stack([ca["octave"], ca["y"], ca["x"]], 1)
+            assert len(np.unique(keys, axis=0)) == len(keys)
+            # idempotence: the staged pipeline on the same device-resident frame gives the same answer
+            if i < 2:
+                staged.extract_batch_device(dev + i * W * H * 4, 1)
+                n = int(staged.batch_counts(1)[0])
+                cs, ds = _sorted(*staged.batch_read(0, n))
+                assert n == counts[i] and np.array_equal(cs, ca) and np.array_equal(ds, da)
+        # a second run over the same input reproduces every count (no state leaks between batches)
+        fused.extract_batch_device(dev, B)
+        assert np.array_equal(fused.batch_counts(B), counts)
+        # spot check against the oracle at full size
+        for i in (5, 200):
+            frame = fused.copy_to_host(dev + i * W * H * 4, W * H * 4).reshape(H, W, 4)
+            ref = oracle.extract(frame, depth=2, threshold=THR, max_features=cap)
+            corners, desc = fused.batch_read(i, int(counts[i]))
+            _assert_frame_equal(oracle, ref, int(counts[i]), corners, desc)
+
+
+def test_threshold_and_reuse(tinyorb, oracle):
+    """set_threshold (orb.rs:585) takes effect on the next extract; a program is reusable across frames."""
+    W, H = 320, 240
+    a, b = oracle.synth_frame(W, H, 31), oracle.synth_frame(W, H, 32)
+    with _program(tinyorb, W, H, 2) as prog:
+        for rgba, thr in [(a, THR), (b, THR), (a, 0.04), (a, 0.2), (b, 0.0)]:
+            prog.set_threshold(thr)
+            total, corners, desc = prog.extract(rgba)
+            ref = oracle.extract(rgba, depth=2, threshold=thr, max_features=8192)
+            assert total == ref["total"]
+            if total <= 8192:
+                _assert_frame_equal(oracle, ref, total, corners, desc)
+
+
+def test_pathological_dense_frame(tinyorb, oracle):
+    """Salt-and-pepper noise: far more pre-test survivors than the LDS queue holds, and more corners
+    than max_features -> exercises the queue-overflow path and the capacity clamp."""
+    rng = np.random.default_rng(12)
+    W, H = 256, 128
+    rgba = np.zeros((H, W, 4), dtype=np.uint8)
+    rgba[..., :3] = (rng.random((H, W, 1)) < 0.08) * 255
+    rgba[..., 3] = 255
+    ref = oracle.extract(rgba, depth=2, threshold=THR, max_features=1 << 16)
+    assert ref["total"] > 1500
+    with _program(tinyorb, W, H, 2, max_features=1 << 16) as prog:
+        total, corners, desc = prog.extract(rgba)
+        _assert_frame_equal(oracle, ref, total, corners, desc)
+    with _program(tinyorb, W, H, 2, max_features=1000) as prog:
+        total, corners, desc = prog.extract(rgba)
+        assert total == ref["total"] and len(corners) == 1000
+        full = {(int(c["octave"]), int(c["y"]), int(c["x"])): (int(c["angle"]), d.tobytes())
+                for c, d in zip(ref["corners"], ref["descriptors"])}
+        seen = set()
+        for c, d in zip(corners, desc):
+            key = (int(c["octave"]), int(c["y"]), int(c["x"]))
+            assert full[key] == (int(c["angle"]), d.tobytes()) and key not in seen
+            seen.add(key)
+
+
+def test_host_batch_and_single_frame_api_agree(tinyorb, oracle):
+    W, H, B = 320, 240, 4
+    frames = np.stack([oracle.synth_frame(W, H, 60 + i) for i in range(B)])
+    with _program(tinyorb, W, H, 2, max_batch=B) as prog:
+        prog.extract_batch_host(frames)
+        counts = prog.batch_counts(B)
+        batch = [_sorted(*prog.batch_read(i, int(counts[i]))) for i in range(B)]
+        for i in range(B):
+            total, corners, desc = prog.extract(frames[i])
+            c, d = _sorted(corners, desc)
+            assert total == counts[i] and np.array_equal(c, batch[i][0]) and np.array_equal(d, batch[i][1])
