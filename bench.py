@@ -154,7 +154,7 @@ def main():
             "metric": "ORB extract throughput, 1280x720 (frames/sec; Mkeypoints/sec alongside)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 arithmetic on f16 (R16Float) planes, u32 keypoints/descriptors",
+            "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (gradient+blobs+wedges+noise, seeds %d.., generated on device)" % SEED0,
             "config": {"workload": "BASELINE.json configs[3]: batch of %d independent 1280x720 RGBA frames per GPU, "
                                    "device-resident, full ORB (FAST-12 + orientation + blur + BRIEF-256)" % B,
@@ -168,7 +168,7 @@ def main():
             "roofline": roofline,
         }
         if world == 1:
-            n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 64
+            n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 128
             if n_cpu > 0:
                 out["cpu_baseline"] = cpu_baseline(n_cpu)
         print(json.dumps(out), flush=True)
