@@ -50,6 +50,9 @@ __host__ __device__ inline uint32_t front_lds_bytes(const FrontGeom& g) {
     return ((kFrontRows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + (kFrontQueue + 4) * 4u;  // queue + q_count + c_count
 }
 
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ushort2_t as_u16x2(uint32_t v) { return __builtin_bit_cast(ushort2_t, v); }
+
 __device__ __forceinline__ float h2f(uint32_t packed, int hi) {
     return from_half(bits_half((uint16_t)(hi ? (packed >> 16) : (packed & 0xffffu))));
 }
@@ -244,23 +247,33 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const uint8_t* __restri
             const uint2 qc = *reinterpret_cast<const uint2*>(rowc + 8);
             const uint4 qu = *reinterpret_cast<const uint4*>(rowc - 3 * LS);
             const uint4 qd = *reinterpret_cast<const uint4*>(rowc + 3 * LS);
-            // ctr[k] = grey(x - 3 + k), k = 0..13
-            const float ctr[14] = {h2f(qa.x, 1), h2f(qa.y, 0), h2f(qa.y, 1), h2f(qb.x, 0), h2f(qb.x, 1),
-                                   h2f(qb.y, 0), h2f(qb.y, 1), h2f(qb.z, 0), h2f(qb.z, 1), h2f(qb.w, 0),
-                                   h2f(qb.w, 1), h2f(qc.x, 0), h2f(qc.x, 1), h2f(qc.y, 0)};
-            const float up[8] = {h2f(qu.x, 0), h2f(qu.x, 1), h2f(qu.y, 0), h2f(qu.y, 1),
-                                 h2f(qu.z, 0), h2f(qu.z, 1), h2f(qu.w, 0), h2f(qu.w, 1)};
-            const float dn[8] = {h2f(qd.x, 0), h2f(qd.x, 1), h2f(qd.y, 0), h2f(qd.y, 1),
-                                 h2f(qd.z, 0), h2f(qd.z, 1), h2f(qd.w, 0), h2f(qd.w, 1)};
+            // "At least 3 of the 4 compass diffs exceed thr" (fast.wgsl:85-95) <=> the 2nd smallest of the four
+            // neighbour values, minus the centre, exceeds thr (v -> fl(v - c) is monotone); likewise the
+            // 2nd largest for the "under" case.  Grey values are non-negative f16, so their bit patterns
+            // order like the values and the selection network runs on packed u16 pairs (2 pixels per op).
+            const uint32_t dw[8] = {qa.x, qa.y, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};  // dw[j] = grey(x-4+2j, x-3+2j)
+            const uint32_t upw[4] = {qu.x, qu.y, qu.z, qu.w}, dnw[4] = {qd.x, qd.y, qd.z, qd.w};
             uint32_t cand = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const float c = ctr[k + 3];
-                const float d0 = ctr[k + 6] - c, d1 = ctr[k] - c, d2 = dn[k] - c, d3 = up[k] - c;  // fast.wgsl:25-30
-                const int n_over = (d0 > thr) + (d1 > thr) + (d2 > thr) + (d3 > thr);
-                const int n_under = (d0 < -thr) + (d1 < -thr) + (d2 < -thr) + (d3 < -thr);
-                const uint32_t gx = (uint32_t)(x + k);
-                if ((n_over >= 3 || n_under >= 3) && gx > 16u && gx < lim_x) cand |= 1u << k;
+            for (int j = 0; j < 4; j++) {  // pixel pair (x+2j, x+2j+1)
+                const ushort2_t left = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 1], dw[j], 16));       // x+2j-3, x+2j-2
+                const ushort2_t right = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 4], dw[j + 3], 16));  // x+2j+3, x+2j+4
+                const ushort2_t upp = as_u16x2(upw[j]), dwn = as_u16x2(dnw[j]);
+                const ushort2_t lo1 = __builtin_elementwise_min(left, right), hi1 = __builtin_elementwise_max(left, right);
+                const ushort2_t lo2 = __builtin_elementwise_min(upp, dwn), hi2 = __builtin_elementwise_max(upp, dwn);
+                const ushort2_t m1 = __builtin_elementwise_max(lo1, lo2), m2 = __builtin_elementwise_min(hi1, hi2);
+                const ushort2_t second_lo = __builtin_elementwise_min(m1, m2), second_hi = __builtin_elementwise_max(m1, m2);
+                const uint32_t cw = dw[j + 2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const float c = h2f(cw, e);
+                    const float d_lo = from_half(bits_half(second_lo[e])) - c;  // CRD-7: one f32 subtraction
+                    const float d_hi = from_half(bits_half(second_hi[e])) - c;
+                    const uint32_t gx = (uint32_t)(x + 2 * j + e);
+                    const uint32_t hit = (uint32_t)(d_lo > thr) | (uint32_t)(d_hi < -thr);  // branch-free on purpose
+                    const uint32_t ok = (uint32_t)(gx > 16u) & (uint32_t)(gx < lim_x);
+                    cand |= (hit & ok) << (2 * j + e);
+                }
             }
             while (cand) {
                 const int k = __builtin_ctz(cand);
