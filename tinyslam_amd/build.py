@@ -18,6 +18,9 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-Wall", "-Wno-unused-function",
+    # wave-aggregate LDS/global atomic adds of lane-varying amounts with a DPP scan; the default
+    # ("Iterative") serialises over the active lanes with a scalar loop of ~8 instructions per lane
+    "-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP",
 ]
 
 

@@ -211,7 +211,8 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
 bool fused_eligible(const OrbProgram* p) {
     if (p->opt.flags & ORB_FLAG_STAGED) return false;
     const Pyramid& pyr = p->pyr;
-    if ((pyr.w[0] & 3u) != 0u || pyr.w[0] > (uint32_t)(kFrontMaxCols * kFrontThreads) || pyr.w[0] < 8u) return false;
+    if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 22)) return false;  // 24-bit index products in k_front
+    if ((pyr.w[0] & 3u) != 0u || pyr.w[0] > (uint32_t)(kFrontMaxCols * 512) || pyr.w[0] < 8u) return false;
     if (pyr.depth > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) return false;
     return true;
 }
@@ -270,11 +271,11 @@ int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
         const dim3 grid(g.n_bands * n);
         if (lvl == 0) {
             LaunchScope ls(p, s, KID_FUSED_L0);
-            hipLaunchKernelGGL(k_front<true>, grid, dim3(kFrontThreads), lds, s, frames, p->frame_bytes, p->d_gray,
+            hipLaunchKernelGGL(k_front<true>, grid, dim3(kFrontThreadsL0), lds, s, frames, p->frame_bytes, p->d_gray,
                                p->d_blur, pyr, g, p->threshold, p->d_seg_counts, p->d_seg);
         } else {
             LaunchScope ls(p, s, KID_FUSED_LN);
-            hipLaunchKernelGGL(k_front<false>, grid, dim3(kFrontThreads), lds, s, frames, p->frame_bytes, p->d_gray,
+            hipLaunchKernelGGL(k_front<false>, grid, dim3(kFrontThreadsLN), lds, s, frames, p->frame_bytes, p->d_gray,
                                p->d_blur, pyr, g, p->threshold, p->d_seg_counts, p->d_seg);
         }
     }

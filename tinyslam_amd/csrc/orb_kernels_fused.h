@@ -24,11 +24,12 @@
 
 namespace orb {
 
-constexpr int kFrontThreads = 512;
+constexpr int kFrontThreadsL0 = 1024;  // level 0: 16 waves per band, two bands per CU -> 8 waves/SIMD
+constexpr int kFrontThreadsLN = 512;
 constexpr int kFrontRows = 16;       // R: band height (even)
 constexpr int kFrontTmpRows = 2;     // rows per blur chunk (double buffered)
-constexpr int kFrontQueue = 2048;    // candidate queue entries
-constexpr int kFrontMaxCols = 4;     // blur columns per thread -> level width <= 4 * kFrontThreads
+constexpr int kFrontQueue = 4096;    // pre-test survivor queue, 16-bit entries
+constexpr int kFrontMaxCols = 4;     // blur columns per thread -> level width <= 4 * 512 = 2 * 1024
 constexpr int kLdsPad = 8;           // halfs of padding left of column 0
 
 struct FrontGeom {
@@ -47,10 +48,13 @@ struct FrontGeom {
 };
 
 __host__ __device__ inline uint32_t front_lds_bytes(const FrontGeom& g) {
-    return ((kFrontRows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + (kFrontQueue + 4) * 4u;  // queue + q_count + c_count
+    // grey rows + blur intermediate + queue A + 4 counters + blur row constants (16 + 4 float4)
+    return ((kFrontRows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + kFrontQueue * 2u + 16u + 20u * 16u;
 }
 
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ushort2_t as_u16x2(uint32_t v) { return __builtin_bit_cast(ushort2_t, v); }
 
 __device__ __forceinline__ float h2f(uint32_t packed, int hi) {
@@ -78,26 +82,52 @@ __device__ __forceinline__ uint32_t pack_half2(float lo, float hi) {
     return (uint32_t)half_bits(to_half(lo)) | ((uint32_t)half_bits(to_half(hi)) << 16);
 }
 
-// Full FAST test of one pre-test survivor; `ctr` points at the pixel inside the LDS grey rows.
-__device__ __forceinline__ bool fast_full_test(const half_t* ctr, int ls, float thr, uint32_t* angle) {
+// ---- FAST on one pixel; `ctr` points at it inside the LDS grey rows (row stride `ls` halfs) ----
+// 16-point masks (fast.wgsl:102-113).  thr >= 0, so `diff > thr` and `diff < -thr` exclude each other
+// and the reference's else-if needs no special handling.
+__device__ __forceinline__ bool ring_is_corner(const half_t* ctr, int ls, float thr) {
     const float c = from_half(ctr[0]);
     uint32_t m_over = 0, m_under = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float diff = from_half(ctr[kRingDy[i] * ls + kRingDx[i]]) - c;  // CRD-7
+        m_over |= (diff > thr) ? (1u << i) : 0u;
+        m_under |= (diff < -thr) ? (1u << i) : 0u;
+    }
+    return (detect_streak_16(m_over) | detect_streak_16(m_under)) != 0u;  // fast.wgsl:117-121
+}
+// ring centroid -> milliradian code (fast.wgsl:106,115,153; CRD-8: ring order, unfused)
+__device__ __forceinline__ uint32_t ring_angle(const half_t* ctr, int ls) {
     float cx = 0.0f, cy = 0.0f;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const float v = from_half(ctr[kRingDy[i] * ls + kRingDx[i]]);
-        const float diff = v - c;
         const float px = v * (float)kRingDx[i];
         const float py = v * (float)kRingDy[i];
-        cx = cx + px;  // CRD-8: ring order, unfused
+        cx = cx + px;
         cy = cy + py;
-        // thr >= 0, so `diff > thr` and `diff < -thr` exclude each other (fast.wgsl:108-112's else-if)
-        m_over |= (diff > thr) ? (1u << i) : 0u;
-        m_under |= (diff < -thr) ? (1u << i) : 0u;
     }
-    if ((detect_streak_16(m_over) | detect_streak_16(m_under)) == 0u) return false;
-    *angle = angle_code(cy, cx);
+    return angle_code(cy, cx);
+}
+__device__ __forceinline__ bool fast_full_test(const half_t* ctr, int ls, float thr, uint32_t* angle) {
+    if (!ring_is_corner(ctr, ls, thr)) return false;
+    *angle = ring_angle(ctr, ls);
     return true;
+}
+// A 12-run on the 16-ring contains at least 3 of the 4 diagonal ring points (+-2,+-2) (ring indices
+// 2, 6, 10, 14 are four apart), with the run's polarity.  Cheap necessary condition used to thin the
+// pre-test survivors (9.4 % of the pixels of a noisy frame) before the 16-point test (-> 2.7 %).
+__device__ __forceinline__ bool diagonal_filter(const half_t* ctr, int ls, float thr, bool over) {
+    const float c = from_half(ctr[0]);
+    const float a = from_half(ctr[-2 * ls - 2]), b = from_half(ctr[-2 * ls + 2]);
+    const float d = from_half(ctr[2 * ls - 2]), e = from_half(ctr[2 * ls + 2]);
+    const float lo1 = fminf(a, b), hi1 = fmaxf(a, b), lo2 = fminf(d, e), hi2 = fmaxf(d, e);
+    const float m1 = fmaxf(lo1, lo2), m2 = fminf(hi1, hi2);
+    // 2nd smallest / 2nd largest of the four; v -> fl(v - c) is monotone, so ">= 3 diffs beyond thr"
+    // is decided by that one value
+    const float sel = over ? fminf(m1, m2) : fmaxf(m1, m2);
+    const float diff = sel - c;
+    return over ? diff > thr : diff < -thr;
 }
 
 // Block-local stream compaction: a band's corners go to its own segment of the scratch list, the
@@ -112,19 +142,31 @@ __device__ __forceinline__ void segment_append(bool is_corner, uint32_t x, uint3
 }
 
 template <bool L0>
-__global__ __launch_bounds__(kFrontThreads) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
+__global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                          uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                                          Pyramid pyr, FrontGeom geo, float thr,
                                                          uint32_t* __restrict__ seg_counts,
                                                          CornerData* __restrict__ segments) {
-    constexpr int NT = kFrontThreads, R = kFrontRows, TC = kFrontTmpRows;
+    constexpr int NT = L0 ? kFrontThreadsL0 : kFrontThreadsLN, R = kFrontRows, TC = kFrontTmpRows;
+    constexpr int NCOL = (kFrontMaxCols * 512) / NT;  // blur columns per thread
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int LS = (int)geo.ls, TS = (int)geo.ts;
     half_t* const grey = reinterpret_cast<half_t*>(lds_raw);             // (R+6) rows x LS
     half_t* const tmp = grey + (R + 6) * LS;                              // 2 x TC rows x TS
-    uint32_t* const queue = reinterpret_cast<uint32_t*>(tmp + 2 * TC * TS);
-    uint32_t* const q_count = queue + kFrontQueue;
-    uint32_t* const c_count = q_count + 1;  // corners found by this band
+    // Queues of the FAST phase, 16-bit entries [15] run polarity (1 = brighter), [14:11] band row, [10:0] x.
+    //   A: pre-test survivors (own storage); B: survivors of the diagonal filter; C: corners.  B and C
+    //   live in the blur intermediate's storage (phase C starts after a barrier).  Whenever a queue is
+    //   full the item is finished in place, so capacities only affect speed.
+    uint16_t* const queue_a = reinterpret_cast<uint16_t*>(tmp + 2 * TC * TS);
+    uint16_t* const queue_b = reinterpret_cast<uint16_t*>(tmp);
+    const uint32_t cap_b = 3u * (uint32_t)TS, cap_c = (uint32_t)TS;
+    uint16_t* const queue_c = queue_b + cap_b;
+    uint32_t* const qa_count = reinterpret_cast<uint32_t*>(queue_a + kFrontQueue);
+    uint32_t* const qb_count = qa_count + 1;
+    uint32_t* const qc_count = qa_count + 2;
+    uint32_t* const c_count = qa_count + 3;  // corners found by this band
+    float4* const blur_k1 = reinterpret_cast<float4*>(qa_count + 4);  // per band row: taps 0, 2, 3 of blur pass 1
+    float4* const blur_k2 = blur_k1 + R;                              // [chunk parity][row of the pair]: same for pass 2
 
     // ---- which band of which frame: keep all bands of a frame on one XCD so halo rows hit its L2
     uint32_t frame, band;
@@ -148,281 +190,348 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const uint8_t* __restri
     const size_t slot = (size_t)frame * geo.n_slots + geo.slot_base + band;
     CornerData* const seg = segments + slot * geo.seg_cap;
 
-    if (tid == 0) {
-        *q_count = 0u;
-        *c_count = 0u;
-    }
+    if (tid < 4) qa_count[tid] = 0u;
 
     // =========================== A: stage grey rows [y0-3, y0+R+3) ===========================
-    if (L0) {
-        // RGBA8 -> luminance of the vertically mirrored row (grayscale.wgsl:16-38), 4 px per item.
-        // Loads are issued kLoadBatch at a time before any is consumed, so a thread has that many
-        // 16-byte HBM requests in flight instead of one.
-        constexpr int U = 8;
-        const int w4 = w >> 2;
-        const float inv_w4 = 1.0f / (float)w4;
-        const uint8_t* src = frames + (size_t)frame * frame_bytes;
-        const int n_items = (R + 6) * w4;
-        for (int ib = tid; ib < n_items; ib += NT * U) {
-            uint4 px[U];
-            int dst[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = ib + u * NT;
-                const int ly = (int)(((float)i + 0.5f) * inv_w4);
-                const int xi = i - ly * w4;
-                const int gy = y0 - 3 + ly;
-                // rows outside the image are never read by a pixel that passes the guard (fast.wgsl:77)
-                const bool ok = i < n_items && gy >= 0 && gy < h;
-                dst[u] = ok ? ly * LS + kLdsPad + xi * 4 : -1;
-                px[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (ok) px[u] = *reinterpret_cast<const uint4*>(src + ((size_t)(h - 1 - gy) * w + (size_t)xi * 4) * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (dst[u] >= 0) {
-                    uint2 out;
-                    out.x = pack_half2(luminance_fast(px[u].x), luminance_fast(px[u].y));
-                    out.y = pack_half2(luminance_fast(px[u].z), luminance_fast(px[u].w));
-                    *reinterpret_cast<uint2*>(grey + dst[u]) = out;
-                }
-            }
-        }
-    } else {
-        // f16 mip from HBM; texels outside the level read as 0 (CRD-6) because at octaves >= 1 the
-        // reference's guard and dispatch size let pixels near/over the level edge through (Q8).
-        constexpr int U = 4;
-        const uint16_t* src = gray_f + pyr.off[lvl];
-        const int w8 = (LS - kLdsPad) >> 3;  // 8-texel groups per LDS row
-        const float inv_w8 = 1.0f / (float)w8;
-        const int n_items = (R + 6) * w8;
-        const bool vec_ok = (w & 7) == 0;
-        for (int ib = tid; ib < n_items; ib += NT * U) {
+    // Thread -> (column group tx, row phase ty): a thread keeps its column group and walks down the
+    // rows, so per item there is one address increment instead of a division; up to eight 16-byte
+    // loads are in flight per thread before the first is consumed.
+    {
+        const int per_row = L0 ? (w >> 2) : ((LS - kLdsPad) >> 3);  // 16-byte items per row (RGBA quads / half8 groups)
+        const int rpp = NT / per_row;                                 // rows covered per pass (>= 1: W <= 2048)
+        const int ty = (int)(((float)tid + 0.5f) * (1.0f / (float)per_row));
+        const int tx = tid - __mul24(ty, per_row);
+        const bool lane_ok = ty < rpp;
+        const uint8_t* src0 = frames + (size_t)frame * frame_bytes;
+        const uint16_t* srcn = gray_f + pyr.off[lvl];
+        constexpr int U = 4;  // 16-byte loads in flight per thread (VGPR budget: 64 at 8 waves/SIMD)
+        for (int lyb = ty; lyb < R + 6; lyb += rpp * U) {
             uint4 v[U];
             int dst[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int i = ib + u * NT;
-                const int ly = (int)(((float)i + 0.5f) * inv_w8);
-                const int xg = i - ly * w8;
+                const int ly = lyb + u * rpp;
                 const int gy = y0 - 3 + ly;
-                const int x = xg * 8;
-                dst[u] = i < n_items ? ly * LS + kLdsPad + x : -1;
+                const bool in_band = lane_ok && ly < R + 6;
                 v[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (i < n_items && gy >= 0 && gy < h) {
-                    const uint16_t* row = src + (size_t)gy * w;
-                    if (vec_ok && x + 8 <= w) {
-                        v[u] = *reinterpret_cast<const uint4*>(row + x);
-                    } else {
-                        uint32_t e[8];
+                if (L0) {
+                    // rows outside the image are never read by a pixel that passes the guard (fast.wgsl:77);
+                    // the input row is the vertically mirrored one (grayscale.wgsl:16-25).  24-bit multiplies:
+                    // pixel offsets inside a frame are < 2^22 (checked at create).  The load itself is
+                    // unconditional (clamped address) so that all eight are issued back to back.
+                    const bool ok = in_band && gy >= 0 && gy < h;
+                    dst[u] = ok ? __mul24(ly, LS) + kLdsPad + tx * 4 : -1;
+                    const int gyc = min(max(gy, 0), h - 1);
+                    const int txc = lane_ok ? tx : 0;
+                    v[u] = *reinterpret_cast<const uint4*>(src0 + (size_t)((uint32_t)(__mul24(h - 1 - gyc, w) + txc * 4) * 4u));
+                } else {
+                    // f16 mip from HBM; texels outside the level are stored as 0 (CRD-6): at octaves >= 1 the
+                    // reference's guard and dispatch size let pixels near/over the level edge through (Q8).
+                    const int x = tx * 8;
+                    dst[u] = in_band ? __mul24(ly, LS) + kLdsPad + x : -1;
+                    if (in_band && gy >= 0 && gy < h && x < w) {
+                        const uint16_t* row = srcn + (size_t)(uint32_t)__mul24(gy, w);
+                        if ((w & 7) == 0 && x + 8 <= w) {
+                            v[u] = *reinterpret_cast<const uint4*>(row + x);
+                        } else {
+                            uint32_t e[8];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) e[k] = (x + k < w) ? (uint32_t)row[x + k] : 0u;
-                        v[u] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+                            for (int k = 0; k < 8; k++) e[k] = (x + k < w) ? (uint32_t)row[x + k] : 0u;
+                            v[u] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16),
+                                              e[6] | (e[7] << 16));
+                        }
                     }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < U; u++)
-                if (dst[u] >= 0) *reinterpret_cast<uint4*>(grey + dst[u]) = v[u];
-        }
-    }
-    __syncthreads();
-
-    // =========================== B1: 4-point pre-test, 8 px per item ===========================
-    if (geo.phase_mask & 1u) {
-        const int g8 = (int)geo.gw >> 3;
-        const float inv_g8 = 1.0f / (float)g8;
-        const int n_items = R * g8;
-        // fast.wgsl:77 -- level-0 dimensions for every octave, u32 arithmetic (Q8)
-        const uint32_t lim_x = pyr.w[0] - 16u, lim_y = pyr.h[0] - 16u;
-        for (int i = tid; i < n_items; i += NT) {
-            const int lyc = (int)(((float)i + 0.5f) * inv_g8);
-            const int x = (i - lyc * g8) * 8;
-            const uint32_t gy = (uint32_t)(y0 + lyc);
-            if (!(gy < geo.gh && gy > 16u && gy < lim_y)) continue;
-            if ((uint32_t)x + 7u <= 16u || (uint32_t)x >= lim_x) continue;
-            const half_t* rowc = grey + (lyc + 3) * LS + kLdsPad + x;
-            const uint2 qa = *reinterpret_cast<const uint2*>(rowc - 4);
-            const uint4 qb = *reinterpret_cast<const uint4*>(rowc);
-            const uint2 qc = *reinterpret_cast<const uint2*>(rowc + 8);
-            const uint4 qu = *reinterpret_cast<const uint4*>(rowc - 3 * LS);
-            const uint4 qd = *reinterpret_cast<const uint4*>(rowc + 3 * LS);
-            // "At least 3 of the 4 compass diffs exceed thr" (fast.wgsl:85-95) <=> the 2nd smallest of the four
-            // neighbour values, minus the centre, exceeds thr (v -> fl(v - c) is monotone); likewise the
-            // 2nd largest for the "under" case.  Grey values are non-negative f16, so their bit patterns
-            // order like the values and the selection network runs on packed u16 pairs (2 pixels per op).
-            const uint32_t dw[8] = {qa.x, qa.y, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};  // dw[j] = grey(x-4+2j, x-3+2j)
-            const uint32_t upw[4] = {qu.x, qu.y, qu.z, qu.w}, dnw[4] = {qd.x, qd.y, qd.z, qd.w};
-            uint32_t cand = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {  // pixel pair (x+2j, x+2j+1)
-                const ushort2_t left = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 1], dw[j], 16));       // x+2j-3, x+2j-2
-                const ushort2_t right = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 4], dw[j + 3], 16));  // x+2j+3, x+2j+4
-                const ushort2_t upp = as_u16x2(upw[j]), dwn = as_u16x2(dnw[j]);
-                const ushort2_t lo1 = __builtin_elementwise_min(left, right), hi1 = __builtin_elementwise_max(left, right);
-                const ushort2_t lo2 = __builtin_elementwise_min(upp, dwn), hi2 = __builtin_elementwise_max(upp, dwn);
-                const ushort2_t m1 = __builtin_elementwise_max(lo1, lo2), m2 = __builtin_elementwise_min(hi1, hi2);
-                const ushort2_t second_lo = __builtin_elementwise_min(m1, m2), second_hi = __builtin_elementwise_max(m1, m2);
-                const uint32_t cw = dw[j + 2];
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const float c = h2f(cw, e);
-                    const float d_lo = from_half(bits_half(second_lo[e])) - c;  // CRD-7: one f32 subtraction
-                    const float d_hi = from_half(bits_half(second_hi[e])) - c;
-                    const uint32_t gx = (uint32_t)(x + 2 * j + e);
-                    const uint32_t hit = (uint32_t)(d_lo > thr) | (uint32_t)(d_hi < -thr);  // branch-free on purpose
-                    const uint32_t ok = (uint32_t)(gx > 16u) & (uint32_t)(gx < lim_x);
-                    cand |= (hit & ok) << (2 * j + e);
-                }
-            }
-            while (cand) {
-                const int k = __builtin_ctz(cand);
-                cand &= cand - 1u;
-                const uint32_t slot = atomicAdd(q_count, 1u);
-                if (slot < (uint32_t)kFrontQueue) {
-                    queue[slot] = ((uint32_t)lyc << 16) | (uint32_t)(x + k);
-                } else {  // queue full (pathological frame): test in place
-                    uint32_t angle;
-                    const bool hit = fast_full_test(rowc + k, LS, thr, &angle);
-                    segment_append(hit, (uint32_t)(x + k), gy, angle, lvl, c_count, seg, geo.seg_cap);
+            for (int u = 0; u < U; u++) {
+                if (dst[u] >= 0) {
+                    if (L0) {
+                        uint2 out;
+                        out.x = pack_half2(luminance_fast(v[u].x), luminance_fast(v[u].y));
+                        out.y = pack_half2(luminance_fast(v[u].z), luminance_fast(v[u].w));
+                        *reinterpret_cast<uint2*>(grey + dst[u]) = out;
+                    } else {
+                        *reinterpret_cast<uint4*>(grey + dst[u]) = v[u];
+                    }
                 }
             }
         }
     }
     __syncthreads();
 
-    // =========================== B2: drain the candidate queue densely ===========================
-    if (geo.phase_mask & 2u) {
-        const uint32_t n_q = min(*q_count, (uint32_t)kFrontQueue);
-        for (uint32_t base = (uint32_t)(tid & ~63); base < n_q; base += NT) {  // wave-uniform trip count
-            const uint32_t i = base + (uint32_t)(tid & 63);
-            bool is_corner = false;
-            uint32_t angle = 0, x = 0, gy = 0;
-            if (i < n_q) {
-                const uint32_t e = queue[i];
-                const int lyc = (int)(e >> 16);
-                x = e & 0xffffu;
-                gy = (uint32_t)(y0 + lyc);
-                is_corner = fast_full_test(grey + (lyc + 3) * LS + kLdsPad + (int)x, LS, thr, &angle);
-            }
-            segment_append(is_corner, x, gy, angle, lvl, c_count, seg, geo.seg_cap);
-        }
+    // Blur taps 0, 2 and 3 always clamp to column 0 / w-1 (offsets are in UV units, Q11), so per row they
+    // are three constants: acc = (((0 + t[0]*w0) + lerp*w1) + t[w-1]*w2) + t[w-1]*w3.  One thread per row
+    // computes them for pass 1 here; the barriers of phase B publish them.
+    if (tid < R) {
+        const half_t* row = grey + (tid + 3) * LS + kLdsPad;
+        const float t0 = from_half(row[0]), tl = from_half(row[w - 1]);
+        const float a0 = t0 * kBlurWgt[0];
+        blur_k1[tid] = make_float4(0.0f + a0, tl * kBlurWgt[2], tl * kBlurWgt[3], 0.0f);
     }
 
+    // Phases B (FAST) and C (mip + blur) only share the read-only grey rows.
+    auto phase_B = [&]() {
+        // =========================== B1: 4-point pre-test, 8 px per item ===========================
+        if (geo.phase_mask & 1u) {
+            const int g8 = (int)geo.gw >> 3;
+            const float inv_g8 = 1.0f / (float)g8;
+            const int n_items = R * g8;
+            // fast.wgsl:77 -- level-0 dimensions for every octave, u32 arithmetic (Q8)
+            const uint32_t lim_x = pyr.w[0] - 16u, lim_y = pyr.h[0] - 16u;
+            // thr_lo: one f16 ulp below RD16(thr) (see below); -min_subnormal when that would pass zero
+            uint32_t tb = half_bits(to_half(thr));
+            if (from_half(bits_half((uint16_t)tb)) > thr) tb--;
+            tb = tb ? tb - 1u : 0x8001u;
+            const half2_t thr_lo2 = __builtin_bit_cast(half2_t, tb | (tb << 16));
+            for (int i = tid; i < n_items; i += NT) {
+                const int lyc = (int)(((float)i + 0.5f) * inv_g8);
+                const int x = (i - __mul24(lyc, g8)) * 8;
+                const uint32_t gy = (uint32_t)(y0 + lyc);
+                if (!(gy < geo.gh && gy > 16u && gy < lim_y)) continue;
+                if ((uint32_t)x + 7u <= 16u || (uint32_t)x >= lim_x) continue;
+                const half_t* rowc = grey + __mul24(lyc + 3, LS) + kLdsPad + x;
+                const uint2 qa = *reinterpret_cast<const uint2*>(rowc - 4);
+                const uint4 qb = *reinterpret_cast<const uint4*>(rowc);
+                const uint2 qc = *reinterpret_cast<const uint2*>(rowc + 8);
+                const uint4 qu = *reinterpret_cast<const uint4*>(rowc - 3 * LS);
+                const uint4 qd = *reinterpret_cast<const uint4*>(rowc + 3 * LS);
+                // Pre-test (fast.wgsl:85-95), as a CONSERVATIVE filter: every pixel the reference's pre-test
+                // passes is kept, a few extra may be; the decision itself is made by the 16-point test, whose
+                // 12-run already implies the 3-of-4 compass condition, so results do not change.
+                //  * ">= 3 of the 4 compass diffs beyond thr" <=> the 2nd smallest (2nd largest) neighbour value
+                //    minus the centre is beyond thr; grey values are non-negative f16, so the selection network
+                //    runs on their bit patterns as packed u16 (2 pixels per op);
+                //  * the two differences and compares run in packed f16 against thr_lo, one f16 ulp below
+                //    RD16(thr): x > thr  =>  RN16(x) >= RD16(thr) > thr_lo, so nothing is missed;
+                //  * compares are subtractions whose sign bits are the answer (a float subtraction has the
+                //    sign of the exact difference).
+                const uint32_t dw[8] = {qa.x, qa.y, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};  // dw[j] = grey(x-4+2j, x-3+2j)
+                const uint32_t upw[4] = {qu.x, qu.y, qu.z, qu.w}, dnw[4] = {qd.x, qd.y, qd.z, qd.w};
+                uint32_t cand = 0, cand_over = 0;
+    #pragma unroll
+                for (int j = 0; j < 4; j++) {  // pixel pair (x+2j, x+2j+1)
+                    const ushort2_t left = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 1], dw[j], 16));       // x+2j-3, x+2j-2
+                    const ushort2_t right = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 4], dw[j + 3], 16));  // x+2j+3, x+2j+4
+                    const ushort2_t upp = as_u16x2(upw[j]), dwn = as_u16x2(dnw[j]);
+                    const ushort2_t lo1 = __builtin_elementwise_min(left, right), hi1 = __builtin_elementwise_max(left, right);
+                    const ushort2_t lo2 = __builtin_elementwise_min(upp, dwn), hi2 = __builtin_elementwise_max(upp, dwn);
+                    const ushort2_t m1 = __builtin_elementwise_max(lo1, lo2), m2 = __builtin_elementwise_min(hi1, hi2);
+                    const half2_t second_lo = __builtin_bit_cast(half2_t, __builtin_elementwise_min(m1, m2));
+                    const half2_t second_hi = __builtin_bit_cast(half2_t, __builtin_elementwise_max(m1, m2));
+                    const half2_t c2 = __builtin_bit_cast(half2_t, dw[j + 2]);
+                    const half2_t e_over = thr_lo2 - (second_lo - c2);   // negative  <=>  second_lo - c > thr_lo
+                    const half2_t e_under = (second_hi - c2) + thr_lo2;  // negative  <=>  second_hi - c < -thr_lo
+                    const uint32_t so = __builtin_bit_cast(uint32_t, e_over) & 0x80008000u;
+                    const uint32_t sa = (so | __builtin_bit_cast(uint32_t, e_under)) & 0x80008000u;
+                    // sign bits 15 and 31 -> mask bits 2j and 2j+1
+                    cand |= (((sa >> 15) & 1u) | (sa >> 30)) << (2 * j);
+                    cand_over |= (((so >> 15) & 1u) | (so >> 30)) << (2 * j);
+                }
+                {  // fast.wgsl:77 guard on x, for the 8 pixels at once: keep bits k with 16 < x+k < lim_x
+                    const int first = 17 - x, past = (int)lim_x - x;
+                    uint32_t keep = 0xffu;
+                    if (first > 0) keep &= 0xffu << first;
+                    if (past < 8) keep &= past > 0 ? (0xffu >> (8 - past)) : 0u;
+                    cand &= keep;
+                }
+                if (cand) {  // one LDS atomic for all survivors of this item
+                    uint32_t qs = atomicAdd(qa_count, (uint32_t)__builtin_popcount(cand));
+                    while (cand) {
+                        const int k = __builtin_ctz(cand);
+                        cand &= cand - 1u;
+                        const bool over = (cand_over >> k) & 1u;
+                        if (qs < (uint32_t)kFrontQueue) {
+                            queue_a[qs] = (uint16_t)((over ? 0x8000u : 0u) | ((uint32_t)lyc << 11) | (uint32_t)(x + k));
+                        } else {  // queue full (pathological frame): finish in place
+                            uint32_t angle;
+                            const bool hit = fast_full_test(rowc + k, LS, thr, &angle);
+                            segment_append(hit, (uint32_t)(x + k), gy, angle, lvl, c_count, seg, geo.seg_cap);
+                        }
+                        qs++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // =========================== B2: thin, test, orient -- each stage on densely packed lanes ===========
+        if (geo.phase_mask & 2u) {
+            auto locate = [&](uint32_t e, uint32_t* x, uint32_t* gy) -> const half_t* {
+                const int lyc = (int)((e >> 11) & 15u);
+                *x = e & 0x7ffu;
+                *gy = (uint32_t)(y0 + lyc);
+                return grey + __mul24(lyc + 3, LS) + kLdsPad + (int)*x;
+            };
+            // stage 1: diagonal 3-of-4 filter (a necessary condition of a 12-run), A -> B
+            const uint32_t n_a = min(*qa_count, (uint32_t)kFrontQueue);
+            for (uint32_t i = (uint32_t)tid; i < n_a; i += NT) {
+                const uint32_t e = queue_a[i];
+                uint32_t x, gy;
+                const half_t* ctr = locate(e, &x, &gy);
+                if (diagonal_filter(ctr, LS, thr, (e & 0x8000u) != 0u)) {
+                    const uint32_t qs = atomicAdd(qb_count, 1u);
+                    if (qs < cap_b) {
+                        queue_b[qs] = (uint16_t)e;
+                    } else {
+                        uint32_t angle;
+                        const bool hit = fast_full_test(ctr, LS, thr, &angle);
+                        segment_append(hit, x, gy, angle, lvl, c_count, seg, geo.seg_cap);
+                    }
+                }
+            }
+            __syncthreads();
+            // stage 2: 16-point masks + 12-streak, B -> C
+            const uint32_t n_b = min(*qb_count, cap_b);
+            for (uint32_t i = (uint32_t)tid; i < n_b; i += NT) {
+                const uint32_t e = queue_b[i];
+                uint32_t x, gy;
+                const half_t* ctr = locate(e, &x, &gy);
+                if (ring_is_corner(ctr, LS, thr)) {
+                    const uint32_t qs = atomicAdd(qc_count, 1u);
+                    if (qs < cap_c)
+                        queue_c[qs] = (uint16_t)e;
+                    else
+                        segment_append(true, x, gy, ring_angle(ctr, LS), lvl, c_count, seg, geo.seg_cap);
+                }
+            }
+            __syncthreads();
+            // stage 3: orientation of the corners, append to the band's segment
+            const uint32_t n_c = min(*qc_count, cap_c);
+            for (uint32_t i = (uint32_t)tid; i < n_c; i += NT) {
+                uint32_t x, gy;
+                const half_t* ctr = locate(queue_c[i], &x, &gy);
+                segment_append(true, x, gy, ring_angle(ctr, LS), lvl, c_count, seg, geo.seg_cap);
+            }
+        }
+        __syncthreads();  // queues B and C share storage with phase C's blur intermediate
+    };
+    auto phase_C = [&]() {
+        // =========================== C0: next mip level (blit.wgsl, exact 2x2 case) ===========================
+        if (geo.write_mip && (geo.phase_mask & 4u)) {
+            const int wd = (int)pyr.w[lvl + 1], hd = (int)pyr.h[lvl + 1];
+            uint16_t* dst = gray_f + pyr.off[lvl + 1];
+            const int g4 = (wd + 3) >> 2;
+            const float inv_g4 = 1.0f / (float)g4;
+            const int n_items = (R / 2) * g4;
+            const bool vec_ok = (wd & 3) == 0;
+            for (int i = tid; i < n_items; i += NT) {
+                const int r = (int)(((float)i + 0.5f) * inv_g4);
+                const int xd = (i - __mul24(r, g4)) * 4;
+                const int yd = (y0 >> 1) + r;
+                if (yd >= hd) continue;
+                const half_t* top = grey + __mul24(2 * r + 3, LS) + kLdsPad + 2 * xd;
+                const uint4 qt = *reinterpret_cast<const uint4*>(top);
+                const uint4 qb = *reinterpret_cast<const uint4*>(top + LS);
+                const uint32_t tw[4] = {qt.x, qt.y, qt.z, qt.w}, bw[4] = {qb.x, qb.y, qb.z, qb.w};
+                uint16_t o[4];
+    #pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float a = h2f(tw[k], 0), b = h2f(tw[k], 1), c = h2f(bw[k], 0), d = h2f(bw[k], 1);
+                    const float st = a + b;
+                    const float sb = c + d;
+                    o[k] = half_bits(to_half((st + sb) * 0.25f));
+                }
+                uint16_t* out = dst + (size_t)(uint32_t)(__mul24(yd, wd) + xd);
+                if (vec_ok) {
+                    *reinterpret_cast<uint2*>(out) = make_uint2(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16));
+                } else {
+    #pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (xd + k < wd) out[k] = o[k];
+                }
+            }
+        }
+
+        // =========================== C: literal blur, both passes ===========================
+        // Two rows at a time: a thread's column has the same tap index/fraction in every row, so the two
+        // rows' lerp and accumulation run as packed-f32 pairs (v_pk_*_f32: two binary32 lanes per op, each
+        // rounded like the scalar op; no fusing, -ffp-contract=off).
+        static_assert(kFrontTmpRows == 2, "the blur works on row pairs");
+        if (geo.phase_mask & 8u) {
+            const int rows = min(R, h - y0);  // band rows that exist in this level (uniform per block)
+            if (rows > 0) {
+                // tap 1 (offset -0.4392 in UV units) per column: index pair and fraction, reused for every row
+                int i0[NCOL], i1[NCOL];
+                float fr[NCOL];
+    #pragma unroll
+                for (int c = 0; c < NCOL; c++) {
+                    const int x = tid + c * NT;
+                    BlurTap t = blur_tap((uint32_t)(x < w ? x : 0), (uint32_t)w, kBlurOff[1]);
+                    i0[c] = t.i0;
+                    i1[c] = t.i1;
+                    fr[c] = t.f;
+                }
+                const int n_chunks = (rows + 1) / 2;
+                auto blur_pair = [&](const half_t* ra, const half_t* rb, const float4 ka, const float4 kb, auto&& emit) {
+                    const float2_t base = {ka.x, kb.x}, a2 = {ka.y, kb.y}, a3 = {ka.z, kb.z};
+    #pragma unroll
+                    for (int c = 0; c < NCOL; c++) {
+                        const int x = tid + c * NT;
+                        if (x < w) {
+                            const float2_t v0 = {from_half(ra[i0[c]]), from_half(rb[i0[c]])};
+                            const float2_t v1 = {from_half(ra[i1[c]]), from_half(rb[i1[c]])};
+                            const float2_t d = v1 - v0;
+                            const float2_t fd = d * fr[c];
+                            const float2_t s2 = v0 + fd;
+                            const float2_t ws = s2 * kBlurWgt[1];
+                            float2_t acc = base + ws;
+                            acc = acc + a2;
+                            acc = acc + a3;
+                            emit(x, to_half(acc.x), to_half(acc.y));
+                        }
+                    }
+                };
+                auto pass1 = [&](int chunk) {
+                    const int r = chunk * 2;
+                    const int rb = r + 1 < rows ? r + 1 : r;  // odd tail: row r twice, second copy unused
+                    half_t* d0 = tmp + (chunk & 1) * 2 * TS;
+                    half_t* d1 = d0 + TS;
+                    float4* k2 = blur_k2 + (chunk & 1) * 2;
+                    blur_pair(grey + (r + 3) * LS + kLdsPad, grey + (rb + 3) * LS + kLdsPad, blur_k1[r], blur_k1[rb],
+                              [&](int x, half_t va, half_t vb) {
+                                  d0[x] = va;
+                                  d1[x] = vb;
+                                  // the owners of columns 0 and w-1 publish pass 2's row constants (f16-rounded values)
+                                  if (x == 0) {
+                                      const float p0 = from_half(va) * kBlurWgt[0], p1 = from_half(vb) * kBlurWgt[0];
+                                      k2[0].x = 0.0f + p0;
+                                      k2[1].x = 0.0f + p1;
+                                  }
+                                  if (x == w - 1) {
+                                      const float la = from_half(va), lb = from_half(vb);
+                                      k2[0].y = la * kBlurWgt[2];
+                                      k2[0].z = la * kBlurWgt[3];
+                                      k2[1].y = lb * kBlurWgt[2];
+                                      k2[1].z = lb * kBlurWgt[3];
+                                  }
+                              });
+                };
+                auto pass2 = [&](int chunk) {
+                    const int r = chunk * 2;
+                    const bool two = r + 1 < rows;
+                    const half_t* s0 = tmp + (chunk & 1) * 2 * TS;
+                    const float4* k2 = blur_k2 + (chunk & 1) * 2;
+                    uint16_t* o0 = blur_lvl + (size_t)(uint32_t)__mul24(y0 + r, w);
+                    uint16_t* o1 = o0 + w;
+                    blur_pair(s0, s0 + TS, k2[0], k2[1], [&](int x, half_t va, half_t vb) {
+                        o0[x] = half_bits(va);
+                        if (two) o1[x] = half_bits(vb);
+                    });
+                };
+                pass1(0);
+                for (int k = 0; k < n_chunks; k++) {
+                    __syncthreads();
+                    if (k + 1 < n_chunks) pass1(k + 1);
+                    pass2(k);
+                }
+            }
+        }
+    };
+    phase_B();
+    phase_C();
     __syncthreads();
     if (tid == 0) seg_counts[slot] = *c_count;  // raw count of the band (may exceed seg_cap)
-
-    // =========================== C0: next mip level (blit.wgsl, exact 2x2 case) ===========================
-    if (geo.write_mip && (geo.phase_mask & 4u)) {
-        const int wd = (int)pyr.w[lvl + 1], hd = (int)pyr.h[lvl + 1];
-        uint16_t* dst = gray_f + pyr.off[lvl + 1];
-        const int g4 = (wd + 3) >> 2;
-        const float inv_g4 = 1.0f / (float)g4;
-        const int n_items = (R / 2) * g4;
-        const bool vec_ok = (wd & 3) == 0;
-        for (int i = tid; i < n_items; i += NT) {
-            const int r = (int)(((float)i + 0.5f) * inv_g4);
-            const int xd = (i - r * g4) * 4;
-            const int yd = (y0 >> 1) + r;
-            if (yd >= hd) continue;
-            const half_t* top = grey + (2 * r + 3) * LS + kLdsPad + 2 * xd;
-            const uint4 qt = *reinterpret_cast<const uint4*>(top);
-            const uint4 qb = *reinterpret_cast<const uint4*>(top + LS);
-            const uint32_t tw[4] = {qt.x, qt.y, qt.z, qt.w}, bw[4] = {qb.x, qb.y, qb.z, qb.w};
-            uint16_t o[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float a = h2f(tw[k], 0), b = h2f(tw[k], 1), c = h2f(bw[k], 0), d = h2f(bw[k], 1);
-                const float st = a + b;
-                const float sb = c + d;
-                o[k] = half_bits(to_half((st + sb) * 0.25f));
-            }
-            uint16_t* out = dst + (size_t)yd * wd + xd;
-            if (vec_ok) {
-                *reinterpret_cast<uint2*>(out) = make_uint2(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16));
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (xd + k < wd) out[k] = o[k];
-            }
-        }
-    }
-
-    // =========================== C: literal blur, both passes ===========================
-    if (geo.phase_mask & 8u) {
-        const int rows = min(R, h - y0);  // band rows that exist in this level
-        if (rows > 0) {                   // uniform per block
-            // tap 1 (offset -0.4392 in UV units) per column, kept in registers for every row
-            int i0[kFrontMaxCols], i1[kFrontMaxCols];
-            float fr[kFrontMaxCols];
-#pragma unroll
-            for (int c = 0; c < kFrontMaxCols; c++) {
-                const int x = tid + c * NT;
-                BlurTap t = blur_tap((uint32_t)(x < w ? x : 0), (uint32_t)w, kBlurOff[1]);
-                i0[c] = t.i0;
-                i1[c] = t.i1;
-                fr[c] = t.f;
-            }
-            const int n_chunks = (rows + TC - 1) / TC;
-            auto pass1 = [&](int chunk) {
-                half_t* dstbuf = tmp + (chunk & 1) * TC * TS;
-                for (int rr = 0; rr < TC; rr++) {
-                    const int r = chunk * TC + rr;
-                    if (r >= rows) break;
-                    const half_t* row = grey + (r + 3) * LS + kLdsPad;
-                    const float t0 = from_half(row[0]), tl = from_half(row[w - 1]);
-                    const float a0 = t0 * kBlurWgt[0], a2 = tl * kBlurWgt[2], a3 = tl * kBlurWgt[3];
-#pragma unroll
-                    for (int c = 0; c < kFrontMaxCols; c++) {
-                        const int x = tid + c * NT;
-                        if (x < w) {
-                            const float v0 = from_half(row[i0[c]]), v1 = from_half(row[i1[c]]);
-                            const float d = v1 - v0;
-                            const float s = v0 + fr[c] * d;
-                            const float ws = s * kBlurWgt[1];
-                            float acc = 0.0f + a0;
-                            acc = acc + ws;
-                            acc = acc + a2;
-                            acc = acc + a3;
-                            dstbuf[rr * TS + x] = to_half(acc);
-                        }
-                    }
-                }
-            };
-            auto pass2 = [&](int chunk) {
-                const half_t* srcbuf = tmp + (chunk & 1) * TC * TS;
-                for (int rr = 0; rr < TC; rr++) {
-                    const int r = chunk * TC + rr;
-                    if (r >= rows) break;
-                    const half_t* row = srcbuf + rr * TS;
-                    const float t0 = from_half(row[0]), tl = from_half(row[w - 1]);
-                    const float a0 = t0 * kBlurWgt[0], a2 = tl * kBlurWgt[2], a3 = tl * kBlurWgt[3];
-                    uint16_t* out = blur_lvl + (size_t)(y0 + r) * w;
-#pragma unroll
-                    for (int c = 0; c < kFrontMaxCols; c++) {
-                        const int x = tid + c * NT;
-                        if (x < w) {
-                            const float v0 = from_half(row[i0[c]]), v1 = from_half(row[i1[c]]);
-                            const float d = v1 - v0;
-                            const float s = v0 + fr[c] * d;
-                            const float ws = s * kBlurWgt[1];
-                            float acc = 0.0f + a0;
-                            acc = acc + ws;
-                            acc = acc + a2;
-                            acc = acc + a3;
-                            out[x] = half_bits(to_half(acc));
-                        }
-                    }
-                }
-            };
-            pass1(0);
-            for (int k = 0; k < n_chunks; k++) {
-                __syncthreads();
-                if (k + 1 < n_chunks) pass1(k + 1);
-                pass2(k);
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
