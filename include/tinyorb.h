@@ -151,6 +151,9 @@ const char *orb_kernel_name(int id);
  * (max_batch frames) and returns its address in *out_dev. */
 int orb_synth_frames_device(OrbProgram *p, uint8_t *frames_dev, uint32_t n_frames, uint32_t seed0, uint32_t flags,
                             uint8_t **out_dev);
+/* Diagnostic: per-workgroup cycle sums of the phases of k_brief_tiles (collected only when the
+ * program was created with TINYORB_STAMPS=1 in the environment; up to 4096 x 6 values). */
+int orb_debug_stamps(OrbProgram *p, unsigned long long *dst, size_t n);
 /* Device-to-host copy helper for tests that have no other HIP binding. */
 int orb_copy_to_host(OrbProgram *p, void *dst_host, const void *src_dev, size_t nbytes);
 

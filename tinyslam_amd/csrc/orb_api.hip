@@ -53,11 +53,14 @@ struct OrbProgram {
     CornerDescriptor* d_desc = nullptr;
     CornerData* d_seg = nullptr;     // fused path: [max_batch][n_slots][seg_cap] band segments
     uint32_t* d_seg_counts = nullptr;  // [max_batch][n_slots]
+    uint32_t* d_seg_before = nullptr;  // [max_batch][n_slots] exclusive prefix of the stored counts
     BandGeom bands{};
     TileGeom tiles{};
     uint32_t* d_pattern = nullptr;
     float* d_cos = nullptr;
     float* d_sin = nullptr;
+    TileDesc* d_tile_desc = nullptr;  // k_brief_tiles: one descriptor per tile of a frame
+    unsigned long long* d_stamps = nullptr;  // TINYORB_STAMPS=1: per-workgroup phase cycle sums of k_brief_tiles
 
     // host staging of the single-frame API (orb.rs:216-218 staging buffers)
     uint32_t* h_count = nullptr;
@@ -70,6 +73,7 @@ struct OrbProgram {
     bool planes_valid = false;
     bool fused = false;
     uint32_t max_lds = 0;
+    uint32_t n_cus = 256;
 
     bool profiling = false;
     std::vector<ProfSpan> pending;
@@ -281,20 +285,20 @@ int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
     }
     {  // orb.rs:523-534, plus the compaction of the band segments into the final lists
         LaunchScope ls(p, s, KID_BRIEF);
-        BriefTables tab{p->d_pattern, p->d_cos, p->d_sin};
-        if (getenv("TINYORB_BRIEF_BANDS")) {
-            BandGeom bg = p->bands;
-            bg.n_frames = n;
-            bg.xcd_swizzle = (n % 8u == 0u) ? 1u : 0u;
-            hipLaunchKernelGGL(k_brief_bands, dim3(bg.n_slots * n), dim3(256), 0, s, p->d_blur, pyr, bg,
-                               p->d_seg_counts, p->d_seg, p->d_counts, p->d_corners, cap, p->d_desc, tab);
-        } else {
-            TileGeom tg = p->tiles;
-            tg.n_frames = n;
-            tg.xcd_swizzle = (n % 8u == 0u) ? 1u : 0u;
-            hipLaunchKernelGGL(k_brief_tiles, dim3(tg.tile_base[pyr.depth] * n), dim3(256), 0, s, p->d_blur, pyr, tg,
-                               p->d_seg_counts, p->d_seg, p->d_counts, p->d_corners, cap, p->d_desc, tab);
-        }
+        hipLaunchKernelGGL(k_slot_prefix, dim3(n), dim3(64), 0, s, p->d_seg_counts, p->d_seg_before, p->d_counts,
+                           p->bands.n_slots, p->bands.seg_cap);
+        TileGeom tg = p->tiles;
+        tg.n_frames = n;
+        tg.xcd_swizzle = (n % 8u == 0u) ? 1u : 0u;
+        // persistent workgroups, two per CU, each walks its XCD's share of the tiles
+        uint32_t n_wg = tg.tiles_per_frame * n;
+        uint32_t per_cu = 2u;
+        if (const char* e = getenv("TINYORB_BRIEF_WG_PER_CU")) per_cu = (uint32_t)atoi(e);
+        if (n_wg > per_cu * p->n_cus) n_wg = per_cu * p->n_cus;
+        if (tg.xcd_swizzle && (n_wg % 8u != 0u || n_wg < 8u)) tg.xcd_swizzle = 0u;
+        tg.stamps = p->d_stamps;
+        hipLaunchKernelGGL(k_brief_tiles, dim3(n_wg), dim3(kBriefThreads), 0, s, p->d_blur, pyr, tg, p->d_seg_counts,
+                           p->d_seg_before, p->d_seg, p->d_corners, cap, p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin});
     }
     HIP_TRY(p, hipGetLastError());
     p->planes_valid = true;  // except the level-0 grey plane, which the fused path keeps in LDS only
@@ -375,6 +379,9 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         int lds_max = 0;
         CREATE_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, p->device));
         p->max_lds = (uint32_t)lds_max;
+        int cus = 0;
+        CREATE_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device));
+        p->n_cus = cus > 0 ? (uint32_t)cus : 256u;
         p->fused = fused_eligible(p);
         if (p->fused) {
             uint32_t need = 0, width = W, height = H;
@@ -432,6 +439,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         CREATE_TRY(hipMalloc(&p->d_seg, B * p->bands.n_slots * (size_t)p->bands.seg_cap * sizeof(CornerData)));
         CREATE_TRY(hipMalloc(&p->d_seg_counts, B * p->bands.n_slots * sizeof(uint32_t)));
         CREATE_TRY(hipMemset(p->d_seg_counts, 0, B * p->bands.n_slots * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc(&p->d_seg_before, B * p->bands.n_slots * sizeof(uint32_t)));
     }
     CREATE_TRY(hipMalloc(&p->d_pattern, 256 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&p->d_cos, ORB_ANGLE_STEPS * sizeof(float)));
@@ -439,6 +447,36 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     CREATE_TRY(hipMemcpy(p->d_pattern, ORB_BRIEF_PATTERN, 1024, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(p->d_cos, ORB_COS_BITS, ORB_ANGLE_STEPS * 4, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(p->d_sin, ORB_SIN_BITS, ORB_ANGLE_STEPS * 4, hipMemcpyHostToDevice));
+    if (p->fused) {
+        // per-tile descriptors of k_brief_tiles (all levels of one frame)
+        TileGeom& tg = p->tiles;
+        std::vector<TileDesc> desc(tg.tile_base[p->pyr.depth]);
+        for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
+            const uint32_t n_bands = tg.slot_base[lvl + 1] - tg.slot_base[lvl];
+            const uint32_t n_tiles = tg.tile_base[lvl + 1] - tg.tile_base[lvl];
+            for (uint32_t t = 0; t < n_tiles; t++) {
+                const uint32_t ty = t / tg.tile_cols[lvl], tx = t % tg.tile_cols[lvl];
+                TileDesc& d = desc[tg.tile_base[lvl] + t];
+                d.lvl = lvl;
+                d.slot_a = tg.slot_base[lvl] + 2u * ty;
+                d.has_b = (2u * ty + 1u < n_bands) ? 1u : 0u;
+                d.plane_off = p->pyr.off[lvl];
+                d.x0 = (int32_t)(tx * kBriefTileW);
+                d.y0 = (int32_t)(ty * kBriefTileH);
+                d.w = (int32_t)p->pyr.w[lvl];
+                d.h = (int32_t)p->pyr.h[lvl];
+            }
+        }
+        tg.tiles_per_frame = (uint32_t)desc.size();
+        tg.inv_tiles_per_frame = 1.0f / (float)desc.size();
+        CREATE_TRY(hipMalloc(&p->d_tile_desc, desc.size() * sizeof(TileDesc)));
+        CREATE_TRY(hipMemcpy(p->d_tile_desc, desc.data(), desc.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+        tg.desc = p->d_tile_desc;
+        if (getenv("TINYORB_STAMPS")) {
+            CREATE_TRY(hipMalloc(&p->d_stamps, 4096 * 6 * sizeof(unsigned long long)));
+            CREATE_TRY(hipMemset(p->d_stamps, 0, 4096 * 6 * sizeof(unsigned long long)));
+        }
+    }
     CREATE_TRY(hipHostMalloc(&p->h_count, sizeof(uint32_t), hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc(&p->h_corners, cap * sizeof(CornerData), hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc(&p->h_desc, cap * sizeof(CornerDescriptor), hipHostMallocDefault));
@@ -464,9 +502,12 @@ void orb_program_destroy(OrbProgram* p) {
     (void)hipFree(p->d_desc);
     (void)hipFree(p->d_seg);
     (void)hipFree(p->d_seg_counts);
+    (void)hipFree(p->d_seg_before);
     (void)hipFree(p->d_pattern);
     (void)hipFree(p->d_cos);
     (void)hipFree(p->d_sin);
+    (void)hipFree(p->d_tile_desc);
+    (void)hipFree(p->d_stamps);
     if (p->h_count) (void)hipHostFree(p->h_count);
     if (p->h_corners) (void)hipHostFree(p->h_corners);
     if (p->h_desc) (void)hipHostFree(p->h_desc);
@@ -702,6 +743,16 @@ int orb_synth_frames_device(OrbProgram* p, uint8_t* frames_dev, uint32_t n_frame
     HIP_TRY(p, hipGetLastError());
     HIP_TRY(p, hipStreamSynchronize(p->stream));
     if (out_dev) *out_dev = frames_dev;
+    return ORB_OK;
+}
+
+int orb_debug_stamps(OrbProgram* p, unsigned long long* dst, size_t n) {
+    if (!p || !dst) return ORB_EINVAL;
+    if (!p->d_stamps) return fail(p, ORB_ESTATE, "stamps are collected only with TINYORB_STAMPS=1");
+    if (n > 4096 * 6) n = 4096 * 6;
+    HIP_TRY(p, hipSetDevice(p->device));
+    HIP_TRY(p, hipDeviceSynchronize());
+    HIP_TRY(p, hipMemcpy(dst, p->d_stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return ORB_OK;
 }
 

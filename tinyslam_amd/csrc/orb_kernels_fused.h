@@ -534,90 +534,11 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     if (tid == 0) seg_counts[slot] = *c_count;  // raw count of the band (may exceed seg_cap)
 }
 
-// ---------------------------------------------------------------------------------------------
-// K6 for the fused pipeline: brief.wgsl:20-68 over the band segments written by k_front.
-// One workgroup = one band slot of one frame, so the keypoints a CU works on share a window of
-// R + 36 blur rows (L1/L2 hits instead of one HBM line per sample), and the final compact lists
-// (orb.rs:159-164 `corners`, 195-199 `descriptors`) are produced here: slot s starts at the sum of
-// the stored counts of the slots before it.  One wave64 per keypoint, lane l owns tests l, 64+l,
-// 128+l, 192+l; four ballots give the eight u32 words (brief.wgsl:47,63,67).
-// ---------------------------------------------------------------------------------------------
+// Band slots of a frame: one per kFrontRows-row band per level, in level order.
 struct BandGeom {
     uint32_t n_slots, seg_cap, n_frames, xcd_swizzle;
     uint32_t slot_base[kMaxLevels + 1];  // first slot of each level; [depth] = n_slots
 };
-
-__global__ __launch_bounds__(256) void k_brief_bands(const uint16_t* __restrict__ blur, Pyramid pyr, BandGeom bg,
-                                                     const uint32_t* __restrict__ seg_counts,
-                                                     const CornerData* __restrict__ segments,
-                                                     uint32_t* __restrict__ counts, CornerData* __restrict__ corners,
-                                                     uint32_t cap, CornerDescriptor* __restrict__ descriptors,
-                                                     BriefTables tab) {
-    uint32_t frame, slot;
-    {
-        const uint32_t L = blockIdx.x;
-        if (bg.xcd_swizzle) {
-            const uint32_t xcd = L & 7u, q = L >> 3;
-            frame = (q / bg.n_slots) * 8u + xcd;
-            slot = q % bg.n_slots;
-        } else {
-            frame = L / bg.n_slots;
-            slot = L % bg.n_slots;
-        }
-    }
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t* sc = seg_counts + (size_t)frame * bg.n_slots;
-
-    // stored keypoints in the slots before this one, and the frame's raw total (orb.rs:550-556)
-    uint32_t before = 0, total = 0;
-    for (uint32_t s0 = 0; s0 < bg.n_slots; s0 += 64u) {
-        const uint32_t s = s0 + lane;
-        const uint32_t raw = s < bg.n_slots ? sc[s] : 0u;
-        total += raw;
-        before += s < slot ? min(raw, bg.seg_cap) : 0u;
-    }
-#pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) {
-        before += __shfl_xor(before, sh);
-        total += __shfl_xor(total, sh);
-    }
-    if (slot == 0u && threadIdx.x == 0u) counts[frame] = total;
-
-    uint32_t lvl = 0;
-    for (uint32_t m = 1; m < pyr.depth; m++)
-        if (slot >= bg.slot_base[m]) lvl = m;
-    const uint32_t w = pyr.w[lvl], h = pyr.h[lvl];
-    const uint16_t* plane = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
-    const uint32_t n_here = min(sc[slot], bg.seg_cap);
-    const CornerData* seg = segments + ((size_t)frame * bg.n_slots + slot) * bg.seg_cap;
-    CornerData* out_kp = corners + (size_t)frame * cap;
-    uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)frame * cap);
-
-    const uint32_t p0 = tab.pattern[lane], p1 = tab.pattern[64u + lane], p2 = tab.pattern[128u + lane],
-                   p3 = tab.pattern[192u + lane];
-    uint4 next = make_uint4(0u, 0u, 0u, 0u);
-    if (wave < n_here) next = *reinterpret_cast<const uint4*>(&seg[wave]);
-    for (uint32_t j = wave; j < n_here; j += 4u) {
-        const uint32_t k = before + j;
-        if (k >= cap) break;  // frame is full (wave-uniform)
-        const uint4 rec = next;  // x, y, angle, octave
-        if (j + 4u < n_here) next = *reinterpret_cast<const uint4*>(&seg[j + 4u]);
-        const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
-        const float ct = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
-        const int px = (int)rec.x, py = (int)rec.y;
-        const uint64_t b0 = __ballot(brief_test(p0, ct, st, nst, px, py, plane, w, h));
-        const uint64_t b1 = __ballot(brief_test(p1, ct, st, nst, px, py, plane, w, h));
-        const uint64_t b2 = __ballot(brief_test(p2, ct, st, nst, px, py, plane, w, h));
-        const uint64_t b3 = __ballot(brief_test(p3, ct, st, nst, px, py, plane, w, h));
-        if (lane < 8u) {
-            const uint64_t src = lane < 2u ? b0 : (lane < 4u ? b1 : (lane < 6u ? b2 : b3));
-            out_desc[(size_t)k * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
-        } else if (lane == 8u) {
-            *reinterpret_cast<uint4*>(&out_kp[k]) = rec;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // K6, tiled: brief.wgsl:20-68 with the sampling window staged in LDS.
@@ -638,163 +559,312 @@ constexpr int kBriefHalo = 18;
 constexpr int kBriefPadX = 24;  // halo rounded up to a multiple of 8 texels (16-byte loads)
 constexpr int kBriefWinW = kBriefTileW + 2 * kBriefPadX;  // 304
 constexpr int kBriefWinH = kBriefTileH + 2 * kBriefHalo;  // 68
-constexpr int kBriefList = 256;
+constexpr int kBriefThreads = 512;
+constexpr int kBriefList = 512;
+
+// One entry per tile of a frame (all levels), built on the host.
+struct TileDesc {
+    uint32_t lvl, slot_a, has_b, plane_off;  // plane_off: texel offset of the level in the packed pyramid
+    int32_t x0, y0, w, h;
+};
 
 struct TileGeom {
     uint32_t n_slots, seg_cap, n_frames, xcd_swizzle;
     uint32_t slot_base[kMaxLevels + 1];
     uint32_t tile_base[kMaxLevels + 1];  // first tile of each level; [depth] = tiles per frame
     uint32_t tile_cols[kMaxLevels];      // column tiles of each level
+    uint32_t tiles_per_frame;
+    float inv_tiles_per_frame;
+    const TileDesc* desc;                // [tiles_per_frame]
+    unsigned long long* stamps;          // diagnostic builds only: per-workgroup cycle sums per phase (else null)
 };
 
-__global__ __launch_bounds__(256) void k_brief_tiles(const uint16_t* __restrict__ blur, Pyramid pyr, TileGeom tg,
-                                                     const uint32_t* __restrict__ seg_counts,
-                                                     const CornerData* __restrict__ segments,
-                                                     uint32_t* __restrict__ counts, CornerData* __restrict__ corners,
-                                                     uint32_t cap, CornerDescriptor* __restrict__ descriptors,
-                                                     BriefTables tab) {
+// Exclusive prefix of the stored keypoints over a frame's band slots (= where each band's keypoints start in
+// the final lists) and the frame's raw counter (orb.rs:550-556).  One wave per frame.
+__global__ __launch_bounds__(64) void k_slot_prefix(const uint32_t* __restrict__ seg_counts,
+                                                    uint32_t* __restrict__ seg_before, uint32_t* __restrict__ counts,
+                                                    uint32_t n_slots, uint32_t seg_cap) {
+    const uint32_t frame = blockIdx.x, lane = threadIdx.x;
+    const uint32_t* sc = seg_counts + (size_t)frame * n_slots;
+    uint32_t* sb = seg_before + (size_t)frame * n_slots;
+    uint32_t carry = 0, total = 0;
+    for (uint32_t s0 = 0; s0 < n_slots; s0 += 64u) {
+        const uint32_t s = s0 + lane;
+        const uint32_t raw = s < n_slots ? sc[s] : 0u;
+        const uint32_t stored = min(raw, seg_cap);
+        uint32_t incl = stored;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += t;
+        }
+        if (s < n_slots) sb[s] = carry + incl - stored;
+        carry += __shfl(incl, 63);
+        uint32_t r = raw;
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) r += __shfl_xor(r, sh);
+        total += r;
+    }
+    if (lane == 0u) counts[frame] = total;
+}
+
+// Persistent workgroups: each walks its XCD's share of the tiles; while the keypoints of one tile are
+// being described out of LDS, the window, band records and counts of the next tile are already in
+// flight into registers (vector loads only: nothing in the loop waits on the scalar cache).
+__global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t* __restrict__ blur, Pyramid pyr,
+                                                                  TileGeom tg, const uint32_t* __restrict__ seg_counts,
+                                                                  const uint32_t* __restrict__ seg_before,
+                                                                  const CornerData* __restrict__ segments,
+                                                                  CornerData* __restrict__ corners, uint32_t cap,
+                                                                  CornerDescriptor* __restrict__ descriptors,
+                                                                  BriefTables tab) {
+    constexpr int NT = kBriefThreads;
+    constexpr int G = kBriefWinW / 8;     // 16-byte groups per window row
+    constexpr int N = kBriefWinH * G;     // 2584
+    constexpr int U = (N + NT - 1) / NT;  // 6
     __shared__ __attribute__((aligned(16))) uint16_t win[kBriefWinH * kBriefWinW];
-    __shared__ uint4 list_rec[kBriefList];   // x, y, angle, octave
-    __shared__ uint32_t list_k[kBriefList];  // output index
+    __shared__ uint4 list_rec[kBriefList];  // x, y, angle, octave
+    __shared__ uint4 list_aux[kBriefList];  // output index, cos bits, sin bits, -
     __shared__ uint32_t list_n;
 
-    const uint32_t tiles_per_frame = tg.tile_base[pyr.depth];
-    uint32_t frame, tile;
-    {
-        const uint32_t L = blockIdx.x;
-        if (tg.xcd_swizzle) {
-            const uint32_t xcd = L & 7u, q = L >> 3;
-            frame = (q / tiles_per_frame) * 8u + xcd;
-            tile = q % tiles_per_frame;
-        } else {
-            frame = L / tiles_per_frame;
-            tile = L % tiles_per_frame;
-        }
-    }
-    uint32_t lvl = 0;
-    for (uint32_t m = 1; m < pyr.depth; m++)
-        if (tile >= tg.tile_base[m]) lvl = m;
-    const uint32_t t_in = tile - tg.tile_base[lvl];
-    const uint32_t ty = t_in / tg.tile_cols[lvl], tx = t_in % tg.tile_cols[lvl];
-    const uint32_t n_bands = tg.slot_base[lvl + 1] - tg.slot_base[lvl];
-    const uint32_t slot_a = tg.slot_base[lvl] + 2u * ty;
-    const bool has_b = 2u * ty + 1u < n_bands;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t* sc = seg_counts + (size_t)frame * tg.n_slots;
+    const bool swz = tg.xcd_swizzle != 0u;
+    const uint32_t xcd = swz ? (blockIdx.x & 7u) : 0u;
+    uint32_t q = swz ? (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t q_step = swz ? (gridDim.x >> 3) : gridDim.x;
+    const uint32_t q_end = swz ? (tg.n_frames >> 3) * tg.tiles_per_frame : tg.n_frames * tg.tiles_per_frame;
+    if (q >= q_end) return;
 
-    // ---- stored keypoints before slot_a, and the frame's raw total (orb.rs:550-556)
-    uint32_t before = 0, total = 0;
-    for (uint32_t s0 = 0; s0 < tg.n_slots; s0 += 64u) {
-        const uint32_t s = s0 + lane;
-        const uint32_t raw = s < tg.n_slots ? sc[s] : 0u;
-        total += raw;
-        before += s < slot_a ? min(raw, tg.seg_cap) : 0u;
-    }
+    struct Tile {
+        uint32_t frame;
+        TileDesc d;
+    };
+    auto decode = [&](uint32_t qq) {
+        Tile t;
+        uint32_t fq = (uint32_t)(((float)qq + 0.5f) * tg.inv_tiles_per_frame);  // qq / tiles_per_frame (qq < 2^23)
+        const uint32_t tile = qq - fq * tg.tiles_per_frame;
+        t.frame = swz ? fq * 8u + xcd : fq;
+        t.d = tg.desc[tile];
+        return t;
+    };
+
+    // this lane's four tests (l, 64+l, 128+l, 192+l) of the pattern (packed int8 x 4) and their unrotated
+    // window offsets
+    uint32_t pat[4], off0[4];
 #pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) {
-        before += __shfl_xor(before, sh);
-        total += __shfl_xor(total, sh);
+    for (int e = 0; e < 4; e++) {
+        const uint32_t packed = tab.pattern[64u * (uint32_t)e + lane];
+        const int ax = (int8_t)(packed & 255u), ay = (int8_t)((packed >> 8) & 255u);
+        const int bx = (int8_t)((packed >> 16) & 255u), by = (int8_t)(packed >> 24);
+        pat[e] = packed;
+        off0[e] = ((uint32_t)(ay * kBriefWinW + ax) & 0xffffu) | ((uint32_t)(by * kBriefWinW + bx) << 16);
     }
-    if (tile == 0u && tid == 0u) counts[frame] = total;
-    const uint32_t n_a = min(sc[slot_a], tg.seg_cap);
-    const uint32_t n_b = has_b ? min(sc[slot_a + 1u], tg.seg_cap) : 0u;
-    if (tid == 0u) list_n = 0u;
-    if (n_a + n_b == 0u) return;  // uniform: nothing detected in these two bands
 
-    // ---- stage the window: rows [y0-18, y0+32+18), columns [x0-24, x0+256+24), zero outside the level
-    const int w = (int)pyr.w[lvl], h = (int)pyr.h[lvl];
-    const int x0 = (int)tx * kBriefTileW, y0 = (int)ty * kBriefTileH;
-    const uint16_t* plane = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
-    {
-        constexpr int G = kBriefWinW / 8;  // 16-byte groups per window row
-        constexpr int N = kBriefWinH * G;
-        constexpr int U = 6;
-        const bool vec_ok = (w & 7) == 0;
-        for (int ib = (int)tid; ib < N; ib += 256 * U) {
-            uint4 v[U];
+    // registers that carry the next tile
+    uint4 wv[U];
+    uint4 rec_a, rec_b;
+    uint32_t v_na = 0, v_nb = 0, v_before = 0;  // per-lane copies of uniform values (vector loads do not block)
+    auto issue = [&](const Tile& t, uint32_t tid) {
+        const uint16_t* plane = blur + (size_t)t.frame * pyr.stride + t.d.plane_off;
+        if ((t.d.w & 7) == 0) {
+            // window columns start at a multiple of 8 texels: a 16-byte group is entirely inside or outside the
+            // level, so load unconditionally from a clamped address and zero the outside ones when storing
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int i = ib + u * 256;
+                const int i = min((int)tid + u * NT, N - 1);
                 const int r = i / G, g = i - r * G;
-                const int gy = y0 - kBriefHalo + r, gx = x0 - kBriefPadX + g * 8;
-                v[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (i < N && gy >= 0 && gy < h && gx + 8 > 0 && gx < w) {
-                    const uint16_t* row = plane + (size_t)gy * w;
-                    if (vec_ok && gx >= 0 && gx + 8 <= w) {
-                        v[u] = *reinterpret_cast<const uint4*>(row + gx);
-                    } else {
-                        uint32_t e[8];
+                const int gy = t.d.y0 - kBriefHalo + r, gx = t.d.x0 - kBriefPadX + g * 8;
+                const int cy = min(max(gy, 0), t.d.h - 1), cx = min(max(gx, 0), t.d.w - 8);
+                wv[u] = *reinterpret_cast<const uint4*>(plane + (size_t)(uint32_t)(__mul24(cy, t.d.w) + cx));
+            }
+        }
+        const size_t slot = (size_t)t.frame * tg.n_slots + t.d.slot_a;
+        const CornerData* seg_a = segments + slot * tg.seg_cap;
+        const uint32_t spec = min(tid, tg.seg_cap - 1u);  // speculative: validity is known once the counts arrive
+        rec_a = *reinterpret_cast<const uint4*>(&seg_a[spec]);
+        rec_b = *reinterpret_cast<const uint4*>(&seg_a[(t.d.has_b ? tg.seg_cap : 0u) + spec]);
+        const uint32_t* cnt = seg_counts + slot + (lane & 0u);  // lane-dependent on purpose: keeps it a vector load
+        v_na = cnt[0];
+        v_nb = t.d.has_b ? cnt[1] : 0u;
+        v_before = (seg_before + slot + (lane & 0u))[0];
+    };
+    // A record belongs to this tile when its x falls in the tile's columns (its rows do by construction).
+    auto wanted = [&](const Tile& t, const uint4& rec, uint32_t k) {
+        return k < cap && rec.x >= (uint32_t)t.d.x0 && rec.x < (uint32_t)(t.d.x0 + kBriefTileW);
+    };
+    auto push = [&](const uint4& rec, uint32_t k, float ct, float st) {
+        const uint32_t idx = atomicAdd(&list_n, 1u);
+        if (idx < (uint32_t)kBriefList) {
+            list_rec[idx] = rec;
+            list_aux[idx] = make_uint4(k, __float_as_uint(ct), __float_as_uint(st), 0u);
+        }
+    };
+    auto pick = [&](const Tile& t, const uint4& rec, uint32_t k) {
+        if (wanted(t, rec, k)) {
+            const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
+            push(rec, k, tab.cos_tab[code], tab.sin_tab[code]);  // CRD-10 table
+        }
+    };
+    // window registers -> LDS (rows [y0-18, y0+32+18), columns [x0-24, x0+256+24), zero outside the level, CRD-6)
+    // and the tile's keypoints -> list
+    auto commit = [&](const Tile& t, uint32_t n_a, uint32_t n_b, uint32_t before, uint32_t tid) {
+        if (tid < n_a) pick(t, rec_a, before + tid);
+        if (tid < n_b) pick(t, rec_b, before + n_a + tid);
+        if ((t.d.w & 7) == 0) {
 #pragma unroll
-                        for (int k = 0; k < 8; k++) e[k] = (gx + k >= 0 && gx + k < w) ? (uint32_t)row[gx + k] : 0u;
-                        v[u] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-                    }
+            for (int u = 0; u < U; u++) {
+                const int i = (int)tid + u * NT;
+                const int r = i / G, g = i - r * G;
+                const int gy = t.d.y0 - kBriefHalo + r, gx = t.d.x0 - kBriefPadX + g * 8;
+                const bool inside = gy >= 0 && gy < t.d.h && gx >= 0 && gx < t.d.w;
+                if (i < N) *reinterpret_cast<uint4*>(&win[i * 8]) = inside ? wv[u] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        } else {  // odd widths: element-wise
+            const uint16_t* plane = blur + (size_t)t.frame * pyr.stride + t.d.plane_off;
+            for (int i = (int)tid; i < N; i += NT) {
+                const int r = i / G, g = i - r * G;
+                const int gy = t.d.y0 - kBriefHalo + r, gx = t.d.x0 - kBriefPadX + g * 8;
+                uint32_t e[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int xx = gx + k;
+                    e[k] = (gy >= 0 && gy < t.d.h && xx >= 0 && xx < t.d.w) ? (uint32_t)plane[(size_t)gy * t.d.w + xx] : 0u;
+                }
+                *reinterpret_cast<uint4*>(&win[i * 8]) =
+                    make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+            }
+        }
+    };
+    // One wave per keypoint of the list, everything it needs is in LDS or registers.  Angle code 0 (R = I:
+    // more than half of all keypoints, Q7) uses the unrotated offsets; otherwise the lane rotates its eight
+    // pattern points with brief.wgsl:38-57's arithmetic (one rounding per op, truncation toward zero).
+    // Blur texels are non-negative f16, so `a > b` (brief.wgsl:62) is decided on the bit patterns; four
+    // ballots give the eight u32 words (brief.wgsl:47,63,67).
+    auto describe = [&](const Tile& t, uint32_t n_l) {
+        CornerData* out_kp = corners + (size_t)t.frame * cap;
+        uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)t.frame * cap);
+        constexpr uint32_t NW = NT / 64;
+        for (uint32_t i = wave; i < n_l; i += NW) {
+            const uint4 rec = list_rec[i];
+            const uint4 aux = list_aux[i];
+            const int cx = (int)rec.x - t.d.x0 + kBriefPadX, cy = (int)rec.y - t.d.y0 + kBriefHalo;
+            const uint16_t* ctr = win + cy * kBriefWinW + cx;
+            // sample offsets of this lane's four tests, then all eight LDS reads back to back
+            int oa[4], ob[4];
+            if (rec.z == 0u) {  // wave-uniform
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    oa[e] = (int)(int16_t)(off0[e] & 0xffffu);
+                    ob[e] = (int)(int16_t)(off0[e] >> 16);
+                }
+            } else {
+                const float ct = __uint_as_float(aux.y), st = __uint_as_float(aux.z), nst = -st;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
+                    const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
+                    // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y)
+                    const float a0 = ct * pax, a1 = st * pay, a2 = nst * pax, a3 = ct * pay;
+                    const float b0 = ct * pbx, b1 = st * pby, b2 = nst * pbx, b3 = ct * pby;
+                    const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+                    oa[e] = (int)ray * kBriefWinW + (int)rax;  // vec2i() truncates
+                    ob[e] = (int)rby * kBriefWinW + (int)rbx;
                 }
             }
+            uint32_t va[4], vb[4];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = ib + u * 256;
-                if (i < N) *reinterpret_cast<uint4*>(&win[i * 8]) = v[u];
+            for (int e = 0; e < 4; e++) {
+                va[e] = ctr[oa[e]];
+                vb[e] = ctr[ob[e]];
             }
-        }
-    }
-
-    const CornerData* seg_a = segments + ((size_t)frame * tg.n_slots + slot_a) * tg.seg_cap;
-    const CornerData* seg_b = seg_a + tg.seg_cap;
-    CornerData* out_kp = corners + (size_t)frame * cap;
-    uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)frame * cap);
-    const uint32_t p0 = tab.pattern[lane], p1 = tab.pattern[64u + lane], p2 = tab.pattern[128u + lane],
-                   p3 = tab.pattern[192u + lane];
-    const uint32_t pats[4] = {p0, p1, p2, p3};
-
-    // ---- rounds of up to 256 segment records: pick this tile's keypoints, then one wave per keypoint
-    const uint32_t n_ab = n_a + n_b;
-    for (uint32_t c0 = 0; c0 < n_ab; c0 += 256u) {
-        __syncthreads();  // window staged / previous round drained
-        const uint32_t j = c0 + tid;
-        if (j < n_ab) {
-            const uint4 rec = *reinterpret_cast<const uint4*>(j < n_a ? &seg_a[j] : &seg_b[j - n_a]);
-            const uint32_t k = before + j;  // segments back to back
-            if (k < cap && rec.x >= (uint32_t)x0 && rec.x < (uint32_t)(x0 + kBriefTileW)) {
-                const uint32_t idx = atomicAdd(&list_n, 1u);
-                list_rec[idx] = rec;
-                list_k[idx] = k;
-            }
-        }
-        __syncthreads();
-        const uint32_t n_l = list_n;
-        for (uint32_t i = wave; i < n_l; i += 4u) {
-            const uint4 rec = list_rec[i];
-            const uint32_t k = list_k[i];
-            const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
-            const float ct = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
-            // keypoint position inside the window
-            const int cx = (int)rec.x - x0 + kBriefPadX, cy = (int)rec.y - y0 + kBriefHalo;
-            const uint16_t* ctr = win + cy * kBriefWinW + cx;
             uint64_t bal[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const uint32_t packed = pats[t];
-                const float ax = (float)(int8_t)(packed & 255u), ay = (float)(int8_t)((packed >> 8) & 255u);
-                const float bx = (float)(int8_t)((packed >> 16) & 255u), by = (float)(int8_t)(packed >> 24);
-                // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y)   brief.wgsl:38-54
-                const float a0 = ct * ax, a1 = st * ay, a2 = nst * ax, a3 = ct * ay;
-                const float b0 = ct * bx, b1 = st * by, b2 = nst * bx, b3 = ct * by;
-                const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
-                const float va = from_half(bits_half(ctr[(int)ray * kBriefWinW + (int)rax]));  // vec2i() truncates
-                const float vb = from_half(bits_half(ctr[(int)rby * kBriefWinW + (int)rbx]));
-                bal[t] = __ballot(va > vb);  // brief.wgsl:62
-            }
+            for (int e = 0; e < 4; e++) bal[e] = __ballot(va[e] > vb[e]);
             if (lane < 8u) {
                 const uint64_t src = lane < 2u ? bal[0] : (lane < 4u ? bal[1] : (lane < 6u ? bal[2] : bal[3]));
-                out_desc[(size_t)k * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
+                out_desc[(size_t)aux.x * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
             } else if (lane == 8u) {
-                *reinterpret_cast<uint4*>(&out_kp[k]) = rec;
+                *reinterpret_cast<uint4*>(&out_kp[aux.x]) = rec;
             }
         }
-        __syncthreads();
+    };
+    // Tiles with more than NT records in a band, or more keypoints than the list holds: rounds of NT/2 records.
+    auto slow_tile = [&](const Tile& t, uint32_t na, uint32_t nb, uint32_t bef) {
+        const size_t slot = (size_t)t.frame * tg.n_slots + t.d.slot_a;
+        for (int half = 0; half < 2; half++) {
+            const CornerData* seg = segments + (slot + (uint32_t)half) * tg.seg_cap;
+            const uint32_t n = half ? nb : na, base = half ? bef + na : bef;
+            for (uint32_t c0 = 0; c0 < n; c0 += NT / 2) {  // NT/2 records per round always fit the list
+                __syncthreads();
+                if (tid == 0u) list_n = 0u;
+                __syncthreads();
+                const uint32_t j = c0 + tid;
+                if (tid < NT / 2 && j < n) pick(t, *reinterpret_cast<const uint4*>(&seg[j]), base + j);
+                __syncthreads();
+                describe(t, min(list_n, (uint32_t)kBriefList));
+            }
+        }
+    };
+
+    // diagnostic stamps (tg.stamps != null): cycles spent by wave 0 in each phase, summed over the tiles
+    unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_last = 0;
+    const bool stamping = tg.stamps != nullptr;
+    auto stamp = [&](int slot) {
+        if (stamping) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            t_acc[slot] += now - t_last;
+            t_last = now;
+        }
+    };
+    if (tid == 0u) list_n = 0u;
+    Tile cur = decode(q);
+    issue(cur, tid);
+    __syncthreads();
+    uint32_t cur_na = min(__builtin_amdgcn_readfirstlane(v_na), tg.seg_cap);
+    uint32_t cur_nb = min(__builtin_amdgcn_readfirstlane(v_nb), tg.seg_cap);
+    uint32_t cur_before = __builtin_amdgcn_readfirstlane(v_before);
+    commit(cur, cur_na, cur_nb, cur_before, tid);
+    __syncthreads();
+    if (stamping) t_last = __builtin_readcyclecounter();
+    for (;;) {
+        const uint32_t qn = q + q_step;
+        const bool has_next = qn < q_end;
+        // Per-thread index math of issue/commit is the same for every tile; an opaque copy of the thread
+        // index per use keeps the optimiser from hoisting it all out of this loop (register pressure).
+        uint32_t tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        Tile nxt_tile = cur;
+        if (has_next) {
+            nxt_tile = decode(qn);
+            issue(nxt_tile, tid_o);  // in flight while the current tile is described
+        }
+        stamp(0);
+        const uint32_t n_l = list_n;
+        if (cur_na > (uint32_t)NT || cur_nb > (uint32_t)NT || n_l > (uint32_t)kBriefList)
+            slow_tile(cur, cur_na, cur_nb, cur_before);
+        else
+            describe(cur, n_l);
+        stamp(1);
+        __syncthreads();  // window and list of the current tile are dead
+        stamp(2);
+        if (!has_next) break;
         if (tid == 0u) list_n = 0u;
+        __syncthreads();
+        stamp(3);
+        cur = nxt_tile;
+        cur_na = min(__builtin_amdgcn_readfirstlane(v_na), tg.seg_cap);
+        cur_nb = min(__builtin_amdgcn_readfirstlane(v_nb), tg.seg_cap);
+        cur_before = __builtin_amdgcn_readfirstlane(v_before);
+        asm volatile("" : "+v"(tid_o));
+        commit(cur, cur_na, cur_nb, cur_before, tid_o);
+        q = qn;
+        stamp(4);
+        __syncthreads();
+        stamp(5);
     }
+    if (stamping && tid == 0u)
+        for (int i = 0; i < 6; i++) tg.stamps[(size_t)blockIdx.x * 6 + i] = t_acc[i];
 }
 
 }  // namespace orb

@@ -36,7 +36,7 @@ EXPORTS = [
     "orb_read_descriptors", "orb_extract_batch_device", "orb_extract_batch_host", "orb_batch_sync",
     "orb_batch_counts", "orb_batch_read", "orb_batch_device_buffers", "orb_level_size",
     "orb_debug_read_plane", "orb_debug_f32_to_f16", "orb_debug_angle_code", "orb_profile_enable",
-    "orb_profile_reset", "orb_profile_get", "orb_synth_frames_device", "orb_copy_to_host",
+    "orb_profile_reset", "orb_profile_get", "orb_synth_frames_device", "orb_copy_to_host", "orb_debug_stamps",
 ]
 
 
@@ -122,6 +122,7 @@ def load_library(path=None):
     L.orb_profile_get.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
     L.orb_synth_frames_device.argtypes = [vp, vp, u32, u32, u32, ctypes.POINTER(vp)]
     L.orb_copy_to_host.argtypes = [vp, vp, vp, sz]
+    L.orb_debug_stamps.argtypes = [vp, vp, sz]
     if L.orb_abi_version() != 1:
         raise OrbError(ORB_EINVAL, "libtinyorb ABI version mismatch")
     if path == LIB_PATH:
@@ -327,6 +328,11 @@ class OrbProgram:
         self._check(self._lib.orb_synth_frames_device(self._handle(), ctypes.c_void_p(frames_dev_ptr) if frames_dev_ptr else None,
                                                       n_frames, seed0 & 0xFFFFFFFF, flags, ctypes.byref(out)))
         return out.value
+
+    def debug_stamps(self, n_workgroups):
+        out = np.zeros((n_workgroups, 6), dtype=np.uint64)
+        self._check(self._lib.orb_debug_stamps(self._handle(), _ptr(out), out.size))
+        return out
 
     def copy_to_host(self, dev_ptr, nbytes):
         out = np.zeros(nbytes, dtype=np.uint8)
