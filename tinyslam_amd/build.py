@@ -48,7 +48,10 @@ def needs_build():
 def build_lib(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    flags = list(HIPCC_FLAGS)
+    if os.environ.get("TINYORB_BUILD_STAMPS"):  # diagnostic build: in-kernel cycle stamps (tools/stamps.py)
+        flags.append("-DTINYORB_STAMPS")
+    cmd = [_hipcc()] + flags + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -268,6 +268,7 @@ int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
         g.slot_base = p->bands.slot_base[lvl];
         g.n_slots = p->bands.n_slots;
         g.seg_cap = p->bands.seg_cap;
+        g.stamps = p->d_stamps ? p->d_stamps + 4096 * 6 : nullptr;
         if (g.n_bands != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: band count mismatch at level %u", lvl);
         const uint32_t lds = front_lds_bytes(g);
@@ -473,8 +474,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         CREATE_TRY(hipMemcpy(p->d_tile_desc, desc.data(), desc.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
         tg.desc = p->d_tile_desc;
         if (getenv("TINYORB_STAMPS")) {
-            CREATE_TRY(hipMalloc(&p->d_stamps, 4096 * 6 * sizeof(unsigned long long)));
-            CREATE_TRY(hipMemset(p->d_stamps, 0, 4096 * 6 * sizeof(unsigned long long)));
+            CREATE_TRY(hipMalloc(&p->d_stamps, (4096 * 6 + 32) * sizeof(unsigned long long)));
+            CREATE_TRY(hipMemset(p->d_stamps, 0, (4096 * 6 + 32) * sizeof(unsigned long long)));
         }
     }
     CREATE_TRY(hipHostMalloc(&p->h_count, sizeof(uint32_t), hipHostMallocDefault));
@@ -749,7 +750,7 @@ int orb_synth_frames_device(OrbProgram* p, uint8_t* frames_dev, uint32_t n_frame
 int orb_debug_stamps(OrbProgram* p, unsigned long long* dst, size_t n) {
     if (!p || !dst) return ORB_EINVAL;
     if (!p->d_stamps) return fail(p, ORB_ESTATE, "stamps are collected only with TINYORB_STAMPS=1");
-    if (n > 4096 * 6) n = 4096 * 6;
+    if (n > 4096 * 6 + 32) n = 4096 * 6 + 32;
     HIP_TRY(p, hipSetDevice(p->device));
     HIP_TRY(p, hipDeviceSynchronize());
     HIP_TRY(p, hipMemcpy(dst, p->d_stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -45,6 +45,7 @@ struct FrontGeom {
     uint32_t slot_base;   // index of this level's band 0 among the frame's band slots
     uint32_t n_slots;     // band slots per frame (all levels)
     uint32_t seg_cap;     // CornerData records per band segment
+    unsigned long long* stamps;  // diagnostic runs only: 16 cycle sums per kernel flavour (else null)
 };
 
 __host__ __device__ inline uint32_t front_lds_bytes(const FrontGeom& g) {
@@ -190,6 +191,19 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     const size_t slot = (size_t)frame * geo.n_slots + geo.slot_base + band;
     CornerData* const seg = segments + slot * geo.seg_cap;
 
+    // diagnostic stamps (geo.stamps != null): cycles of wave 0 between consecutive marks, summed over workgroups
+#ifdef TINYORB_STAMPS
+    unsigned long long t_last = geo.stamps ? __builtin_readcyclecounter() : 0ull;
+    auto stamp = [&](int slot) {
+        if (geo.stamps && tid == 0) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            atomicAdd(geo.stamps + (L0 ? 0 : 16) + slot, now - t_last);
+            t_last = now;
+        }
+    };
+#else
+    auto stamp = [](int) {};  // the shipped build executes no stamp
+#endif
     if (tid < 4) qa_count[tid] = 0u;
 
     // =========================== A: stage grey rows [y0-3, y0+R+3) ===========================
@@ -258,7 +272,9 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
             }
         }
     }
+    stamp(0);  // A: staging
     __syncthreads();
+    stamp(1);  // barrier
 
     // Blur taps 0, 2 and 3 always clamp to column 0 / w-1 (offsets are in UV units, Q11), so per row they
     // are three constants: acc = (((0 + t[0]*w0) + lerp*w1) + t[w-1]*w2) + t[w-1]*w3.  One thread per row
@@ -353,7 +369,9 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 }
             }
         }
+        stamp(2);  // B1
         __syncthreads();
+        stamp(3);
 
         // =========================== B2: thin, test, orient -- each stage on densely packed lanes ===========
         if (geo.phase_mask & 2u) {
@@ -380,7 +398,9 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     }
                 }
             }
+            stamp(4);  // S1
             __syncthreads();
+            stamp(5);
             // stage 2: 16-point masks + 12-streak, B -> C
             const uint32_t n_b = min(*qb_count, cap_b);
             for (uint32_t i = (uint32_t)tid; i < n_b; i += NT) {
@@ -395,7 +415,9 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                         segment_append(true, x, gy, ring_angle(ctr, LS), lvl, c_count, seg, geo.seg_cap);
                 }
             }
+            stamp(6);  // S2
             __syncthreads();
+            stamp(7);
             // stage 3: orientation of the corners, append to the band's segment
             const uint32_t n_c = min(*qc_count, cap_c);
             for (uint32_t i = (uint32_t)tid; i < n_c; i += NT) {
@@ -404,7 +426,9 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 segment_append(true, x, gy, ring_angle(ctr, LS), lvl, c_count, seg, geo.seg_cap);
             }
         }
+        stamp(8);  // S3
         __syncthreads();  // queues B and C share storage with phase C's blur intermediate
+        stamp(9);
     };
     auto phase_C = [&]() {
         // =========================== C0: next mip level (blit.wgsl, exact 2x2 case) ===========================
@@ -443,6 +467,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
             }
         }
 
+        stamp(10);  // C0
         // =========================== C: literal blur, both passes ===========================
         // Two rows at a time: a thread's column has the same tap index/fraction in every row, so the two
         // rows' lerp and accumulation run as packed-f32 pairs (v_pk_*_f32: two binary32 lanes per op, each
@@ -530,7 +555,9 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     };
     phase_B();
     phase_C();
+    stamp(11);  // C
     __syncthreads();
+    stamp(12);
     if (tid == 0) seg_counts[slot] = *c_count;  // raw count of the band (may exceed seg_cap)
 }
 
@@ -808,6 +835,7 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
     };
 
     // diagnostic stamps (tg.stamps != null): cycles spent by wave 0 in each phase, summed over the tiles
+#ifdef TINYORB_STAMPS
     unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_last = 0;
     const bool stamping = tg.stamps != nullptr;
     auto stamp = [&](int slot) {
@@ -817,6 +845,9 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
             t_last = now;
         }
     };
+#else
+    auto stamp = [](int) {};  // the shipped build executes no stamp
+#endif
     if (tid == 0u) list_n = 0u;
     Tile cur = decode(q);
     issue(cur, tid);
@@ -826,7 +857,9 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
     uint32_t cur_before = __builtin_amdgcn_readfirstlane(v_before);
     commit(cur, cur_na, cur_nb, cur_before, tid);
     __syncthreads();
+#ifdef TINYORB_STAMPS
     if (stamping) t_last = __builtin_readcyclecounter();
+#endif
     for (;;) {
         const uint32_t qn = q + q_step;
         const bool has_next = qn < q_end;
@@ -863,8 +896,10 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
         __syncthreads();
         stamp(5);
     }
+#ifdef TINYORB_STAMPS
     if (stamping && tid == 0u)
         for (int i = 0; i < 6; i++) tg.stamps[(size_t)blockIdx.x * 6 + i] = t_acc[i];
+#endif
 }
 
 }  // namespace orb
