@@ -74,29 +74,74 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < n_dev else local_rank % max(n_dev, 1)  # rehearsal: ranks share a GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" is RCCL on ROCm.  TINYORB_DIST_BACKEND=gloo only exists to rehearse the N > 1 code path
+        # on a one-GPU box (several ranks sharing device 0, which RCCL refuses).
+        backend = os.environ.get("TINYORB_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     B = args.frames
     cfg = orb.OrbConfig(orb.Extent3d(W, H), max_features=MAX_FEATURES, hierarchy_depth=DEPTH,
-                        initial_threshold=THRESHOLD, device=local_rank, max_batch=B,
-                        flags=orb.ORB_FLAG_STAGED if args.staged else 0)
+                        initial_threshold=THRESHOLD, device=dev_index, max_batch=B,
+                        flags=(orb.ORB_FLAG_STAGED if args.staged else 0) | (orb.ORB_FLAG_DOUBLE_OUTPUT if world > 1 else 0))
     prog = orb.OrbProgram(cfg).init()
     frames_dev = prog.synth_frames_device(B, SEED0 + rank * B)  # rank g owns frames [g*B, (g+1)*B)
-    d_counts, d_corners, d_desc = prog.batch_device_buffers()
-    counts_t = node.as_tensor(d_counts, (B,), "<i4", dev)
-    corners_t = node.as_tensor(d_corners, (B, MAX_FEATURES, 4), "<i4", dev)
-    desc_t = node.as_tensor(d_desc, (B, MAX_FEATURES, 8), "<i4", dev)
+    n_sets = 2 if world > 1 else 1
+    views = []
+    for s_ in range(n_sets):
+        prog.batch_select_output(s_)
+        d_counts, d_corners, d_desc = prog.batch_device_buffers()
+        views.append((node.as_tensor(d_counts, (B,), "<i4", dev), node.as_tensor(d_corners, (B, MAX_FEATURES, 4), "<i4", dev),
+                      node.as_tensor(d_desc, (B, MAX_FEATURES, 8), "<i4", dev)))
+    prog.batch_select_output(0)
+    state = {"k": 0, "pending": None}
+    free = [None, None]
+    compute_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+
+    def collate(pending):
+        slot, done = pending
+        counts_t, corners_t, desc_t = views[slot]
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(done)  # the kernels that wrote this output set
+            node.collate_to_root(counts_t, corners_t, desc_t, MAX_FEATURES)
+            free[slot] = torch.cuda.Event()
+            free[slot].record(comm_stream)  # the gather has read this output set
 
     def step():
-        prog.extract_batch_device(frames_dev, B)
-        if world > 1:
-            prog.batch_sync()  # the collate runs on torch's stream
-            node.collate_to_root(counts_t, corners_t, desc_t, MAX_FEATURES)
+        """N = 1: extract.  N > 1: launch batch k into output set k%2 on the compute stream, then collate
+        batch k-1 on the communication stream (it waits on the event recorded behind batch k-1's kernels):
+        the RCCL gather of one batch overlaps the kernels of the next.  Every batch is collated inside the
+        timed region (flush() drains the last one)."""
+        if world == 1:
+            prog.extract_batch_device(frames_dev, B)
+            return
+        slot = state["k"] & 1
+        prog.batch_select_output(slot)
+        if free[slot] is not None:
+            compute_stream.wait_event(free[slot])  # do not overwrite a set that is still being gathered
+        prog.extract_batch_device(frames_dev, B, stream=compute_stream.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(compute_stream)
+        if state["pending"] is not None:
+            collate(state["pending"])
+        state["pending"] = (slot, done)
+        state["k"] += 1
+
+    def flush():
+        if world > 1 and state["pending"] is not None:
+            collate(state["pending"])
+            state["pending"] = None
 
     def fence():
+        flush()
         prog.batch_sync()
         torch.cuda.synchronize()
         if world > 1:
@@ -161,7 +206,7 @@ def main():
                        "frames_per_gpu": B, "width": W, "height": H, "hierarchy_depth": DEPTH,
                        "max_features": MAX_FEATURES, "threshold": THRESHOLD, "mode": "literal",
                        "pipeline": "staged" if args.staged else "default",
-                       "collate": "RCCL gather to rank 0 each step" if world > 1 else "none (1 GPU)"},
+                       "collate": "RCCL gather of every batch to rank 0, overlapped with the next batch's kernels" if world > 1 else "none (1 GPU)"},
             "mkeypoints_per_s": kp_per_step * args.steps / elapsed / 1e6,
             "keypoints_per_frame": n_mean,
             "hbm_algorithmic_gbs": bytes_per_frame * fps / 1e9,

@@ -75,7 +75,8 @@ typedef struct OrbOptions {
     uint32_t reserved[5];
 } OrbOptions;
 
-#define ORB_FLAG_STAGED 1u  /* force the one-kernel-per-stage pipeline (cross-check of the fused path) */
+#define ORB_FLAG_STAGED 1u        /* force the one-kernel-per-stage pipeline (cross-check of the fused path) */
+#define ORB_FLAG_DOUBLE_OUTPUT 2u /* two sets of output slabs: batch k+1 computes while batch k is collated */
 
 typedef struct OrbProgram OrbProgram; /* opaque; replaces orb.rs:47-51 `OrbProgram` */
 
@@ -117,6 +118,9 @@ int orb_batch_sync(OrbProgram *p);
 int orb_batch_counts(OrbProgram *p, uint32_t *totals, uint32_t n_frames);
 /* Copy up to n records of one frame of the last batch to the host (synchronises). */
 int orb_batch_read(OrbProgram *p, uint32_t frame, CornerData *corners, CornerDescriptor *descriptors, size_t n);
+/* Selects which output set (0 or 1; 1 needs ORB_FLAG_DOUBLE_OUTPUT) the next batched call writes and the
+ * batch read/buffer calls refer to. */
+int orb_batch_select_output(OrbProgram *p, uint32_t set);
 /* Device pointers of the output slabs, for a device-side collate (RCCL gather):
  * counts[max_batch] u32, corners[max_batch][max_features], descriptors[max_batch][max_features]. */
 int orb_batch_device_buffers(OrbProgram *p, void **counts, void **corners, void **descriptors);

@@ -259,3 +259,28 @@ def test_host_batch_and_single_frame_api_agree(tinyorb, oracle):
             total, corners, desc = prog.extract(frames[i])
             c, d = _sorted(corners, desc)
             assert total == counts[i] and np.array_equal(c, batch[i][0]) and np.array_equal(d, batch[i][1])
+
+
+def test_double_output_sets(tinyorb, oracle):
+    """ORB_FLAG_DOUBLE_OUTPUT: two independent output sets (batch k+1 computes while batch k is collated)."""
+    W, H, B = 320, 240, 3
+    with _program(tinyorb, W, H, 2, max_batch=B, flags=tinyorb.ORB_FLAG_DOUBLE_OUTPUT) as prog:
+        dev_a = prog.synth_frames_device(B, 500)
+        frames_a = prog.copy_to_host(dev_a, B * W * H * 4).reshape(B, H, W, 4).copy()
+        prog.batch_select_output(0)
+        prog.extract_batch_device(dev_a, B)
+        prog.batch_sync()
+        prog.synth_frames_device(B, 600)  # same slab, new frames
+        frames_b = prog.copy_to_host(dev_a, B * W * H * 4).reshape(B, H, W, 4).copy()
+        prog.batch_select_output(1)
+        prog.extract_batch_device(dev_a, B)
+        for slot, frames in ((0, frames_a), (1, frames_b)):
+            prog.batch_select_output(slot)
+            counts = prog.batch_counts(B)
+            for i in range(B):
+                ref = oracle.extract(frames[i], depth=2, threshold=THR)
+                corners, desc = prog.batch_read(i, int(counts[i]))
+                _assert_frame_equal(oracle, ref, int(counts[i]), corners, desc)
+    with _program(tinyorb, W, H, 2) as prog:
+        with pytest.raises(tinyorb.OrbError):
+            prog.batch_select_output(1)

@@ -48,9 +48,12 @@ struct OrbProgram {
     uint8_t* d_input = nullptr;  // max_batch frames (single-frame API, host batches, synth)
     uint16_t* d_gray = nullptr;  // max_batch x pyr.stride
     uint16_t* d_blur = nullptr;
-    uint32_t* d_counts = nullptr;
+    uint32_t* d_counts = nullptr;  // currently selected output set (orb_batch_select_output)
     CornerData* d_corners = nullptr;
     CornerDescriptor* d_desc = nullptr;
+    uint32_t* out_counts[2] = {nullptr, nullptr};
+    CornerData* out_corners[2] = {nullptr, nullptr};
+    CornerDescriptor* out_desc[2] = {nullptr, nullptr};
     CornerData* d_seg = nullptr;     // fused path: [max_batch][n_slots][seg_cap] band segments
     uint32_t* d_seg_counts = nullptr;  // [max_batch][n_slots]
     uint32_t* d_seg_before = nullptr;  // [max_batch][n_slots] exclusive prefix of the stored counts
@@ -430,12 +433,17 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     const size_t B = p->max_batch, cap = config->max_features;
     CREATE_TRY(hipMalloc(&p->d_gray, B * p->pyr.stride * sizeof(uint16_t)));
     CREATE_TRY(hipMalloc(&p->d_blur, B * p->pyr.stride * sizeof(uint16_t)));
-    CREATE_TRY(hipMalloc(&p->d_counts, B * sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc(&p->d_corners, B * cap * sizeof(CornerData)));
-    CREATE_TRY(hipMalloc(&p->d_desc, B * cap * sizeof(CornerDescriptor)));
-    CREATE_TRY(hipMemset(p->d_counts, 0, B * sizeof(uint32_t)));
-    CREATE_TRY(hipMemset(p->d_corners, 0, B * cap * sizeof(CornerData)));
-    CREATE_TRY(hipMemset(p->d_desc, 0, B * cap * sizeof(CornerDescriptor)));
+    for (int set = 0; set < ((p->opt.flags & ORB_FLAG_DOUBLE_OUTPUT) ? 2 : 1); set++) {
+        CREATE_TRY(hipMalloc(&p->out_counts[set], B * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc(&p->out_corners[set], B * cap * sizeof(CornerData)));
+        CREATE_TRY(hipMalloc(&p->out_desc[set], B * cap * sizeof(CornerDescriptor)));
+        CREATE_TRY(hipMemset(p->out_counts[set], 0, B * sizeof(uint32_t)));
+        CREATE_TRY(hipMemset(p->out_corners[set], 0, B * cap * sizeof(CornerData)));
+        CREATE_TRY(hipMemset(p->out_desc[set], 0, B * cap * sizeof(CornerDescriptor)));
+    }
+    p->d_counts = p->out_counts[0];
+    p->d_corners = p->out_corners[0];
+    p->d_desc = p->out_desc[0];
     if (p->fused) {
         CREATE_TRY(hipMalloc(&p->d_seg, B * p->bands.n_slots * (size_t)p->bands.seg_cap * sizeof(CornerData)));
         CREATE_TRY(hipMalloc(&p->d_seg_counts, B * p->bands.n_slots * sizeof(uint32_t)));
@@ -498,9 +506,11 @@ void orb_program_destroy(OrbProgram* p) {
     (void)hipFree(p->d_input);
     (void)hipFree(p->d_gray);
     (void)hipFree(p->d_blur);
-    (void)hipFree(p->d_counts);
-    (void)hipFree(p->d_corners);
-    (void)hipFree(p->d_desc);
+    for (int set = 0; set < 2; set++) {
+        (void)hipFree(p->out_counts[set]);
+        (void)hipFree(p->out_corners[set]);
+        (void)hipFree(p->out_desc[set]);
+    }
     (void)hipFree(p->d_seg);
     (void)hipFree(p->d_seg_counts);
     (void)hipFree(p->d_seg_before);
@@ -624,6 +634,16 @@ int orb_batch_read(OrbProgram* p, uint32_t frame, CornerData* corners, CornerDes
     if (descriptors)
         HIP_TRY(p, hipMemcpy(descriptors, p->d_desc + (size_t)frame * cap, n * sizeof(CornerDescriptor),
                              hipMemcpyDeviceToHost));
+    return ORB_OK;
+}
+
+int orb_batch_select_output(OrbProgram* p, uint32_t set) {
+    if (!p) return ORB_EINVAL;
+    if (set > 1u || !p->out_counts[set])
+        return fail(p, ORB_EINVAL, "output set %u does not exist (create with ORB_FLAG_DOUBLE_OUTPUT)", set);
+    p->d_counts = p->out_counts[set];
+    p->d_corners = p->out_corners[set];
+    p->d_desc = p->out_desc[set];
     return ORB_OK;
 }
 

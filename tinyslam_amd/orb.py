@@ -22,6 +22,7 @@ ORB_OK, ORB_EINVAL, ORB_EHIP, ORB_ECAPACITY, ORB_ESTATE = 0, 1, 2, 3, 4
 ORB_PLANE_GRAY, ORB_PLANE_BLUR = 0, 1
 ORB_KERNEL_COUNT = 8
 ORB_FLAG_STAGED = 1
+ORB_FLAG_DOUBLE_OUTPUT = 2
 SYN_GRADIENT, SYN_BLOBS, SYN_WEDGES, SYN_NOISE = 1, 2, 4, 8
 SYN_ALL = 15
 
@@ -34,7 +35,7 @@ EXPORTS = [
     "orb_abi_version", "orb_pipeline", "orb_last_error", "orb_kernel_name", "orb_program_create", "orb_program_destroy",
     "orb_write_input_image", "orb_set_threshold", "orb_extract_corners", "orb_read_corners",
     "orb_read_descriptors", "orb_extract_batch_device", "orb_extract_batch_host", "orb_batch_sync",
-    "orb_batch_counts", "orb_batch_read", "orb_batch_device_buffers", "orb_level_size",
+    "orb_batch_counts", "orb_batch_read", "orb_batch_select_output", "orb_batch_device_buffers", "orb_level_size",
     "orb_debug_read_plane", "orb_debug_f32_to_f16", "orb_debug_angle_code", "orb_profile_enable",
     "orb_profile_reset", "orb_profile_get", "orb_synth_frames_device", "orb_copy_to_host", "orb_debug_stamps",
 ]
@@ -112,6 +113,7 @@ def load_library(path=None):
     L.orb_batch_sync.argtypes = [vp]
     L.orb_batch_counts.argtypes = [vp, vp, u32]
     L.orb_batch_read.argtypes = [vp, u32, vp, vp, sz]
+    L.orb_batch_select_output.argtypes = [vp, u32]
     L.orb_batch_device_buffers.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.orb_level_size.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.orb_debug_read_plane.argtypes = [vp, u32, ctypes.c_int, u32, vp, sz]
@@ -272,6 +274,9 @@ class OrbProgram:
         desc = np.zeros((n, 8), dtype=np.uint32)
         self._check(self._lib.orb_batch_read(self._handle(), frame, _ptr(corners), _ptr(desc), n))
         return corners, desc
+
+    def batch_select_output(self, slot):
+        self._check(self._lib.orb_batch_select_output(self._handle(), slot))
 
     def batch_device_buffers(self):
         a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
