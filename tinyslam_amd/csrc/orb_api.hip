@@ -251,9 +251,19 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
 }
 
 // The fused pipeline: one k_front launch per level + BRIEF.
-int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
+// The fused pipeline for frames [f0, f0 + n) of the batch on stream s: one k_front launch per level + BRIEF.
+int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint32_t n, hipStream_t s) {
     const Pyramid& pyr = p->pyr;
     const uint32_t D = pyr.depth, cap = p->cfg.max_features;
+    const uint8_t* frames = frames_all + (size_t)f0 * p->frame_bytes;
+    uint16_t* const d_gray = p->d_gray + (size_t)f0 * pyr.stride;
+    uint16_t* const d_blur = p->d_blur + (size_t)f0 * pyr.stride;
+    uint32_t* const d_seg_counts = p->d_seg_counts + (size_t)f0 * p->bands.n_slots;
+    uint32_t* const d_seg_before = p->d_seg_before + (size_t)f0 * p->bands.n_slots;
+    CornerData* const d_seg = p->d_seg + (size_t)f0 * p->bands.n_slots * p->bands.seg_cap;
+    uint32_t* const d_counts = p->d_counts + f0;
+    CornerData* const d_corners = p->d_corners + (size_t)f0 * cap;
+    CornerDescriptor* const d_desc = p->d_desc + (size_t)f0 * cap;
     // orb.rs:475 clear_buffer(counter): every band slot's count is rewritten by its k_front block and
     // counts[] by k_brief_bands, so nothing needs clearing here.
     uint32_t width = pyr.w[0], height = pyr.h[0];  // orb.rs:501-519
@@ -264,7 +274,7 @@ int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
         if (lvl > 0 && !(pyr.w[lvl - 1] == 2u * pyr.w[lvl] && pyr.h[lvl - 1] == 2u * pyr.h[lvl])) {
             LaunchScope ls(p, s, KID_MIP);  // inexact reduction (odd source size): generic bilinear blit
             dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 3u) / 4u, n);
-            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, p->d_gray, pyr, lvl);
+            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, d_gray, pyr, lvl);
         }
         FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n);
         if (gw == 0) g.gh = 0;  // no FAST dispatch at this octave (orb.rs:511-515 with width 0)
@@ -279,17 +289,17 @@ int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
         const dim3 grid(g.n_bands * n);
         if (lvl == 0) {
             LaunchScope ls(p, s, KID_FUSED_L0);
-            hipLaunchKernelGGL(k_front<true>, grid, dim3(kFrontThreadsL0), lds, s, frames, p->frame_bytes, p->d_gray,
-                               p->d_blur, pyr, g, p->threshold, p->d_seg_counts, p->d_seg);
+            hipLaunchKernelGGL(k_front<true>, grid, dim3(kFrontThreadsL0), lds, s, frames, p->frame_bytes, d_gray,
+                               d_blur, pyr, g, p->threshold, d_seg_counts, d_seg);
         } else {
             LaunchScope ls(p, s, KID_FUSED_LN);
-            hipLaunchKernelGGL(k_front<false>, grid, dim3(kFrontThreadsLN), lds, s, frames, p->frame_bytes, p->d_gray,
-                               p->d_blur, pyr, g, p->threshold, p->d_seg_counts, p->d_seg);
+            hipLaunchKernelGGL(k_front<false>, grid, dim3(kFrontThreadsLN), lds, s, frames, p->frame_bytes, d_gray,
+                               d_blur, pyr, g, p->threshold, d_seg_counts, d_seg);
         }
     }
     {  // orb.rs:523-534, plus the compaction of the band segments into the final lists
         LaunchScope ls(p, s, KID_BRIEF);
-        hipLaunchKernelGGL(k_slot_prefix, dim3(n), dim3(64), 0, s, p->d_seg_counts, p->d_seg_before, p->d_counts,
+        hipLaunchKernelGGL(k_slot_prefix, dim3(n), dim3(64), 0, s, d_seg_counts, d_seg_before, d_counts,
                            p->bands.n_slots, p->bands.seg_cap);
         TileGeom tg = p->tiles;
         tg.n_frames = n;
@@ -301,10 +311,17 @@ int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
         if (n_wg > per_cu * p->n_cus) n_wg = per_cu * p->n_cus;
         if (tg.xcd_swizzle && (n_wg % 8u != 0u || n_wg < 8u)) tg.xcd_swizzle = 0u;
         tg.stamps = p->d_stamps;
-        hipLaunchKernelGGL(k_brief_tiles, dim3(n_wg), dim3(kBriefThreads), 0, s, p->d_blur, pyr, tg, p->d_seg_counts,
-                           p->d_seg_before, p->d_seg, p->d_corners, cap, p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin});
+        hipLaunchKernelGGL(k_brief_tiles, dim3(n_wg), dim3(kBriefThreads), 0, s, d_blur, pyr, tg, d_seg_counts,
+                           d_seg_before, d_seg, d_corners, cap, d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin});
     }
     HIP_TRY(p, hipGetLastError());
+    return ORB_OK;
+}
+
+int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
+    // One launch per kernel for the whole batch.  Cutting the batch into chunks that alternate between two
+    // streams was measured (2/4/8 chunks: +5 %, +4 %, +6 % time): each kernel fills the chip on its own.
+    if (int rc = run_fused_range(p, frames, 0, n, s)) return rc;
     p->planes_valid = true;  // except the level-0 grey plane, which the fused path keeps in LDS only
     return ORB_OK;
 }
