@@ -244,6 +244,14 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
     g.ts = (w + 7u) & ~7u;
     g.write_mip = (lvl + 1 < pyr.depth && w == 2u * pyr.w[lvl + 1] && h == 2u * pyr.h[lvl + 1]) ? 1u : 0u;
     g.xcd_swizzle = (n_frames % 8u == 0u) ? 1u : 0u;
+    {   // constant stretches of the literal blur (tap 1 is monotone in x): see k_front phase C
+        uint32_t P = 0;
+        while (P < w && blur_tap(P, w, kBlurOffHost).i1 == 0) P++;
+        uint32_t Q = 0;
+        if (P > 0) while (Q < w && (uint32_t)blur_tap(Q, w, kBlurOffHost).i1 < P) Q++;
+        g.blur_p = P;
+        g.blur_q = Q;
+    }
     g.phase_mask = 15u;
     if (const char* e = getenv("TINYORB_PHASE_MASK")) g.phase_mask = (uint32_t)atoi(e);
     if (const char* e = getenv("TINYORB_NO_SWIZZLE")) g.xcd_swizzle = atoi(e) ? 0u : g.xcd_swizzle;

@@ -87,6 +87,7 @@ __device__ constexpr int kRingDx[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 
 __device__ constexpr int kRingDy[16] = {0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1};
 
 // gaussian_blur_x.wgsl:14-26 (binary32 roundings of the literals)
+constexpr float kBlurOffHost = -0.4391873198428642f;  // tap 1, for host-side geometry
 __device__ constexpr float kBlurOff[4] = {-2.2273038885157046f, -0.4391873198428642f, 1.3243948342247673f, 3.0f};
 __device__ constexpr float kBlurWgt[4] = {0.13748623236806098f, 0.5037756553768409f, 0.32748695702046415f,
                                           0.031251155234634016f};
@@ -96,7 +97,7 @@ struct BlurTap {
     int i0, i1;
     float f;
 };
-__device__ __forceinline__ BlurTap blur_tap(uint32_t x, uint32_t w, float off) {
+__host__ __device__ __forceinline__ BlurTap blur_tap(uint32_t x, uint32_t w, float off) {
     float fw = (float)w;
     float u = ((float)x + 0.5f) / fw;
     float uo = u + off;

@@ -45,12 +45,14 @@ struct FrontGeom {
     uint32_t slot_base;   // index of this level's band 0 among the frame's band slots
     uint32_t n_slots;     // band slots per frame (all levels)
     uint32_t seg_cap;     // CornerData records per band segment
+    uint32_t blur_p;      // columns [0, blur_p) of blur pass 1 are one constant per row (tap 1 clamps to column 0)
+    uint32_t blur_q;      // columns [0, blur_q) of the final blur are one constant per row
     unsigned long long* stamps;  // diagnostic runs only: 16 cycle sums per kernel flavour (else null)
 };
 
 __host__ __device__ inline uint32_t front_lds_bytes(const FrontGeom& g) {
-    // grey rows + blur intermediate + queue A + 4 counters + blur row constants (16 + 4 float4)
-    return ((kFrontRows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + kFrontQueue * 2u + 16u + 20u * 16u;
+    // grey rows + queues B/C + queue A + 4 counters + blur row constants (2 x 16 float4)
+    return ((kFrontRows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + kFrontQueue * 2u + 16u + 32u * 16u;
 }
 
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     uint32_t* const qc_count = qa_count + 2;
     uint32_t* const c_count = qa_count + 3;  // corners found by this band
     float4* const blur_k1 = reinterpret_cast<float4*>(qa_count + 4);  // per band row: taps 0, 2, 3 of blur pass 1
-    float4* const blur_k2 = blur_k1 + R;                              // [chunk parity][row of the pair]: same for pass 2
+    float4* const blur_k2 = blur_k1 + R;                              // per band row: the same for pass 2, and c2
 
     // ---- which band of which frame: keep all bands of a frame on one XCD so halo rows hit its L2
     uint32_t frame, band;
@@ -276,14 +278,38 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     __syncthreads();
     stamp(1);  // barrier
 
-    // Blur taps 0, 2 and 3 always clamp to column 0 / w-1 (offsets are in UV units, Q11), so per row they
-    // are three constants: acc = (((0 + t[0]*w0) + lerp*w1) + t[w-1]*w2) + t[w-1]*w3.  One thread per row
-    // computes them for pass 1 here; the barriers of phase B publish them.
+    // ---- blur row constants (one thread per band row; published by the barriers of phase B) ----
+    // The reference adds its blur offsets to the normalised u coordinate (Q11), so taps 0, 2 and 3 always clamp
+    // to column 0 / w-1 and are three constants per row: acc = (((0 + t[0]*w0) + lerp*w1) + t[w-1]*w2) + t[w-1]*w3.
+    // Tap 1 samples 0.4392*w texels to the left: for x < blur_p it clamps to column 0 as well and pass 1 is one
+    // value per row there (c1); pass 2 reads pass 1 at x - 0.4392*w again, so the final blur is one value per
+    // row (c2) for every x < blur_q -- 88 % of the columns.
+    //   blur_k1[r] = pass 1: {0 + t0*w0, tl*w2, tl*w3, c1}          (t0, tl: grey row r at columns 0, w-1)
+    //   blur_k2[r] = pass 2: {0 + c1*w0, p1l*w2, p1l*w3, c2}        (p1l: pass 1 at column w-1)
     if (tid < R) {
         const half_t* row = grey + (tid + 3) * LS + kLdsPad;
         const float t0 = from_half(row[0]), tl = from_half(row[w - 1]);
-        const float a0 = t0 * kBlurWgt[0];
-        blur_k1[tid] = make_float4(0.0f + a0, tl * kBlurWgt[2], tl * kBlurWgt[3], 0.0f);
+        const float a0 = t0 * kBlurWgt[0], a2 = tl * kBlurWgt[2], a3 = tl * kBlurWgt[3];
+        const float base = 0.0f + a0;
+        auto finish = [&](float bs, float lerp, float k2, float k3) {
+            const float ws = lerp * kBlurWgt[1];
+            float acc = bs + ws;
+            acc = acc + k2;
+            acc = acc + k3;
+            return from_half(to_half(acc));  // R16Float store (CRD-3)
+        };
+        const float c1 = finish(base, t0, a2, a3);
+        float p1l = c1;  // pass 1 at the last column
+        if ((int)geo.blur_p < w) {
+            const BlurTap t = blur_tap((uint32_t)(w - 1), (uint32_t)w, kBlurOff[1]);
+            const float v0 = from_half(row[t.i0]), v1 = from_half(row[t.i1]);
+            const float d = v1 - v0;
+            p1l = finish(base, v0 + t.f * d, a2, a3);
+        }
+        const float b0 = c1 * kBlurWgt[0], b2 = p1l * kBlurWgt[2], b3 = p1l * kBlurWgt[3];
+        const float base2 = 0.0f + b0;
+        blur_k1[tid] = make_float4(base, a2, a3, c1);
+        blur_k2[tid] = make_float4(base2, b2, b3, finish(base2, c1, b2, b3));
     }
 
     // Phases B (FAST) and C (mip + blur) only share the read-only grey rows.
@@ -469,86 +495,72 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
 
         stamp(10);  // C0
         // =========================== C: literal blur, both passes ===========================
-        // Two rows at a time: a thread's column has the same tap index/fraction in every row, so the two
-        // rows' lerp and accumulation run as packed-f32 pairs (v_pk_*_f32: two binary32 lanes per op, each
-        // rounded like the scalar op; no fusing, -ffp-contract=off).
-        static_assert(kFrontTmpRows == 2, "the blur works on row pairs");
+        // Columns < blur_q get the row constant c2 (16-byte stores).  For a column x >= blur_q, pass 2 needs
+        // pass 1 at two neighbouring columns j0, j1 (>= blur_p - 1), each of which needs two grey texels: the
+        // thread evaluates those two pass-1 values itself (f16-rounded like the R16Float intermediate,
+        // orb.rs:291-304) -- no intermediate plane, no barrier.  Pass 1 at any other column is never read.
         if (geo.phase_mask & 8u) {
             const int rows = min(R, h - y0);  // band rows that exist in this level (uniform per block)
+            const int P = (int)geo.blur_p, Q = (int)geo.blur_q;
             if (rows > 0) {
-                // tap 1 (offset -0.4392 in UV units) per column: index pair and fraction, reused for every row
-                int i0[NCOL], i1[NCOL];
-                float fr[NCOL];
-    #pragma unroll
-                for (int c = 0; c < NCOL; c++) {
-                    const int x = tid + c * NT;
-                    BlurTap t = blur_tap((uint32_t)(x < w ? x : 0), (uint32_t)w, kBlurOff[1]);
-                    i0[c] = t.i0;
-                    i1[c] = t.i1;
-                    fr[c] = t.f;
-                }
-                const int n_chunks = (rows + 1) / 2;
-                auto blur_pair = [&](const half_t* ra, const half_t* rb, const float4 ka, const float4 kb, auto&& emit) {
-                    const float2_t base = {ka.x, kb.x}, a2 = {ka.y, kb.y}, a3 = {ka.z, kb.z};
-    #pragma unroll
-                    for (int c = 0; c < NCOL; c++) {
-                        const int x = tid + c * NT;
-                        if (x < w) {
-                            const float2_t v0 = {from_half(ra[i0[c]]), from_half(rb[i0[c]])};
-                            const float2_t v1 = {from_half(ra[i1[c]]), from_half(rb[i1[c]])};
-                            const float2_t d = v1 - v0;
-                            const float2_t fd = d * fr[c];
-                            const float2_t s2 = v0 + fd;
-                            const float2_t ws = s2 * kBlurWgt[1];
-                            float2_t acc = base + ws;
-                            acc = acc + a2;
-                            acc = acc + a3;
-                            emit(x, to_half(acc.x), to_half(acc.y));
-                        }
+                // constant stretch
+                if ((w & 7) == 0) {
+                    const int q8 = Q >> 3;  // whole 16-byte groups
+                    const int n_items = rows * q8;
+                    const float inv_q8 = 1.0f / (float)(q8 > 0 ? q8 : 1);
+                    for (int i = tid; i < n_items; i += NT) {
+                        const int r = (int)(((float)i + 0.5f) * inv_q8);
+                        const int g = i - __mul24(r, q8);
+                        const uint32_t c2 = half_bits(to_half(blur_k2[r].w));
+                        const uint32_t pk = c2 | (c2 << 16);
+                        *reinterpret_cast<uint4*>(blur_lvl + (size_t)(uint32_t)(__mul24(y0 + r, w) + g * 8)) =
+                            make_uint4(pk, pk, pk, pk);
                     }
-                };
-                auto pass1 = [&](int chunk) {
-                    const int r = chunk * 2;
-                    const int rb = r + 1 < rows ? r + 1 : r;  // odd tail: row r twice, second copy unused
-                    half_t* d0 = tmp + (chunk & 1) * 2 * TS;
-                    half_t* d1 = d0 + TS;
-                    float4* k2 = blur_k2 + (chunk & 1) * 2;
-                    blur_pair(grey + (r + 3) * LS + kLdsPad, grey + (rb + 3) * LS + kLdsPad, blur_k1[r], blur_k1[rb],
-                              [&](int x, half_t va, half_t vb) {
-                                  d0[x] = va;
-                                  d1[x] = vb;
-                                  // the owners of columns 0 and w-1 publish pass 2's row constants (f16-rounded values)
-                                  if (x == 0) {
-                                      const float p0 = from_half(va) * kBlurWgt[0], p1 = from_half(vb) * kBlurWgt[0];
-                                      k2[0].x = 0.0f + p0;
-                                      k2[1].x = 0.0f + p1;
-                                  }
-                                  if (x == w - 1) {
-                                      const float la = from_half(va), lb = from_half(vb);
-                                      k2[0].y = la * kBlurWgt[2];
-                                      k2[0].z = la * kBlurWgt[3];
-                                      k2[1].y = lb * kBlurWgt[2];
-                                      k2[1].z = lb * kBlurWgt[3];
-                                  }
-                              });
-                };
-                auto pass2 = [&](int chunk) {
-                    const int r = chunk * 2;
-                    const bool two = r + 1 < rows;
-                    const half_t* s0 = tmp + (chunk & 1) * 2 * TS;
-                    const float4* k2 = blur_k2 + (chunk & 1) * 2;
-                    uint16_t* o0 = blur_lvl + (size_t)(uint32_t)__mul24(y0 + r, w);
-                    uint16_t* o1 = o0 + w;
-                    blur_pair(s0, s0 + TS, k2[0], k2[1], [&](int x, half_t va, half_t vb) {
-                        o0[x] = half_bits(va);
-                        if (two) o1[x] = half_bits(vb);
-                    });
-                };
-                pass1(0);
-                for (int k = 0; k < n_chunks; k++) {
-                    __syncthreads();
-                    if (k + 1 < n_chunks) pass1(k + 1);
-                    pass2(k);
+                    for (int i = tid; i < rows * (Q & 7); i += NT) {  // the odd columns before blur_q
+                        const int r = i / (Q & 7), x = (Q & ~7) + i % (Q & 7);
+                        blur_lvl[(size_t)(uint32_t)(__mul24(y0 + r, w) + x)] = half_bits(to_half(blur_k2[r].w));
+                    }
+                } else {
+                    for (int i = tid; i < rows * Q; i += NT) {
+                        const int r = i / Q, x = i - r * Q;
+                        blur_lvl[(size_t)(uint32_t)(__mul24(y0 + r, w) + x)] = half_bits(to_half(blur_k2[r].w));
+                    }
+                }
+                // per-pixel stretch [Q, w)
+                const int nvar = w - Q;
+                if (nvar > 0) {
+                    const float inv_nvar = 1.0f / (float)nvar;
+                    const int n_items = rows * nvar;
+                    for (int i = tid; i < n_items; i += NT) {
+                        const int r = (int)(((float)i + 0.5f) * inv_nvar);
+                        const int x = Q + (i - __mul24(r, nvar));
+                        const half_t* row = grey + (r + 3) * LS + kLdsPad;
+                        const float4 k1 = blur_k1[r], k2 = blur_k2[r];
+                        auto pass1_at = [&](int j) {  // pass 1 at column j of this row, as stored (f16)
+                            if (j < P) return k1.w;
+                            const BlurTap t = blur_tap((uint32_t)j, (uint32_t)w, kBlurOff[1]);
+                            const float v0 = from_half(row[t.i0]), v1 = from_half(row[t.i1]);
+                            const float d = v1 - v0;
+                            const float fd = t.f * d;
+                            const float lerp = v0 + fd;
+                            const float ws = lerp * kBlurWgt[1];
+                            float acc = k1.x + ws;
+                            acc = acc + k1.y;
+                            acc = acc + k1.z;
+                            return from_half(to_half(acc));
+                        };
+                        const BlurTap t2 = blur_tap((uint32_t)x, (uint32_t)w, kBlurOff[1]);
+                        const float u0 = pass1_at(t2.i0);
+                        const float u1 = t2.i1 == t2.i0 ? u0 : pass1_at(t2.i1);
+                        const float d = u1 - u0;
+                        const float fd = t2.f * d;
+                        const float lerp = u0 + fd;
+                        const float ws = lerp * kBlurWgt[1];
+                        float acc = k2.x + ws;
+                        acc = acc + k2.y;
+                        acc = acc + k2.z;
+                        blur_lvl[(size_t)(uint32_t)(__mul24(y0 + r, w) + x)] = half_bits(to_half(acc));
+                    }
                 }
             }
         }

@@ -1,1 +1,1 @@
-for c in 1 2 4 8; do echo -n "chunks $c: "; TINYORB_CHUNKS=$c python bench.py --cpu-sample 0 --steps 10 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print(d['value'], d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'])"; done
+python bench.py --cpu-sample 0 --steps 10 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print(d['value'], d['roofline']['all_kernels_ms_per_step'], d['keypoints_per_frame'])"
