@@ -48,6 +48,8 @@ struct OrbProgram {
     uint8_t* d_input = nullptr;  // max_batch frames (single-frame API, host batches, synth)
     uint16_t* d_gray = nullptr;  // max_batch x pyr.stride
     uint16_t* d_blur = nullptr;
+    uint16_t* d_blur_rowc = nullptr;  // fused path: [max_batch][row_stride] blur row constants (columns < qa)
+    uint32_t blur_qa[kMaxLevels] = {0};  // fused path: per level, columns [0, qa) of the blur plane live in d_blur_rowc
     uint32_t* d_counts = nullptr;  // currently selected output set (orb_batch_select_output)
     CornerData* d_corners = nullptr;
     CornerDescriptor* d_desc = nullptr;
@@ -165,6 +167,12 @@ void layout_pyramid(uint32_t W, uint32_t H, uint32_t depth, Pyramid* pyr) {
         off = (off + 7u) & ~7u;  // keep every level 16-byte aligned
     }
     pyr->stride = (off + 63u) & ~63u;
+    uint32_t rows = 0;
+    for (uint32_t m = 0; m < depth; m++) {
+        pyr->row_off[m] = rows;
+        rows += pyr->h[m];
+    }
+    pyr->row_stride = (rows + 7u) & ~7u;
 }
 
 // The staged pipeline for `n` frames starting at device pointer `frames` (orb.rs:469-534).
@@ -266,6 +274,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
     const uint8_t* frames = frames_all + (size_t)f0 * p->frame_bytes;
     uint16_t* const d_gray = p->d_gray + (size_t)f0 * pyr.stride;
     uint16_t* const d_blur = p->d_blur + (size_t)f0 * pyr.stride;
+    uint16_t* const d_blur_rowc = p->d_blur_rowc + (size_t)f0 * pyr.row_stride;
     uint32_t* const d_seg_counts = p->d_seg_counts + (size_t)f0 * p->bands.n_slots;
     uint32_t* const d_seg_before = p->d_seg_before + (size_t)f0 * p->bands.n_slots;
     CornerData* const d_seg = p->d_seg + (size_t)f0 * p->bands.n_slots * p->bands.seg_cap;
@@ -298,11 +307,11 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         if (lvl == 0) {
             LaunchScope ls(p, s, KID_FUSED_L0);
             hipLaunchKernelGGL(k_front<true>, grid, dim3(kFrontThreadsL0), lds, s, frames, p->frame_bytes, d_gray,
-                               d_blur, pyr, g, p->threshold, d_seg_counts, d_seg);
+                               d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg);
         } else {
             LaunchScope ls(p, s, KID_FUSED_LN);
             hipLaunchKernelGGL(k_front<false>, grid, dim3(kFrontThreadsLN), lds, s, frames, p->frame_bytes, d_gray,
-                               d_blur, pyr, g, p->threshold, d_seg_counts, d_seg);
+                               d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg);
         }
     }
     {  // orb.rs:523-534, plus the compaction of the band segments into the final lists
@@ -319,7 +328,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         if (n_wg > per_cu * p->n_cus) n_wg = per_cu * p->n_cus;
         if (tg.xcd_swizzle && (n_wg % 8u != 0u || n_wg < 8u)) tg.xcd_swizzle = 0u;
         tg.stamps = p->d_stamps;
-        hipLaunchKernelGGL(k_brief_tiles, dim3(n_wg), dim3(kBriefThreads), 0, s, d_blur, pyr, tg, d_seg_counts,
+        hipLaunchKernelGGL(k_brief_tiles, dim3(n_wg), dim3(kBriefThreads), 0, s, d_blur, d_blur_rowc, pyr, tg, d_seg_counts,
                            d_seg_before, d_seg, d_corners, cap, d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin});
     }
     HIP_TRY(p, hipGetLastError());
@@ -470,6 +479,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     p->d_corners = p->out_corners[0];
     p->d_desc = p->out_desc[0];
     if (p->fused) {
+        CREATE_TRY(hipMalloc(&p->d_blur_rowc, B * p->pyr.row_stride * sizeof(uint16_t)));
+        CREATE_TRY(hipMemset(p->d_blur_rowc, 0, B * p->pyr.row_stride * sizeof(uint16_t)));
         CREATE_TRY(hipMalloc(&p->d_seg, B * p->bands.n_slots * (size_t)p->bands.seg_cap * sizeof(CornerData)));
         CREATE_TRY(hipMalloc(&p->d_seg_counts, B * p->bands.n_slots * sizeof(uint32_t)));
         CREATE_TRY(hipMemset(p->d_seg_counts, 0, B * p->bands.n_slots * sizeof(uint32_t)));
@@ -485,6 +496,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         // per-tile descriptors of k_brief_tiles (all levels of one frame)
         TileGeom& tg = p->tiles;
         std::vector<TileDesc> desc(tg.tile_base[p->pyr.depth]);
+        for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++)
+            p->blur_qa[lvl] = front_geometry(p->pyr, lvl, 8, 8, 1).blur_q & ~7u;
         for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
             const uint32_t n_bands = tg.slot_base[lvl + 1] - tg.slot_base[lvl];
             const uint32_t n_tiles = tg.tile_base[lvl + 1] - tg.tile_base[lvl];
@@ -499,6 +512,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 d.y0 = (int32_t)(ty * kBriefTileH);
                 d.w = (int32_t)p->pyr.w[lvl];
                 d.h = (int32_t)p->pyr.h[lvl];
+                d.qa = (int32_t)p->blur_qa[lvl];
+                d.row_off = p->pyr.row_off[lvl];
             }
         }
         tg.tiles_per_frame = (uint32_t)desc.size();
@@ -531,6 +546,7 @@ void orb_program_destroy(OrbProgram* p) {
     (void)hipFree(p->d_input);
     (void)hipFree(p->d_gray);
     (void)hipFree(p->d_blur);
+    (void)hipFree(p->d_blur_rowc);
     for (int set = 0; set < 2; set++) {
         (void)hipFree(p->out_counts[set]);
         (void)hipFree(p->out_corners[set]);
@@ -698,6 +714,15 @@ int orb_debug_read_plane(OrbProgram* p, uint32_t frame, int kind, uint32_t level
     if (int rc = orb_batch_sync(p)) return rc;
     const uint16_t* base = (kind == ORB_PLANE_GRAY ? p->d_gray : p->d_blur) + (size_t)frame * p->pyr.stride + p->pyr.off[level];
     HIP_TRY(p, hipMemcpy(dst, base, texels * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    if (p->fused && kind == ORB_PLANE_BLUR && p->blur_qa[level] > 0) {
+        // the fused path keeps columns [0, qa) of a blur level as one constant per row (k_front, phase C)
+        const uint32_t w = p->pyr.w[level], h = p->pyr.h[level], qa = p->blur_qa[level];
+        std::vector<uint16_t> rowc(h);
+        HIP_TRY(p, hipMemcpy(rowc.data(), p->d_blur_rowc + (size_t)frame * p->pyr.row_stride + p->pyr.row_off[level],
+                             h * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        for (uint32_t y = 0; y < h; y++)
+            for (uint32_t x = 0; x < qa && x < w; x++) dst[(size_t)y * w + x] = rowc[y];
+    }
     return ORB_OK;
 }
 

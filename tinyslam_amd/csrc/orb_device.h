@@ -19,6 +19,8 @@ struct Pyramid {
     uint32_t h[kMaxLevels];
     uint32_t off[kMaxLevels];  // texel offset of each level
     uint32_t stride;           // texels per frame (sum of levels, rounded up to 64)
+    uint32_t row_off[kMaxLevels];  // first row of each level in a per-row array (fused path: blur row constants)
+    uint32_t row_stride;           // rows per frame over all levels, rounded up to 8
 };
 
 typedef _Float16 half_t;

@@ -147,11 +147,10 @@ __device__ __forceinline__ void segment_append(bool is_corner, uint32_t x, uint3
 template <bool L0>
 __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                          uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
-                                                         Pyramid pyr, FrontGeom geo, float thr,
-                                                         uint32_t* __restrict__ seg_counts,
+                                                         uint16_t* __restrict__ blur_rowc, Pyramid pyr,
+                                                         FrontGeom geo, float thr, uint32_t* __restrict__ seg_counts,
                                                          CornerData* __restrict__ segments) {
     constexpr int NT = L0 ? kFrontThreadsL0 : kFrontThreadsLN, R = kFrontRows, TC = kFrontTmpRows;
-    constexpr int NCOL = (kFrontMaxCols * 512) / NT;  // blur columns per thread
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int LS = (int)geo.ls, TS = (int)geo.ts;
     half_t* const grey = reinterpret_cast<half_t*>(lds_raw);             // (R+6) rows x LS
@@ -503,28 +502,16 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
             const int rows = min(R, h - y0);  // band rows that exist in this level (uniform per block)
             const int P = (int)geo.blur_p, Q = (int)geo.blur_q;
             if (rows > 0) {
-                // constant stretch
-                if ((w & 7) == 0) {
-                    const int q8 = Q >> 3;  // whole 16-byte groups
-                    const int n_items = rows * q8;
-                    const float inv_q8 = 1.0f / (float)(q8 > 0 ? q8 : 1);
-                    for (int i = tid; i < n_items; i += NT) {
-                        const int r = (int)(((float)i + 0.5f) * inv_q8);
-                        const int g = i - __mul24(r, q8);
-                        const uint32_t c2 = half_bits(to_half(blur_k2[r].w));
-                        const uint32_t pk = c2 | (c2 << 16);
-                        *reinterpret_cast<uint4*>(blur_lvl + (size_t)(uint32_t)(__mul24(y0 + r, w) + g * 8)) =
-                            make_uint4(pk, pk, pk, pk);
-                    }
-                    for (int i = tid; i < rows * (Q & 7); i += NT) {  // the odd columns before blur_q
-                        const int r = i / (Q & 7), x = (Q & ~7) + i % (Q & 7);
-                        blur_lvl[(size_t)(uint32_t)(__mul24(y0 + r, w) + x)] = half_bits(to_half(blur_k2[r].w));
-                    }
-                } else {
-                    for (int i = tid; i < rows * Q; i += NT) {
-                        const int r = i / Q, x = i - r * Q;
-                        blur_lvl[(size_t)(uint32_t)(__mul24(y0 + r, w) + x)] = half_bits(to_half(blur_k2[r].w));
-                    }
+                // constant stretch: one f16 per row in the row-constant array covers columns [0, Qa), Qa = Q rounded
+                // down to a multiple of 8 (the plane itself is only written from column Qa on: k_brief_tiles
+                // rebuilds the window from the constants, the plane's first 88 % never travel through HBM)
+                const int Qa = Q & ~7;
+                if (tid < rows)
+                    blur_rowc[(size_t)frame * pyr.row_stride + pyr.row_off[lvl] + (uint32_t)(y0 + tid)] =
+                        half_bits(to_half(blur_k2[tid].w));
+                for (int i = tid; i < rows * (Q - Qa); i += NT) {
+                    const int r = i / (Q - Qa), x = Qa + i % (Q - Qa);
+                    blur_lvl[(size_t)(uint32_t)(__mul24(y0 + r, w) + x)] = half_bits(to_half(blur_k2[r].w));
                 }
                 // per-pixel stretch [Q, w)
                 const int nvar = w - Q;
@@ -605,6 +592,9 @@ constexpr int kBriefList = 512;
 struct TileDesc {
     uint32_t lvl, slot_a, has_b, plane_off;  // plane_off: texel offset of the level in the packed pyramid
     int32_t x0, y0, w, h;
+    int32_t qa;        // columns [0, qa) of the level's blur are one constant per row (qa is a multiple of 8)
+    uint32_t row_off;  // the level's first row in the row-constant array
+    uint32_t pad[2];
 };
 
 struct TileGeom {
@@ -650,7 +640,8 @@ __global__ __launch_bounds__(64) void k_slot_prefix(const uint32_t* __restrict__
 // Persistent workgroups: each walks its XCD's share of the tiles; while the keypoints of one tile are
 // being described out of LDS, the window, band records and counts of the next tile are already in
 // flight into registers (vector loads only: nothing in the loop waits on the scalar cache).
-__global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t* __restrict__ blur, Pyramid pyr,
+__global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t* __restrict__ blur,
+                                                                  const uint16_t* __restrict__ blur_rowc, Pyramid pyr,
                                                                   TileGeom tg, const uint32_t* __restrict__ seg_counts,
                                                                   const uint32_t* __restrict__ seg_before,
                                                                   const CornerData* __restrict__ segments,
@@ -708,14 +699,23 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
         const uint16_t* plane = blur + (size_t)t.frame * pyr.stride + t.d.plane_off;
         if ((t.d.w & 7) == 0) {
             // window columns start at a multiple of 8 texels: a 16-byte group is entirely inside or outside the
-            // level, so load unconditionally from a clamped address and zero the outside ones when storing
+            // level (zeroed when storing) and entirely inside or outside the row-constant stretch [0, qa): there
+            // the group is the row's constant (2-byte load), elsewhere 16 bytes of the plane; clamped addresses,
+            // no wait between the loads
+            const uint16_t* rowc = blur_rowc + (size_t)t.frame * pyr.row_stride + t.d.row_off;
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int i = min((int)tid + u * NT, N - 1);
                 const int r = i / G, g = i - r * G;
                 const int gy = t.d.y0 - kBriefHalo + r, gx = t.d.x0 - kBriefPadX + g * 8;
                 const int cy = min(max(gy, 0), t.d.h - 1), cx = min(max(gx, 0), t.d.w - 8);
-                wv[u] = *reinterpret_cast<const uint4*>(plane + (size_t)(uint32_t)(__mul24(cy, t.d.w) + cx));
+                if (cx < t.d.qa) {
+                    const uint32_t c = rowc[cy];
+                    const uint32_t pk = c | (c << 16);
+                    wv[u] = make_uint4(pk, pk, pk, pk);
+                } else {
+                    wv[u] = *reinterpret_cast<const uint4*>(plane + (size_t)(uint32_t)(__mul24(cy, t.d.w) + cx));
+                }
             }
         }
         const size_t slot = (size_t)t.frame * tg.n_slots + t.d.slot_a;
@@ -768,7 +768,10 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const int xx = gx + k;
-                    e[k] = (gy >= 0 && gy < t.d.h && xx >= 0 && xx < t.d.w) ? (uint32_t)plane[(size_t)gy * t.d.w + xx] : 0u;
+                    e[k] = (gy >= 0 && gy < t.d.h && xx >= 0 && xx < t.d.w)
+                               ? (uint32_t)(xx < t.d.qa ? blur_rowc[(size_t)t.frame * pyr.row_stride + t.d.row_off + gy]
+                                                        : plane[(size_t)gy * t.d.w + xx])
+                               : 0u;
                 }
                 *reinterpret_cast<uint4*>(&win[i * 8]) =
                     make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
