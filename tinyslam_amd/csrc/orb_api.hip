@@ -514,6 +514,9 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 d.h = (int32_t)p->pyr.h[lvl];
                 d.qa = (int32_t)p->blur_qa[lvl];
                 d.row_off = p->pyr.row_off[lvl];
+                // flat: the tile's sample columns [x0 - 18, x0 + 256 + 18) all lie in the level and in [0, qa)
+                d.flat = (d.x0 >= kBriefHalo && d.x0 + kBriefTileW + kBriefHalo <= d.qa) ? 1u : 0u;
+                d.pad = 0;
             }
         }
         tg.tiles_per_frame = (uint32_t)desc.size();

@@ -594,7 +594,8 @@ struct TileDesc {
     int32_t x0, y0, w, h;
     int32_t qa;        // columns [0, qa) of the level's blur are one constant per row (qa is a multiple of 8)
     uint32_t row_off;  // the level's first row in the row-constant array
-    uint32_t pad[2];
+    uint32_t flat;     // 1: every sample column of every keypoint of the tile lies in [0, qa): rows are all that matter
+    uint32_t pad;
 };
 
 struct TileGeom {
@@ -697,7 +698,13 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
     uint32_t v_na = 0, v_nb = 0, v_before = 0;  // per-lane copies of uniform values (vector loads do not block)
     auto issue = [&](const Tile& t, uint32_t tid) {
         const uint16_t* plane = blur + (size_t)t.frame * pyr.stride + t.d.plane_off;
-        if ((t.d.w & 7) == 0) {
+        if (t.d.flat) {
+            // the window is one value per row: thread r fetches row y0 - 18 + r of the row constants
+            const int gy = t.d.y0 - kBriefHalo + (int)tid;
+            const int cy = min(max(gy, 0), t.d.h - 1);
+            const uint32_t c = blur_rowc[(size_t)t.frame * pyr.row_stride + t.d.row_off + (uint32_t)cy];
+            wv[0].x = (tid < (uint32_t)kBriefWinH && gy >= 0 && gy < t.d.h) ? c : 0u;  // outside the level: 0 (CRD-6)
+        } else if ((t.d.w & 7) == 0) {
             // window columns start at a multiple of 8 texels: a 16-byte group is entirely inside or outside the
             // level (zeroed when storing) and entirely inside or outside the row-constant stretch [0, qa): there
             // the group is the row's constant (2-byte load), elsewhere 16 bytes of the plane; clamped addresses,
@@ -750,7 +757,9 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
     auto commit = [&](const Tile& t, uint32_t n_a, uint32_t n_b, uint32_t before, uint32_t tid) {
         if (tid < n_a) pick(t, rec_a, before + tid);
         if (tid < n_b) pick(t, rec_b, before + n_a + tid);
-        if ((t.d.w & 7) == 0) {
+        if (t.d.flat) {
+            if (tid < (uint32_t)kBriefWinH) win[tid] = (uint16_t)wv[0].x;
+        } else if ((t.d.w & 7) == 0) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int i = (int)tid + u * NT;
@@ -791,14 +800,17 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
             const uint4 rec = list_rec[i];
             const uint4 aux = list_aux[i];
             const int cx = (int)rec.x - t.d.x0 + kBriefPadX, cy = (int)rec.y - t.d.y0 + kBriefHalo;
-            const uint16_t* ctr = win + cy * kBriefWinW + cx;
+            // flat tiles: the blur is one value per row around this keypoint (columns < qa), the window is a
+            // column of kBriefWinH values and only the rotated points' rows matter
+            const bool flat = t.d.flat != 0u;
+            const uint16_t* ctr = flat ? win + cy : win + cy * kBriefWinW + cx;
             // sample offsets of this lane's four tests, then all eight LDS reads back to back
             int oa[4], ob[4];
             if (rec.z == 0u) {  // wave-uniform
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    oa[e] = (int)(int16_t)(off0[e] & 0xffffu);
-                    ob[e] = (int)(int16_t)(off0[e] >> 16);
+                    oa[e] = flat ? (int)(int8_t)((pat[e] >> 8) & 255u) : (int)(int16_t)(off0[e] & 0xffffu);
+                    ob[e] = flat ? (int)(int8_t)(pat[e] >> 24) : (int)(int16_t)(off0[e] >> 16);
                 }
             } else {
                 const float ct = __uint_as_float(aux.y), st = __uint_as_float(aux.z), nst = -st;
@@ -807,11 +819,17 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
                     const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
                     const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
                     // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y)
-                    const float a0 = ct * pax, a1 = st * pay, a2 = nst * pax, a3 = ct * pay;
-                    const float b0 = ct * pbx, b1 = st * pby, b2 = nst * pbx, b3 = ct * pby;
-                    const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
-                    oa[e] = (int)ray * kBriefWinW + (int)rax;  // vec2i() truncates
-                    ob[e] = (int)rby * kBriefWinW + (int)rbx;
+                    const float a2 = nst * pax, a3 = ct * pay, b2 = nst * pbx, b3 = ct * pby;
+                    const float ray = a2 + a3, rby = b2 + b3;
+                    if (flat) {
+                        oa[e] = (int)ray;  // vec2i() truncates
+                        ob[e] = (int)rby;
+                    } else {
+                        const float a0 = ct * pax, a1 = st * pay, b0 = ct * pbx, b1 = st * pby;
+                        const float rax = a0 + a1, rbx = b0 + b1;
+                        oa[e] = (int)ray * kBriefWinW + (int)rax;
+                        ob[e] = (int)rby * kBriefWinW + (int)rbx;
+                    }
                 }
             }
             uint32_t va[4], vb[4];
