@@ -450,9 +450,14 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
                     tg.slot_base[lvl] = bg.slot_base[lvl];
                     tg.tile_base[lvl] = tiles;
+                    // per pair of bands: one flat tile for x < qa - 18 (if any), then 256-wide 2-D tiles
                     const uint32_t gw = (((W >> lvl) + 7u) / 8u) * 8u;
                     const uint32_t cols = p->pyr.w[lvl] > gw ? p->pyr.w[lvl] : gw;
-                    tg.tile_cols[lvl] = (cols + kBriefTileW - 1) / kBriefTileW;
+                    const uint32_t qa = front_geometry(p->pyr, lvl, 8, 8, 1).blur_q & ~7u;
+                    p->blur_qa[lvl] = qa;
+                    const uint32_t flat_end = qa > (uint32_t)kBriefHalo ? qa - kBriefHalo : 0u;
+                    const uint32_t first2d = flat_end & ~7u;
+                    tg.tile_cols[lvl] = (flat_end ? 1u : 0u) + (cols > first2d ? (cols - first2d + kBriefTileW - 1) / kBriefTileW : 0u);
                     tiles += ((front_bands(p->pyr, lvl) + 1u) / 2u) * tg.tile_cols[lvl];
                 }
                 tg.slot_base[p->pyr.depth] = bg.n_slots;
@@ -496,11 +501,12 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         // per-tile descriptors of k_brief_tiles (all levels of one frame)
         TileGeom& tg = p->tiles;
         std::vector<TileDesc> desc(tg.tile_base[p->pyr.depth]);
-        for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++)
-            p->blur_qa[lvl] = front_geometry(p->pyr, lvl, 8, 8, 1).blur_q & ~7u;
         for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
             const uint32_t n_bands = tg.slot_base[lvl + 1] - tg.slot_base[lvl];
             const uint32_t n_tiles = tg.tile_base[lvl + 1] - tg.tile_base[lvl];
+            const uint32_t qa = p->blur_qa[lvl];
+            const uint32_t flat_end = qa > (uint32_t)kBriefHalo ? qa - kBriefHalo : 0u;  // x + 18 < qa
+            const uint32_t first2d = flat_end & ~7u;
             for (uint32_t t = 0; t < n_tiles; t++) {
                 const uint32_t ty = t / tg.tile_cols[lvl], tx = t % tg.tile_cols[lvl];
                 TileDesc& d = desc[tg.tile_base[lvl] + t];
@@ -508,15 +514,24 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 d.slot_a = tg.slot_base[lvl] + 2u * ty;
                 d.has_b = (2u * ty + 1u < n_bands) ? 1u : 0u;
                 d.plane_off = p->pyr.off[lvl];
-                d.x0 = (int32_t)(tx * kBriefTileW);
                 d.y0 = (int32_t)(ty * kBriefTileH);
                 d.w = (int32_t)p->pyr.w[lvl];
                 d.h = (int32_t)p->pyr.h[lvl];
-                d.qa = (int32_t)p->blur_qa[lvl];
+                d.qa = (int32_t)qa;
                 d.row_off = p->pyr.row_off[lvl];
-                // flat: the tile's sample columns [x0 - 18, x0 + 256 + 18) all lie in the level and in [0, qa)
-                d.flat = (d.x0 >= kBriefHalo && d.x0 + kBriefTileW + kBriefHalo <= d.qa) ? 1u : 0u;
                 d.pad = 0;
+                if (flat_end && tx == 0) {  // every sample column of these keypoints is below qa (or < 0: edge path)
+                    d.flat = 1u;
+                    d.x0 = 0;
+                    d.px0 = 0;
+                    d.px1 = (int32_t)flat_end;
+                } else {
+                    const uint32_t k = tx - (flat_end ? 1u : 0u);
+                    d.flat = 0u;
+                    d.x0 = (int32_t)(first2d + k * kBriefTileW);  // window origin, multiple of 8
+                    d.px0 = k == 0 ? (int32_t)flat_end : d.x0;
+                    d.px1 = d.x0 + kBriefTileW;
+                }
             }
         }
         tg.tiles_per_frame = (uint32_t)desc.size();

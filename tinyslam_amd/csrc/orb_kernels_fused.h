@@ -594,7 +594,8 @@ struct TileDesc {
     int32_t x0, y0, w, h;
     int32_t qa;        // columns [0, qa) of the level's blur are one constant per row (qa is a multiple of 8)
     uint32_t row_off;  // the level's first row in the row-constant array
-    uint32_t flat;     // 1: every sample column of every keypoint of the tile lies in [0, qa): rows are all that matter
+    uint32_t flat;     // 1: every sample column of the tile's keypoints lies below qa: rows are all that matter
+    int32_t px0, px1;  // the tile takes the keypoints with px0 <= x < px1 (2-D tiles: x0 <= px0, px1 <= x0 + 256)
     uint32_t pad;
 };
 
@@ -737,7 +738,7 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
     };
     // A record belongs to this tile when its x falls in the tile's columns (its rows do by construction).
     auto wanted = [&](const Tile& t, const uint4& rec, uint32_t k) {
-        return k < cap && rec.x >= (uint32_t)t.d.x0 && rec.x < (uint32_t)(t.d.x0 + kBriefTileW);
+        return k < cap && rec.x >= (uint32_t)t.d.px0 && rec.x < (uint32_t)t.d.px1;
     };
     auto push = [&](const uint4& rec, uint32_t k, float ct, float st) {
         const uint32_t idx = atomicAdd(&list_n, 1u);
@@ -833,10 +834,26 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
                 }
             }
             uint32_t va[4], vb[4];
+            if (flat && rec.x < (uint32_t)kBriefHalo) {
+                // (wave-uniform, rare) a keypoint this close to the left border can sample columns < 0, which read
+                // as 0 (CRD-6): redo the points with their columns
+                const float ct = __uint_as_float(aux.y), st = __uint_as_float(aux.z), nst = -st;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                va[e] = ctr[oa[e]];
-                vb[e] = ctr[ob[e]];
+                for (int e = 0; e < 4; e++) {
+                    const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
+                    const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
+                    const float a0 = ct * pax, a1 = st * pay, a2 = nst * pax, a3 = ct * pay;
+                    const float b0 = ct * pbx, b1 = st * pby, b2 = nst * pbx, b3 = ct * pby;
+                    const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+                    va[e] = ((int)rec.x + (int)rax < 0) ? 0u : (uint32_t)ctr[(int)ray];
+                    vb[e] = ((int)rec.x + (int)rbx < 0) ? 0u : (uint32_t)ctr[(int)rby];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    va[e] = ctr[oa[e]];
+                    vb[e] = ctr[ob[e]];
+                }
             }
             uint64_t bal[4];
 #pragma unroll
