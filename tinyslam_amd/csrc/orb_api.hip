@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/tinyorb.h"
@@ -534,6 +535,10 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 }
             }
         }
+        // Persistent workgroups take tiles q, q + step, ...: with the flat (many keypoints) and 2-D (few keypoints,
+        // big window) tiles alternating, an even step would hand some workgroups only the heavy kind.  Flat tiles
+        // first, 2-D tiles after: every workgroup's sequence then crosses both halves.
+        std::stable_partition(desc.begin(), desc.end(), [](const TileDesc& d) { return d.flat != 0u; });
         tg.tiles_per_frame = (uint32_t)desc.size();
         tg.inv_tiles_per_frame = 1.0f / (float)desc.size();
         CREATE_TRY(hipMalloc(&p->d_tile_desc, desc.size() * sizeof(TileDesc)));

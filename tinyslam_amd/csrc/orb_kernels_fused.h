@@ -900,6 +900,7 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
 #endif
     if (tid == 0u) list_n = 0u;
     Tile cur = decode(q);
+    Tile nxt_tile = decode(min(q + q_step, q_end - 1u));  // descriptors are fetched one tile ahead of their use
     issue(cur, tid);
     __syncthreads();
     uint32_t cur_na = min(__builtin_amdgcn_readfirstlane(v_na), tg.seg_cap);
@@ -917,11 +918,8 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
         // index per use keeps the optimiser from hoisting it all out of this loop (register pressure).
         uint32_t tid_o = tid;
         asm volatile("" : "+v"(tid_o));
-        Tile nxt_tile = cur;
-        if (has_next) {
-            nxt_tile = decode(qn);
-            issue(nxt_tile, tid_o);  // in flight while the current tile is described
-        }
+        const Tile nn_tile = decode(min(qn + q_step, q_end - 1u));  // scalar loads land during this iteration
+        if (has_next) issue(nxt_tile, tid_o);                       // in flight while the current tile is described
         stamp(0);
         const uint32_t n_l = list_n;
         if (cur_na > (uint32_t)NT || cur_nb > (uint32_t)NT || n_l > (uint32_t)kBriefList)
@@ -936,6 +934,7 @@ __global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t
         __syncthreads();
         stamp(3);
         cur = nxt_tile;
+        nxt_tile = nn_tile;
         cur_na = min(__builtin_amdgcn_readfirstlane(v_na), tg.seg_cap);
         cur_nb = min(__builtin_amdgcn_readfirstlane(v_nb), tg.seg_cap);
         cur_before = __builtin_amdgcn_readfirstlane(v_before);
