@@ -138,7 +138,7 @@ int orb_debug_f32_to_f16(OrbProgram *p, const float *src, uint16_t *dst, size_t 
 int orb_debug_angle_code(OrbProgram *p, const float *cy, const float *cx, uint32_t *dst, size_t n);
 
 /* ---- measurement ---- */
-#define ORB_KERNEL_COUNT 8
+#define ORB_KERNEL_COUNT 10
 /* When enabled every kernel launch is bracketed by hipEvents on its stream. */
 int orb_profile_enable(OrbProgram *p, int enable);
 int orb_profile_reset(OrbProgram *p);
@@ -155,8 +155,8 @@ const char *orb_kernel_name(int id);
  * (max_batch frames) and returns its address in *out_dev. */
 int orb_synth_frames_device(OrbProgram *p, uint8_t *frames_dev, uint32_t n_frames, uint32_t seed0, uint32_t flags,
                             uint8_t **out_dev);
-/* Diagnostic: per-workgroup cycle sums of the phases of k_brief_tiles (collected only when the
- * program was created with TINYORB_STAMPS=1 in the environment; up to 4096 x 6 values). */
+/* Diagnostic: cycle sums of the phases of k_front (2 x 16 values: level 0, levels >= 1); filled only by a
+ * diagnostic build (TINYORB_BUILD_STAMPS=1) when the program was created with TINYORB_STAMPS=1. */
 int orb_debug_stamps(OrbProgram *p, unsigned long long *dst, size_t n);
 /* Device-to-host copy helper for tests that have no other HIP binding. */
 int orb_copy_to_host(OrbProgram *p, void *dst_host, const void *src_dev, size_t nbytes);

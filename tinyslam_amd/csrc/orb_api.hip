@@ -23,9 +23,9 @@ using namespace orb;
 
 namespace {
 
-enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH };
-const char* const kKernelNames[ORB_KERNEL_COUNT] = {"k_grayscale", "k_mip",      "k_blur_rows", "k_fast",
-                                                    "k_brief",     "k_front_l0", "k_front_ln",  "k_synth"};
+enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX };
+const char* const kKernelNames[ORB_KERNEL_COUNT] = {"k_grayscale", "k_mip",      "k_blur_rows", "k_fast",       "k_brief",
+                                                    "k_front_l0",  "k_front_ln", "k_synth",     "k_brief_rows", "k_slot_prefix"};
 
 thread_local std::string g_create_error;
 
@@ -61,12 +61,11 @@ struct OrbProgram {
     uint32_t* d_seg_counts = nullptr;  // [max_batch][n_slots]
     uint32_t* d_seg_before = nullptr;  // [max_batch][n_slots] exclusive prefix of the stored counts
     BandGeom bands{};
-    TileGeom tiles{};
+    RowsGeom rows{};
     uint32_t* d_pattern = nullptr;
     float* d_cos = nullptr;
     float* d_sin = nullptr;
-    TileDesc* d_tile_desc = nullptr;  // k_brief_tiles: one descriptor per tile of a frame
-    unsigned long long* d_stamps = nullptr;  // TINYORB_STAMPS=1: per-workgroup phase cycle sums of k_brief_tiles
+    unsigned long long* d_stamps = nullptr;  // TINYORB_STAMPS=1: phase cycle sums of k_front (2 x 16 slots)
 
     // host staging of the single-frame API (orb.rs:216-218 staging buffers)
     uint32_t* h_count = nullptr;
@@ -299,7 +298,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         g.slot_base = p->bands.slot_base[lvl];
         g.n_slots = p->bands.n_slots;
         g.seg_cap = p->bands.seg_cap;
-        g.stamps = p->d_stamps ? p->d_stamps + 4096 * 6 : nullptr;
+        g.stamps = p->d_stamps;
         if (g.n_bands != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: band count mismatch at level %u", lvl);
         const uint32_t lds = front_lds_bytes(g);
@@ -315,21 +314,15 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
                                d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg);
         }
     }
-    {  // orb.rs:523-534, plus the compaction of the band segments into the final lists
-        LaunchScope ls(p, s, KID_BRIEF);
+    // orb.rs:523-534, plus the compaction of the band segments into the final lists
+    {
+        LaunchScope ls(p, s, KID_PREFIX);
         hipLaunchKernelGGL(k_slot_prefix, dim3(n), dim3(64), 0, s, d_seg_counts, d_seg_before, d_counts,
                            p->bands.n_slots, p->bands.seg_cap);
-        TileGeom tg = p->tiles;
-        tg.n_frames = n;
-        tg.xcd_swizzle = (n % 8u == 0u) ? 1u : 0u;
-        // persistent workgroups, two per CU, each walks its XCD's share of the tiles
-        uint32_t n_wg = tg.tiles_per_frame * n;
-        uint32_t per_cu = 2u;
-        if (const char* e = getenv("TINYORB_BRIEF_WG_PER_CU")) per_cu = (uint32_t)atoi(e);
-        if (n_wg > per_cu * p->n_cus) n_wg = per_cu * p->n_cus;
-        if (tg.xcd_swizzle && (n_wg % 8u != 0u || n_wg < 8u)) tg.xcd_swizzle = 0u;
-        tg.stamps = p->d_stamps;
-        hipLaunchKernelGGL(k_brief_tiles, dim3(n_wg), dim3(kBriefThreads), 0, s, d_blur, d_blur_rowc, pyr, tg, d_seg_counts,
+    }
+    {
+        LaunchScope ls(p, s, KID_BRIEF_ROWS);
+        hipLaunchKernelGGL(k_brief_rows, dim3(p->rows.n_slots, n), dim3(256), 0, s, d_blur, d_blur_rowc, pyr, p->rows, d_seg_counts,
                            d_seg_before, d_seg, d_corners, cap, d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin});
     }
     HIP_TRY(p, hipGetLastError());
@@ -444,25 +437,17 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 bg.n_slots = slots;
                 const uint64_t band_px = (uint64_t)kFrontRows * (((uint64_t)W + 7u) / 8u * 8u);
                 bg.seg_cap = (uint32_t)(band_px < config->max_features ? band_px : config->max_features);
-                TileGeom& tg = p->tiles;
-                tg.n_slots = bg.n_slots;
-                tg.seg_cap = bg.seg_cap;
-                uint32_t tiles = 0;
+                RowsGeom& rg = p->rows;
+                rg.n_slots = bg.n_slots;
+                rg.seg_cap = bg.seg_cap;
+                for (uint32_t lvl = 0; lvl <= p->pyr.depth; lvl++) rg.slot_base[lvl] = bg.slot_base[lvl];
                 for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
-                    tg.slot_base[lvl] = bg.slot_base[lvl];
-                    tg.tile_base[lvl] = tiles;
-                    // per pair of bands: one flat tile for x < qa - 18 (if any), then 256-wide 2-D tiles
-                    const uint32_t gw = (((W >> lvl) + 7u) / 8u) * 8u;
-                    const uint32_t cols = p->pyr.w[lvl] > gw ? p->pyr.w[lvl] : gw;
+                    // columns [0, qa) of the level's blur are kept as one constant per row (k_front, phase C)
                     const uint32_t qa = front_geometry(p->pyr, lvl, 8, 8, 1).blur_q & ~7u;
                     p->blur_qa[lvl] = qa;
-                    const uint32_t flat_end = qa > (uint32_t)kBriefHalo ? qa - kBriefHalo : 0u;
-                    const uint32_t first2d = flat_end & ~7u;
-                    tg.tile_cols[lvl] = (flat_end ? 1u : 0u) + (cols > first2d ? (cols - first2d + kBriefTileW - 1) / kBriefTileW : 0u);
-                    tiles += ((front_bands(p->pyr, lvl) + 1u) / 2u) * tg.tile_cols[lvl];
+                    rg.qa[lvl] = qa;
+                    rg.flat_end[lvl] = qa > (uint32_t)kBriefHalo ? qa - kBriefHalo : 0u;
                 }
-                tg.slot_base[p->pyr.depth] = bg.n_slots;
-                tg.tile_base[p->pyr.depth] = tiles;
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<false>),
@@ -498,56 +483,9 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     CREATE_TRY(hipMemcpy(p->d_pattern, ORB_BRIEF_PATTERN, 1024, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(p->d_cos, ORB_COS_BITS, ORB_ANGLE_STEPS * 4, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(p->d_sin, ORB_SIN_BITS, ORB_ANGLE_STEPS * 4, hipMemcpyHostToDevice));
-    if (p->fused) {
-        // per-tile descriptors of k_brief_tiles (all levels of one frame)
-        TileGeom& tg = p->tiles;
-        std::vector<TileDesc> desc(tg.tile_base[p->pyr.depth]);
-        for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
-            const uint32_t n_bands = tg.slot_base[lvl + 1] - tg.slot_base[lvl];
-            const uint32_t n_tiles = tg.tile_base[lvl + 1] - tg.tile_base[lvl];
-            const uint32_t qa = p->blur_qa[lvl];
-            const uint32_t flat_end = qa > (uint32_t)kBriefHalo ? qa - kBriefHalo : 0u;  // x + 18 < qa
-            const uint32_t first2d = flat_end & ~7u;
-            for (uint32_t t = 0; t < n_tiles; t++) {
-                const uint32_t ty = t / tg.tile_cols[lvl], tx = t % tg.tile_cols[lvl];
-                TileDesc& d = desc[tg.tile_base[lvl] + t];
-                d.lvl = lvl;
-                d.slot_a = tg.slot_base[lvl] + 2u * ty;
-                d.has_b = (2u * ty + 1u < n_bands) ? 1u : 0u;
-                d.plane_off = p->pyr.off[lvl];
-                d.y0 = (int32_t)(ty * kBriefTileH);
-                d.w = (int32_t)p->pyr.w[lvl];
-                d.h = (int32_t)p->pyr.h[lvl];
-                d.qa = (int32_t)qa;
-                d.row_off = p->pyr.row_off[lvl];
-                d.pad = 0;
-                if (flat_end && tx == 0) {  // every sample column of these keypoints is below qa (or < 0: edge path)
-                    d.flat = 1u;
-                    d.x0 = 0;
-                    d.px0 = 0;
-                    d.px1 = (int32_t)flat_end;
-                } else {
-                    const uint32_t k = tx - (flat_end ? 1u : 0u);
-                    d.flat = 0u;
-                    d.x0 = (int32_t)(first2d + k * kBriefTileW);  // window origin, multiple of 8
-                    d.px0 = k == 0 ? (int32_t)flat_end : d.x0;
-                    d.px1 = d.x0 + kBriefTileW;
-                }
-            }
-        }
-        // Persistent workgroups take tiles q, q + step, ...: with the flat (many keypoints) and 2-D (few keypoints,
-        // big window) tiles alternating, an even step would hand some workgroups only the heavy kind.  Flat tiles
-        // first, 2-D tiles after: every workgroup's sequence then crosses both halves.
-        std::stable_partition(desc.begin(), desc.end(), [](const TileDesc& d) { return d.flat != 0u; });
-        tg.tiles_per_frame = (uint32_t)desc.size();
-        tg.inv_tiles_per_frame = 1.0f / (float)desc.size();
-        CREATE_TRY(hipMalloc(&p->d_tile_desc, desc.size() * sizeof(TileDesc)));
-        CREATE_TRY(hipMemcpy(p->d_tile_desc, desc.data(), desc.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
-        tg.desc = p->d_tile_desc;
-        if (getenv("TINYORB_STAMPS")) {
-            CREATE_TRY(hipMalloc(&p->d_stamps, (4096 * 6 + 32) * sizeof(unsigned long long)));
-            CREATE_TRY(hipMemset(p->d_stamps, 0, (4096 * 6 + 32) * sizeof(unsigned long long)));
-        }
+    if (p->fused && getenv("TINYORB_STAMPS")) {  // diagnostic builds only (tools/stamps.py)
+        CREATE_TRY(hipMalloc(&p->d_stamps, 32 * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemset(p->d_stamps, 0, 32 * sizeof(unsigned long long)));
     }
     CREATE_TRY(hipHostMalloc(&p->h_count, sizeof(uint32_t), hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc(&p->h_corners, cap * sizeof(CornerData), hipHostMallocDefault));
@@ -581,7 +519,6 @@ void orb_program_destroy(OrbProgram* p) {
     (void)hipFree(p->d_pattern);
     (void)hipFree(p->d_cos);
     (void)hipFree(p->d_sin);
-    (void)hipFree(p->d_tile_desc);
     (void)hipFree(p->d_stamps);
     if (p->h_count) (void)hipHostFree(p->h_count);
     if (p->h_corners) (void)hipHostFree(p->h_corners);
@@ -843,7 +780,7 @@ int orb_synth_frames_device(OrbProgram* p, uint8_t* frames_dev, uint32_t n_frame
 int orb_debug_stamps(OrbProgram* p, unsigned long long* dst, size_t n) {
     if (!p || !dst) return ORB_EINVAL;
     if (!p->d_stamps) return fail(p, ORB_ESTATE, "stamps are collected only with TINYORB_STAMPS=1");
-    if (n > 4096 * 6 + 32) n = 4096 * 6 + 32;
+    if (n > 32) n = 32;
     HIP_TRY(p, hipSetDevice(p->device));
     HIP_TRY(p, hipDeviceSynchronize());
     HIP_TRY(p, hipMemcpy(dst, p->d_stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -503,8 +503,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
             const int P = (int)geo.blur_p, Q = (int)geo.blur_q;
             if (rows > 0) {
                 // constant stretch: one f16 per row in the row-constant array covers columns [0, Qa), Qa = Q rounded
-                // down to a multiple of 8 (the plane itself is only written from column Qa on: k_brief_tiles
-                // rebuilds the window from the constants, the plane's first 88 % never travel through HBM)
+                // down to a multiple of 8 (the plane itself is only written from column Qa on: k_brief_rows
+                // samples the constants directly, the first 88 % of the plane never travel through HBM)
                 const int Qa = Q & ~7;
                 if (tid < rows)
                     blur_rowc[(size_t)frame * pyr.row_stride + pyr.row_off[lvl] + (uint32_t)(y0 + tid)] =
@@ -566,49 +566,134 @@ struct BandGeom {
     uint32_t slot_base[kMaxLevels + 1];  // first slot of each level; [depth] = n_slots
 };
 
-// ---------------------------------------------------------------------------------------------
-// K6, tiled: brief.wgsl:20-68 with the sampling window staged in LDS.
-//
-// A 64-lane gather of 2-byte texels through the vector memory path costs about one address per
-// cycle, and BRIEF needs 512 of them per keypoint; the same gather from LDS runs at bank speed.
-// So a workgroup owns a tile of kBriefTileH x kBriefTileW keypoint positions of one level of one
-// frame (two k_front bands high), copies the blurred window tile + 18 px halo into LDS once with
-// 16-byte loads (texels outside the level become 0, CRD-6, so the sampling loop needs no bounds
-// checks), picks the tile's keypoints out of the two band segments, and then runs one wave64 per
-// keypoint.  |trunc(R(-theta) p)| <= 18 for every pattern point (max radius 18.38).
-// Output index of a keypoint = stored keypoints in earlier band slots + its index in its band
-// segment, i.e. the final lists are the band segments back to back.
-// ---------------------------------------------------------------------------------------------
-constexpr int kBriefTileH = 2 * kFrontRows;  // 32 rows = two band slots
-constexpr int kBriefTileW = 256;
-constexpr int kBriefHalo = 18;
-constexpr int kBriefPadX = 24;  // halo rounded up to a multiple of 8 texels (16-byte loads)
-constexpr int kBriefWinW = kBriefTileW + 2 * kBriefPadX;  // 304
-constexpr int kBriefWinH = kBriefTileH + 2 * kBriefHalo;  // 68
-constexpr int kBriefThreads = 512;
-constexpr int kBriefList = 512;
+constexpr int kBriefHalo = 18;  // |trunc(R(-theta) p)| <= 18 for every pattern point (max radius 18.38)
 
-// One entry per tile of a frame (all levels), built on the host.
-struct TileDesc {
-    uint32_t lvl, slot_a, has_b, plane_off;  // plane_off: texel offset of the level in the packed pyramid
-    int32_t x0, y0, w, h;
-    int32_t qa;        // columns [0, qa) of the level's blur are one constant per row (qa is a multiple of 8)
-    uint32_t row_off;  // the level's first row in the row-constant array
-    uint32_t flat;     // 1: every sample column of the tile's keypoints lies below qa: rows are all that matter
-    int32_t px0, px1;  // the tile takes the keypoints with px0 <= x < px1 (2-D tiles: x0 <= px0, px1 <= x0 + 256)
-    uint32_t pad;
-};
-
-struct TileGeom {
-    uint32_t n_slots, seg_cap, n_frames, xcd_swizzle;
+// ---------------------------------------------------------------------------------------------
+// K6  brief.wgsl:20-68 for the fused pipeline, plus the compaction of the band segments into the final
+// lists (orb.rs:159-164 `corners`, 195-199 `descriptors`).
+// The literal blur is one value per row for every column below qa (88 % of the width, see k_front phase
+// C), so for a keypoint with 18 <= x < qa - 18 the 37x37 patch is 37 values.  One wave64 per keypoint, no
+// LDS: lane r holds the row constant of row y - 18 + r (0 outside the level, CRD-6), a sample is a
+// cross-lane read (ds_bpermute) at the rotated point's row, four ballots give the eight u32 words
+// (brief.wgsl:47,63,67).  The other 12 % of the keypoints (right end of the rows, left border) take
+// the general path: per sample 0 / row constant / a 2-byte load from the plane's stored tail.
+// Workgroup = one band slot of one frame; output index = seg_before[slot] + index in the segment, so the
+// final lists are the band segments back to back; counts[frame] comes from k_slot_prefix.
+// ---------------------------------------------------------------------------------------------
+struct RowsGeom {
+    uint32_t n_slots, seg_cap;
     uint32_t slot_base[kMaxLevels + 1];
-    uint32_t tile_base[kMaxLevels + 1];  // first tile of each level; [depth] = tiles per frame
-    uint32_t tile_cols[kMaxLevels];      // column tiles of each level
-    uint32_t tiles_per_frame;
-    float inv_tiles_per_frame;
-    const TileDesc* desc;                // [tiles_per_frame]
-    unsigned long long* stamps;          // diagnostic builds only: per-workgroup cycle sums per phase (else null)
+    uint32_t flat_end[kMaxLevels];  // qa - 18: a keypoint with 18 <= x < flat_end samples only columns in [0, qa)
+    uint32_t qa[kMaxLevels];        // columns [0, qa) of the level's blur are the row constants
 };
+
+__global__ __launch_bounds__(256) void k_brief_rows(const uint16_t* __restrict__ blur,
+                                                    const uint16_t* __restrict__ blur_rowc, Pyramid pyr, RowsGeom rg,
+                                                    const uint32_t* __restrict__ seg_counts,
+                                                    const uint32_t* __restrict__ seg_before,
+                                                    const CornerData* __restrict__ segments,
+                                                    CornerData* __restrict__ corners, uint32_t cap,
+                                                    CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
+    const uint32_t slot = blockIdx.x, frame = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t lvl = 0;
+    for (uint32_t m = 1; m < pyr.depth; m++)
+        if (slot >= rg.slot_base[m]) lvl = m;
+    const uint32_t fe = rg.flat_end[lvl];
+    const int qa = (int)rg.qa[lvl];
+    const int w = (int)pyr.w[lvl], h = (int)pyr.h[lvl];
+    const size_t sidx = (size_t)frame * rg.n_slots + slot;
+    const uint32_t n = min(seg_counts[sidx], rg.seg_cap);
+    const uint32_t before = seg_before[sidx];
+    if (wave >= n) return;
+    const CornerData* seg = segments + sidx * rg.seg_cap;
+    const uint16_t* rowc = blur_rowc + (size_t)frame * pyr.row_stride + pyr.row_off[lvl];
+    const uint16_t* plane = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
+    CornerData* out_kp = corners + (size_t)frame * cap;
+    uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)frame * cap);
+    // this lane's four tests (l, 64+l, 128+l, 192+l) of the pattern (packed int8 x 4)
+    uint32_t pat[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) pat[e] = tab.pattern[64u * (uint32_t)e + lane];
+
+    uint4 nxt = *reinterpret_cast<const uint4*>(&seg[wave]);
+    for (uint32_t j = wave; j < n; j += 4u) {
+        const uint4 rec = nxt;  // x, y, angle, octave
+        if (j + 4u < n) nxt = *reinterpret_cast<const uint4*>(&seg[j + 4u]);
+        const uint32_t k = before + j;
+        if (k >= cap) break;  // frame is full (indices only grow)
+        const int gy = (int)rec.y - kBriefHalo + (int)lane;  // lanes 0..36 are the patch rows
+        const uint32_t rowv = (gy >= 0 && gy < h && lane < 37u) ? (uint32_t)rowc[gy] : 0u;
+        uint64_t bal[4];
+        if (rec.x >= (uint32_t)kBriefHalo && rec.x < fe) {
+            // ---- every sample column lies in [0, qa): only the rows of the rotated points matter
+            int ra[4], rb[4];
+            if (rec.z == 0u) {  // R = I (more than half of all keypoints, Q7)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    ra[e] = (int)(int8_t)((pat[e] >> 8) & 255u);
+                    rb[e] = (int)(int8_t)(pat[e] >> 24);
+                }
+            } else {
+                const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
+                const float ct = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;  // CRD-10 table
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
+                    const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
+                    // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y); rows only
+                    const float a2 = nst * pax, a3 = ct * pay, b2 = nst * pbx, b3 = ct * pby;
+                    const float ray = a2 + a3, rby = b2 + b3;
+                    ra[e] = (int)ray;  // vec2i() truncates
+                    rb[e] = (int)rby;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t va = (uint32_t)__shfl((int)rowv, ra[e] + kBriefHalo);
+                const uint32_t vb = (uint32_t)__shfl((int)rowv, rb[e] + kBriefHalo);
+                bal[e] = __ballot(va > vb);  // non-negative f16: bit patterns order like the values (brief.wgsl:62)
+            }
+        } else {
+            // ---- general case (12 % of the keypoints: near the right end of the row, or within 18 px of the left
+            //      border): a sample is 0 outside the level (CRD-6), the row constant for columns < qa, and a
+            //      2-byte load from the plane's stored tail otherwise
+            const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
+            const float ct = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
+                const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
+                const float a0 = ct * pax, a1 = st * pay, a2 = nst * pax, a3 = ct * pay;
+                const float b0 = ct * pbx, b1 = st * pby, b2 = nst * pbx, b3 = ct * pby;
+                const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+                const int dya = (int)ray, dyb = (int)rby;
+                const int xa = (int)rec.x + (int)rax, ya = (int)rec.y + dya;
+                const int xb = (int)rec.x + (int)rbx, yb = (int)rec.y + dyb;
+                uint32_t va = (uint32_t)__shfl((int)rowv, dya + kBriefHalo);  // 0 when the row is outside the level
+                uint32_t vb = (uint32_t)__shfl((int)rowv, dyb + kBriefHalo);
+                const bool ina = xa >= 0 && xa < w && ya >= 0 && ya < h;
+                const bool inb = xb >= 0 && xb < w && yb >= 0 && yb < h;
+                if (!ina)
+                    va = 0u;
+                else if (xa >= qa)
+                    va = plane[(size_t)(uint32_t)(__mul24(ya, w) + xa)];
+                if (!inb)
+                    vb = 0u;
+                else if (xb >= qa)
+                    vb = plane[(size_t)(uint32_t)(__mul24(yb, w) + xb)];
+                bal[e] = __ballot(va > vb);
+            }
+        }
+        if (lane < 8u) {
+            const uint64_t src = lane < 2u ? bal[0] : (lane < 4u ? bal[1] : (lane < 6u ? bal[2] : bal[3]));
+            out_desc[(size_t)k * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
+        } else if (lane == 8u) {
+            *reinterpret_cast<uint4*>(&out_kp[k]) = rec;
+        }
+    }
+}
 
 // Exclusive prefix of the stored keypoints over a frame's band slots (= where each band's keypoints start in
 // the final lists) and the frame's raw counter (orb.rs:550-556).  One wave per frame.
@@ -637,318 +722,6 @@ __global__ __launch_bounds__(64) void k_slot_prefix(const uint32_t* __restrict__
         total += r;
     }
     if (lane == 0u) counts[frame] = total;
-}
-
-// Persistent workgroups: each walks its XCD's share of the tiles; while the keypoints of one tile are
-// being described out of LDS, the window, band records and counts of the next tile are already in
-// flight into registers (vector loads only: nothing in the loop waits on the scalar cache).
-__global__ __launch_bounds__(kBriefThreads, 4) void k_brief_tiles(const uint16_t* __restrict__ blur,
-                                                                  const uint16_t* __restrict__ blur_rowc, Pyramid pyr,
-                                                                  TileGeom tg, const uint32_t* __restrict__ seg_counts,
-                                                                  const uint32_t* __restrict__ seg_before,
-                                                                  const CornerData* __restrict__ segments,
-                                                                  CornerData* __restrict__ corners, uint32_t cap,
-                                                                  CornerDescriptor* __restrict__ descriptors,
-                                                                  BriefTables tab) {
-    constexpr int NT = kBriefThreads;
-    constexpr int G = kBriefWinW / 8;     // 16-byte groups per window row
-    constexpr int N = kBriefWinH * G;     // 2584
-    constexpr int U = (N + NT - 1) / NT;  // 6
-    __shared__ __attribute__((aligned(16))) uint16_t win[kBriefWinH * kBriefWinW];
-    __shared__ uint4 list_rec[kBriefList];  // x, y, angle, octave
-    __shared__ uint4 list_aux[kBriefList];  // output index, cos bits, sin bits, -
-    __shared__ uint32_t list_n;
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool swz = tg.xcd_swizzle != 0u;
-    const uint32_t xcd = swz ? (blockIdx.x & 7u) : 0u;
-    uint32_t q = swz ? (blockIdx.x >> 3) : blockIdx.x;
-    const uint32_t q_step = swz ? (gridDim.x >> 3) : gridDim.x;
-    const uint32_t q_end = swz ? (tg.n_frames >> 3) * tg.tiles_per_frame : tg.n_frames * tg.tiles_per_frame;
-    if (q >= q_end) return;
-
-    struct Tile {
-        uint32_t frame;
-        TileDesc d;
-    };
-    auto decode = [&](uint32_t qq) {
-        Tile t;
-        uint32_t fq = (uint32_t)(((float)qq + 0.5f) * tg.inv_tiles_per_frame);  // qq / tiles_per_frame (qq < 2^23)
-        const uint32_t tile = qq - fq * tg.tiles_per_frame;
-        t.frame = swz ? fq * 8u + xcd : fq;
-        t.d = tg.desc[tile];
-        return t;
-    };
-
-    // this lane's four tests (l, 64+l, 128+l, 192+l) of the pattern (packed int8 x 4) and their unrotated
-    // window offsets
-    uint32_t pat[4], off0[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const uint32_t packed = tab.pattern[64u * (uint32_t)e + lane];
-        const int ax = (int8_t)(packed & 255u), ay = (int8_t)((packed >> 8) & 255u);
-        const int bx = (int8_t)((packed >> 16) & 255u), by = (int8_t)(packed >> 24);
-        pat[e] = packed;
-        off0[e] = ((uint32_t)(ay * kBriefWinW + ax) & 0xffffu) | ((uint32_t)(by * kBriefWinW + bx) << 16);
-    }
-
-    // registers that carry the next tile
-    uint4 wv[U];
-    uint4 rec_a, rec_b;
-    uint32_t v_na = 0, v_nb = 0, v_before = 0;  // per-lane copies of uniform values (vector loads do not block)
-    auto issue = [&](const Tile& t, uint32_t tid) {
-        const uint16_t* plane = blur + (size_t)t.frame * pyr.stride + t.d.plane_off;
-        if (t.d.flat) {
-            // the window is one value per row: thread r fetches row y0 - 18 + r of the row constants
-            const int gy = t.d.y0 - kBriefHalo + (int)tid;
-            const int cy = min(max(gy, 0), t.d.h - 1);
-            const uint32_t c = blur_rowc[(size_t)t.frame * pyr.row_stride + t.d.row_off + (uint32_t)cy];
-            wv[0].x = (tid < (uint32_t)kBriefWinH && gy >= 0 && gy < t.d.h) ? c : 0u;  // outside the level: 0 (CRD-6)
-        } else if ((t.d.w & 7) == 0) {
-            // window columns start at a multiple of 8 texels: a 16-byte group is entirely inside or outside the
-            // level (zeroed when storing) and entirely inside or outside the row-constant stretch [0, qa): there
-            // the group is the row's constant (2-byte load), elsewhere 16 bytes of the plane; clamped addresses,
-            // no wait between the loads
-            const uint16_t* rowc = blur_rowc + (size_t)t.frame * pyr.row_stride + t.d.row_off;
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = min((int)tid + u * NT, N - 1);
-                const int r = i / G, g = i - r * G;
-                const int gy = t.d.y0 - kBriefHalo + r, gx = t.d.x0 - kBriefPadX + g * 8;
-                const int cy = min(max(gy, 0), t.d.h - 1), cx = min(max(gx, 0), t.d.w - 8);
-                if (cx < t.d.qa) {
-                    const uint32_t c = rowc[cy];
-                    const uint32_t pk = c | (c << 16);
-                    wv[u] = make_uint4(pk, pk, pk, pk);
-                } else {
-                    wv[u] = *reinterpret_cast<const uint4*>(plane + (size_t)(uint32_t)(__mul24(cy, t.d.w) + cx));
-                }
-            }
-        }
-        const size_t slot = (size_t)t.frame * tg.n_slots + t.d.slot_a;
-        const CornerData* seg_a = segments + slot * tg.seg_cap;
-        const uint32_t spec = min(tid, tg.seg_cap - 1u);  // speculative: validity is known once the counts arrive
-        rec_a = *reinterpret_cast<const uint4*>(&seg_a[spec]);
-        rec_b = *reinterpret_cast<const uint4*>(&seg_a[(t.d.has_b ? tg.seg_cap : 0u) + spec]);
-        const uint32_t* cnt = seg_counts + slot + (lane & 0u);  // lane-dependent on purpose: keeps it a vector load
-        v_na = cnt[0];
-        v_nb = t.d.has_b ? cnt[1] : 0u;
-        v_before = (seg_before + slot + (lane & 0u))[0];
-    };
-    // A record belongs to this tile when its x falls in the tile's columns (its rows do by construction).
-    auto wanted = [&](const Tile& t, const uint4& rec, uint32_t k) {
-        return k < cap && rec.x >= (uint32_t)t.d.px0 && rec.x < (uint32_t)t.d.px1;
-    };
-    auto push = [&](const uint4& rec, uint32_t k, float ct, float st) {
-        const uint32_t idx = atomicAdd(&list_n, 1u);
-        if (idx < (uint32_t)kBriefList) {
-            list_rec[idx] = rec;
-            list_aux[idx] = make_uint4(k, __float_as_uint(ct), __float_as_uint(st), 0u);
-        }
-    };
-    auto pick = [&](const Tile& t, const uint4& rec, uint32_t k) {
-        if (wanted(t, rec, k)) {
-            const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
-            push(rec, k, tab.cos_tab[code], tab.sin_tab[code]);  // CRD-10 table
-        }
-    };
-    // window registers -> LDS (rows [y0-18, y0+32+18), columns [x0-24, x0+256+24), zero outside the level, CRD-6)
-    // and the tile's keypoints -> list
-    auto commit = [&](const Tile& t, uint32_t n_a, uint32_t n_b, uint32_t before, uint32_t tid) {
-        if (tid < n_a) pick(t, rec_a, before + tid);
-        if (tid < n_b) pick(t, rec_b, before + n_a + tid);
-        if (t.d.flat) {
-            if (tid < (uint32_t)kBriefWinH) win[tid] = (uint16_t)wv[0].x;
-        } else if ((t.d.w & 7) == 0) {
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = (int)tid + u * NT;
-                const int r = i / G, g = i - r * G;
-                const int gy = t.d.y0 - kBriefHalo + r, gx = t.d.x0 - kBriefPadX + g * 8;
-                const bool inside = gy >= 0 && gy < t.d.h && gx >= 0 && gx < t.d.w;
-                if (i < N) *reinterpret_cast<uint4*>(&win[i * 8]) = inside ? wv[u] : make_uint4(0u, 0u, 0u, 0u);
-            }
-        } else {  // odd widths: element-wise
-            const uint16_t* plane = blur + (size_t)t.frame * pyr.stride + t.d.plane_off;
-            for (int i = (int)tid; i < N; i += NT) {
-                const int r = i / G, g = i - r * G;
-                const int gy = t.d.y0 - kBriefHalo + r, gx = t.d.x0 - kBriefPadX + g * 8;
-                uint32_t e[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int xx = gx + k;
-                    e[k] = (gy >= 0 && gy < t.d.h && xx >= 0 && xx < t.d.w)
-                               ? (uint32_t)(xx < t.d.qa ? blur_rowc[(size_t)t.frame * pyr.row_stride + t.d.row_off + gy]
-                                                        : plane[(size_t)gy * t.d.w + xx])
-                               : 0u;
-                }
-                *reinterpret_cast<uint4*>(&win[i * 8]) =
-                    make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-            }
-        }
-    };
-    // One wave per keypoint of the list, everything it needs is in LDS or registers.  Angle code 0 (R = I:
-    // more than half of all keypoints, Q7) uses the unrotated offsets; otherwise the lane rotates its eight
-    // pattern points with brief.wgsl:38-57's arithmetic (one rounding per op, truncation toward zero).
-    // Blur texels are non-negative f16, so `a > b` (brief.wgsl:62) is decided on the bit patterns; four
-    // ballots give the eight u32 words (brief.wgsl:47,63,67).
-    auto describe = [&](const Tile& t, uint32_t n_l) {
-        CornerData* out_kp = corners + (size_t)t.frame * cap;
-        uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)t.frame * cap);
-        constexpr uint32_t NW = NT / 64;
-        for (uint32_t i = wave; i < n_l; i += NW) {
-            const uint4 rec = list_rec[i];
-            const uint4 aux = list_aux[i];
-            const int cx = (int)rec.x - t.d.x0 + kBriefPadX, cy = (int)rec.y - t.d.y0 + kBriefHalo;
-            // flat tiles: the blur is one value per row around this keypoint (columns < qa), the window is a
-            // column of kBriefWinH values and only the rotated points' rows matter
-            const bool flat = t.d.flat != 0u;
-            const uint16_t* ctr = flat ? win + cy : win + cy * kBriefWinW + cx;
-            // sample offsets of this lane's four tests, then all eight LDS reads back to back
-            int oa[4], ob[4];
-            if (rec.z == 0u) {  // wave-uniform
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    oa[e] = flat ? (int)(int8_t)((pat[e] >> 8) & 255u) : (int)(int16_t)(off0[e] & 0xffffu);
-                    ob[e] = flat ? (int)(int8_t)(pat[e] >> 24) : (int)(int16_t)(off0[e] >> 16);
-                }
-            } else {
-                const float ct = __uint_as_float(aux.y), st = __uint_as_float(aux.z), nst = -st;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
-                    const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
-                    // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y)
-                    const float a2 = nst * pax, a3 = ct * pay, b2 = nst * pbx, b3 = ct * pby;
-                    const float ray = a2 + a3, rby = b2 + b3;
-                    if (flat) {
-                        oa[e] = (int)ray;  // vec2i() truncates
-                        ob[e] = (int)rby;
-                    } else {
-                        const float a0 = ct * pax, a1 = st * pay, b0 = ct * pbx, b1 = st * pby;
-                        const float rax = a0 + a1, rbx = b0 + b1;
-                        oa[e] = (int)ray * kBriefWinW + (int)rax;
-                        ob[e] = (int)rby * kBriefWinW + (int)rbx;
-                    }
-                }
-            }
-            uint32_t va[4], vb[4];
-            if (flat && rec.x < (uint32_t)kBriefHalo) {
-                // (wave-uniform, rare) a keypoint this close to the left border can sample columns < 0, which read
-                // as 0 (CRD-6): redo the points with their columns
-                const float ct = __uint_as_float(aux.y), st = __uint_as_float(aux.z), nst = -st;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
-                    const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
-                    const float a0 = ct * pax, a1 = st * pay, a2 = nst * pax, a3 = ct * pay;
-                    const float b0 = ct * pbx, b1 = st * pby, b2 = nst * pbx, b3 = ct * pby;
-                    const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
-                    va[e] = ((int)rec.x + (int)rax < 0) ? 0u : (uint32_t)ctr[(int)ray];
-                    vb[e] = ((int)rec.x + (int)rbx < 0) ? 0u : (uint32_t)ctr[(int)rby];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    va[e] = ctr[oa[e]];
-                    vb[e] = ctr[ob[e]];
-                }
-            }
-            uint64_t bal[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) bal[e] = __ballot(va[e] > vb[e]);
-            if (lane < 8u) {
-                const uint64_t src = lane < 2u ? bal[0] : (lane < 4u ? bal[1] : (lane < 6u ? bal[2] : bal[3]));
-                out_desc[(size_t)aux.x * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
-            } else if (lane == 8u) {
-                *reinterpret_cast<uint4*>(&out_kp[aux.x]) = rec;
-            }
-        }
-    };
-    // Tiles with more than NT records in a band, or more keypoints than the list holds: rounds of NT/2 records.
-    auto slow_tile = [&](const Tile& t, uint32_t na, uint32_t nb, uint32_t bef) {
-        const size_t slot = (size_t)t.frame * tg.n_slots + t.d.slot_a;
-        for (int half = 0; half < 2; half++) {
-            const CornerData* seg = segments + (slot + (uint32_t)half) * tg.seg_cap;
-            const uint32_t n = half ? nb : na, base = half ? bef + na : bef;
-            for (uint32_t c0 = 0; c0 < n; c0 += NT / 2) {  // NT/2 records per round always fit the list
-                __syncthreads();
-                if (tid == 0u) list_n = 0u;
-                __syncthreads();
-                const uint32_t j = c0 + tid;
-                if (tid < NT / 2 && j < n) pick(t, *reinterpret_cast<const uint4*>(&seg[j]), base + j);
-                __syncthreads();
-                describe(t, min(list_n, (uint32_t)kBriefList));
-            }
-        }
-    };
-
-    // diagnostic stamps (tg.stamps != null): cycles spent by wave 0 in each phase, summed over the tiles
-#ifdef TINYORB_STAMPS
-    unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_last = 0;
-    const bool stamping = tg.stamps != nullptr;
-    auto stamp = [&](int slot) {
-        if (stamping) {
-            const unsigned long long now = __builtin_readcyclecounter();
-            t_acc[slot] += now - t_last;
-            t_last = now;
-        }
-    };
-#else
-    auto stamp = [](int) {};  // the shipped build executes no stamp
-#endif
-    if (tid == 0u) list_n = 0u;
-    Tile cur = decode(q);
-    Tile nxt_tile = decode(min(q + q_step, q_end - 1u));  // descriptors are fetched one tile ahead of their use
-    issue(cur, tid);
-    __syncthreads();
-    uint32_t cur_na = min(__builtin_amdgcn_readfirstlane(v_na), tg.seg_cap);
-    uint32_t cur_nb = min(__builtin_amdgcn_readfirstlane(v_nb), tg.seg_cap);
-    uint32_t cur_before = __builtin_amdgcn_readfirstlane(v_before);
-    commit(cur, cur_na, cur_nb, cur_before, tid);
-    __syncthreads();
-#ifdef TINYORB_STAMPS
-    if (stamping) t_last = __builtin_readcyclecounter();
-#endif
-    for (;;) {
-        const uint32_t qn = q + q_step;
-        const bool has_next = qn < q_end;
-        // Per-thread index math of issue/commit is the same for every tile; an opaque copy of the thread
-        // index per use keeps the optimiser from hoisting it all out of this loop (register pressure).
-        uint32_t tid_o = tid;
-        asm volatile("" : "+v"(tid_o));
-        const Tile nn_tile = decode(min(qn + q_step, q_end - 1u));  // scalar loads land during this iteration
-        if (has_next) issue(nxt_tile, tid_o);                       // in flight while the current tile is described
-        stamp(0);
-        const uint32_t n_l = list_n;
-        if (cur_na > (uint32_t)NT || cur_nb > (uint32_t)NT || n_l > (uint32_t)kBriefList)
-            slow_tile(cur, cur_na, cur_nb, cur_before);
-        else
-            describe(cur, n_l);
-        stamp(1);
-        __syncthreads();  // window and list of the current tile are dead
-        stamp(2);
-        if (!has_next) break;
-        if (tid == 0u) list_n = 0u;
-        __syncthreads();
-        stamp(3);
-        cur = nxt_tile;
-        nxt_tile = nn_tile;
-        cur_na = min(__builtin_amdgcn_readfirstlane(v_na), tg.seg_cap);
-        cur_nb = min(__builtin_amdgcn_readfirstlane(v_nb), tg.seg_cap);
-        cur_before = __builtin_amdgcn_readfirstlane(v_before);
-        asm volatile("" : "+v"(tid_o));
-        commit(cur, cur_na, cur_nb, cur_before, tid_o);
-        q = qn;
-        stamp(4);
-        __syncthreads();
-        stamp(5);
-    }
-#ifdef TINYORB_STAMPS
-    if (stamping && tid == 0u)
-        for (int i = 0; i < 6; i++) tg.stamps[(size_t)blockIdx.x * 6 + i] = t_acc[i];
-#endif
 }
 
 }  // namespace orb

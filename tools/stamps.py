@@ -11,18 +11,12 @@ dev = prog.synth_frames_device(B, 1000)
 for _ in range(3):
     prog.extract_batch_device(dev, B)
 prog.batch_sync()
-raw = np.zeros(4096 * 6 + 32, dtype=np.uint64)
+raw = np.zeros(32, dtype=np.uint64)
 prog._check(prog._lib.orb_debug_stamps(prog._handle(), raw.ctypes.data, raw.size))
-front = raw[4096 * 6:].astype(np.float64)
+front = raw.astype(np.float64)
 fn = ["A stage", "bar", "B1 pretest", "bar", "S1 diag", "bar", "S2 ring", "bar", "S3 angle", "bar", "C0 mip", "C blur", "bar"]
 for base, name in ((0, "k_front<L0>"), (16, "k_front<LN>")):
     tot = front[base:base + 13].sum()
     print(name, "wave-0 cycles per launch set: %.3e" % tot)
     for i, n in enumerate(fn):
         print("   %-12s %5.1f%%" % (n, 100 * front[base + i] / max(tot, 1)))
-st = raw[:512 * 6].reshape(512, 6).astype(np.float64)
-names = ["issue", "describe", "bar_after_describe", "bar_reset", "commit", "bar_after_commit"]
-tot = st.sum(1)
-print("per-workgroup total cycles: mean %.0f min %.0f max %.0f" % (tot.mean(), tot.min(), tot.max()))
-for i, n in enumerate(names):
-    print("%-20s mean %9.0f cycles  %5.1f%%" % (n, st[:, i].mean(), 100 * st[:, i].sum() / tot.sum()))
