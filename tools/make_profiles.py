@@ -30,7 +30,7 @@ for name in ("bench.json", "bench_under_rocprof.json"):
 
 
 def short(name):
-    for k in ("k_front<true>", "k_front<false>", "k_brief_tiles", "k_slot_prefix", "k_synth", "k_grayscale", "k_mip",
+    for k in ("k_front<true>", "k_front<false>", "k_brief_rows", "k_slot_prefix", "k_synth", "k_grayscale", "k_mip",
               "k_blur_rows", "k_fast", "k_brief"):
         if k in name:
             return k
@@ -52,7 +52,7 @@ pmc.to_csv(os.path.join(dst, tag + "_pmc_summary.csv"), index=False)
 
 piv = pmc.pivot(index="kernel", columns="counter", values="mean_per_launch")
 bench = json.load(open(os.path.join(src, "bench.json")))
-dom = {"k_front_l0": "k_front<true>", "k_front_ln": "k_front<false>", "k_brief": "k_brief_tiles"}.get(
+dom = {"k_front_l0": "k_front<true>", "k_front_ln": "k_front<false>"}.get(
     bench["roofline"]["kernel"], bench["roofline"]["kernel"])
 fetch_kb, write_kb = float(piv.loc[dom, "FETCH_SIZE"]), float(piv.loc[dom, "WRITE_SIZE"])
 traffic = {
