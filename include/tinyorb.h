@@ -110,7 +110,8 @@ int orb_read_descriptors(OrbProgram *p, CornerDescriptor *dst, size_t n);
  * NULL for the program's own stream).  Asynchronous: results stay device-resident in the
  * program's output slabs until the next batched call. */
 int orb_extract_batch_device(OrbProgram *p, const uint8_t *frames_dev, uint32_t n_frames, void *stream);
-/* Same with host frames: pinned double-buffered upload overlapped with compute. */
+/* Same with host frames: they are pinned in place for the call and uploaded in chunks on a copy stream while the
+ * kernels of the chunks already on the device run.  Blocks until the uploads are done; results as above. */
 int orb_extract_batch_host(OrbProgram *p, const uint8_t *frames_host, uint32_t n_frames);
 /* Wait for the last batched call to finish. */
 int orb_batch_sync(OrbProgram *p);

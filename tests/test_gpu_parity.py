@@ -39,7 +39,8 @@ def _assert_frame_equal(oracle, ref, total, corners, desc):
 
 
 @pytest.mark.parametrize("W,H,depth,seed", [(64, 48, 2, 3), (160, 120, 3, 1), (200, 97, 3, 7), (640, 480, 2, 1),
-                                            (1284, 250, 4, 5), (332, 202, 5, 11), (2048, 64, 2, 4), (2052, 40, 1, 6)])
+                                            (1284, 250, 4, 5), (332, 202, 5, 11), (2048, 64, 2, 4), (2052, 40, 1, 6),
+                                            (36, 40, 2, 8), (12, 10, 1, 9), (8, 8, 1, 10), (44, 36, 3, 12), (1920, 56, 2, 13)])
 @pytest.mark.parametrize("flags", [1, 0])
 def test_single_frame_matches_oracle(tinyorb, oracle, W, H, depth, seed, flags):
     rgba = oracle.synth_frame(W, H, seed)

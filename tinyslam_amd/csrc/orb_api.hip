@@ -41,6 +41,7 @@ struct OrbProgram {
     OrbOptions opt{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // chunked uploads of orb_extract_batch_host
     Pyramid pyr{};
     size_t frame_bytes = 0;
     uint32_t max_batch = 1;
@@ -524,6 +525,7 @@ void orb_program_destroy(OrbProgram* p) {
     if (p->h_corners) (void)hipHostFree(p->h_corners);
     if (p->h_desc) (void)hipHostFree(p->h_desc);
     if (p->stream) (void)hipStreamDestroy(p->stream);
+    if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     delete p;
 }
 
@@ -605,8 +607,53 @@ int orb_extract_batch_host(OrbProgram* p, const uint8_t* frames_host, uint32_t n
         return fail(p, ORB_EINVAL, "n_frames %u outside 1..=max_batch (%u)", n_frames, p->max_batch);
     HIP_TRY(p, hipSetDevice(p->device));
     if (int rc = ensure_input(p)) return rc;
-    HIP_TRY(p, hipMemcpyAsync(p->d_input, frames_host, p->frame_bytes * n_frames, hipMemcpyHostToDevice, p->stream));
-    return orb_extract_batch_device(p, p->d_input, n_frames, nullptr);
+    hipStream_t s = p->stream;
+    // Ingest (README.md:42 of the reference): the caller's frames are pinned in place for the
+    // duration of the call and uploaded in chunks on a copy stream; the kernels of chunk c run while chunk c+1 is
+    // still crossing PCIe.  Only the fused path can work on a sub-range of the batch.
+    const uint32_t chunk = 16;
+    const size_t total = p->frame_bytes * n_frames;
+    const bool pinned = hipHostRegister(const_cast<uint8_t*>(frames_host), total, hipHostRegisterDefault) == hipSuccess;
+    if (!pinned) (void)hipGetLastError();
+    int rc = ORB_OK;
+    if (!p->fused || !pinned || n_frames <= chunk) {
+        hipError_t e = hipMemcpyAsync(p->d_input, frames_host, total, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) rc = fail(p, ORB_EHIP, "upload failed: %s", hipGetErrorString(e));
+        if (!rc) rc = run_pipeline(p, p->d_input, n_frames, s);
+    } else {
+        if (!p->copy_stream) {
+            hipError_t e = hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking);
+            if (e != hipSuccess) rc = fail(p, ORB_EHIP, "copy stream: %s", hipGetErrorString(e));
+        }
+        std::vector<hipEvent_t> up((n_frames + chunk - 1) / chunk, nullptr);
+        for (uint32_t c = 0, f0 = 0; !rc && f0 < n_frames; c++, f0 += chunk) {
+            const uint32_t m = n_frames - f0 < chunk ? n_frames - f0 : chunk;
+            hipError_t e = hipMemcpyAsync(p->d_input + (size_t)f0 * p->frame_bytes, frames_host + (size_t)f0 * p->frame_bytes,
+                                          (size_t)m * p->frame_bytes, hipMemcpyHostToDevice, p->copy_stream);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&up[c], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(up[c], p->copy_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s, up[c], 0);
+            if (e != hipSuccess) {
+                rc = fail(p, ORB_EHIP, "chunked upload failed: %s", hipGetErrorString(e));
+                break;
+            }
+            rc = run_fused_range(p, p->d_input, f0, m, s);
+        }
+        if (hipStreamSynchronize(p->copy_stream) != hipSuccess && !rc) rc = fail(p, ORB_EHIP, "copy stream sync failed");
+        for (hipEvent_t ev : up)
+            if (ev) (void)hipEventDestroy(ev);
+        if (!rc) p->planes_valid = true;
+    }
+    if (pinned) {
+        // the host pages must stay pinned until the last upload has finished
+        if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(p, ORB_EHIP, "stream sync failed");
+        (void)hipHostUnregister(const_cast<uint8_t*>(frames_host));
+    }
+    if (rc) return rc;
+    p->last_batch = n_frames;
+    p->last_stream = s;
+    p->single_valid = false;
+    return ORB_OK;
 }
 
 int orb_batch_sync(OrbProgram* p) {
