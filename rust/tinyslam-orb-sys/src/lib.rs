@@ -1,0 +1,147 @@
+//! `tinyslam::orb` over libtinyorb (include/tinyorb.h).  Same public items as the reference module:
+//! `OrbConfig`, `OrbProgram::{init, write_input_image, set_threshold, extract_corners, read_corners,
+//! read_descriptors}`, `CornerData`, `CornerDescriptor`.  UNVERIFIED SOURCE: the build image has no rustc; the
+//! same ABI is exercised from Python by the repository's tests.
+pub mod orb {
+    use std::os::raw::{c_char, c_int, c_void};
+
+    #[repr(C)]
+    #[derive(Clone, Copy, Default, Debug, PartialEq, Eq)]
+    pub struct CornerData {
+        pub x: u32,
+        pub y: u32,
+        pub angle: u32,
+        pub octave: u32,
+    }
+
+    #[repr(C)]
+    #[derive(Clone, Copy, Debug, PartialEq, Eq)]
+    pub struct CornerDescriptor {
+        pub bits: [u8; 32],
+    }
+    impl Default for CornerDescriptor {
+        fn default() -> Self {
+            Self { bits: [0; 32] }
+        }
+    }
+
+    /// Stand-in for `wgpu::Extent3d` (the only wgpu type in the reference's public surface).
+    #[derive(Clone, Copy, Debug)]
+    pub struct Extent3d {
+        pub width: u32,
+        pub height: u32,
+        pub depth_or_array_layers: u32,
+    }
+
+    pub struct OrbConfig {
+        pub image_size: Extent3d,
+        pub max_features: u32,
+        pub hierarchy_depth: u32,
+        pub initial_threshold: f32,
+    }
+
+    #[repr(C)]
+    struct Extent3dC {
+        width: u32,
+        height: u32,
+        depth_or_array_layers: u32,
+    }
+    #[repr(C)]
+    struct OrbConfigC {
+        image_size: Extent3dC,
+        max_features: u32,
+        hierarchy_depth: u32,
+        initial_threshold: f32,
+    }
+    #[repr(C)]
+    #[derive(Default)]
+    struct OrbOptionsC {
+        device: i32,
+        max_batch: u32,
+        flags: u32,
+        reserved: [u32; 5],
+    }
+
+    extern "C" {
+        fn orb_program_create(cfg: *const OrbConfigC, opt: *const OrbOptionsC, out: *mut *mut c_void) -> c_int;
+        fn orb_program_destroy(p: *mut c_void);
+        fn orb_last_error(p: *const c_void) -> *const c_char;
+        fn orb_write_input_image(p: *mut c_void, bytes: *const u8, len: usize) -> c_int;
+        fn orb_set_threshold(p: *mut c_void, threshold: f32) -> c_int;
+        fn orb_extract_corners(p: *mut c_void, corner_count: *mut u32) -> c_int;
+        fn orb_read_corners(p: *mut c_void, dst: *mut CornerData, n: usize) -> c_int;
+        fn orb_read_descriptors(p: *mut c_void, dst: *mut CornerDescriptor, n: usize) -> c_int;
+    }
+
+    const ORB_OK: c_int = 0;
+    const ORB_ECAPACITY: c_int = 3;
+
+    pub struct OrbProgram {
+        pub config: OrbConfig,
+        handle: *mut c_void,
+    }
+
+    impl OrbProgram {
+        /// The reference builds `OrbProgram { config, compute, storage }` by struct literal; the wgpu
+        /// objects are gone, so construction takes the config only.
+        pub fn new(config: OrbConfig) -> Self {
+            Self { config, handle: std::ptr::null_mut() }
+        }
+
+        fn check(&self, rc: c_int) {
+            if rc != ORB_OK && rc != ORB_ECAPACITY {
+                let msg = unsafe { std::ffi::CStr::from_ptr(orb_last_error(self.handle)) };
+                panic!("tinyorb: {}", msg.to_string_lossy()); // the reference panics on every failure too
+            }
+        }
+
+        pub fn init(&mut self) {
+            let c = OrbConfigC {
+                image_size: Extent3dC {
+                    width: self.config.image_size.width,
+                    height: self.config.image_size.height,
+                    depth_or_array_layers: self.config.image_size.depth_or_array_layers,
+                },
+                max_features: self.config.max_features,
+                hierarchy_depth: self.config.hierarchy_depth,
+                initial_threshold: self.config.initial_threshold,
+            };
+            let rc = unsafe { orb_program_create(&c, &OrbOptionsC::default(), &mut self.handle) };
+            self.check(rc);
+        }
+
+        pub fn write_input_image(&self, bytes: &[u8]) {
+            self.check(unsafe { orb_write_input_image(self.handle, bytes.as_ptr(), bytes.len()) });
+        }
+
+        pub fn set_threshold(&self, threshold: f32) {
+            self.check(unsafe { orb_set_threshold(self.handle, threshold) });
+        }
+
+        /// Returns the raw detection counter (it may exceed `max_features`, as in the reference).
+        pub fn extract_corners(&self) -> u32 {
+            let mut n = 0u32;
+            self.check(unsafe { orb_extract_corners(self.handle, &mut n) });
+            n
+        }
+
+        pub fn read_corners(&self, dst: &mut [CornerData]) {
+            self.check(unsafe { orb_read_corners(self.handle, dst.as_mut_ptr(), dst.len()) });
+        }
+
+        pub fn read_descriptors(&self, dst: &mut [CornerDescriptor]) {
+            self.check(unsafe { orb_read_descriptors(self.handle, dst.as_mut_ptr(), dst.len()) });
+        }
+    }
+
+    impl Drop for OrbProgram {
+        fn drop(&mut self) {
+            if !self.handle.is_null() {
+                unsafe { orb_program_destroy(self.handle) }
+            }
+        }
+    }
+
+    // One program = one device + its streams; calls on one program must be serialised by the caller.
+    unsafe impl Send for OrbProgram {}
+}
