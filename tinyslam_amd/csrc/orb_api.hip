@@ -323,7 +323,10 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
     }
     {
         LaunchScope ls(p, s, KID_BRIEF_ROWS);
-        hipLaunchKernelGGL(k_brief_rows, dim3(p->rows.n_slots, n), dim3(256), 0, s, d_blur, d_blur_rowc, pyr, p->rows, d_seg_counts,
+        RowsGeom rg = p->rows;
+        rg.split = 1u;  // small batches: several workgroups per band slot so that the chip still sees ~2000 of them
+        while (rg.split < 16u && rg.n_slots * n * rg.split < 2048u) rg.split *= 2u;
+        hipLaunchKernelGGL(k_brief_rows, dim3(rg.n_slots * rg.split, n), dim3(256), 0, s, d_blur, d_blur_rowc, pyr, rg, d_seg_counts,
                            d_seg_before, d_seg, d_corners, cap, d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin});
     }
     HIP_TRY(p, hipGetLastError());

@@ -585,6 +585,7 @@ struct RowsGeom {
     uint32_t slot_base[kMaxLevels + 1];
     uint32_t flat_end[kMaxLevels];  // qa - 18: a keypoint with 18 <= x < flat_end samples only columns in [0, qa)
     uint32_t qa[kMaxLevels];        // columns [0, qa) of the level's blur are the row constants
+    uint32_t split;                 // workgroups per band slot (> 1 for small batches: more waves in flight)
 };
 
 __global__ __launch_bounds__(256) void k_brief_rows(const uint16_t* __restrict__ blur,
@@ -594,9 +595,11 @@ __global__ __launch_bounds__(256) void k_brief_rows(const uint16_t* __restrict__
                                                     const CornerData* __restrict__ segments,
                                                     CornerData* __restrict__ corners, uint32_t cap,
                                                     CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
-    const uint32_t slot = blockIdx.x, frame = blockIdx.y;
+    const uint32_t slot = blockIdx.x / rg.split, frame = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // this wave takes keypoints wave, wave + stride, ... of the band segment
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x % rg.split) * 4u + (threadIdx.x >> 6));
+    const uint32_t stride = 4u * rg.split;
     uint32_t lvl = 0;
     for (uint32_t m = 1; m < pyr.depth; m++)
         if (slot >= rg.slot_base[m]) lvl = m;
@@ -618,9 +621,9 @@ __global__ __launch_bounds__(256) void k_brief_rows(const uint16_t* __restrict__
     for (int e = 0; e < 4; e++) pat[e] = tab.pattern[64u * (uint32_t)e + lane];
 
     uint4 nxt = *reinterpret_cast<const uint4*>(&seg[wave]);
-    for (uint32_t j = wave; j < n; j += 4u) {
+    for (uint32_t j = wave; j < n; j += stride) {
         const uint4 rec = nxt;  // x, y, angle, octave
-        if (j + 4u < n) nxt = *reinterpret_cast<const uint4*>(&seg[j + 4u]);
+        if (j + stride < n) nxt = *reinterpret_cast<const uint4*>(&seg[j + stride]);
         const uint32_t k = before + j;
         if (k >= cap) break;  // frame is full (indices only grow)
         const int gy = (int)rec.y - kBriefHalo + (int)lane;  // lanes 0..36 are the patch rows
