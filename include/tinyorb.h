@@ -72,11 +72,15 @@ typedef struct OrbOptions {
     int32_t device;       /* HIP device ordinal */
     uint32_t max_batch;   /* frames per batched call; 0 -> 1 */
     uint32_t flags;       /* ORB_FLAG_* */
-    uint32_t reserved[5];
+    uint32_t fast_arc;    /* 0 -> 12 (the reference's FAST-12, fast.wgsl:56-60); 9..16: corner = run of >= fast_arc */
+    uint32_t reserved[4];
 } OrbOptions;
 
 #define ORB_FLAG_STAGED 1u        /* force the one-kernel-per-stage pipeline (cross-check of the fused path) */
 #define ORB_FLAG_DOUBLE_OUTPUT 2u /* two sets of output slabs: batch k+1 computes while batch k is collated */
+#define ORB_FLAG_NMS 4u           /* opt-in, NOT in the reference: 3x3 non-maximum suppression per
+                                   * octave on the arc score sum(|v - c| - threshold); the counter is then the number
+                                   * of survivors.  fast_arc != 12 or NMS run on the staged pipeline. */
 
 typedef struct OrbProgram OrbProgram; /* opaque; replaces orb.rs:47-51 `OrbProgram` */
 

@@ -313,3 +313,97 @@ def synth_frame(W, H, seed, flags=15):
         out[..., k] = chans[k].astype(np.uint8)
     out[..., 3] = 255
     return out
+
+
+# ------------------------------------------------------------------ opt-in extensions (not in the reference)
+def _has_run(mask, arc):
+    dbl = mask.astype(np.uint64) | (mask.astype(np.uint64) << np.uint64(16))
+    want = np.uint64(0xFFFF if arc >= 16 else (1 << arc) - 1)
+    out = np.zeros(mask.shape, dtype=bool)
+    for s in range(16):
+        out |= ((dbl >> np.uint64(s)) & want) == want
+    return out
+
+
+def fast_ex(gray_levels_bits, threshold, arc=12):
+    """Arc length 9..16 (no pre-test: it is only a necessary condition for arc >= 12) + the NMS score
+    S = sum over the run's polarity of (|v - c| - thr), binary32, ring order.  Definitions: oracle/orb_oracle.h."""
+    thr = F(threshold)
+    H0, W0 = gray_levels_bits[0].shape
+    lim_x = (W0 - 16) & 0xFFFFFFFF
+    lim_y = (H0 - 16) & 0xFFFFFFFF
+    rows, scores = [], []
+    width, height = W0, H0
+    for octv, bits in enumerate(gray_levels_bits):
+        lvl = from_f16_bits(bits)
+        gw, gh = (width + 7) // 8 * 8, (height + 7) // 8 * 8
+        width //= 2
+        height //= 2
+        if gw == 0 or gh == 0:
+            continue
+        gx, gy = np.meshgrid(np.arange(gw, dtype=np.int64), np.arange(gh, dtype=np.int64))
+        guard = (gx > 16) & (gy > 16) & (gx < lim_x) & (gy < lim_y)
+        if not guard.any():
+            continue
+        gx, gy = gx[guard], gy[guard]
+        c = _load(lvl, gx, gy)
+        m_over = np.zeros(gx.shape, dtype=np.uint32)
+        m_under = np.zeros(gx.shape, dtype=np.uint32)
+        cx = np.zeros(gx.shape, dtype=np.float32)
+        cy = np.zeros(gx.shape, dtype=np.float32)
+        s_over = np.zeros(gx.shape, dtype=np.float32)
+        s_under = np.zeros(gx.shape, dtype=np.float32)
+        for i, (dx, dy) in enumerate(RING16):
+            v = _load(lvl, gx + dx, gy + dy)
+            diff = v - c
+            cx = cx + v * F(dx)
+            cy = cy + v * F(dy)
+            is_o = diff > thr
+            is_u = (~is_o) & (diff < -thr)
+            m_over |= (is_o.astype(np.uint32) << np.uint32(i))
+            m_under |= (is_u.astype(np.uint32) << np.uint32(i))
+            s_over = np.where(is_o, s_over + (diff - thr), s_over).astype(np.float32)
+            s_under = np.where(is_u, s_under + ((-diff) - thr), s_under).astype(np.float32)
+        ro, ru = _has_run(m_over, arc), _has_run(m_under, arc)
+        corner = ro | ru
+        ang = atan2f(cy, cx)
+        code = np.where((cy < 0) | (ang < 0), F(0), np.trunc(ang * F(1000.0))).astype(np.uint32)
+        sc = np.where(ro, s_over, s_under)
+        for k in np.nonzero(corner)[0]:
+            rows.append((int(gx[k]), int(gy[k]), int(code[k]), octv))
+            scores.append(sc[k])
+    return np.array(rows, dtype=np.uint32).reshape(-1, 4), np.array(scores, dtype=np.float32)
+
+
+def nms(corners, scores):
+    """3x3 non-maximum suppression per octave; ties keep the earlier raster position."""
+    table = {(int(o), int(y), int(x)): (s, i) for i, ((x, y, _, o), s) in enumerate(zip(corners, scores))}
+    keep = []
+    for i, ((x, y, _, o), s) in enumerate(zip(corners, scores)):
+        ok = True
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dx == 0 and dy == 0:
+                    continue
+                t = table.get((int(o), int(y) + dy, int(x) + dx))
+                if t is None:
+                    continue
+                later = dy > 0 or (dy == 0 and dx > 0)
+                if t[0] > s or (t[0] == s and not later):
+                    ok = False
+        if ok:
+            keep.append(i)
+    return corners[keep]
+
+
+def extract_ex(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=12, use_nms=False):
+    gray = [grayscale(rgba)]
+    for _ in range(1, depth):
+        gray.append(mip(gray[-1]))
+    blur = [blur_pass(blur_pass(g)) for g in gray]
+    kps, scores = fast_ex(gray, threshold, arc)
+    if use_nms:
+        kps = nms(kps, scores)
+    total = kps.shape[0]
+    kps = kps[:max_features]
+    return dict(total=total, corners=kps, descriptors=brief(blur, kps))

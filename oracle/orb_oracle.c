@@ -395,6 +395,150 @@ int orc_extract(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, flo
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Opt-in extensions: arc length other than 12 and 3x3 non-maximum suppression (definitions in orb_oracle.h).
+ * ---------------------------------------------------------------------------------------- */
+static int has_run(uint32_t mask16, uint32_t arc) {
+    uint32_t dbl = mask16 | (mask16 << 16);
+    uint32_t want = arc >= 16 ? 0xffffu : ((1u << arc) - 1u);
+    for (int s = 0; s < 16; s++)
+        if (((dbl >> s) & want) == want) return 1;
+    return 0;
+}
+
+void orc_fast_ex(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, uint32_t arc, orc_corner_t *out,
+                 float *scores, uint32_t cap, uint32_t *total) {
+    if (arc == 0) arc = 12;
+    uint32_t count = 0;
+    uint32_t W0 = lay->w[0], H0 = lay->h[0];
+    uint32_t lim_x = W0 - 16u, lim_y = H0 - 16u;
+    uint32_t width = W0, height = H0;
+    for (uint32_t oct = 0; oct < lay->depth; oct++) {
+        uint32_t gw = ((width + 7) / 8) * 8, gh = ((height + 7) / 8) * 8;
+        for (uint32_t gy = 0; gy < gh; gy++)
+            for (uint32_t gx = 0; gx < gw; gx++) {
+                if (!(gx > 16u && gy > 16u && gx < lim_x && gy < lim_y)) continue;
+                float c = level_load(pyr, lay, oct, gx, gy);
+                uint32_t is_over = 0, is_under = 0;
+                float cx = 0.0f, cy = 0.0f, s_over = 0.0f, s_under = 0.0f;
+                for (int i = 0; i < 16; i++) {
+                    float v = level_load(pyr, lay, oct, (int64_t)gx + RING16[i][0], (int64_t)gy + RING16[i][1]);
+                    float diff = v - c;
+                    float px = v * (float)RING16[i][0];
+                    float py = v * (float)RING16[i][1];
+                    cx = cx + px;
+                    cy = cy + py;
+                    if (diff > threshold) {
+                        is_over |= 1u << i;
+                        float e = diff - threshold;
+                        s_over = s_over + e;
+                    } else if (diff < -threshold) {
+                        is_under |= 1u << i;
+                        float nd = -diff;
+                        float e = nd - threshold;
+                        s_under = s_under + e;
+                    }
+                }
+                int ro = has_run(is_over, arc), ru = has_run(is_under, arc);
+                if (ro || ru) {
+                    if (count < cap) {
+                        out[count].x = gx;
+                        out[count].y = gy;
+                        out[count].angle = orc_angle_code(cy, cx);
+                        out[count].octave = oct;
+                        if (scores) scores[count] = ro ? s_over : s_under;
+                    }
+                    count++;
+                }
+            }
+        width /= 2;
+        height /= 2;
+    }
+    *total = count;
+}
+
+uint32_t orc_nms(const orc_pyramid_t *lay, const orc_corner_t *in, const float *scores, uint32_t n, orc_corner_t *out) {
+    /* score planes per octave: 0 = no corner (a corner's score is > 0: its run has >= 9 terms each > 0) */
+    float *plane = (float *)calloc(lay->total ? lay->total * 4 : 1, sizeof(float));
+    size_t *off = (size_t *)calloc(ORC_MAX_LEVELS, sizeof(size_t));
+    uint32_t gws[ORC_MAX_LEVELS], ghs[ORC_MAX_LEVELS];
+    size_t acc = 0;
+    uint32_t width = lay->w[0], height = lay->h[0];
+    for (uint32_t m = 0; m < lay->depth; m++) { /* corners live on the 8-rounded dispatch grid of their octave */
+        gws[m] = ((width + 7) / 8) * 8 + 2;
+        ghs[m] = ((height + 7) / 8) * 8 + 2;
+        off[m] = acc;
+        acc += (size_t)gws[m] * ghs[m];
+        width /= 2;
+        height /= 2;
+    }
+    free(plane);
+    plane = (float *)calloc(acc ? acc : 1, sizeof(float));
+    for (uint32_t i = 0; i < n; i++)
+        plane[off[in[i].octave] + (size_t)(in[i].y + 1) * gws[in[i].octave] + in[i].x + 1] = scores[i];
+    uint32_t kept = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t o = in[i].octave;
+        float s = scores[i];
+        int keep = 1;
+        for (int dy = -1; dy <= 1 && keep; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                if (!dx && !dy) continue;
+                float t = plane[off[o] + (size_t)((int)in[i].y + 1 + dy) * gws[o] + (size_t)((int)in[i].x + 1 + dx)];
+                if (t <= 0.0f) continue; /* not a corner */
+                int later = dy > 0 || (dy == 0 && dx > 0); /* neighbour comes later in raster order */
+                if (t > s || (t == s && !later)) {
+                    keep = 0;
+                    break;
+                }
+            }
+        if (keep) out[kept++] = in[i];
+    }
+    free(plane);
+    free(off);
+    return kept;
+}
+
+int orc_extract_ex(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, float threshold, uint32_t max_features,
+                   const orc_options_t *opt, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total) {
+    if (!rgba || !W || !H || depth < 1 || depth > ORC_MAX_LEVELS || !total) return -1;
+    uint32_t arc = opt && opt->arc ? opt->arc : 12;
+    if (arc < 9 || arc > 16) return -1;
+    orc_pyramid_t lay;
+    orc_pyramid_layout(W, H, depth, &lay);
+    uint16_t *gray = (uint16_t *)malloc(lay.total * sizeof(uint16_t));
+    uint16_t *tmp = (uint16_t *)malloc(lay.total * sizeof(uint16_t));
+    uint16_t *blur = (uint16_t *)malloc(lay.total * sizeof(uint16_t));
+    orc_grayscale(rgba, W, H, gray);
+    for (uint32_t m = 1; m < depth; m++)
+        orc_mip(gray + lay.offset[m - 1], lay.w[m - 1], lay.h[m - 1], gray + lay.offset[m], lay.w[m], lay.h[m]);
+    for (uint32_t m = 0; m < depth; m++) orc_blur_pass(gray + lay.offset[m], lay.w[m], lay.h[m], tmp + lay.offset[m]);
+    for (uint32_t m = 0; m < depth; m++) orc_blur_pass(tmp + lay.offset[m], lay.w[m], lay.h[m], blur + lay.offset[m]);
+    /* provisional list: every detection (the NMS must see all of them) */
+    uint32_t cap_all = 0;
+    for (uint32_t m = 0; m < depth; m++) cap_all += (((W >> m) + 7) / 8 * 8) * (((H >> m) + 7) / 8 * 8);
+    orc_corner_t *all = (orc_corner_t *)malloc((size_t)(cap_all ? cap_all : 1) * sizeof(orc_corner_t));
+    float *scores = (float *)malloc((size_t)(cap_all ? cap_all : 1) * sizeof(float));
+    uint32_t n = 0;
+    orc_fast_ex(gray, &lay, threshold, arc, all, scores, cap_all, &n);
+    if (opt && opt->nms) {
+        orc_corner_t *kept = (orc_corner_t *)malloc((size_t)(n ? n : 1) * sizeof(orc_corner_t));
+        n = orc_nms(&lay, all, scores, n, kept);
+        memcpy(all, kept, (size_t)n * sizeof(orc_corner_t));
+        free(kept);
+    }
+    uint32_t stored = n < max_features ? n : max_features;
+    memcpy(corners, all, (size_t)stored * sizeof(orc_corner_t));
+    if (descriptors) orc_brief(blur, &lay, corners, stored, descriptors);
+    *total = n;
+    free(all);
+    free(scores);
+    free(gray);
+    free(tmp);
+    free(blur);
+    return 0;
+}
+
 int orc_extract_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth, float threshold,
                       uint32_t max_features, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *totals,
                       int n_threads) {

@@ -74,6 +74,25 @@ int orc_extract(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, flo
                 orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total, uint16_t *gray_pyr,
                 uint16_t *blur_pyr);
 
+/* ---- opt-in extensions (NOT in the reference, no parity target: the definitions
+ * below are the build's own and are pinned only by the NumPy restatement and the GPU tests) ----
+ * arc: a corner needs a circular run of >= arc ring pixels (9..16) all brighter or all darker than the centre by
+ *      more than the threshold.  arc = 12 is the reference's detector (fast.wgsl:56-60); the reference's 4-point
+ *      pre-test is a necessary condition only for arc >= 12, so other arcs test every guarded pixel.
+ * nms: 3x3 non-maximum suppression per octave on the score S = sum over the 16 ring pixels of
+ *      max(|v - c| - threshold, 0) restricted to the run's polarity (binary32, ring order).  A corner survives
+ *      iff every 8-neighbour that is also a corner has a smaller score, or an equal score and a later raster
+ *      position (y, then x).  The returned counter is the number of survivors. */
+typedef struct {
+    uint32_t arc; /* 0 -> 12 */
+    uint32_t nms; /* 0 / 1 */
+} orc_options_t;
+void orc_fast_ex(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, uint32_t arc, orc_corner_t *out,
+                 float *scores, uint32_t cap, uint32_t *total);
+uint32_t orc_nms(const orc_pyramid_t *lay, const orc_corner_t *in, const float *scores, uint32_t n, orc_corner_t *out);
+int orc_extract_ex(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, float threshold, uint32_t max_features,
+                   const orc_options_t *opt, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total);
+
 /* Frame-parallel batch for the CPU baseline leg of bench.py: n_frames contiguous RGBA frames,
  * outputs strided by max_features.  n_threads <= 1 runs serially. */
 int orc_extract_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth, float threshold,

@@ -71,6 +71,8 @@ def lib():
         L.orc_brief.argtypes = [vp, ctypes.POINTER(_Pyramid), vp, u32, vp]
         L.orc_extract.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, u32p, vp, vp]
         L.orc_extract.restype = ctypes.c_int
+        L.orc_extract_ex.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, vp, u32p]
+        L.orc_extract_ex.restype = ctypes.c_int
         L.orc_extract_batch.argtypes = [vp, u32, u32, u32, u32, f32, u32, vp, vp, vp, ctypes.c_int]
         L.orc_extract_batch.restype = ctypes.c_int
         L.orc_synth_frame.argtypes = [vp, u32, u32, u32, u32]
@@ -166,6 +168,22 @@ def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=Fal
         raise ValueError("orc_extract: invalid arguments")
     n = min(total.value, max_features)
     return dict(total=total.value, corners=corners[:n], descriptors=desc[:n], gray=gray, blur=blur)
+
+
+def extract_ex(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=12, nms=False):
+    """Opt-in extensions (arc length 9..16, 3x3 NMS); definitions in orb_oracle.h.  Not in the reference."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    H, W = rgba.shape[:2]
+    corners = np.zeros(max_features, dtype=CORNER_DTYPE)
+    desc = np.zeros((max_features, 8), dtype=np.uint32)
+    total = ctypes.c_uint32(0)
+    opt = (ctypes.c_uint32 * 2)(int(arc), 1 if nms else 0)
+    rc = lib().orc_extract_ex(_ptr(rgba), W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
+                              ctypes.cast(opt, ctypes.c_void_p), _ptr(corners), _ptr(desc), ctypes.byref(total))
+    if rc != 0:
+        raise ValueError("orc_extract_ex: invalid arguments")
+    n = min(total.value, max_features)
+    return dict(total=total.value, corners=corners[:n], descriptors=desc[:n])
 
 
 def extract_batch(frames, depth=2, threshold=20.0 / 255.0, max_features=8192, n_threads=1):

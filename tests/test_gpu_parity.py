@@ -285,3 +285,27 @@ def test_double_output_sets(tinyorb, oracle):
     with _program(tinyorb, W, H, 2) as prog:
         with pytest.raises(tinyorb.OrbError):
             prog.batch_select_output(1)
+
+
+# ---------------------------------------------------------------------------------------------
+# opt-in extensions: FAST arc length and 3x3 NMS.  Not in the reference;
+# the definitions are the build's own (oracle/orb_oracle.h) -- GPU vs C oracle, bit for bit.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("arc,nms", [(9, False), (9, True), (12, True), (10, False), (16, True), (12, False)])
+def test_arc_length_and_nms_extensions(tinyorb, oracle, arc, nms):
+    W, H = 320, 240
+    rgba = oracle.synth_frame(W, H, 77)
+    ref = oracle.extract_ex(rgba, depth=2, threshold=THR, max_features=1 << 15, arc=arc, nms=nms)
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=1 << 15, hierarchy_depth=2, initial_threshold=THR,
+                            flags=tinyorb.ORB_FLAG_NMS if nms else 0, fast_arc=arc)
+    with tinyorb.OrbProgram(cfg) as prog:
+        assert prog.pipeline() == ("fused" if arc == 12 and not nms else "staged")
+        total, corners, desc = prog.extract(rgba)
+        _assert_frame_equal(oracle, ref, total, corners, desc)
+    if arc == 9 and not nms:
+        assert ref["total"] > oracle.extract(rgba, depth=2, threshold=THR)["total"]  # FAST-9 finds more than FAST-12
+
+
+def test_bad_arc_is_rejected(tinyorb):
+    with pytest.raises(tinyorb.OrbError):
+        tinyorb.OrbProgram(tinyorb.OrbConfig(tinyorb.Extent3d(64, 48), fast_arc=8)).init()

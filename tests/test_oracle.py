@@ -258,3 +258,36 @@ def test_batch_threads_equal_serial(oracle):
     assert np.array_equal(t1, t4) and np.array_equal(c1, c4) and np.array_equal(d1, d4)
     one = oracle.extract(frames[3], depth=2, threshold=THR, max_features=512)
     assert one["total"] == t1[3] and np.array_equal(one["corners"], c1[3][:one["total"]])
+
+
+# ---------------------------------------------------------------- opt-in extensions (arc length, NMS)
+@pytest.mark.parametrize("arc,nms", [(9, False), (9, True), (12, True), (14, False), (16, True)])
+def test_extensions_c_and_numpy_agree(oracle, arc, nms):
+    rgba = oracle.synth_frame(168, 130, 40)
+    a = oracle.extract_ex(rgba, depth=2, threshold=THR, max_features=1 << 15, arc=arc, nms=nms)
+    b = orb_numpy.extract_ex(rgba, depth=2, threshold=THR, max_features=1 << 15, arc=arc, use_nms=nms)
+    ka = np.stack([a["corners"][k] for k in ("x", "y", "angle", "octave")], 1)
+    assert a["total"] == b["total"] and np.array_equal(ka, b["corners"])
+    assert np.array_equal(a["descriptors"], b["descriptors"])
+
+
+def test_extensions_known_answers(oracle):
+    rgba = oracle.synth_frame(200, 150, 41)
+    lit = oracle.extract(rgba, depth=2, threshold=THR)
+    same = oracle.extract_ex(rgba, depth=2, threshold=THR, arc=12, nms=False)
+    assert same["total"] == lit["total"] and np.array_equal(same["corners"], lit["corners"])
+    totals = [oracle.extract_ex(rgba, depth=2, threshold=THR, max_features=1 << 15, arc=a)["total"] for a in (9, 10, 12, 14, 16)]
+    assert totals == sorted(totals, reverse=True) and totals[0] > totals[2] > totals[-1]  # longer arcs are subsets
+    # NMS: a bright 3x3 square gives 9 FAST-12 corners; exactly one survives, never two adjacent
+    img = _frame_with_squares(128, 96, [(60, 40, 3)])
+    assert oracle.extract_ex(img, depth=1, threshold=THR, arc=12, nms=False)["total"] == 9
+    kept = oracle.extract_ex(img, depth=1, threshold=THR, arc=12, nms=True)
+    assert 1 <= kept["total"] <= 3
+    pts = [(int(c["x"]), int(c["y"])) for c in kept["corners"]]
+    for i, p in enumerate(pts):
+        for q in pts[i + 1:]:
+            assert max(abs(p[0] - q[0]), abs(p[1] - q[1])) > 1
+    # FAST-9 fires on the corner pixels of a large bright square, FAST-12 does not (SURVEY.md 8c KAT 4)
+    big = _frame_with_squares(128, 96, [(50, 30, 20)])
+    assert oracle.extract_ex(big, depth=1, threshold=THR, arc=12)["total"] == 0
+    assert oracle.extract_ex(big, depth=1, threshold=THR, arc=9)["total"] >= 4

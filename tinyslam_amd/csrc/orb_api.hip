@@ -46,6 +46,14 @@ struct OrbProgram {
     size_t frame_bytes = 0;
     uint32_t max_batch = 1;
     float threshold = 0.f;
+    uint32_t arc = 12;  // FAST arc length (opt-in extension, 9..16)
+    // opt-in NMS (staged pipeline): provisional detections + score planes
+    uint32_t cap_prov = 0;
+    uint32_t* d_prov_counts = nullptr;
+    CornerData* d_prov = nullptr;
+    float* d_prov_scores = nullptr;
+    float* d_score_planes = nullptr;
+    ScoreLayout score_layout{};
 
     uint8_t* d_input = nullptr;  // max_batch frames (single-frame API, host batches, synth)
     uint16_t* d_gray = nullptr;  // max_batch x pyr.stride
@@ -197,17 +205,33 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
         size_t lds = (size_t)pyr.w[m] * 2u * sizeof(uint16_t);
         hipLaunchKernelGGL(k_blur_rows, grid, dim3(256), lds, s, p->d_gray, p->d_blur, pyr, m);
     }
+    const bool nms = (p->opt.flags & ORB_FLAG_NMS) != 0u;
+    if (nms) {
+        HIP_TRY(p, hipMemsetAsync(p->d_prov_counts, 0, sizeof(uint32_t) * n, s));
+        HIP_TRY(p, hipMemsetAsync(p->d_score_planes, 0, sizeof(float) * (size_t)p->score_layout.stride * n, s));
+    }
     uint32_t width = W, height = H;  // orb.rs:501-519
     for (uint32_t oct = 0; oct < D; oct++) {
         const uint32_t gw = ((width + 7u) / 8u) * 8u, gh = ((height + 7u) / 8u) * 8u;
         if (gw && gh) {
             LaunchScope ls(p, s, KID_FAST);
             dim3 grid((gw + 15u) / 16u, (gh + 15u) / 16u, n);
-            hipLaunchKernelGGL(k_fast, grid, dim3(16, 16), 0, s, p->d_gray, pyr, oct, gw, gh, p->threshold, p->d_counts,
-                               p->d_corners, cap);
+            if (nms)
+                hipLaunchKernelGGL(k_fast, grid, dim3(16, 16), 0, s, p->d_gray, pyr, oct, gw, gh, p->threshold, p->arc,
+                                   p->d_prov_counts, p->d_prov, p->cap_prov, p->d_prov_scores, p->d_score_planes,
+                                   p->score_layout);
+            else
+                hipLaunchKernelGGL(k_fast, grid, dim3(16, 16), 0, s, p->d_gray, pyr, oct, gw, gh, p->threshold, p->arc,
+                                   p->d_counts, p->d_corners, cap, (float*)nullptr, (float*)nullptr, p->score_layout);
         }
         width /= 2u;
         height /= 2u;
+    }
+    if (nms) {
+        LaunchScope ls(p, s, KID_FAST);
+        hipLaunchKernelGGL(k_nms, dim3((p->cap_prov + 255u) / 256u, 1, n), dim3(256), 0, s, p->d_prov_counts, p->d_prov,
+                           p->d_prov_scores, p->cap_prov, p->d_score_planes, p->score_layout, p->d_counts, p->d_corners,
+                           cap);
     }
     {  // orb.rs:523-534
         LaunchScope ls(p, s, KID_BRIEF);
@@ -225,7 +249,8 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
 
 // Can the fused per-level kernels handle this configuration?  (Otherwise: staged pipeline.)
 bool fused_eligible(const OrbProgram* p) {
-    if (p->opt.flags & ORB_FLAG_STAGED) return false;
+    if (p->opt.flags & (ORB_FLAG_STAGED | ORB_FLAG_NMS)) return false;
+    if (p->arc != 12u) return false;  // the fused FAST phase is specialised for the reference's 12-run
     const Pyramid& pyr = p->pyr;
     if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 22)) return false;  // 24-bit index products in k_front
     if ((pyr.w[0] & 3u) != 0u || pyr.w[0] > (uint32_t)(kFrontMaxCols * 512) || pyr.w[0] < 8u) return false;
@@ -375,6 +400,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     if (config->max_features == 0 || config->max_features > (1u << 24))
         return fail(nullptr, ORB_EINVAL, "max_features must be 1..=2^24");
     if (!(config->initial_threshold >= 0.f)) return fail(nullptr, ORB_EINVAL, "initial_threshold must be >= 0");
+    if (options && options->fast_arc != 0 && (options->fast_arc < 9 || options->fast_arc > 16))
+        return fail(nullptr, ORB_EINVAL, "fast_arc must be 0 (= 12) or 9..16");
 
     OrbProgram* p = new (std::nothrow) OrbProgram();
     if (!p) return fail(nullptr, ORB_EINVAL, "out of host memory");
@@ -383,6 +410,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     p->device = p->opt.device;
     p->max_batch = p->opt.max_batch ? p->opt.max_batch : 1u;
     p->threshold = config->initial_threshold;  // orb.rs:178
+    p->arc = p->opt.fast_arc ? p->opt.fast_arc : 12u;
     p->frame_bytes = (size_t)W * H * 4u;
     layout_pyramid(W, H, config->hierarchy_depth, &p->pyr);
 
@@ -481,6 +509,24 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         CREATE_TRY(hipMemset(p->d_seg_counts, 0, B * p->bands.n_slots * sizeof(uint32_t)));
         CREATE_TRY(hipMalloc(&p->d_seg_before, B * p->bands.n_slots * sizeof(uint32_t)));
     }
+    if (p->opt.flags & ORB_FLAG_NMS) {
+        // score planes: one float per dispatch-grid pixel of every octave + a 1-px border; provisional list
+        uint32_t off = 0, width = W, height = H;
+        for (uint32_t m = 0; m < p->pyr.depth; m++) {
+            const uint32_t gw = ((width + 7u) / 8u) * 8u, gh = ((height + 7u) / 8u) * 8u;
+            p->score_layout.off[m] = off;
+            p->score_layout.pitch[m] = gw + 2u;
+            off += (gw + 2u) * (gh + 2u);
+            width /= 2u;
+            height /= 2u;
+        }
+        p->score_layout.stride = (off + 63u) & ~63u;
+        p->cap_prov = (uint32_t)std::min<uint64_t>((uint64_t)cap * 4u, 1u << 24);
+        CREATE_TRY(hipMalloc(&p->d_score_planes, B * (size_t)p->score_layout.stride * sizeof(float)));
+        CREATE_TRY(hipMalloc(&p->d_prov_counts, B * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc(&p->d_prov, B * (size_t)p->cap_prov * sizeof(CornerData)));
+        CREATE_TRY(hipMalloc(&p->d_prov_scores, B * (size_t)p->cap_prov * sizeof(float)));
+    }
     CREATE_TRY(hipMalloc(&p->d_pattern, 256 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&p->d_cos, ORB_ANGLE_STEPS * sizeof(float)));
     CREATE_TRY(hipMalloc(&p->d_sin, ORB_ANGLE_STEPS * sizeof(float)));
@@ -520,6 +566,10 @@ void orb_program_destroy(OrbProgram* p) {
     (void)hipFree(p->d_seg);
     (void)hipFree(p->d_seg_counts);
     (void)hipFree(p->d_seg_before);
+    (void)hipFree(p->d_score_planes);
+    (void)hipFree(p->d_prov_counts);
+    (void)hipFree(p->d_prov);
+    (void)hipFree(p->d_prov_scores);
     (void)hipFree(p->d_pattern);
     (void)hipFree(p->d_cos);
     (void)hipFree(p->d_sin);

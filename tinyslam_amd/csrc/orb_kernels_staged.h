@@ -138,9 +138,33 @@ __device__ __forceinline__ void append_corners(bool is_corner, uint32_t x, uint3
     }
 }
 
+// Opt-in extensions of the detector (not in the reference, default off):
+//   arc   a corner needs a circular run of >= arc ring pixels (9..16); 12 is the reference's fast.wgsl:56-60.
+//         A run of N contiguous ring positions contains at least floor(N/4) of the 4 compass positions, which
+//         is the pre-test count used (3 for arc 12 = the reference's shortcut, 2 for FAST-9).
+//   score S = sum over the run's polarity of (|v - c| - threshold), binary32 in ring order; written to a
+//         per-octave score plane (one float per dispatch-grid pixel + 1-px border, 0 = no corner) for k_nms.
+struct ScoreLayout {
+    uint32_t off[kMaxLevels];     // float offset of each level's plane
+    uint32_t pitch[kMaxLevels];   // gw + 2
+    uint32_t stride;              // floats per frame
+};
+
+__device__ __forceinline__ bool has_run_16(uint32_t mask, uint32_t arc) {
+    if (arc == 12u) return detect_streak_16(mask) != 0u;  // fast.wgsl:56-60
+    const uint32_t dbl = mask | (mask << 16);
+    const uint32_t want = arc >= 16u ? 0xffffu : ((1u << arc) - 1u);
+    bool hit = false;
+#pragma unroll
+    for (int s0 = 0; s0 < 16; s0++) hit |= ((dbl >> s0) & want) == want;
+    return hit;
+}
+
 __global__ __launch_bounds__(256) void k_fast(const uint16_t* __restrict__ gray, Pyramid pyr, uint32_t oct,
-                                              uint32_t gw, uint32_t gh, float threshold, uint32_t* __restrict__ counts,
-                                              CornerData* __restrict__ corners, uint32_t cap) {
+                                              uint32_t gw, uint32_t gh, float threshold, uint32_t arc,
+                                              uint32_t* __restrict__ counts, CornerData* __restrict__ corners,
+                                              uint32_t cap, float* __restrict__ scores_list,
+                                              float* __restrict__ score_planes, ScoreLayout sl) {
     constexpr int T = 16, R = 3, S = T + 2 * R;
     __shared__ float tile[S][S + 1];
     const uint32_t w = pyr.w[oct], h = pyr.h[oct];
@@ -160,6 +184,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint16_t* __restrict__ gray,
     const int lx = (int)threadIdx.x + R, ly = (int)threadIdx.y + R;
     bool is_corner = false;
     uint32_t angle = 0;
+    float score = 0.0f;
+    const uint32_t need = arc >> 2;  // compass points any run of `arc` must contain (fast.wgsl:95 for arc 12)
     // fast.wgsl:77 -- textureDimensions() is the level-0 size for every octave (Q8); u32 wrap kept.
     const uint32_t lim_x = pyr.w[0] - 16u, lim_y = pyr.h[0] - 16u;
     if (gx < gw && gy < gh && gx > 16u && gy > 16u && gx < lim_x && gy < lim_y) {
@@ -174,9 +200,9 @@ __global__ __launch_bounds__(256) void k_fast(const uint16_t* __restrict__ gray,
             else if (diff < -threshold)
                 n_under++;
         }
-        if (n_over >= 3u || n_under >= 3u) {
+        if (n_over >= need || n_under >= need) {
             uint32_t m_over = 0, m_under = 0;
-            float cx = 0.0f, cy = 0.0f;
+            float cx = 0.0f, cy = 0.0f, s_over = 0.0f, s_under = 0.0f;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 float v = tile[ly + kRingDy[i]][lx + kRingDx[i]];
@@ -185,18 +211,73 @@ __global__ __launch_bounds__(256) void k_fast(const uint16_t* __restrict__ gray,
                 float py = v * (float)kRingDy[i];
                 cx = cx + px;
                 cy = cy + py;
-                if (diff > threshold)
+                if (diff > threshold) {
                     m_over |= 1u << i;
-                else if (diff < -threshold)
+                    float e = diff - threshold;
+                    s_over = s_over + e;
+                } else if (diff < -threshold) {
                     m_under |= 1u << i;
+                    float nd = -diff;
+                    float e = nd - threshold;
+                    s_under = s_under + e;
+                }
             }
-            if ((detect_streak_16(m_over) | detect_streak_16(m_under)) > 0u) {
+            const bool ro = has_run_16(m_over, arc), ru = has_run_16(m_under, arc);
+            if (ro || ru) {
                 is_corner = true;
                 angle = angle_code(cy, cx);
+                score = ro ? s_over : s_under;
             }
         }
     }
-    append_corners(is_corner, gx, gy, angle, oct, counts + f, corners + (size_t)f * cap, cap);
+    if (is_corner && score_planes)
+        score_planes[(size_t)f * sl.stride + sl.off[oct] + (size_t)(gy + 1u) * sl.pitch[oct] + gx + 1u] = score;
+    // append (as append_corners) with the score next to the record
+    const uint64_t mask = __ballot(is_corner);
+    if (mask == 0ull) return;
+    const uint32_t lane = __lane_id();
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(counts + f, (uint32_t)__builtin_popcountll(mask));
+    base = __shfl(base, __builtin_ctzll(mask));
+    if (is_corner) {
+        const uint32_t idx = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (idx < cap) {
+            *reinterpret_cast<uint4*>(&corners[(size_t)f * cap + idx]) = make_uint4(gx, gy, angle, oct);
+            if (scores_list) scores_list[(size_t)f * cap + idx] = score;
+        }
+    }
+}
+
+// 3x3 non-maximum suppression per octave over the provisional corners of k_fast: a corner survives iff every
+// 8-neighbour that is also a corner has a smaller score, or an equal score and a later raster position.
+// grid: (ceil(cap_prov/256), 1, frames)
+__global__ __launch_bounds__(256) void k_nms(const uint32_t* __restrict__ prov_counts,
+                                             const CornerData* __restrict__ prov, const float* __restrict__ prov_scores,
+                                             uint32_t cap_prov, const float* __restrict__ score_planes, ScoreLayout sl,
+                                             uint32_t* __restrict__ counts, CornerData* __restrict__ corners,
+                                             uint32_t cap) {
+    const uint32_t f = blockIdx.z;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n = min(prov_counts[f], cap_prov);
+    bool keep = false;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (i < n) {
+        rec = *reinterpret_cast<const uint4*>(&prov[(size_t)f * cap_prov + i]);
+        const float s = prov_scores[(size_t)f * cap_prov + i];
+        const float* plane = score_planes + (size_t)f * sl.stride + sl.off[rec.w];
+        const uint32_t pitch = sl.pitch[rec.w];
+        keep = true;
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+            for (int dx = -1; dx <= 1; dx++) {
+                if (dx == 0 && dy == 0) continue;
+                const float t = plane[(size_t)((int)rec.y + 1 + dy) * pitch + (size_t)((int)rec.x + 1 + dx)];
+                const bool later = dy > 0 || (dy == 0 && dx > 0);
+                if (t > 0.0f && (t > s || (t == s && !later))) keep = false;
+            }
+    }
+    append_corners(keep, rec.x, rec.y, rec.z, rec.w, counts + f, corners + (size_t)f * cap, cap);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -23,6 +23,7 @@ ORB_PLANE_GRAY, ORB_PLANE_BLUR = 0, 1
 ORB_KERNEL_COUNT = 10
 ORB_FLAG_STAGED = 1
 ORB_FLAG_DOUBLE_OUTPUT = 2
+ORB_FLAG_NMS = 4
 SYN_GRADIENT, SYN_BLOBS, SYN_WEDGES, SYN_NOISE = 1, 2, 4, 8
 SYN_ALL = 15
 
@@ -58,7 +59,7 @@ class _Config(ctypes.Structure):
 
 class _Options(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("max_batch", ctypes.c_uint32), ("flags", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32 * 5)]
+                ("fast_arc", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 4)]
 
 
 _lib = None
@@ -151,6 +152,7 @@ class OrbConfig:
     device: int = 0
     max_batch: int = 1
     flags: int = 0
+    fast_arc: int = 0  # 0 -> 12 (reference); 9..16 opt-in
 
 
 def _ptr(a):
@@ -178,7 +180,7 @@ class OrbProgram:
         c = self.config
         cfg = _Config(_Extent3d(c.image_size.width, c.image_size.height, c.image_size.depth_or_array_layers),
                       c.max_features, c.hierarchy_depth, float(np.float32(c.initial_threshold)))
-        opt = _Options(c.device, c.max_batch, c.flags)
+        opt = _Options(c.device, c.max_batch, c.flags, c.fast_arc)
         h = ctypes.c_void_p()
         rc = L.orb_program_create(ctypes.byref(cfg), ctypes.byref(opt), ctypes.byref(h))
         if rc != ORB_OK:
