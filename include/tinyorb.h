@@ -72,7 +72,8 @@ typedef struct OrbOptions {
     int32_t device;       /* HIP device ordinal */
     uint32_t max_batch;   /* frames per batched call; 0 -> 1 */
     uint32_t flags;       /* ORB_FLAG_* */
-    uint32_t fast_arc;    /* 0 -> 12 (the reference's FAST-12, fast.wgsl:56-60); 9..16: corner = run of >= fast_arc */
+    uint32_t fast_arc;    /* 0 -> 12 (the reference's FAST-12, fast.wgsl:56-60; 9 with ORB_FLAG_INTENDED);
+                           * 9..16: corner = run of >= fast_arc */
     uint32_t reserved[4];
 } OrbOptions;
 
@@ -81,6 +82,13 @@ typedef struct OrbOptions {
 #define ORB_FLAG_NMS 4u           /* opt-in, NOT in the reference: 3x3 non-maximum suppression per
                                    * octave on the arc score sum(|v - c| - threshold); the counter is then the number
                                    * of survivors.  fast_arc != 12 or NMS run on the staged pipeline. */
+#define ORB_FLAG_INTENDED 8u      /* opt-in, NOT in the reference: the algorithm the reference's
+                                   * README describes, with the shaders' accidents repaired -- BT.601 luminance (0.299),
+                                   * no vertical mirror, a true separable 7-tap Gaussian (X then Y), the octave's own
+                                   * border guard, angle codes over the full circle (0..6283 mrad), BRIEF rotated by
+                                   * +theta, fast_arc 0 -> 9, optional ORB_FLAG_NMS, and when more than max_features
+                                   * keypoints remain the max_features best by score are kept (ties: smaller octave, y,
+                                   * x).  Definitions IM-1..IM-8 in DESIGN.md; runs on the staged pipeline. */
 
 typedef struct OrbProgram OrbProgram; /* opaque; replaces orb.rs:47-51 `OrbProgram` */
 

@@ -407,3 +407,147 @@ def extract_ex(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=12,
     total = kps.shape[0]
     kps = kps[:max_features]
     return dict(total=total, corners=kps, descriptors=brief(blur, kps))
+
+
+# ------------------------------------------------------------------ "intended" mode (definitions IM-1..IM-8: oracle/orb_oracle.h)
+GAUSS = [F(0.282523781), F(0.221251875), F(0.106235079), F(0.0312511548)]
+
+
+def grayscale_intended(rgba):
+    """IM-1: BT.601 luminance, no mirror."""
+    chan = np.asarray(rgba, dtype=np.uint8).astype(np.float32) / F(255.0)
+    lum = (F(0.299) * chan[..., 0] + F(0.587) * chan[..., 1]) + F(0.114) * chan[..., 2]
+    return to_f16_bits(lum)
+
+
+def gauss_pass(src_bits, vertical):
+    """IM-3: one pass of the 7-tap kernel along x (vertical=False) or y, clamp-to-edge, f16 store."""
+    src = from_f16_bits(src_bits)
+    if vertical:
+        src = src.T
+    n = src.shape[1]
+    idx = np.arange(n)
+
+    def tap(k):
+        return src[:, np.clip(idx + k, 0, n - 1)]
+
+    acc = GAUSS[0] * tap(0)
+    for k in (1, 2, 3):
+        acc = acc + GAUSS[k] * (tap(-k) + tap(k))
+    if vertical:
+        acc = acc.T
+    return to_f16_bits(acc)
+
+
+def angle_code_signed(cy, cx):
+    """IM-5: milliradians over the full circle, 0..6283."""
+    r = atan2f(cy, cx)
+    r = np.where(r < 0, r + F(6.28318531), r).astype(np.float32)
+    return np.minimum(np.trunc(r * F(1000.0)).astype(np.uint32), np.uint32(6283))
+
+
+def fast_intended(gray_levels_bits, threshold, arc=9):
+    """IM-4/IM-5: segment test with the octave's own guard, score as fast_ex."""
+    thr = F(threshold)
+    rows, scores = [], []
+    for octv, bits in enumerate(gray_levels_bits):
+        lvl = from_f16_bits(bits)
+        h, w = lvl.shape
+        if w <= 33 or h <= 33:
+            continue
+        gx, gy = np.meshgrid(np.arange(17, w - 16, dtype=np.int64), np.arange(17, h - 16, dtype=np.int64))
+        gx, gy = gx.ravel(), gy.ravel()
+        c = lvl[gy, gx]
+        m_over = np.zeros(gx.shape, dtype=np.uint32)
+        m_under = np.zeros(gx.shape, dtype=np.uint32)
+        cx = np.zeros(gx.shape, dtype=np.float32)
+        cy = np.zeros(gx.shape, dtype=np.float32)
+        s_over = np.zeros(gx.shape, dtype=np.float32)
+        s_under = np.zeros(gx.shape, dtype=np.float32)
+        for i, (dx, dy) in enumerate(RING16):
+            v = lvl[gy + dy, gx + dx]  # always inside the level: the guard is 16 px wide
+            diff = v - c
+            cx = cx + v * F(dx)
+            cy = cy + v * F(dy)
+            is_o = diff > thr
+            is_u = (~is_o) & (diff < -thr)
+            m_over |= (is_o.astype(np.uint32) << np.uint32(i))
+            m_under |= (is_u.astype(np.uint32) << np.uint32(i))
+            s_over = np.where(is_o, s_over + (diff - thr), s_over).astype(np.float32)
+            s_under = np.where(is_u, s_under + ((-diff) - thr), s_under).astype(np.float32)
+        ro, ru = _has_run(m_over, arc), _has_run(m_under, arc)
+        sel = np.nonzero(ro | ru)[0]
+        code = angle_code_signed(cy[sel], cx[sel])
+        sc = np.where(ro, s_over, s_under)[sel]
+        for k, i in enumerate(sel):
+            rows.append((int(gx[i]), int(gy[i]), int(code[k]), octv))
+            scores.append(sc[k])
+    return np.array(rows, dtype=np.uint32).reshape(-1, 4), np.array(scores, dtype=np.float32)
+
+
+def brief_intended(blur_levels_bits, corners):
+    """IM-6: pattern rotated by +theta."""
+    corners = np.asarray(corners, dtype=np.uint32).reshape(-1, 4)
+    n = corners.shape[0]
+    out = np.zeros((n, 8), dtype=np.uint32)
+    levels = [from_f16_bits(b) for b in blur_levels_bits]
+    theta = corners[:, 2].astype(np.float32) / F(1000.0)
+    ct = np.cos(theta.astype(np.float64)).astype(np.float32)
+    st = np.sin(theta.astype(np.float64)).astype(np.float32)
+    px = corners[:, 0].astype(np.int64)
+    py = corners[:, 1].astype(np.int64)
+    for j in range(256):
+        ax, ay, bx, by = (F(v) for v in PATTERN[j])
+        rax = ct * ax + (-st) * ay
+        ray = st * ax + ct * ay
+        rbx = ct * bx + (-st) * by
+        rby = st * bx + ct * by
+        tax, tay = np.trunc(rax).astype(np.int64) + px, np.trunc(ray).astype(np.int64) + py
+        tbx, tby = np.trunc(rbx).astype(np.int64) + px, np.trunc(rby).astype(np.int64) + py
+        va = np.zeros(n, dtype=np.float32)
+        vb = np.zeros(n, dtype=np.float32)
+        for octv, lvl in enumerate(levels):
+            sel = corners[:, 3] == octv
+            if sel.any():
+                va[sel] = _load(lvl, tax[sel], tay[sel])
+                vb[sel] = _load(lvl, tbx[sel], tby[sel])
+        out[:, j >> 5] |= ((va > vb).astype(np.uint32) << np.uint32(j & 31))
+    return out
+
+
+def nms_indices(corners, scores):
+    """Indices of the survivors of nms() (same rule)."""
+    table = {(int(o), int(y), int(x)): s for (x, y, _, o), s in zip(corners, scores)}
+    keep = []
+    for i, ((x, y, _, o), s) in enumerate(zip(corners, scores)):
+        ok = True
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                t = table.get((int(o), int(y) + dy, int(x) + dx)) if (dx or dy) else None
+                if t is not None and (t > s or (t == s and not (dy > 0 or (dy == 0 and dx > 0)))):
+                    ok = False
+        if ok:
+            keep.append(i)
+    return np.array(keep, dtype=np.int64)
+
+
+def topk(corners, scores, k):
+    """IM-8: the k best by (score desc, octave, y, x)."""
+    if corners.shape[0] <= k:
+        return corners
+    order = np.lexsort((corners[:, 0], corners[:, 1], corners[:, 3], -scores.astype(np.float64)))
+    return corners[order[:k]]
+
+
+def extract_intended(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=9, use_nms=False):
+    gray = [grayscale_intended(rgba)]
+    for _ in range(1, depth):
+        gray.append(mip(gray[-1]))
+    blur = [gauss_pass(gauss_pass(g, False), True) for g in gray]
+    kps, scores = fast_intended(gray, threshold, arc)
+    if use_nms:
+        keep = nms_indices(kps, scores)
+        kps, scores = kps[keep], scores[keep]
+    total = kps.shape[0]
+    kps = topk(kps, scores, max_features)
+    return dict(total=total, corners=kps, descriptors=brief_intended(blur, kps), gray=gray, blur=blur)

@@ -559,6 +559,214 @@ int orc_extract_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t W, uint32
 }
 
 /* ------------------------------------------------------------------------------------------
+ * "intended" mode: the algorithm the reference's README describes, with the literal
+ * shaders' defects (Q1, Q2, Q7, Q8, Q11, Q12, Q14) repaired.  NOT in the reference: there is no parity target,
+ * the definitions IM-1..IM-8 in orb_oracle.h are the build's own.
+ * ---------------------------------------------------------------------------------------- */
+void orc_grayscale_intended(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray) { /* IM-1 */
+    for (uint32_t y = 0; y < H; y++) {
+        const uint8_t *src = rgba + (size_t)y * W * 4;
+        for (uint32_t x = 0; x < W; x++) {
+            float r = orc_unorm8(src[4 * x + 0]);
+            float g = orc_unorm8(src[4 * x + 1]);
+            float b = orc_unorm8(src[4 * x + 2]);
+            float pr = 0.299f * r;
+            float pg = 0.587f * g;
+            float pb = 0.114f * b;
+            float lum = (pr + pg) + pb;
+            gray[(size_t)y * W + x] = orc_f32_to_f16(lum);
+        }
+    }
+}
+
+/* IM-3: the reference's four bilinear taps read in texel units are this symmetric 7-tap kernel
+ * (gaussian_blur_x.wgsl:14-26; centre first). */
+static const float GAUSS[4] = {0.282523781f, 0.221251875f, 0.106235079f, 0.0312511548f};
+
+void orc_gauss_pass(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, int vertical) {
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            float t[7];
+            for (int k = -3; k <= 3; k++) {
+                uint32_t xx = vertical ? x : clamp_idx((int64_t)x + k, w);
+                uint32_t yy = vertical ? clamp_idx((int64_t)y + k, h) : y;
+                t[k + 3] = orc_f16_to_f32(src[(size_t)yy * w + xx]);
+            }
+            float acc = GAUSS[0] * t[3];
+            for (int k = 1; k <= 3; k++) {
+                float pair = t[3 - k] + t[3 + k];
+                float term = GAUSS[k] * pair;
+                acc = acc + term;
+            }
+            dst[(size_t)y * w + x] = orc_f32_to_f16(acc);
+        }
+}
+
+uint32_t orc_angle_code_signed(float cy, float cx) { /* IM-5 */
+    float r = orc_atan2f(cy, cx);
+    if (r < 0.0f) r = r + 6.28318531f;
+    float m = truncf(r * 1000.0f);
+    uint32_t code = (uint32_t)m;
+    return code > 6283u ? 6283u : code;
+}
+
+void orc_fast_intended(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, uint32_t arc, orc_corner_t *out,
+                       float *scores, uint32_t cap, uint32_t *total) { /* IM-4, IM-5, score of orc_fast_ex */
+    if (arc == 0) arc = 9;
+    uint32_t count = 0;
+    for (uint32_t oct = 0; oct < lay->depth; oct++) {
+        uint32_t w = lay->w[oct], h = lay->h[oct];
+        if (w <= 33u || h <= 33u) continue; /* no pixel satisfies 16 < x < w - 16 */
+        for (uint32_t gy = 17; gy < h - 16u; gy++)
+            for (uint32_t gx = 17; gx < w - 16u; gx++) {
+                float c = level_load(pyr, lay, oct, gx, gy);
+                uint32_t is_over = 0, is_under = 0;
+                float cx = 0.0f, cy = 0.0f, s_over = 0.0f, s_under = 0.0f;
+                for (int i = 0; i < 16; i++) {
+                    float v = level_load(pyr, lay, oct, (int64_t)gx + RING16[i][0], (int64_t)gy + RING16[i][1]);
+                    float diff = v - c;
+                    float px = v * (float)RING16[i][0];
+                    float py = v * (float)RING16[i][1];
+                    cx = cx + px;
+                    cy = cy + py;
+                    if (diff > threshold) {
+                        is_over |= 1u << i;
+                        float e = diff - threshold;
+                        s_over = s_over + e;
+                    } else if (diff < -threshold) {
+                        is_under |= 1u << i;
+                        float nd = -diff;
+                        float e = nd - threshold;
+                        s_under = s_under + e;
+                    }
+                }
+                int ro = has_run(is_over, arc), ru = has_run(is_under, arc);
+                if (ro || ru) {
+                    if (count < cap) {
+                        out[count].x = gx;
+                        out[count].y = gy;
+                        out[count].angle = orc_angle_code_signed(cy, cx);
+                        out[count].octave = oct;
+                        if (scores) scores[count] = ro ? s_over : s_under;
+                    }
+                    count++;
+                }
+            }
+    }
+    *total = count;
+}
+
+void orc_brief_intended(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
+                        orc_descriptor_t *out) { /* IM-6 */
+    for (uint32_t fidx = 0; fidx < n; fidx++) {
+        const orc_corner_t *k = &corners[fidx];
+        uint32_t oct = k->octave;
+        float theta = (float)k->angle / 1000.0f;
+        float ct = (float)cos((double)theta);
+        float st = (float)sin((double)theta);
+        float nst = -st;
+        for (uint32_t word = 0; word < 8; word++) {
+            uint32_t bits = 0;
+            for (uint32_t i = 0; i < 32; i++) {
+                const int8_t *row = &ORC_BRIEF_PATTERN[4 * ((word << 5) | i)];
+                float ax = (float)row[0], ay = (float)row[1], bx = (float)row[2], by = (float)row[3];
+                /* R(+theta) p = (ct*x - st*y, st*x + ct*y) */
+                float a0 = ct * ax, a1 = nst * ay, a2 = st * ax, a3 = ct * ay;
+                float b0 = ct * bx, b1 = nst * by, b2 = st * bx, b3 = ct * by;
+                float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+                int64_t tax = (int64_t)(int32_t)rax + (int64_t)k->x, tay = (int64_t)(int32_t)ray + (int64_t)k->y;
+                int64_t tbx = (int64_t)(int32_t)rbx + (int64_t)k->x, tby = (int64_t)(int32_t)rby + (int64_t)k->y;
+                float va = 0.0f, vb = 0.0f;
+                if (oct < lay->depth) {
+                    va = level_load(blur_pyr, lay, oct, tax, tay);
+                    vb = level_load(blur_pyr, lay, oct, tbx, tby);
+                }
+                if (va > vb) bits |= 1u << i;
+            }
+            out[fidx].word[word] = bits;
+        }
+    }
+}
+
+/* IM-8: order "better first": larger score, then smaller (octave, y, x). */
+typedef struct {
+    float score;
+    orc_corner_t c;
+} scored_t;
+static int scored_cmp(const void *pa, const void *pb) {
+    const scored_t *a = (const scored_t *)pa, *b = (const scored_t *)pb;
+    if (a->score != b->score) return a->score > b->score ? -1 : 1;
+    if (a->c.octave != b->c.octave) return a->c.octave < b->c.octave ? -1 : 1;
+    if (a->c.y != b->c.y) return a->c.y < b->c.y ? -1 : 1;
+    if (a->c.x != b->c.x) return a->c.x < b->c.x ? -1 : 1;
+    return 0;
+}
+uint32_t orc_topk(const orc_corner_t *in, const float *scores, uint32_t n, uint32_t k, orc_corner_t *out) {
+    if (n <= k) {
+        memcpy(out, in, (size_t)n * sizeof(orc_corner_t));
+        return n;
+    }
+    scored_t *all = (scored_t *)malloc((size_t)n * sizeof(scored_t));
+    for (uint32_t i = 0; i < n; i++) {
+        all[i].score = scores[i];
+        all[i].c = in[i];
+    }
+    qsort(all, n, sizeof(scored_t), scored_cmp);
+    for (uint32_t i = 0; i < k; i++) out[i] = all[i].c;
+    free(all);
+    return k;
+}
+
+int orc_extract_intended(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, float threshold,
+                         uint32_t max_features, const orc_options_t *opt, orc_corner_t *corners,
+                         orc_descriptor_t *descriptors, uint32_t *total, uint16_t *gray_pyr, uint16_t *blur_pyr) {
+    if (!rgba || !W || !H || depth < 1 || depth > ORC_MAX_LEVELS || !total) return -1;
+    uint32_t arc = opt && opt->arc ? opt->arc : 9;
+    if (arc < 9 || arc > 16) return -1;
+    orc_pyramid_t lay;
+    orc_pyramid_layout(W, H, depth, &lay);
+    uint16_t *gray = (uint16_t *)malloc(lay.total * sizeof(uint16_t));
+    uint16_t *tmp = (uint16_t *)malloc(lay.total * sizeof(uint16_t));
+    uint16_t *blur = (uint16_t *)malloc(lay.total * sizeof(uint16_t));
+    orc_grayscale_intended(rgba, W, H, gray);
+    for (uint32_t m = 1; m < depth; m++)
+        orc_mip(gray + lay.offset[m - 1], lay.w[m - 1], lay.h[m - 1], gray + lay.offset[m], lay.w[m], lay.h[m]);
+    for (uint32_t m = 0; m < depth; m++) {
+        orc_gauss_pass(gray + lay.offset[m], lay.w[m], lay.h[m], tmp + lay.offset[m], 0);
+        orc_gauss_pass(tmp + lay.offset[m], lay.w[m], lay.h[m], blur + lay.offset[m], 1);
+    }
+    size_t cap_all = lay.total ? lay.total : 1;
+    orc_corner_t *all = (orc_corner_t *)malloc(cap_all * sizeof(orc_corner_t));
+    orc_corner_t *kept = (orc_corner_t *)malloc(cap_all * sizeof(orc_corner_t));
+    float *scores = (float *)malloc(cap_all * sizeof(float));
+    uint32_t n = 0;
+    orc_fast_intended(gray, &lay, threshold, arc, all, scores, (uint32_t)cap_all, &n);
+    if (opt && opt->nms) {
+        /* survivors keep their scores: recompute the index map through a marker pass */
+        uint32_t m = orc_nms(&lay, all, scores, n, kept);
+        /* orc_nms preserves order, so walk both lists */
+        uint32_t j = 0;
+        for (uint32_t i = 0; i < n && j < m; i++)
+            if (all[i].x == kept[j].x && all[i].y == kept[j].y && all[i].octave == kept[j].octave) scores[j++] = scores[i];
+        memcpy(all, kept, (size_t)m * sizeof(orc_corner_t));
+        n = m;
+    }
+    uint32_t stored = orc_topk(all, scores, n, max_features, kept);
+    memcpy(corners, kept, (size_t)stored * sizeof(orc_corner_t));
+    if (descriptors) orc_brief_intended(blur, &lay, corners, stored, descriptors);
+    *total = n;
+    if (gray_pyr) memcpy(gray_pyr, gray, lay.total * sizeof(uint16_t));
+    if (blur_pyr) memcpy(blur_pyr, blur, lay.total * sizeof(uint16_t));
+    free(all);
+    free(kept);
+    free(scores);
+    free(gray);
+    free(tmp);
+    free(blur);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Synthetic frames.  Counter-based so that C, NumPy and a GPU generator
  * produce identical bytes without sharing a sequential random stream.
  * ---------------------------------------------------------------------------------------- */

@@ -93,6 +93,36 @@ uint32_t orc_nms(const orc_pyramid_t *lay, const orc_corner_t *in, const float *
 int orc_extract_ex(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, float threshold, uint32_t max_features,
                    const orc_options_t *opt, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total);
 
+/* ---- "intended" mode (NOT in the reference, no parity target).  The reference's README
+ * describes ORB; its shaders deviate from that in ways that look accidental (SURVEY.md Q1, Q2, Q7, Q8, Q11, Q12,
+ * Q14).  This mode is the repaired algorithm, defined here and pinned by the NumPy restatement + the GPU tests:
+ * IM-1 grey(x,y) = f16((0.299f*r + 0.587f*g) + 0.114f*b) of input(x,y): BT.601 weight, no vertical mirror.
+ * IM-2 mip chain as CRD-4.
+ * IM-3 blur = separable 7-tap Gaussian, X pass then Y pass, each stored as f16 (CRD-3).  The taps are the
+ *      reference's four bilinear taps read in texel units: weights g0..g3 = 0.282523781f, 0.221251875f,
+ *      0.106235079f, 0.0312511548f (centre outwards); one pass = ((g0*t0 + g1*(t-1 + t+1)) + g2*(t-2 + t+2)) +
+ *      g3*(t-3 + t+3) in binary32, unfused, indices clamped to the level.
+ * IM-4 detector = orc_fast_ex's (arc 9..16, 0 -> 9; no pre-test) with the guard taken from the octave's own
+ *      size: 16 < x < w - 16 and 16 < y < h - 16 (octaves with w <= 33 or h <= 33 hold no keypoint).
+ * IM-5 angle code = trunc(1000 * a), a = atan2(cy, cx) of the ring centroid (CRD-8/-9), plus 6.28318531f when
+ *      negative: 0..6283 milliradians, the full circle.
+ * IM-6 BRIEF samples the IM-3 blur at p + trunc(R(+theta) q): (ct*x - st*y, st*x + ct*y), products and sums
+ *      rounded on their own, ct/st the correctly rounded cos/sin of fl32(code/1000.0f).
+ * IM-7 optional 3x3 NMS exactly as orc_nms.
+ * IM-8 when more than max_features keypoints remain, the max_features best are kept: larger score first, ties by
+ *      smaller (octave, y, x).  The returned counter is still the number before this cut. */
+void orc_grayscale_intended(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray);
+void orc_gauss_pass(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, int vertical);
+uint32_t orc_angle_code_signed(float cy, float cx);
+void orc_fast_intended(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, uint32_t arc, orc_corner_t *out,
+                       float *scores, uint32_t cap, uint32_t *total);
+void orc_brief_intended(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
+                        orc_descriptor_t *out);
+uint32_t orc_topk(const orc_corner_t *in, const float *scores, uint32_t n, uint32_t k, orc_corner_t *out);
+int orc_extract_intended(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, float threshold,
+                         uint32_t max_features, const orc_options_t *opt, orc_corner_t *corners,
+                         orc_descriptor_t *descriptors, uint32_t *total, uint16_t *gray_pyr, uint16_t *blur_pyr);
+
 /* Frame-parallel batch for the CPU baseline leg of bench.py: n_frames contiguous RGBA frames,
  * outputs strided by max_features.  n_threads <= 1 runs serially. */
 int orc_extract_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth, float threshold,

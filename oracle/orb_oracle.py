@@ -73,6 +73,12 @@ def lib():
         L.orc_extract.restype = ctypes.c_int
         L.orc_extract_ex.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, vp, u32p]
         L.orc_extract_ex.restype = ctypes.c_int
+        L.orc_extract_intended.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, vp, u32p, vp, vp]
+        L.orc_extract_intended.restype = ctypes.c_int
+        L.orc_gauss_pass.argtypes = [vp, u32, u32, vp, ctypes.c_int]
+        L.orc_grayscale_intended.argtypes = [vp, u32, u32, vp]
+        L.orc_angle_code_signed.argtypes = [f32, f32]
+        L.orc_angle_code_signed.restype = u32
         L.orc_extract_batch.argtypes = [vp, u32, u32, u32, u32, f32, u32, vp, vp, vp, ctypes.c_int]
         L.orc_extract_batch.restype = ctypes.c_int
         L.orc_synth_frame.argtypes = [vp, u32, u32, u32, u32]
@@ -184,6 +190,38 @@ def extract_ex(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=12,
         raise ValueError("orc_extract_ex: invalid arguments")
     n = min(total.value, max_features)
     return dict(total=total.value, corners=corners[:n], descriptors=desc[:n])
+
+
+def extract_intended(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=9, nms=False, planes=False):
+    """"intended" mode (IM-1..IM-8 in orb_oracle.h).  Not in the reference."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    H, W = rgba.shape[:2]
+    corners = np.zeros(max_features, dtype=CORNER_DTYPE)
+    desc = np.zeros((max_features, 8), dtype=np.uint32)
+    total = ctypes.c_uint32(0)
+    _, ntex = level_dims(W, H, depth)
+    gray = np.zeros(ntex, dtype=np.uint16) if planes else None
+    blur = np.zeros(ntex, dtype=np.uint16) if planes else None
+    opt = (ctypes.c_uint32 * 2)(int(arc), 1 if nms else 0)
+    rc = lib().orc_extract_intended(_ptr(rgba), W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
+                                    ctypes.cast(opt, ctypes.c_void_p), _ptr(corners), _ptr(desc), ctypes.byref(total),
+                                    _ptr(gray) if planes else None, _ptr(blur) if planes else None)
+    if rc != 0:
+        raise ValueError("orc_extract_intended: invalid arguments")
+    n = min(total.value, max_features)
+    return dict(total=total.value, corners=corners[:n], descriptors=desc[:n], gray=gray, blur=blur)
+
+
+def gauss_pass(src, vertical):
+    src = np.ascontiguousarray(src, dtype=np.uint16)
+    h, w = src.shape
+    out = np.empty((h, w), dtype=np.uint16)
+    lib().orc_gauss_pass(_ptr(src), w, h, _ptr(out), 1 if vertical else 0)
+    return out
+
+
+def angle_code_signed(cy, cx):
+    return int(lib().orc_angle_code_signed(float(np.float32(cy)), float(np.float32(cx))))
 
 
 def extract_batch(frames, depth=2, threshold=20.0 / 255.0, max_features=8192, n_threads=1):

@@ -58,8 +58,9 @@ pub mod orb {
     struct OrbOptionsC {
         device: i32,
         max_batch: u32,
-        flags: u32,
-        reserved: [u32; 5],
+        flags: u32,    // 0 = the reference's literal algorithm
+        fast_arc: u32, // 0 = FAST-12
+        reserved: [u32; 4],
     }
 
     extern "C" {

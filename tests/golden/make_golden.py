@@ -32,6 +32,16 @@ CASES = [
 ]
 
 
+# "intended" mode (definitions IM-1..IM-8 in oracle/orb_oracle.h): name, W, H, depth, seed,
+# flags, max_features, arc, nms.  Kept in tests/golden/intended/.
+INTENDED_CASES = [
+    ("i160x120_d2_arc9", 160, 120, 2, 21, 15, 8192, 9, 0),
+    ("i320x240_d3_arc9_nms", 320, 240, 3, 22, 15, 8192, 9, 1),
+    ("i332x202_d4_arc12_top200", 332, 202, 4, 23, 15, 200, 12, 0),
+    ("i640x480_d2_arc9_nms_top500", 640, 480, 2, 24, 15, 500, 9, 1),
+]
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -61,6 +71,30 @@ def main():
             corners=np.stack([corners[k] for k in ("x", "y", "angle", "octave")], 1).astype(np.uint32),
             descriptors=desc.astype(np.uint32))
         print(name, "total", ref["total"])
+    os.makedirs(os.path.join(HERE, "intended"), exist_ok=True)
+    for name, W, H, depth, seed, flags, cap, arc, nms in INTENDED_CASES:
+        rgba = orb_oracle.synth_frame(W, H, seed, flags)
+        ref = orb_oracle.extract_intended(rgba, depth=depth, threshold=THR, max_features=cap, arc=arc, nms=bool(nms),
+                                          planes=True)
+        alt = orb_numpy.extract_intended(rgba, depth=depth, threshold=THR, max_features=cap, arc=arc, use_nms=bool(nms))
+        corners, desc = orb_oracle.sort_keypoints(ref["corners"], ref["descriptors"])
+        kc = np.stack([corners[k] for k in ("x", "y", "angle", "octave")], 1).astype(np.uint32)
+        order = np.lexsort((alt["corners"][:, 0], alt["corners"][:, 1], alt["corners"][:, 3]))
+        assert ref["total"] == alt["total"] and np.array_equal(kc, alt["corners"][order])
+        assert np.array_equal(desc, alt["descriptors"][order])
+        dims, _ = orb_oracle.level_dims(W, H, depth)
+        gray_sha, blur_sha = [], []
+        for m, (w, h, off) in enumerate(dims):
+            g, b = ref["gray"][off:off + w * h], ref["blur"][off:off + w * h]
+            assert np.array_equal(g, alt["gray"][m].ravel()) and np.array_equal(b, alt["blur"][m].ravel())
+            gray_sha.append(sha(g))
+            blur_sha.append(sha(b))
+        np.savez_compressed(
+            os.path.join(HERE, "intended", name + ".npz"),
+            params=np.array([W, H, depth, seed, flags, cap, arc, nms], dtype=np.int64), threshold=THR,
+            rgba_sha256=sha(rgba), gray_sha256=np.array(gray_sha), blur_sha256=np.array(blur_sha),
+            total=np.int64(ref["total"]), corners=kc, descriptors=desc.astype(np.uint32))
+        print(name, "total", ref["total"], "stored", len(kc))
 
 
 if __name__ == "__main__":

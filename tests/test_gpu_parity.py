@@ -309,3 +309,77 @@ def test_arc_length_and_nms_extensions(tinyorb, oracle, arc, nms):
 def test_bad_arc_is_rejected(tinyorb):
     with pytest.raises(tinyorb.OrbError):
         tinyorb.OrbProgram(tinyorb.OrbConfig(tinyorb.Extent3d(64, 48), fast_arc=8)).init()
+
+
+# ---------------------------------------------------------------------------------------------
+# "intended" mode (ORB_FLAG_INTENDED; definitions IM-1..IM-8 in oracle/orb_oracle.h).
+# Not in the reference -- GPU vs the build's C oracle, bit for bit, planes included.
+# ---------------------------------------------------------------------------------------------
+def _intended_program(tinyorb, W, H, depth, cap, arc, nms, max_batch=1):
+    flags = tinyorb.ORB_FLAG_INTENDED | (tinyorb.ORB_FLAG_NMS if nms else 0)
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=cap, hierarchy_depth=depth, initial_threshold=THR,
+                            max_batch=max_batch, flags=flags, fast_arc=arc)
+    return tinyorb.OrbProgram(cfg).init()
+
+
+@pytest.mark.parametrize("W,H,depth,arc,nms,cap", [(160, 120, 2, 0, False, 8192), (320, 240, 3, 9, True, 8192),
+                                                   (200, 97, 3, 12, False, 8192), (332, 202, 4, 10, True, 100),
+                                                   (640, 480, 2, 9, False, 777), (36, 40, 2, 9, False, 64),
+                                                   (70, 34, 1, 9, True, 64), (1280, 720, 2, 9, True, 8192)])
+def test_intended_mode_matches_oracle(tinyorb, oracle, W, H, depth, arc, nms, cap):
+    rgba = oracle.synth_frame(W, H, 90 + depth)
+    ref = oracle.extract_intended(rgba, depth=depth, threshold=THR, max_features=cap, arc=arc or 9, nms=nms, planes=True)
+    with _intended_program(tinyorb, W, H, depth, cap, arc, nms) as prog:
+        assert prog.pipeline() == "staged"
+        total, corners, desc = prog.extract(rgba)
+        dims, _ = oracle.level_dims(W, H, depth)
+        for m, (w, h, off) in enumerate(dims):
+            assert np.array_equal(prog.read_plane(tinyorb.ORB_PLANE_GRAY, m).ravel(), ref["gray"][off:off + w * h])
+            assert np.array_equal(prog.read_plane(tinyorb.ORB_PLANE_BLUR, m).ravel(), ref["blur"][off:off + w * h])
+        assert total == ref["total"]
+        n = min(total, cap)
+        c, d = _sorted(corners[:n], desc[:n])
+        rc, rd = oracle.sort_keypoints(ref["corners"], ref["descriptors"])
+        for k in ("octave", "y", "x", "angle"):
+            assert np.array_equal(c[k], rc[k]), k
+        assert np.array_equal(d, rd)
+
+
+_INTENDED = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "intended", "*.npz")))
+
+
+@pytest.mark.parametrize("path", _INTENDED, ids=[os.path.basename(p) for p in _INTENDED])
+def test_intended_golden_fixture_on_gpu(tinyorb, path):
+    g = np.load(path)
+    W, H, depth, seed, syn_flags, cap, arc, nms = (int(v) for v in g["params"])
+    with _intended_program(tinyorb, W, H, depth, cap, arc, bool(nms)) as prog:
+        dev = prog.synth_frames_device(1, seed, syn_flags)
+        prog.extract_batch_device(dev, 1)
+        total = int(prog.batch_counts(1)[0])
+        assert total == int(g["total"])
+        corners, desc = prog.batch_read(0, min(total, cap))
+        c, d = _sorted(corners, desc)
+        assert np.array_equal(np.stack([c[k] for k in ("x", "y", "angle", "octave")], 1), g["corners"])
+        assert np.array_equal(d, g["descriptors"])
+        for m in range(depth):
+            assert hashlib.sha256(prog.read_plane(tinyorb.ORB_PLANE_GRAY, m).tobytes()).hexdigest() == str(g["gray_sha256"][m])
+            assert hashlib.sha256(prog.read_plane(tinyorb.ORB_PLANE_BLUR, m).tobytes()).hexdigest() == str(g["blur_sha256"][m])
+
+
+def test_intended_batch_with_top_k(tinyorb, oracle):
+    """Batched call: every frame gets its own cut; frames below the capacity are untouched."""
+    W, H, cap = 320, 240, 300
+    frames = np.stack([oracle.synth_frame(W, H, 200 + i, flags) for i, flags in enumerate((15, 15, 7, 1, 15))])
+    with _intended_program(tinyorb, W, H, 2, cap, 9, True, max_batch=5) as prog:
+        prog.extract_batch_host(frames)
+        counts = prog.batch_counts(5)
+        for i in range(5):
+            ref = oracle.extract_intended(frames[i], depth=2, threshold=THR, max_features=cap, arc=9, nms=True)
+            assert int(counts[i]) == ref["total"]
+            n = min(ref["total"], cap)
+            c, d = _sorted(*prog.batch_read(i, n))
+            rc, rd = oracle.sort_keypoints(ref["corners"], ref["descriptors"])
+            assert np.array_equal(np.stack([c[k] for k in ("x", "y", "angle", "octave")], 1),
+                                  np.stack([rc[k] for k in ("x", "y", "angle", "octave")], 1))
+            assert np.array_equal(d, rd)
+        assert int(counts.max()) > cap and int(counts.min()) < cap

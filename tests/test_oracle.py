@@ -66,7 +66,8 @@ def test_pattern_fingerprint():
 
 
 def test_trig_table_matches_libm_and_numpy(oracle):
-    """CRD-10: the committed cos/sin table == double libm rounded to binary32, for all 3142 codes."""
+    """CRD-10: the committed cos/sin table == double libm rounded to binary32, for all 3142 codes of the
+    reference and the 6284 codes of the opt-in "intended" mode (full circle)."""
     import re
     text = open(os.path.join(os.path.dirname(__file__), "..", "tinyslam_amd", "csrc", "orb_tables.h")).read()
 
@@ -75,8 +76,8 @@ def test_trig_table_matches_libm_and_numpy(oracle):
         body = body[body.index("{") + 1:body.index("}")]
         return np.array([int(v, 16) for v in re.findall(r"0x[0-9a-f]{8}", body)], dtype=np.uint32).view(np.float32)
     cos_t, sin_t = table("ORB_COS_BITS"), table("ORB_SIN_BITS")
-    assert cos_t.size == 3142 and sin_t.size == 3142
-    theta = np.arange(3142, dtype=np.float32) / np.float32(1000.0)
+    assert cos_t.size == 6284 and sin_t.size == 6284
+    theta = np.arange(6284, dtype=np.float32) / np.float32(1000.0)
     assert np.array_equal(cos_t, np.cos(theta.astype(np.float64)).astype(np.float32))
     assert np.array_equal(sin_t, np.sin(theta.astype(np.float64)).astype(np.float32))
 
@@ -291,3 +292,114 @@ def test_extensions_known_answers(oracle):
     big = _frame_with_squares(128, 96, [(50, 30, 20)])
     assert oracle.extract_ex(big, depth=1, threshold=THR, arc=12)["total"] == 0
     assert oracle.extract_ex(big, depth=1, threshold=THR, arc=9)["total"] >= 4
+
+
+# ---------------------------------------------------------------- "intended" mode (IM-1..IM-8)
+INTENDED = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "intended", "*.npz")))
+
+
+def _keys(corners):
+    return np.stack([corners[k] for k in ("x", "y", "angle", "octave")], 1).astype(np.uint32)
+
+
+@pytest.mark.parametrize("W,H,depth,arc,nms,cap", [(168, 130, 2, 9, False, 8192), (200, 97, 3, 12, True, 8192),
+                                                   (168, 130, 2, 9, False, 64), (240, 200, 3, 10, True, 150)])
+def test_intended_c_and_numpy_agree(oracle, W, H, depth, arc, nms, cap):
+    rgba = oracle.synth_frame(W, H, 60)
+    a = oracle.extract_intended(rgba, depth=depth, threshold=THR, max_features=cap, arc=arc, nms=nms, planes=True)
+    b = orb_numpy.extract_intended(rgba, depth=depth, threshold=THR, max_features=cap, arc=arc, use_nms=nms)
+    ca, da = oracle.sort_keypoints(a["corners"], a["descriptors"])
+    order = np.lexsort((b["corners"][:, 0], b["corners"][:, 1], b["corners"][:, 3]))
+    assert a["total"] == b["total"] and np.array_equal(_keys(ca), b["corners"][order])
+    assert np.array_equal(da, b["descriptors"][order])
+    assert np.array_equal(a["gray"], np.concatenate([g.ravel() for g in b["gray"]]))
+    assert np.array_equal(a["blur"], np.concatenate([g.ravel() for g in b["blur"]]))
+
+
+@pytest.mark.parametrize("path", INTENDED, ids=[os.path.basename(p) for p in INTENDED])
+def test_intended_golden_fixture(oracle, path):
+    g = np.load(path)
+    W, H, depth, seed, flags, cap, arc, nms = (int(v) for v in g["params"])
+    rgba = oracle.synth_frame(W, H, seed, flags)
+    assert _sha(rgba) == str(g["rgba_sha256"])
+    r = oracle.extract_intended(rgba, depth=depth, threshold=g["threshold"], max_features=cap, arc=arc, nms=bool(nms),
+                                planes=True)
+    assert r["total"] == int(g["total"])
+    dims, _ = oracle.level_dims(W, H, depth)
+    for m, (w, h, off) in enumerate(dims):
+        assert _sha(r["gray"][off:off + w * h]) == str(g["gray_sha256"][m])
+        assert _sha(r["blur"][off:off + w * h]) == str(g["blur_sha256"][m])
+    c, d = oracle.sort_keypoints(r["corners"], r["descriptors"])
+    assert np.array_equal(_keys(c), g["corners"]) and np.array_equal(d, g["descriptors"])
+
+
+def test_intended_known_answers(oracle):
+    f16 = lambda v: np.asarray(v, dtype=np.float32).astype(np.float16)  # noqa: E731
+    gk = np.array([0.0312511548, 0.106235079, 0.221251875, 0.282523781, 0.221251875, 0.106235079, 0.0312511548],
+                  dtype=np.float32)
+    # IM-3: the kernel is the reference's four bilinear taps read in texel units (gaussian_blur_x.wgsl:14-26)
+    off = [-2.2273038885157046, -0.4391873198428642, 1.3243948342247673, 3.0]
+    wgt = [0.13748623236806098, 0.5037756553768409, 0.32748695702046415, 0.031251155234634016]
+    taps = np.zeros(8)
+    for o, w in zip(off, wgt):
+        i = int(np.floor(o))
+        taps[i + 3] += w * (1 - (o - i))
+        taps[i + 4] += w * (o - i)
+    assert np.array_equal(taps[:7].astype(np.float32), gk) and abs(float(gk.astype(np.float64).sum()) - 1.0) < 1e-7
+    # impulse response = separable outer product with an f16 store after each pass
+    img = np.zeros((21, 23), dtype=np.float16)
+    img[10, 11] = 1.0
+    px = oracle.gauss_pass(img.view(np.uint16), False)
+    py = oracle.gauss_pass(px, True).view(np.float16)
+    row = f16(gk)  # X pass of the impulse
+    want = f16(gk[:, None] * row.astype(np.float32)[None, :])
+    assert np.array_equal(py[7:14, 8:15], want) and float(np.abs(py.astype(np.float32)).sum()) == float(want.astype(np.float32).sum())
+    # clamp-to-edge: a constant plane stays put to within one f16 ulp
+    const = np.full((9, 12), np.float16(0.7311))
+    out = oracle.gauss_pass(oracle.gauss_pass(const.view(np.uint16), False), True)
+    assert int(np.abs(out.astype(np.int32) - int(const.view(np.uint16)[0, 0])).max()) <= 1
+    # IM-5: the full circle
+    assert oracle.angle_code_signed(0.0, 1.0) == 0 and oracle.angle_code_signed(1.0, 0.0) == 1570
+    assert oracle.angle_code_signed(0.0, -1.0) == 3141 and oracle.angle_code_signed(-1.0, 0.0) == 4712
+    assert oracle.angle_code_signed(-1.0, 1.0) == 5497 and oracle.angle_code_signed(0.0, 0.0) == 0
+    assert oracle.angle_code_signed(-1e-30, 1.0) in (6283, 0)
+    # IM-1: no mirror -- a bright 3x3 square is found where it is drawn (the literal mode reports H-1-y, Q2)
+    img = _frame_with_squares(128, 96, [(60, 30, 3)])
+    r = oracle.extract_intended(img, depth=1, threshold=THR, arc=12)
+    assert r["total"] == 9 and set(int(v) for v in r["corners"]["y"]) == {30, 31, 32}
+    lit = oracle.extract(img, depth=1, threshold=THR)
+    assert set(int(v) for v in lit["corners"]["y"]) == {96 - 1 - 30, 96 - 1 - 31, 96 - 1 - 32}
+    # IM-4: the guard follows the octave: nothing within 16 px of any octave's border
+    rgba = oracle.synth_frame(256, 192, 61)
+    r = oracle.extract_intended(rgba, depth=3, threshold=THR, max_features=1 << 15)
+    for o in range(3):
+        c = r["corners"][r["corners"]["octave"] == o]
+        w, h = 256 >> o, 192 >> o
+        assert len(c) > 0 and c["x"].min() > 16 and c["y"].min() > 16 and c["x"].max() < w - 16 and c["y"].max() < h - 16
+    assert int((r["corners"]["angle"] > 3141).sum()) > 0 and int(r["corners"]["angle"].max()) <= 6283
+    # IM-8: a cut keeps a subset of the uncut result, and the counter still reports the uncut number
+    cut = oracle.extract_intended(rgba, depth=3, threshold=THR, max_features=100)
+    assert cut["total"] == r["total"] and len(cut["corners"]) == 100
+    full = {tuple(int(v) for v in k) for k in _keys(r["corners"])}
+    assert all(tuple(int(v) for v in k) in full for k in _keys(cut["corners"]))
+
+
+def test_intended_descriptors_follow_a_half_turn(oracle):
+    """Rotating the frame by 180 degrees moves every keypoint to the mirrored position, adds pi to its angle and
+    leaves its descriptor (nearly) unchanged -- the property the literal mode lacks (Q7, Q14)."""
+    W, H = 200, 160
+    rgba = oracle.synth_frame(W, H, 62)
+    a = oracle.extract_intended(rgba, depth=1, threshold=THR, max_features=1 << 14, arc=9)
+    b = oracle.extract_intended(np.ascontiguousarray(rgba[::-1, ::-1]), depth=1, threshold=THR, max_features=1 << 14, arc=9)
+    tb = {(int(c["x"]), int(c["y"])): i for i, c in enumerate(b["corners"])}
+    ham, dang, n = [], [], 0
+    for i, c in enumerate(a["corners"]):
+        j = tb.get((W - 1 - int(c["x"]), H - 1 - int(c["y"])))
+        if j is None:
+            continue
+        n += 1
+        d = (int(b["corners"]["angle"][j]) - int(c["angle"])) % 6283
+        dang.append(min(abs(d - 3141), abs(d - 3142)))
+        ham.append(int(np.unpackbits((a["descriptors"][i] ^ b["descriptors"][j]).view(np.uint8)).sum()))
+    assert n > 0.9 * len(a["corners"]) and max(dang) <= 2
+    assert float(np.median(ham)) <= 4 and float(np.mean(ham)) < 12

@@ -54,6 +54,11 @@ struct OrbProgram {
     float* d_prov_scores = nullptr;
     float* d_score_planes = nullptr;
     ScoreLayout score_layout{};
+    // "intended" mode: survivors of the NMS with their scores, input of the top-K cut
+    bool intended = false;
+    uint32_t* d_prov2_counts = nullptr;
+    CornerData* d_prov2 = nullptr;
+    float* d_prov2_scores = nullptr;
 
     uint8_t* d_input = nullptr;  // max_batch frames (single-frame API, host batches, synth)
     uint16_t* d_gray = nullptr;  // max_batch x pyr.stride
@@ -192,7 +197,10 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
     {
         LaunchScope ls(p, s, KID_GRAY);
         dim3 grid((W + 1023u) / 1024u, H, n);
-        hipLaunchKernelGGL(k_grayscale, grid, dim3(256), 0, s, frames, p->frame_bytes, p->d_gray, pyr);
+        if (p->intended)
+            hipLaunchKernelGGL(k_grayscale<true>, grid, dim3(256), 0, s, frames, p->frame_bytes, p->d_gray, pyr);
+        else
+            hipLaunchKernelGGL(k_grayscale<false>, grid, dim3(256), 0, s, frames, p->frame_bytes, p->d_gray, pyr);
     }
     for (uint32_t m = 1; m < D; m++) {  // orb.rs:413-429
         LaunchScope ls(p, s, KID_MIP);
@@ -201,13 +209,21 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
     }
     for (uint32_t m = 0; m < D; m++) {  // orb.rs:432-466 (both passes)
         LaunchScope ls(p, s, KID_BLUR);
+        if (p->intended) {
+            hipLaunchKernelGGL(k_gauss, dim3((pyr.w[m] + 63u) / 64u, (pyr.h[m] + 15u) / 16u, n), dim3(256), 0, s,
+                               p->d_gray, p->d_blur, pyr, m);
+            continue;
+        }
         dim3 grid(pyr.h[m], 1, n);
         size_t lds = (size_t)pyr.w[m] * 2u * sizeof(uint16_t);
         hipLaunchKernelGGL(k_blur_rows, grid, dim3(256), lds, s, p->d_gray, p->d_blur, pyr, m);
     }
     const bool nms = (p->opt.flags & ORB_FLAG_NMS) != 0u;
+    const uint32_t im = p->intended ? 1u : 0u;
+    const bool prov = nms || p->intended;  // the detector writes the provisional list
+    if (prov) HIP_TRY(p, hipMemsetAsync(p->d_prov_counts, 0, sizeof(uint32_t) * n, s));
+    if (nms && p->intended) HIP_TRY(p, hipMemsetAsync(p->d_prov2_counts, 0, sizeof(uint32_t) * n, s));
     if (nms) {
-        HIP_TRY(p, hipMemsetAsync(p->d_prov_counts, 0, sizeof(uint32_t) * n, s));
         HIP_TRY(p, hipMemsetAsync(p->d_score_planes, 0, sizeof(float) * (size_t)p->score_layout.stride * n, s));
     }
     uint32_t width = W, height = H;  // orb.rs:501-519
@@ -216,22 +232,32 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
         if (gw && gh) {
             LaunchScope ls(p, s, KID_FAST);
             dim3 grid((gw + 15u) / 16u, (gh + 15u) / 16u, n);
-            if (nms)
-                hipLaunchKernelGGL(k_fast, grid, dim3(16, 16), 0, s, p->d_gray, pyr, oct, gw, gh, p->threshold, p->arc,
-                                   p->d_prov_counts, p->d_prov, p->cap_prov, p->d_prov_scores, p->d_score_planes,
-                                   p->score_layout);
+            if (prov)
+                hipLaunchKernelGGL(k_fast, grid, dim3(16, 16), 0, s, p->d_gray, pyr, oct, gw, gh, p->threshold, p->arc, im,
+                                   p->d_prov_counts, p->d_prov, p->cap_prov, p->d_prov_scores,
+                                   nms ? p->d_score_planes : (float*)nullptr, p->score_layout);
             else
-                hipLaunchKernelGGL(k_fast, grid, dim3(16, 16), 0, s, p->d_gray, pyr, oct, gw, gh, p->threshold, p->arc,
+                hipLaunchKernelGGL(k_fast, grid, dim3(16, 16), 0, s, p->d_gray, pyr, oct, gw, gh, p->threshold, p->arc, im,
                                    p->d_counts, p->d_corners, cap, (float*)nullptr, (float*)nullptr, p->score_layout);
         }
         width /= 2u;
         height /= 2u;
     }
-    if (nms) {
+    if (nms && !p->intended) {
         LaunchScope ls(p, s, KID_FAST);
         hipLaunchKernelGGL(k_nms, dim3((p->cap_prov + 255u) / 256u, 1, n), dim3(256), 0, s, p->d_prov_counts, p->d_prov,
                            p->d_prov_scores, p->cap_prov, p->d_score_planes, p->score_layout, p->d_counts, p->d_corners,
-                           cap);
+                           cap, (float*)nullptr);
+    }
+    if (p->intended) {  // [NMS ->] top-K cut -> final list (IM-7, IM-8)
+        LaunchScope ls(p, s, KID_FAST);
+        if (nms)
+            hipLaunchKernelGGL(k_nms, dim3((p->cap_prov + 255u) / 256u, 1, n), dim3(256), 0, s, p->d_prov_counts,
+                               p->d_prov, p->d_prov_scores, p->cap_prov, p->d_score_planes, p->score_layout,
+                               p->d_prov2_counts, p->d_prov2, p->cap_prov, p->d_prov2_scores);
+        hipLaunchKernelGGL(k_topk, dim3(n), dim3(1024), 0, s, nms ? p->d_prov2_counts : p->d_prov_counts,
+                           nms ? p->d_prov2 : p->d_prov, nms ? p->d_prov2_scores : p->d_prov_scores, p->cap_prov,
+                           p->d_counts, p->d_corners, cap);
     }
     {  // orb.rs:523-534
         LaunchScope ls(p, s, KID_BRIEF);
@@ -240,7 +266,7 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
         if (bx > 64u) bx = 64u;
         if (bx < 1u) bx = 1u;
         hipLaunchKernelGGL(k_brief, dim3(bx, 1, n), dim3(256), 0, s, p->d_blur, pyr, p->d_counts, p->d_corners, cap,
-                           p->d_desc, tab);
+                           p->d_desc, tab, im);
     }
     HIP_TRY(p, hipGetLastError());
     p->planes_valid = true;
@@ -249,7 +275,7 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
 
 // Can the fused per-level kernels handle this configuration?  (Otherwise: staged pipeline.)
 bool fused_eligible(const OrbProgram* p) {
-    if (p->opt.flags & (ORB_FLAG_STAGED | ORB_FLAG_NMS)) return false;
+    if (p->opt.flags & (ORB_FLAG_STAGED | ORB_FLAG_NMS | ORB_FLAG_INTENDED)) return false;
     if (p->arc != 12u) return false;  // the fused FAST phase is specialised for the reference's 12-run
     const Pyramid& pyr = p->pyr;
     if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 22)) return false;  // 24-bit index products in k_front
@@ -402,6 +428,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     if (!(config->initial_threshold >= 0.f)) return fail(nullptr, ORB_EINVAL, "initial_threshold must be >= 0");
     if (options && options->fast_arc != 0 && (options->fast_arc < 9 || options->fast_arc > 16))
         return fail(nullptr, ORB_EINVAL, "fast_arc must be 0 (= 12) or 9..16");
+    if (options && (options->flags & ORB_FLAG_INTENDED) && (W > 16384u || H > 16384u))
+        return fail(nullptr, ORB_EINVAL, "ORB_FLAG_INTENDED needs W, H <= 16384 (14-bit coordinates in the top-K key)");
 
     OrbProgram* p = new (std::nothrow) OrbProgram();
     if (!p) return fail(nullptr, ORB_EINVAL, "out of host memory");
@@ -410,7 +438,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     p->device = p->opt.device;
     p->max_batch = p->opt.max_batch ? p->opt.max_batch : 1u;
     p->threshold = config->initial_threshold;  // orb.rs:178
-    p->arc = p->opt.fast_arc ? p->opt.fast_arc : 12u;
+    p->intended = (p->opt.flags & ORB_FLAG_INTENDED) != 0u;
+    p->arc = p->opt.fast_arc ? p->opt.fast_arc : (p->intended ? 9u : 12u);
     p->frame_bytes = (size_t)W * H * 4u;
     layout_pyramid(W, H, config->hierarchy_depth, &p->pyr);
 
@@ -509,7 +538,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         CREATE_TRY(hipMemset(p->d_seg_counts, 0, B * p->bands.n_slots * sizeof(uint32_t)));
         CREATE_TRY(hipMalloc(&p->d_seg_before, B * p->bands.n_slots * sizeof(uint32_t)));
     }
-    if (p->opt.flags & ORB_FLAG_NMS) {
+    if (p->opt.flags & (ORB_FLAG_NMS | ORB_FLAG_INTENDED)) {
         // score planes: one float per dispatch-grid pixel of every octave + a 1-px border; provisional list
         uint32_t off = 0, width = W, height = H;
         for (uint32_t m = 0; m < p->pyr.depth; m++) {
@@ -522,17 +551,28 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         }
         p->score_layout.stride = (off + 63u) & ~63u;
         p->cap_prov = (uint32_t)std::min<uint64_t>((uint64_t)cap * 4u, 1u << 24);
+        if (p->intended) {  // the top-K cut must see every candidate: up to 16x the final capacity, at most every texel
+            const uint64_t want = std::max<uint64_t>((uint64_t)cap * 16u, 65536u);
+            p->cap_prov = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(want, p->pyr.stride), 1u << 24);
+            if (p->cap_prov < cap) p->cap_prov = (uint32_t)cap;
+        }
+        if (p->opt.flags & ORB_FLAG_NMS)
         CREATE_TRY(hipMalloc(&p->d_score_planes, B * (size_t)p->score_layout.stride * sizeof(float)));
         CREATE_TRY(hipMalloc(&p->d_prov_counts, B * sizeof(uint32_t)));
         CREATE_TRY(hipMalloc(&p->d_prov, B * (size_t)p->cap_prov * sizeof(CornerData)));
         CREATE_TRY(hipMalloc(&p->d_prov_scores, B * (size_t)p->cap_prov * sizeof(float)));
+        if (p->intended && (p->opt.flags & ORB_FLAG_NMS)) {
+            CREATE_TRY(hipMalloc(&p->d_prov2_counts, B * sizeof(uint32_t)));
+            CREATE_TRY(hipMalloc(&p->d_prov2, B * (size_t)p->cap_prov * sizeof(CornerData)));
+            CREATE_TRY(hipMalloc(&p->d_prov2_scores, B * (size_t)p->cap_prov * sizeof(float)));
+        }
     }
     CREATE_TRY(hipMalloc(&p->d_pattern, 256 * sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc(&p->d_cos, ORB_ANGLE_STEPS * sizeof(float)));
-    CREATE_TRY(hipMalloc(&p->d_sin, ORB_ANGLE_STEPS * sizeof(float)));
+    CREATE_TRY(hipMalloc(&p->d_cos, ORB_ANGLE_STEPS_FULL * sizeof(float)));
+    CREATE_TRY(hipMalloc(&p->d_sin, ORB_ANGLE_STEPS_FULL * sizeof(float)));
     CREATE_TRY(hipMemcpy(p->d_pattern, ORB_BRIEF_PATTERN, 1024, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(p->d_cos, ORB_COS_BITS, ORB_ANGLE_STEPS * 4, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(p->d_sin, ORB_SIN_BITS, ORB_ANGLE_STEPS * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(p->d_cos, ORB_COS_BITS, ORB_ANGLE_STEPS_FULL * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(p->d_sin, ORB_SIN_BITS, ORB_ANGLE_STEPS_FULL * 4, hipMemcpyHostToDevice));
     if (p->fused && getenv("TINYORB_STAMPS")) {  // diagnostic builds only (tools/stamps.py)
         CREATE_TRY(hipMalloc(&p->d_stamps, 32 * sizeof(unsigned long long)));
         CREATE_TRY(hipMemset(p->d_stamps, 0, 32 * sizeof(unsigned long long)));
@@ -570,6 +610,9 @@ void orb_program_destroy(OrbProgram* p) {
     (void)hipFree(p->d_prov_counts);
     (void)hipFree(p->d_prov);
     (void)hipFree(p->d_prov_scores);
+    (void)hipFree(p->d_prov2_counts);
+    (void)hipFree(p->d_prov2);
+    (void)hipFree(p->d_prov2_scores);
     (void)hipFree(p->d_pattern);
     (void)hipFree(p->d_cos);
     (void)hipFree(p->d_sin);

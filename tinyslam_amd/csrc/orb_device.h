@@ -42,6 +42,17 @@ __device__ __forceinline__ float luminance(uint32_t rgba) {
     return (pr + pg) + pb;
 }
 
+// "intended" mode IM-1 (not in the reference): BT.601 weight for red.
+__device__ __forceinline__ float luminance_601(uint32_t rgba) {
+    float r = (float)(rgba & 255u) / 255.0f;
+    float g = (float)((rgba >> 8) & 255u) / 255.0f;
+    float b = (float)((rgba >> 16) & 255u) / 255.0f;
+    float pr = 0.299f * r;
+    float pg = 0.587f * g;
+    float pb = 0.114f * b;
+    return (pr + pg) + pb;
+}
+
 // fast.wgsl:51-60 detect_streak_16: non-zero iff the 16-bit circular mask holds a run of >= 12.
 __device__ __forceinline__ uint32_t rotate_bits_16(uint32_t v, uint32_t c) {
     return (v >> c) | ((v << (16u - c)) & 0xffffu);
@@ -84,6 +95,14 @@ __device__ __forceinline__ uint32_t angle_code(float cy, float cx) {
     return (uint32_t)__builtin_truncf(r * 1000.0f);
 }
 
+// "intended" mode IM-5: the full circle, 0..6283 milliradians.
+__device__ __forceinline__ uint32_t angle_code_signed(float cy, float cx) {
+    float r = atan2_canonical(cy, cx);
+    if (r < 0.0f) r = r + 6.28318531f;
+    const uint32_t code = (uint32_t)__builtin_truncf(r * 1000.0f);
+    return code > 6283u ? 6283u : code;
+}
+
 // FAST ring, fast.wgsl:32-49 (index order matters for the centroid sum, CRD-8).
 __device__ constexpr int kRingDx[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
 __device__ constexpr int kRingDy[16] = {0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1};
@@ -93,6 +112,9 @@ constexpr float kBlurOffHost = -0.4391873198428642f;  // tap 1, for host-side ge
 __device__ constexpr float kBlurOff[4] = {-2.2273038885157046f, -0.4391873198428642f, 1.3243948342247673f, 3.0f};
 __device__ constexpr float kBlurWgt[4] = {0.13748623236806098f, 0.5037756553768409f, 0.32748695702046415f,
                                           0.031251155234634016f};
+
+// "intended" mode IM-3: the same four bilinear taps read in texel units = a symmetric 7-tap kernel (centre first)
+__device__ constexpr float kGauss[4] = {0.282523781f, 0.221251875f, 0.106235079f, 0.0312511548f};
 
 // One literal blur tap position (CRD-5): indices of the two texels and the lerp fraction.
 struct BlurTap {

@@ -15,26 +15,29 @@ namespace orb {
 // One thread = 4 horizontally adjacent pixels: one 16-byte load, one 8-byte store.
 // grid: (ceil(W/4/256), H, frames)
 // ---------------------------------------------------------------------------------------------
+// INTENDED (IM-1, not in the reference): BT.601 red weight and no mirror.
+template <bool INTENDED>
 __global__ __launch_bounds__(256) void k_grayscale(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                    uint16_t* __restrict__ gray, Pyramid pyr) {
+    auto lum = [](uint32_t v) { return INTENDED ? luminance_601(v) : luminance(v); };
     const uint32_t W = pyr.w[0], H = pyr.h[0];
     const uint32_t y = blockIdx.y, f = blockIdx.z;
     const uint32_t x0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
     if (x0 >= W) return;
-    const uint8_t* src_row = frames + (size_t)f * frame_bytes + (size_t)(H - 1u - y) * W * 4u;
+    const uint8_t* src_row = frames + (size_t)f * frame_bytes + (size_t)(INTENDED ? y : H - 1u - y) * W * 4u;
     uint16_t* dst_row = gray + (size_t)f * pyr.stride + pyr.off[0] + (size_t)y * W;
     if (x0 + 4u <= W && (W & 3u) == 0u) {
         const uint4 px = *reinterpret_cast<const uint4*>(src_row + (size_t)x0 * 4u);
         ushort4 out;
-        out.x = half_bits(to_half(luminance(px.x)));
-        out.y = half_bits(to_half(luminance(px.y)));
-        out.z = half_bits(to_half(luminance(px.z)));
-        out.w = half_bits(to_half(luminance(px.w)));
+        out.x = half_bits(to_half(lum(px.x)));
+        out.y = half_bits(to_half(lum(px.y)));
+        out.z = half_bits(to_half(lum(px.z)));
+        out.w = half_bits(to_half(lum(px.w)));
         *reinterpret_cast<ushort4*>(dst_row + x0) = out;
     } else {
         for (uint32_t x = x0; x < W && x < x0 + 4u; x++) {
             uint32_t v = *reinterpret_cast<const uint32_t*>(src_row + (size_t)x * 4u);
-            dst_row[x] = half_bits(to_half(luminance(v)));
+            dst_row[x] = half_bits(to_half(lum(v)));
         }
     }
 }
@@ -115,16 +118,65 @@ __global__ __launch_bounds__(256) void k_blur_rows(const uint16_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// "intended" mode IM-3 (not in the reference, which runs its X shader twice with UV-unit offsets): separable
+// 7-tap Gaussian, X pass then Y pass, both f16-rounded.  One block = a 64x16 tile: the grey tile with a 3-px
+// halo (clamp-to-edge) goes to LDS, the X pass fills (16+6) x 64 intermediate values in LDS, the Y pass writes.
+// grid: (ceil(w/64), ceil(h/16), frames)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gauss(const uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
+                                               Pyramid pyr, uint32_t m) {
+    constexpr int TW = 64, TH = 16, R = 3;
+    __shared__ float src[TH + 2 * R][TW + 2 * R + 2];
+    __shared__ float mid[TH + 2 * R][TW];
+    const int w = (int)pyr.w[m], h = (int)pyr.h[m];
+    const size_t base = (size_t)blockIdx.z * pyr.stride + pyr.off[m];
+    const int bx = (int)blockIdx.x * TW, by = (int)blockIdx.y * TH;
+    const int tid = (int)threadIdx.x;
+    for (int i = tid; i < (TH + 2 * R) * (TW + 2 * R); i += 256) {
+        const int ty = i / (TW + 2 * R), tx = i - ty * (TW + 2 * R);
+        const int gx = min(max(bx + tx - R, 0), w - 1), gy = min(max(by + ty - R, 0), h - 1);
+        src[ty][tx] = from_half(bits_half(gray[base + (size_t)gy * w + gx]));
+    }
+    __syncthreads();
+    for (int i = tid; i < (TH + 2 * R) * TW; i += 256) {
+        const int ty = i / TW, tx = i - ty * TW;
+        float acc = kGauss[0] * src[ty][tx + R];
+#pragma unroll
+        for (int k = 1; k <= R; k++) {
+            const float pair = src[ty][tx + R - k] + src[ty][tx + R + k];
+            const float term = kGauss[k] * pair;
+            acc = acc + term;
+        }
+        mid[ty][tx] = from_half(to_half(acc));
+    }
+    __syncthreads();
+    for (int i = tid; i < TH * TW; i += 256) {
+        const int ty = i / TW, tx = i - ty * TW;
+        const int gx = bx + tx, gy = by + ty;
+        if (gx >= w || gy >= h) continue;
+        float acc = kGauss[0] * mid[ty + R][tx];
+#pragma unroll
+        for (int k = 1; k <= R; k++) {
+            const float pair = mid[ty + R - k][tx] + mid[ty + R + k][tx];
+            const float term = kGauss[k] * pair;
+            acc = acc + term;
+        }
+        blur[base + (size_t)gy * w + gx] = half_bits(to_half(acc));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K5  fast.wgsl:62-159 for one octave (one dispatch of orb.rs:509-519).
 // 16x16 pixels per block, tile + 3-pixel halo staged in LDS as f32; out-of-level texels are 0
 // (CRD-6).  The reference's per-thread LDS atomic + one global atomic per workgroup
 // (fast.wgsl:123-141) becomes a wave64 ballot/prefix and one global atomic per wave.
 // grid: (ceil(gw/16), ceil(gh/16), frames) with gw,gh the reference's 8-rounded dispatch size.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void append_corners(bool is_corner, uint32_t x, uint32_t y, uint32_t angle, uint32_t oct,
-                                               uint32_t* counter, CornerData* out, uint32_t cap) {
+// Returns the slot the record went to, or ~0u (not a corner / list full).
+__device__ __forceinline__ uint32_t append_corners(bool is_corner, uint32_t x, uint32_t y, uint32_t angle, uint32_t oct,
+                                                   uint32_t* counter, CornerData* out, uint32_t cap) {
     const uint64_t mask = __ballot(is_corner);
-    if (mask == 0ull) return;
+    if (mask == 0ull) return ~0u;
     const uint32_t lane = __lane_id();
     uint32_t base = 0;
     if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(mask));
@@ -134,8 +186,10 @@ __device__ __forceinline__ void append_corners(bool is_corner, uint32_t x, uint3
         if (idx < cap) {
             uint4 rec = make_uint4(x, y, angle, oct);
             *reinterpret_cast<uint4*>(&out[idx]) = rec;
+            return idx;
         }
     }
+    return ~0u;
 }
 
 // Opt-in extensions of the detector (not in the reference, default off):
@@ -162,7 +216,7 @@ __device__ __forceinline__ bool has_run_16(uint32_t mask, uint32_t arc) {
 
 __global__ __launch_bounds__(256) void k_fast(const uint16_t* __restrict__ gray, Pyramid pyr, uint32_t oct,
                                               uint32_t gw, uint32_t gh, float threshold, uint32_t arc,
-                                              uint32_t* __restrict__ counts, CornerData* __restrict__ corners,
+                                              uint32_t intended, uint32_t* __restrict__ counts, CornerData* __restrict__ corners,
                                               uint32_t cap, float* __restrict__ scores_list,
                                               float* __restrict__ score_planes, ScoreLayout sl) {
     constexpr int T = 16, R = 3, S = T + 2 * R;
@@ -187,8 +241,11 @@ __global__ __launch_bounds__(256) void k_fast(const uint16_t* __restrict__ gray,
     float score = 0.0f;
     const uint32_t need = arc >> 2;  // compass points any run of `arc` must contain (fast.wgsl:95 for arc 12)
     // fast.wgsl:77 -- textureDimensions() is the level-0 size for every octave (Q8); u32 wrap kept.
+    // "intended" mode (IM-4): the octave's own size, signed so that tiny octaves hold no keypoint.
     const uint32_t lim_x = pyr.w[0] - 16u, lim_y = pyr.h[0] - 16u;
-    if (gx < gw && gy < gh && gx > 16u && gy > 16u && gx < lim_x && gy < lim_y) {
+    const bool guard = intended ? ((int)gx > 16 && (int)gy > 16 && (int)gx < (int)w - 16 && (int)gy < (int)h - 16)
+                                : (gx > 16u && gy > 16u && gx < lim_x && gy < lim_y);
+    if (gx < gw && gy < gh && guard) {
         const float c = tile[ly][lx];
         uint32_t n_over = 0, n_under = 0;
         const float v4[4] = {tile[ly][lx + 3], tile[ly][lx - 3], tile[ly + 3][lx], tile[ly - 3][lx]};
@@ -225,7 +282,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint16_t* __restrict__ gray,
             const bool ro = has_run_16(m_over, arc), ru = has_run_16(m_under, arc);
             if (ro || ru) {
                 is_corner = true;
-                angle = angle_code(cy, cx);
+                angle = intended ? angle_code_signed(cy, cx) : angle_code(cy, cx);
                 score = ro ? s_over : s_under;
             }
         }
@@ -255,15 +312,16 @@ __global__ __launch_bounds__(256) void k_nms(const uint32_t* __restrict__ prov_c
                                              const CornerData* __restrict__ prov, const float* __restrict__ prov_scores,
                                              uint32_t cap_prov, const float* __restrict__ score_planes, ScoreLayout sl,
                                              uint32_t* __restrict__ counts, CornerData* __restrict__ corners,
-                                             uint32_t cap) {
+                                             uint32_t cap, float* __restrict__ out_scores) {
     const uint32_t f = blockIdx.z;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t n = min(prov_counts[f], cap_prov);
     bool keep = false;
     uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    float s = 0.0f;
     if (i < n) {
         rec = *reinterpret_cast<const uint4*>(&prov[(size_t)f * cap_prov + i]);
-        const float s = prov_scores[(size_t)f * cap_prov + i];
+        s = prov_scores[(size_t)f * cap_prov + i];
         const float* plane = score_planes + (size_t)f * sl.stride + sl.off[rec.w];
         const uint32_t pitch = sl.pitch[rec.w];
         keep = true;
@@ -277,7 +335,75 @@ __global__ __launch_bounds__(256) void k_nms(const uint32_t* __restrict__ prov_c
                 if (t > 0.0f && (t > s || (t == s && !later))) keep = false;
             }
     }
-    append_corners(keep, rec.x, rec.y, rec.z, rec.w, counts + f, corners + (size_t)f * cap, cap);
+    const uint32_t idx = append_corners(keep, rec.x, rec.y, rec.z, rec.w, counts + f, corners + (size_t)f * cap, cap);
+    if (out_scores && idx != ~0u) out_scores[(size_t)f * cap + idx] = s;
+}
+
+// "intended" mode IM-8 (not in the reference, which keeps whichever records win the atomic, Q9/Q10): when a
+// frame has more candidates than `cap`, keep the `cap` best -- larger score first, ties by smaller
+// (octave, y, x).  Keys are unique 64-bit integers (score bits : ~position), so the cap-th largest key is found
+// by an 8-pass MSB radix select over LDS histograms; one workgroup per frame.  counts[f] = candidates before
+// the cut (raw counter of the detector / NMS).
+__global__ __launch_bounds__(1024) void k_topk(const uint32_t* __restrict__ in_counts,
+                                               const CornerData* __restrict__ in, const float* __restrict__ in_scores,
+                                               uint32_t cap_in, uint32_t* __restrict__ counts,
+                                               CornerData* __restrict__ out, uint32_t cap) {
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long sel_prefix;
+    __shared__ uint32_t sel_want, out_n;
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const uint32_t raw = in_counts[f], n = min(raw, cap_in);
+    const CornerData* src = in + (size_t)f * cap_in;
+    const float* sc = in_scores + (size_t)f * cap_in;
+    CornerData* dst = out + (size_t)f * cap;
+    if (tid == 0u) counts[f] = raw;
+    if (n <= cap) {
+        for (uint32_t i = tid; i < n; i += 1024u)
+            *reinterpret_cast<uint4*>(&dst[i]) = *reinterpret_cast<const uint4*>(&src[i]);
+        return;
+    }
+    auto key_of = [&](uint32_t i) -> unsigned long long {
+        const uint4 r = *reinterpret_cast<const uint4*>(&src[i]);
+        const uint32_t pos = (r.w << 28) | (r.y << 14) | r.x;  // x, y < 2^14 (checked at create)
+        return ((unsigned long long)__float_as_uint(sc[i]) << 32) | (unsigned long long)(0xffffffffu - pos);
+    };
+    if (tid == 0u) {
+        sel_prefix = 0ull;
+        sel_want = cap;
+        out_n = 0u;
+    }
+    unsigned long long known = 0ull;  // mask of the key bits fixed so far
+    for (int pass = 7; pass >= 0; pass--) {
+        if (tid < 256u) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = sel_prefix;
+        for (uint32_t i = tid; i < n; i += 1024u) {
+            const unsigned long long k = key_of(i);
+            if ((k & known) == prefix) atomicAdd(&hist[(uint32_t)(k >> (8 * pass)) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0u) {
+            uint32_t acc = 0, want = sel_want, digit = 0;
+            for (int b = 255; b >= 0; b--) {
+                if (acc + hist[b] >= want) {
+                    digit = (uint32_t)b;
+                    break;
+                }
+                acc += hist[b];
+            }
+            sel_want = want - acc;
+            sel_prefix = prefix | ((unsigned long long)digit << (8 * pass));
+        }
+        known |= 0xffull << (8 * pass);
+        __syncthreads();
+    }
+    const unsigned long long kth = sel_prefix;  // exactly `cap` keys are >= kth
+    for (uint32_t i = tid; i < n; i += 1024u) {
+        if (key_of(i) >= kth) {
+            const uint32_t idx = atomicAdd(&out_n, 1u);
+            if (idx < cap) *reinterpret_cast<uint4*>(&dst[idx]) = *reinterpret_cast<const uint4*>(&src[i]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -288,7 +414,7 @@ __global__ __launch_bounds__(256) void k_nms(const uint32_t* __restrict__ prov_c
 // ---------------------------------------------------------------------------------------------
 struct BriefTables {
     const uint32_t* pattern;  // 256 x packed (ax, ay, bx, by) int8
-    const float* cos_tab;     // ORB_ANGLE_STEPS entries
+    const float* cos_tab;     // ORB_ANGLE_STEPS_FULL entries (the reference's codes use the first ORB_ANGLE_STEPS)
     const float* sin_tab;
 };
 
@@ -297,13 +423,14 @@ __device__ __forceinline__ float level_load(const uint16_t* lvl, uint32_t w, uin
     return from_half(bits_half(lvl[(size_t)y * w + x]));
 }
 
-__device__ __forceinline__ bool brief_test(uint32_t packed, float ct, float st, float nst, int px, int py,
+// (s1, s2) = (st, -st): the reference's R(-theta); (-st, st): "intended" mode IM-6, R(+theta).
+__device__ __forceinline__ bool brief_test(uint32_t packed, float ct, float s1, float s2, int px, int py,
                                            const uint16_t* lvl, uint32_t w, uint32_t h) {
     const float ax = (float)(int8_t)(packed & 255u), ay = (float)(int8_t)((packed >> 8) & 255u);
     const float bx = (float)(int8_t)((packed >> 16) & 255u), by = (float)(int8_t)(packed >> 24);
     // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y)   brief.wgsl:38-54
-    float a0 = ct * ax, a1 = st * ay, a2 = nst * ax, a3 = ct * ay;
-    float b0 = ct * bx, b1 = st * by, b2 = nst * bx, b3 = ct * by;
+    float a0 = ct * ax, a1 = s1 * ay, a2 = s2 * ax, a3 = ct * ay;
+    float b0 = ct * bx, b1 = s1 * by, b2 = s2 * bx, b3 = ct * by;
     float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
     const float va = level_load(lvl, w, h, (int)rax + px, (int)ray + py);  // vec2i() truncates, brief.wgsl:56-57
     const float vb = level_load(lvl, w, h, (int)rbx + px, (int)rby + py);
@@ -313,10 +440,12 @@ __device__ __forceinline__ bool brief_test(uint32_t packed, float ct, float st, 
 __global__ __launch_bounds__(256) void k_brief(const uint16_t* __restrict__ blur, Pyramid pyr,
                                                const uint32_t* __restrict__ counts,
                                                const CornerData* __restrict__ corners, uint32_t cap,
-                                               CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
+                                               CornerDescriptor* __restrict__ descriptors, BriefTables tab,
+                                               uint32_t intended) {
     const uint32_t f = blockIdx.z;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t steps = intended ? ORB_ANGLE_STEPS_FULL : ORB_ANGLE_STEPS;
     const uint32_t n_waves = gridDim.x * 4u;
     const uint32_t n = min(counts[f], cap);
     const CornerData* kp = corners + (size_t)f * cap;
@@ -328,8 +457,9 @@ __global__ __launch_bounds__(256) void k_brief(const uint16_t* __restrict__ blur
         const uint32_t oct = rec.w;
         uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
         if (oct < pyr.depth) {
-            const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
-            const float ct = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
+            const uint32_t code = min(rec.z, steps - 1u);
+            const float ct = tab.cos_tab[code], sn = tab.sin_tab[code];
+            const float st = intended ? -sn : sn, nst = -st;
             const uint32_t w = pyr.w[oct], h = pyr.h[oct];
             const uint16_t* lvl = blur + (size_t)f * pyr.stride + pyr.off[oct];
             const int px = (int)rec.x, py = (int)rec.y;

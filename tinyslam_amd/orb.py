@@ -24,6 +24,7 @@ ORB_KERNEL_COUNT = 10
 ORB_FLAG_STAGED = 1
 ORB_FLAG_DOUBLE_OUTPUT = 2
 ORB_FLAG_NMS = 4
+ORB_FLAG_INTENDED = 8
 SYN_GRADIENT, SYN_BLOBS, SYN_WEDGES, SYN_NOISE = 1, 2, 4, 8
 SYN_ALL = 15
 
@@ -152,7 +153,7 @@ class OrbConfig:
     device: int = 0
     max_batch: int = 1
     flags: int = 0
-    fast_arc: int = 0  # 0 -> 12 (reference); 9..16 opt-in
+    fast_arc: int = 0  # 0 -> 12 (reference; 9 with ORB_FLAG_INTENDED); 9..16 opt-in
 
 
 def _ptr(a):
