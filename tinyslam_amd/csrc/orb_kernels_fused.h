@@ -64,13 +64,14 @@ __device__ __forceinline__ float h2f(uint32_t packed, int hi) {
     return from_half(bits_half((uint16_t)(hi ? (packed >> 16) : (packed & 0xffffu))));
 }
 
-// Exact byte/255 (CRD-1) without the divide sequence: one Newton correction with true FMAs gives
-// the correctly rounded quotient for all 256 inputs (checked exhaustively on host and device).
+// Exact byte/255 (CRD-1) without the divide sequence: 1/255 as a double-float (hi + lo), the product with the
+// byte accumulated in one true FMA.  b*hi is exact inside the FMA and b*lo carries a relative error of 2^-24 on
+// a term 2^-25 times smaller, so the result is the correctly rounded quotient unless b/255 lies within ~2^-48 of
+// a rounding boundary, which no multiple of 1/255 does (checked for all 256 bytes on host and device).
 __device__ __forceinline__ float unorm8_exact(float b) {
-    const float rc = 1.0f / 255.0f;
-    float q = b * rc;
-    float r = __builtin_fmaf(-q, 255.0f, b);
-    return __builtin_fmaf(r, rc, q);
+    const float rc_hi = 0x1.010102p-8f, rc_lo = -0x1.fdfdfep-33f;  // rc_hi + rc_lo = 1/255 to 2^-57
+    const float t = b * rc_lo;
+    return __builtin_fmaf(b, rc_hi, t);
 }
 __device__ __forceinline__ float luminance_fast(uint32_t rgba) {
     float r = unorm8_exact((float)(rgba & 255u));
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 //    sign of the exact difference).
                 const uint32_t dw[8] = {qa.x, qa.y, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};  // dw[j] = grey(x-4+2j, x-3+2j)
                 const uint32_t upw[4] = {qu.x, qu.y, qu.z, qu.w}, dnw[4] = {qd.x, qd.y, qd.z, qd.w};
-                uint32_t cand = 0, cand_over = 0;
+                uint32_t e_any[4], e_ovr[4];  // sign bit of each half = the answer for that pixel
     #pragma unroll
                 for (int j = 0; j < 4; j++) {  // pixel pair (x+2j, x+2j+1)
                     const ushort2_t left = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 1], dw[j], 16));       // x+2j-3, x+2j-2
@@ -363,25 +364,35 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     const half2_t c2 = __builtin_bit_cast(half2_t, dw[j + 2]);
                     const half2_t e_over = thr_lo2 - (second_lo - c2);   // negative  <=>  second_lo - c > thr_lo
                     const half2_t e_under = (second_hi - c2) + thr_lo2;  // negative  <=>  second_hi - c < -thr_lo
-                    const uint32_t so = __builtin_bit_cast(uint32_t, e_over) & 0x80008000u;
-                    const uint32_t sa = (so | __builtin_bit_cast(uint32_t, e_under)) & 0x80008000u;
-                    // sign bits 15 and 31 -> mask bits 2j and 2j+1
-                    cand |= (((sa >> 15) & 1u) | (sa >> 30)) << (2 * j);
-                    cand_over |= (((so >> 15) & 1u) | (so >> 30)) << (2 * j);
+                    e_ovr[j] = __builtin_bit_cast(uint32_t, e_over);
+                    e_any[j] = e_ovr[j] | __builtin_bit_cast(uint32_t, e_under);
                 }
-                {  // fast.wgsl:77 guard on x, for the 8 pixels at once: keep bits k with 16 < x+k < lim_x
+                // Gather the eight sign bits (bit 7 of bytes 1 and 3 of each word) into one word with two byte
+                // permutes: pixel k of the item sits at bit kFrontSignPos(k) = 8*(k & 3) + (k < 4 ? 7 : 3).
+                auto gather_signs = [](const uint32_t (&e)[4]) {
+                    const uint32_t p01 = __builtin_amdgcn_perm(e[1], e[0], 0x07050301u);  // pixels 0..3 -> bytes 0..3
+                    const uint32_t p23 = __builtin_amdgcn_perm(e[3], e[2], 0x07050301u);  // pixels 4..7
+                    return (p01 & 0x80808080u) | ((p23 & 0x80808080u) >> 4);
+                };
+                uint32_t cand = gather_signs(e_any);
+                {  // fast.wgsl:77 guard on x: keep pixels k with 16 < x+k < lim_x (only the two items at the ends of a row cut)
                     const int first = 17 - x, past = (int)lim_x - x;
-                    uint32_t keep = 0xffu;
-                    if (first > 0) keep &= 0xffu << first;
-                    if (past < 8) keep &= past > 0 ? (0xffu >> (8 - past)) : 0u;
-                    cand &= keep;
+                    if (first > 0 || past < 8) {
+                        uint32_t keep = 0;
+    #pragma unroll
+                        for (int k = 0; k < 8; k++)
+                            if (k >= first && k < past) keep |= 1u << (8 * (k & 3) + (k < 4 ? 7 : 3));
+                        cand &= keep;
+                    }
                 }
                 if (cand) {  // one LDS atomic for all survivors of this item
+                    const uint32_t cand_over = gather_signs(e_ovr);
                     uint32_t qs = atomicAdd(qa_count, (uint32_t)__builtin_popcount(cand));
                     while (cand) {
-                        const int k = __builtin_ctz(cand);
+                        const int p = __builtin_ctz(cand);
                         cand &= cand - 1u;
-                        const bool over = (cand_over >> k) & 1u;
+                        const int k = (p >> 3) | ((p & 4) ^ 4);
+                        const bool over = (cand_over >> p) & 1u;
                         if (qs < (uint32_t)kFrontQueue) {
                             queue_a[qs] = (uint16_t)((over ? 0x8000u : 0u) | ((uint32_t)lyc << 11) | (uint32_t)(x + k));
                         } else {  // queue full (pathological frame): finish in place

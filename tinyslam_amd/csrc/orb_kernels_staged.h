@@ -206,12 +206,14 @@ struct ScoreLayout {
 
 __device__ __forceinline__ bool has_run_16(uint32_t mask, uint32_t arc) {
     if (arc == 12u) return detect_streak_16(mask) != 0u;  // fast.wgsl:56-60
-    const uint32_t dbl = mask | (mask << 16);
-    const uint32_t want = arc >= 16u ? 0xffffu : ((1u << arc) - 1u);
-    bool hit = false;
-#pragma unroll
-    for (int s0 = 0; s0 < 16; s0++) hit |= ((dbl >> s0) & want) == want;
-    return hit;
+    // bit i of r <=> positions i .. i+have-1 (circular) are all set; doubling `have` by AND-ing shifted copies
+    uint32_t r = mask | (mask << 16);
+    for (uint32_t have = 1u; have < arc;) {
+        const uint32_t s = min(have, arc - have);
+        r &= r >> s;
+        have += s;
+    }
+    return (r & 0xffffu) != 0u;
 }
 
 __global__ __launch_bounds__(256) void k_fast(const uint16_t* __restrict__ gray, Pyramid pyr, uint32_t oct,
@@ -289,15 +291,19 @@ __global__ __launch_bounds__(256) void k_fast(const uint16_t* __restrict__ gray,
     }
     if (is_corner && score_planes)
         score_planes[(size_t)f * sl.stride + sl.off[oct] + (size_t)(gy + 1u) * sl.pitch[oct] + gx + 1u] = score;
-    // append (as append_corners) with the score next to the record
+    // append: one global atomic per workgroup (the reference's scheme, fast.wgsl:123-141), wave ballots inside
+    __shared__ uint32_t wave_n[4], block_base;
     const uint64_t mask = __ballot(is_corner);
-    if (mask == 0ull) return;
-    const uint32_t lane = __lane_id();
-    uint32_t base = 0;
-    if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(counts + f, (uint32_t)__builtin_popcountll(mask));
-    base = __shfl(base, __builtin_ctzll(mask));
+    const uint32_t lane = __lane_id(), wv = (uint32_t)tid >> 6;
+    if (lane == 0u) wave_n[wv] = (uint32_t)__builtin_popcountll(mask);
+    __syncthreads();
+    const uint32_t total = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+    if (total == 0u) return;  // uniform
+    if (tid == 0) block_base = atomicAdd(counts + f, total);
+    __syncthreads();
     if (is_corner) {
-        const uint32_t idx = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        uint32_t idx = block_base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        for (uint32_t k = 0; k < wv; k++) idx += wave_n[k];
         if (idx < cap) {
             *reinterpret_cast<uint4*>(&corners[(size_t)f * cap + idx]) = make_uint4(gx, gy, angle, oct);
             if (scores_list) scores_list[(size_t)f * cap + idx] = score;
