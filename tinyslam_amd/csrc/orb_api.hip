@@ -243,16 +243,17 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
         width /= 2u;
         height /= 2u;
     }
+    const uint32_t nms_blocks = std::min<uint32_t>((p->cap_prov + 255u) / 256u, 64u);
     if (nms && !p->intended) {
         LaunchScope ls(p, s, KID_FAST);
-        hipLaunchKernelGGL(k_nms, dim3((p->cap_prov + 255u) / 256u, 1, n), dim3(256), 0, s, p->d_prov_counts, p->d_prov,
+        hipLaunchKernelGGL(k_nms, dim3(nms_blocks, 1, n), dim3(256), 0, s, p->d_prov_counts, p->d_prov,
                            p->d_prov_scores, p->cap_prov, p->d_score_planes, p->score_layout, p->d_counts, p->d_corners,
                            cap, (float*)nullptr);
     }
     if (p->intended) {  // [NMS ->] top-K cut -> final list (IM-7, IM-8)
         LaunchScope ls(p, s, KID_FAST);
         if (nms)
-            hipLaunchKernelGGL(k_nms, dim3((p->cap_prov + 255u) / 256u, 1, n), dim3(256), 0, s, p->d_prov_counts,
+            hipLaunchKernelGGL(k_nms, dim3(nms_blocks, 1, n), dim3(256), 0, s, p->d_prov_counts,
                                p->d_prov, p->d_prov_scores, p->cap_prov, p->d_score_planes, p->score_layout,
                                p->d_prov2_counts, p->d_prov2, p->cap_prov, p->d_prov2_scores);
         hipLaunchKernelGGL(k_topk, dim3(n), dim3(1024), 0, s, nms ? p->d_prov2_counts : p->d_prov_counts,
@@ -550,12 +551,9 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
             height /= 2u;
         }
         p->score_layout.stride = (off + 63u) & ~63u;
-        p->cap_prov = (uint32_t)std::min<uint64_t>((uint64_t)cap * 4u, 1u << 24);
-        if (p->intended) {  // the top-K cut must see every candidate: up to 16x the final capacity, at most every texel
-            const uint64_t want = std::max<uint64_t>((uint64_t)cap * 16u, 65536u);
-            p->cap_prov = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(want, p->pyr.stride), 1u << 24);
-            if (p->cap_prov < cap) p->cap_prov = (uint32_t)cap;
-        }
+        // The provisional list must hold every detection (the NMS and the top-K cut have to see all of them): one
+        // slot per texel of the pyramid is the worst case and what is allocated (20 bytes per texel and frame).
+        p->cap_prov = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(p->pyr.stride, cap), 1u << 24);
         if (p->opt.flags & ORB_FLAG_NMS)
         CREATE_TRY(hipMalloc(&p->d_score_planes, B * (size_t)p->score_layout.stride * sizeof(float)));
         CREATE_TRY(hipMalloc(&p->d_prov_counts, B * sizeof(uint32_t)));

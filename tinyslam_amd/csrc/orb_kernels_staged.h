@@ -313,36 +313,39 @@ __global__ __launch_bounds__(256) void k_fast(const uint16_t* __restrict__ gray,
 
 // 3x3 non-maximum suppression per octave over the provisional corners of k_fast: a corner survives iff every
 // 8-neighbour that is also a corner has a smaller score, or an equal score and a later raster position.
-// grid: (ceil(cap_prov/256), 1, frames)
+// grid: (blocks, 1, frames); the blocks of a frame stride over its provisional list (every wave stays whole until
+// its last round, append_corners ballots over the wave).
 __global__ __launch_bounds__(256) void k_nms(const uint32_t* __restrict__ prov_counts,
                                              const CornerData* __restrict__ prov, const float* __restrict__ prov_scores,
                                              uint32_t cap_prov, const float* __restrict__ score_planes, ScoreLayout sl,
                                              uint32_t* __restrict__ counts, CornerData* __restrict__ corners,
                                              uint32_t cap, float* __restrict__ out_scores) {
     const uint32_t f = blockIdx.z;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t n = min(prov_counts[f], cap_prov);
-    bool keep = false;
-    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-    float s = 0.0f;
-    if (i < n) {
-        rec = *reinterpret_cast<const uint4*>(&prov[(size_t)f * cap_prov + i]);
-        s = prov_scores[(size_t)f * cap_prov + i];
-        const float* plane = score_planes + (size_t)f * sl.stride + sl.off[rec.w];
-        const uint32_t pitch = sl.pitch[rec.w];
-        keep = true;
+    for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {  // uniform per workgroup
+        const uint32_t i = i0 + threadIdx.x;
+        bool keep = false;
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+        float s = 0.0f;
+        if (i < n) {
+            rec = *reinterpret_cast<const uint4*>(&prov[(size_t)f * cap_prov + i]);
+            s = prov_scores[(size_t)f * cap_prov + i];
+            const float* plane = score_planes + (size_t)f * sl.stride + sl.off[rec.w];
+            const uint32_t pitch = sl.pitch[rec.w];
+            keep = true;
 #pragma unroll
-        for (int dy = -1; dy <= 1; dy++)
+            for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
-            for (int dx = -1; dx <= 1; dx++) {
-                if (dx == 0 && dy == 0) continue;
-                const float t = plane[(size_t)((int)rec.y + 1 + dy) * pitch + (size_t)((int)rec.x + 1 + dx)];
-                const bool later = dy > 0 || (dy == 0 && dx > 0);
-                if (t > 0.0f && (t > s || (t == s && !later))) keep = false;
-            }
+                for (int dx = -1; dx <= 1; dx++) {
+                    if (dx == 0 && dy == 0) continue;
+                    const float t = plane[(size_t)((int)rec.y + 1 + dy) * pitch + (size_t)((int)rec.x + 1 + dx)];
+                    const bool later = dy > 0 || (dy == 0 && dx > 0);
+                    if (t > 0.0f && (t > s || (t == s && !later))) keep = false;
+                }
+        }
+        const uint32_t idx = append_corners(keep, rec.x, rec.y, rec.z, rec.w, counts + f, corners + (size_t)f * cap, cap);
+        if (out_scores && idx != ~0u) out_scores[(size_t)f * cap + idx] = s;
     }
-    const uint32_t idx = append_corners(keep, rec.x, rec.y, rec.z, rec.w, counts + f, corners + (size_t)f * cap, cap);
-    if (out_scores && idx != ~0u) out_scores[(size_t)f * cap + idx] = s;
 }
 
 // "intended" mode IM-8 (not in the reference, which keeps whichever records win the atomic, Q9/Q10): when a
