@@ -315,8 +315,8 @@ def test_bad_arc_is_rejected(tinyorb):
 # "intended" mode (ORB_FLAG_INTENDED; definitions IM-1..IM-8 in oracle/orb_oracle.h).
 # Not in the reference -- GPU vs the build's C oracle, bit for bit, planes included.
 # ---------------------------------------------------------------------------------------------
-def _intended_program(tinyorb, W, H, depth, cap, arc, nms, max_batch=1):
-    flags = tinyorb.ORB_FLAG_INTENDED | (tinyorb.ORB_FLAG_NMS if nms else 0)
+def _intended_program(tinyorb, W, H, depth, cap, arc, nms, max_batch=1, staged=False):
+    flags = tinyorb.ORB_FLAG_INTENDED | (tinyorb.ORB_FLAG_NMS if nms else 0) | (tinyorb.ORB_FLAG_STAGED if staged else 0)
     cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=cap, hierarchy_depth=depth, initial_threshold=THR,
                             max_batch=max_batch, flags=flags, fast_arc=arc)
     return tinyorb.OrbProgram(cfg).init()
@@ -325,12 +325,15 @@ def _intended_program(tinyorb, W, H, depth, cap, arc, nms, max_batch=1):
 @pytest.mark.parametrize("W,H,depth,arc,nms,cap", [(160, 120, 2, 0, False, 8192), (320, 240, 3, 9, True, 8192),
                                                    (200, 97, 3, 12, False, 8192), (332, 202, 4, 10, True, 100),
                                                    (640, 480, 2, 9, False, 777), (36, 40, 2, 9, False, 64),
-                                                   (70, 34, 1, 9, True, 64), (1280, 720, 2, 9, True, 8192)])
-def test_intended_mode_matches_oracle(tinyorb, oracle, W, H, depth, arc, nms, cap):
+                                                   (70, 34, 1, 9, True, 64), (1280, 720, 2, 9, True, 8192),
+                                                   (1284, 250, 4, 9, True, 8192), (648, 100, 3, 16, True, 8192),
+                                                   (322, 202, 2, 9, False, 8192), (1920, 120, 2, 11, True, 50)])
+@pytest.mark.parametrize("staged", [False, True])
+def test_intended_mode_matches_oracle(tinyorb, oracle, W, H, depth, arc, nms, cap, staged):
     rgba = oracle.synth_frame(W, H, 90 + depth)
     ref = oracle.extract_intended(rgba, depth=depth, threshold=THR, max_features=cap, arc=arc or 9, nms=nms, planes=True)
-    with _intended_program(tinyorb, W, H, depth, cap, arc, nms) as prog:
-        assert prog.pipeline() == "staged"
+    with _intended_program(tinyorb, W, H, depth, cap, arc, nms, staged=staged) as prog:
+        assert prog.pipeline() == ("fused" if W % 4 == 0 and not staged else "staged")
         total, corners, desc = prog.extract(rgba)
         dims, _ = oracle.level_dims(W, H, depth)
         for m, (w, h, off) in enumerate(dims):
@@ -349,10 +352,11 @@ _INTENDED = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "
 
 
 @pytest.mark.parametrize("path", _INTENDED, ids=[os.path.basename(p) for p in _INTENDED])
-def test_intended_golden_fixture_on_gpu(tinyorb, path):
+@pytest.mark.parametrize("staged", [False, True])
+def test_intended_golden_fixture_on_gpu(tinyorb, path, staged):
     g = np.load(path)
     W, H, depth, seed, syn_flags, cap, arc, nms = (int(v) for v in g["params"])
-    with _intended_program(tinyorb, W, H, depth, cap, arc, bool(nms)) as prog:
+    with _intended_program(tinyorb, W, H, depth, cap, arc, bool(nms), staged=staged) as prog:
         dev = prog.synth_frames_device(1, seed, syn_flags)
         prog.extract_batch_device(dev, 1)
         total = int(prog.batch_counts(1)[0])
@@ -383,3 +387,24 @@ def test_intended_batch_with_top_k(tinyorb, oracle):
                                   np.stack([rc[k] for k in ("x", "y", "angle", "octave")], 1))
             assert np.array_equal(d, rd)
         assert int(counts.max()) > cap and int(counts.min()) < cap
+
+
+def test_intended_pathological_dense_tile(tinyorb, oracle):
+    """A frame dense enough to overflow the tile queues of the fused kernel: the direct path must give the same list."""
+    W, H = 640, 128
+    rng = np.random.default_rng(5)
+    rgba = np.zeros((H, W, 4), dtype=np.uint8)
+    rgba[..., :3] = (rng.random((H, W, 1)) < 0.2) * 255  # bright dots: a tenth of all pixels are FAST-9 corners
+    rgba[..., 3] = 255
+    for nms in (False, True):
+        ref = oracle.extract_intended(rgba, depth=2, threshold=THR, max_features=1 << 16, arc=9, nms=nms)
+        assert ref["total"] > 4000
+        with _intended_program(tinyorb, W, H, 2, 1 << 16, 9, nms) as prog:
+            assert prog.pipeline() == "fused"
+            total, corners, desc = prog.extract(rgba)
+            assert total == ref["total"]
+            c, d = _sorted(corners, desc)
+            rc, rd = oracle.sort_keypoints(ref["corners"], ref["descriptors"])
+            for k in ("octave", "y", "x", "angle"):
+                assert np.array_equal(c[k], rc[k]), k
+            assert np.array_equal(d, rd)

@@ -17,15 +17,17 @@
 
 #include "../../include/tinyorb.h"
 #include "orb_kernels_fused.h"
+#include "orb_kernels_intended.h"
 #include "orb_kernels_staged.h"
 
 using namespace orb;
 
 namespace {
 
-enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX };
+enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I };
 const char* const kKernelNames[ORB_KERNEL_COUNT] = {"k_grayscale", "k_mip",      "k_blur_rows", "k_fast",       "k_brief",
-                                                    "k_front_l0",  "k_front_ln", "k_synth",     "k_brief_rows", "k_slot_prefix"};
+                                                    "k_front_l0",  "k_front_ln", "k_synth",     "k_brief_rows", "k_slot_prefix",
+                                                    "k_front_i",   "k_select_i", "k_brief_i"};
 
 thread_local std::string g_create_error;
 
@@ -56,6 +58,14 @@ struct OrbProgram {
     ScoreLayout score_layout{};
     // "intended" mode: survivors of the NMS with their scores, input of the top-K cut
     bool intended = false;
+    // fused "intended" pipeline (orb_kernels_intended.h): tile slots, their segments (record + score), the cut
+    bool fused_i = false;
+    IBriefGeom itiles{};
+    CornerData* d_iseg = nullptr;
+    float* d_iseg_scores = nullptr;
+    uint32_t* d_iseg_counts = nullptr;
+    uint32_t* d_iseg_before = nullptr;
+    unsigned long long* d_thr_key = nullptr;
     uint32_t* d_prov2_counts = nullptr;
     CornerData* d_prov2 = nullptr;
     float* d_prov2_scores = nullptr;
@@ -393,7 +403,80 @@ int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
     return ORB_OK;
 }
 
+// Tile width of a level for the fused "intended" pipeline.
+uint32_t itile_width(uint32_t w) {
+    const uint32_t w8 = (w + 7u) & ~7u;
+    return w8 < (uint32_t)kITileW ? w8 : (uint32_t)kITileW;
+}
+
+bool fused_i_eligible(const OrbProgram* p) {
+    if (!p->intended || (p->opt.flags & ORB_FLAG_STAGED)) return false;
+    const Pyramid& pyr = p->pyr;
+    if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 22)) return false;  // 24-bit index products
+    if ((pyr.w[0] & 3u) != 0u || pyr.w[0] < 8u) return false;       // level 0 is read as RGBA quads
+    return true;
+}
+
+// The fused "intended" pipeline: k_front_i per level (+ k_mip where a level is not an exact half), k_gauss per
+// level, k_select_i, k_brief_i.
+int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
+    const Pyramid& pyr = p->pyr;
+    const uint32_t D = pyr.depth, cap = p->cfg.max_features;
+    const IBriefGeom& bg = p->itiles;
+    for (uint32_t lvl = 0; lvl < D; lvl++) {
+        if (lvl > 0 && !(pyr.w[lvl - 1] == 2u * pyr.w[lvl] && pyr.h[lvl - 1] == 2u * pyr.h[lvl])) {
+            LaunchScope ls(p, s, KID_MIP);
+            dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 3u) / 4u, n);
+            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, p->d_gray, pyr, lvl);
+        }
+        IGeom g{};
+        g.lvl = lvl;
+        g.tw = bg.tw[lvl];
+        g.n_ct = bg.n_ct[lvl];
+        g.n_bands = (pyr.h[lvl] + kFrontRows - 1) / kFrontRows;
+        g.ls = kIPad + g.tw + 16u;
+        g.write_mip = (lvl + 1 < D && pyr.w[lvl] == 2u * pyr.w[lvl + 1] && pyr.h[lvl] == 2u * pyr.h[lvl + 1]) ? 1u : 0u;
+        g.xcd_swizzle = (n % 8u == 0u) ? 1u : 0u;
+        g.slot_base = bg.slot_base[lvl];
+        g.n_slots = bg.n_slots;
+        g.seg_cap = bg.seg_cap;
+        g.arc = p->arc;
+        g.nms = (p->opt.flags & ORB_FLAG_NMS) ? 1u : 0u;
+        if (g.n_bands * g.n_ct != bg.slot_base[lvl + 1] - bg.slot_base[lvl])
+            return fail(p, ORB_EINVAL, "internal: tile count mismatch at level %u", lvl);
+        const dim3 grid(g.n_bands * g.n_ct * n);
+        LaunchScope ls(p, s, KID_FRONT_I);
+        if (lvl == 0)
+            hipLaunchKernelGGL(k_front_i<true>, grid, dim3(kIThreads), ifront_lds_bytes(g), s, frames, p->frame_bytes,
+                               p->d_gray, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
+        else
+            hipLaunchKernelGGL(k_front_i<false>, grid, dim3(kIThreads), ifront_lds_bytes(g), s, frames, p->frame_bytes,
+                               p->d_gray, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
+    }
+    for (uint32_t m = 0; m < D; m++) {
+        LaunchScope ls(p, s, KID_BLUR);
+        hipLaunchKernelGGL(k_gauss, dim3((pyr.w[m] + 63u) / 64u, (pyr.h[m] + 15u) / 16u, n), dim3(256), 0, s, p->d_gray,
+                           p->d_blur, pyr, m);
+    }
+    {
+        LaunchScope ls(p, s, KID_SELECT_I);
+        hipLaunchKernelGGL(k_select_i, dim3(n), dim3(1024), 0, s, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores, bg.n_slots,
+                           bg.seg_cap, cap, p->d_counts, p->d_thr_key, p->d_iseg_before);
+    }
+    {
+        LaunchScope ls(p, s, KID_BRIEF_I);
+        const size_t lds = (size_t)kIBriefRows * bg.pitch * sizeof(uint16_t);
+        hipLaunchKernelGGL(k_brief_i, dim3(bg.n_slots, n), dim3(256), lds, s, p->d_blur, pyr, bg, p->d_iseg_counts,
+                           p->d_iseg_before, p->d_thr_key, p->d_iseg, p->d_iseg_scores, p->d_corners, cap, p->d_desc,
+                           BriefTables{p->d_pattern, p->d_cos, p->d_sin});
+    }
+    HIP_TRY(p, hipGetLastError());
+    p->planes_valid = true;
+    return ORB_OK;
+}
+
 int run_pipeline(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
+    if (p->fused_i) return run_fused_i(p, frames, n, s);
     return p->fused ? run_fused(p, frames, n, s) : run_staged(p, frames, n, s);
 }
 
@@ -410,7 +493,7 @@ uint32_t orb_abi_version(void) { return TINYORB_ABI_VERSION; }
 
 const char* orb_last_error(const OrbProgram* p) { return p ? p->err.c_str() : g_create_error.c_str(); }
 
-const char* orb_pipeline(const OrbProgram* p) { return p ? (p->fused ? "fused" : "staged") : ""; }
+const char* orb_pipeline(const OrbProgram* p) { return p ? ((p->fused || p->fused_i) ? "fused" : "staged") : ""; }
 
 const char* orb_kernel_name(int id) { return (id >= 0 && id < ORB_KERNEL_COUNT) ? kKernelNames[id] : ""; }
 
@@ -517,6 +600,22 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
             }
         }
     }
+    p->fused_i = fused_i_eligible(p);
+    if (p->fused_i) {
+        IBriefGeom& bg = p->itiles;
+        uint32_t slots = 0;
+        for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
+            bg.tw[lvl] = itile_width(p->pyr.w[lvl]);
+            bg.n_ct[lvl] = (p->pyr.w[lvl] + bg.tw[lvl] - 1u) / bg.tw[lvl];
+            bg.slot_base[lvl] = slots;
+            slots += ((p->pyr.h[lvl] + kFrontRows - 1) / kFrontRows) * bg.n_ct[lvl];
+        }
+        bg.slot_base[p->pyr.depth] = slots;
+        bg.n_slots = slots;
+        const uint64_t tile_px = (uint64_t)kFrontRows * bg.tw[0];
+        bg.seg_cap = (uint32_t)(tile_px < config->max_features ? tile_px : config->max_features);
+        bg.pitch = (uint32_t)kITileW + 2u * kIBriefApronX;
+    }
     const size_t B = p->max_batch, cap = config->max_features;
     CREATE_TRY(hipMalloc(&p->d_gray, B * p->pyr.stride * sizeof(uint16_t)));
     CREATE_TRY(hipMalloc(&p->d_blur, B * p->pyr.stride * sizeof(uint16_t)));
@@ -539,7 +638,15 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         CREATE_TRY(hipMemset(p->d_seg_counts, 0, B * p->bands.n_slots * sizeof(uint32_t)));
         CREATE_TRY(hipMalloc(&p->d_seg_before, B * p->bands.n_slots * sizeof(uint32_t)));
     }
-    if (p->opt.flags & (ORB_FLAG_NMS | ORB_FLAG_INTENDED)) {
+    if (p->fused_i) {
+        const size_t n_seg = B * (size_t)p->itiles.n_slots;
+        CREATE_TRY(hipMalloc(&p->d_iseg, n_seg * p->itiles.seg_cap * sizeof(CornerData)));
+        CREATE_TRY(hipMalloc(&p->d_iseg_scores, n_seg * p->itiles.seg_cap * sizeof(float)));
+        CREATE_TRY(hipMalloc(&p->d_iseg_counts, n_seg * sizeof(uint32_t)));
+        CREATE_TRY(hipMemset(p->d_iseg_counts, 0, n_seg * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc(&p->d_iseg_before, n_seg * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc(&p->d_thr_key, B * sizeof(unsigned long long)));
+    } else if (p->opt.flags & (ORB_FLAG_NMS | ORB_FLAG_INTENDED)) {
         // score planes: one float per dispatch-grid pixel of every octave + a 1-px border; provisional list
         uint32_t off = 0, width = W, height = H;
         for (uint32_t m = 0; m < p->pyr.depth; m++) {
@@ -608,6 +715,11 @@ void orb_program_destroy(OrbProgram* p) {
     (void)hipFree(p->d_prov_counts);
     (void)hipFree(p->d_prov);
     (void)hipFree(p->d_prov_scores);
+    (void)hipFree(p->d_iseg);
+    (void)hipFree(p->d_iseg_scores);
+    (void)hipFree(p->d_iseg_counts);
+    (void)hipFree(p->d_iseg_before);
+    (void)hipFree(p->d_thr_key);
     (void)hipFree(p->d_prov2_counts);
     (void)hipFree(p->d_prov2);
     (void)hipFree(p->d_prov2_scores);

@@ -1,0 +1,738 @@
+// orb_kernels_intended.h -- fused pipeline of the opt-in "intended" mode (ORB_FLAG_INTENDED; definitions IM-1..IM-8
+// in DESIGN.md section 8; NOT in the reference, whose literal algorithm is orb_kernels_fused.h).
+//
+//   k_front_i<L0>   per level: grey tile in LDS (level 0: RGBA -> BT.601 luminance, no mirror, grey plane also
+//                   stored for k_gauss; level >= 1: the f16 mip) -> segment test with arc 9..16 on the octave's
+//                   own guard -> score + full-circle angle -> 3x3 NMS inside the tile -> survivors appended to
+//                   the tile's segment (record + score) -> next mip level.
+//   k_gauss         (orb_kernels_staged.h) separable 7-tap blur per level.
+//   k_select_i      per frame: raw counter, the top-K cut (IM-8) as a 64-bit key threshold, and where each tile's
+//                   kept keypoints start in the final lists.
+//   k_brief_i       per tile: blur window in LDS, rotated BRIEF-256 (+theta) of the kept keypoints.
+//
+// A workgroup of k_front_i owns a 16-row x TW-column tile (TW = 320 at 1280) with a 4-px apron: 3 for the
+// FAST ring plus 1 so that the 3x3 NMS of the tile's own pixels sees every neighbour's score without another
+// pass.  ~26 KB of LDS -> 6 workgroups of 256 threads per CU, each in its own phase (the literal kernel's
+// A/B measurement showed column tiles on a par with full-width bands).
+#pragma once
+#include "orb_kernels_fused.h"
+
+namespace orb {
+
+constexpr int kIThreads = 256;
+constexpr int kITileW = 320;   // widest tile (multiple of 8)
+constexpr int kIPad = 16;      // LDS columns left of the tile's column 0 (multiple of 8, >= 8 + 4)
+constexpr int kIApron = 4;     // grey rows above / below the tile
+constexpr int kIRows = kFrontRows + 2 * kIApron;  // 24 LDS rows; LDS row j <-> image row y0 - 4 + j
+constexpr int kIQueueA = 3072, kIQueueB = 1024, kIQueueC = 512, kIList = 512;
+
+struct IGeom {
+    uint32_t lvl;
+    uint32_t tw;         // tile width (multiple of 8, <= kITileW)
+    uint32_t n_ct;       // column tiles per band
+    uint32_t n_bands;    // ceil(h / 16)
+    uint32_t ls;         // LDS row stride in halfs: kIPad + tw + 16
+    uint32_t write_mip;  // level lvl+1 exists and is the exact 2x2 reduction
+    uint32_t xcd_swizzle;
+    uint32_t slot_base;  // first tile slot of this level
+    uint32_t n_slots;    // tile slots per frame (all levels)
+    uint32_t seg_cap;    // records per tile segment
+    uint32_t arc;        // 9..16
+    uint32_t nms;        // 0 / 1
+};
+
+__host__ __device__ inline uint32_t ifront_lds_bytes(const IGeom& g) {
+    return kIRows * g.ls * 2u + (kIQueueA + kIQueueB + kIQueueC) * 2u + 32u;
+}
+
+__device__ __forceinline__ bool has_run_bits(uint32_t mask, uint32_t n_bits, uint32_t need) {
+    // circular run of >= need set bits in an n_bits-bit mask (n_bits <= 16, need <= n_bits)
+    uint32_t r = mask | (mask << n_bits);
+    for (uint32_t have = 1u; have < need;) {
+        const uint32_t s = min(have, need - have);
+        r &= r >> s;
+        have += s;
+    }
+    return (r & ((1u << n_bits) - 1u)) != 0u;
+}
+
+// Every second ring point (ring indices 0, 2, .., 14): a run of `arc` ring positions contains floor(arc / 2)
+// consecutive ones of these eight.  Necessary condition used to thin the pre-test survivors.
+__device__ __forceinline__ bool even_ring_filter(const half_t* ctr, int ls, float thr, uint32_t need, bool try_over,
+                                                 bool try_under) {
+    const float c = from_half(ctr[0]);
+    uint32_t m_over = 0, m_under = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float diff = from_half(ctr[kRingDy[2 * i] * ls + kRingDx[2 * i]]) - c;
+        m_over |= (diff > thr) ? (1u << i) : 0u;
+        m_under |= (diff < -thr) ? (1u << i) : 0u;
+    }
+    return (try_over && has_run_bits(m_over, 8u, need)) || (try_under && has_run_bits(m_under, 8u, need));
+}
+
+// Segment test on the full ring (orc_fast_intended): corner <=> run of >= arc in either polarity.
+__device__ __forceinline__ bool ring_has_arc(const half_t* ctr, int ls, float thr, uint32_t arc) {
+    const float c = from_half(ctr[0]);
+    uint32_t m_over = 0, m_under = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float diff = from_half(ctr[kRingDy[i] * ls + kRingDx[i]]) - c;
+        m_over |= (diff > thr) ? (1u << i) : 0u;
+        m_under |= (diff < -thr) ? (1u << i) : 0u;
+    }
+    return has_run_16(m_over, arc) || has_run_16(m_under, arc);
+}
+
+// Score (sum over the run's polarity of |diff| - thr, ring order, binary32) and full-circle angle of a corner.
+__device__ __forceinline__ void ring_score_angle(const half_t* ctr, int ls, float thr, uint32_t arc, float* score,
+                                                 uint32_t* angle) {
+    const float c = from_half(ctr[0]);
+    uint32_t m_over = 0;
+    float cx = 0.0f, cy = 0.0f, s_over = 0.0f, s_under = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float v = from_half(ctr[kRingDy[i] * ls + kRingDx[i]]);
+        const float diff = v - c;
+        const float px = v * (float)kRingDx[i];
+        const float py = v * (float)kRingDy[i];
+        cx = cx + px;
+        cy = cy + py;
+        if (diff > thr) {
+            m_over |= 1u << i;
+            const float e = diff - thr;
+            s_over = s_over + e;
+        } else if (diff < -thr) {
+            const float nd = -diff;
+            const float e = nd - thr;
+            s_under = s_under + e;
+        }
+    }
+    *score = has_run_16(m_over, arc) ? s_over : s_under;
+    *angle = angle_code_signed(cy, cx);
+}
+
+template <bool L0>
+__global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restrict__ frames, size_t frame_bytes,
+                                                          uint16_t* __restrict__ gray, Pyramid pyr, IGeom geo, float thr,
+                                                          uint32_t* __restrict__ seg_counts,
+                                                          CornerData* __restrict__ segments,
+                                                          float* __restrict__ seg_scores) {
+    constexpr int NT = kIThreads, R = kFrontRows;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const int LS = (int)geo.ls, TW = (int)geo.tw;
+    half_t* const grey = reinterpret_cast<half_t*>(lds_raw);  // kIRows x LS; LDS column kIPad <-> image column cx0
+    // 16-bit queue entries: [15] try brighter, [14] try darker, [13:9] region row (0 <-> y0-1), [8:0] LDS column.
+    // A: pre-test survivors; B: survivors of the even-ring filter; C: corners.  The corner list of the NMS
+    // (position, angle, score) reuses A's storage once A has been drained.
+    uint16_t* const queue_a = reinterpret_cast<uint16_t*>(grey + kIRows * LS);
+    uint16_t* const queue_b = queue_a + kIQueueA;
+    uint16_t* const queue_c = queue_b + kIQueueB;
+    uint32_t* const counters = reinterpret_cast<uint32_t*>(queue_c + kIQueueC);
+    uint32_t* const qa_count = counters;
+    uint32_t* const qb_count = counters + 1;
+    uint32_t* const qc_count = counters + 2;
+    uint32_t* const list_count = counters + 3;
+    uint32_t* const c_count = counters + 4;   // corners appended by this tile
+    uint32_t* const overflow = counters + 5;  // some queue was full: the tile is redone by the direct path
+    uint16_t* const list_pos = queue_a;                                          // kIList
+    uint16_t* const list_ang = queue_a + kIList;                                 // kIList
+    float* const list_score = reinterpret_cast<float*>(queue_a + 2 * kIList);   // kIList (6 KB in all = A's storage)
+
+    uint32_t frame, band, ct;
+    {
+        const uint32_t per_frame = geo.n_bands * geo.n_ct;
+        const uint32_t L = blockIdx.x;
+        uint32_t rem;
+        if (geo.xcd_swizzle) {
+            const uint32_t xcd = L & 7u, s2 = L >> 3;
+            frame = (s2 / per_frame) * 8u + xcd;
+            rem = s2 % per_frame;
+        } else {
+            frame = L / per_frame;
+            rem = L % per_frame;
+        }
+        band = rem / geo.n_ct;
+        ct = rem % geo.n_ct;
+    }
+    const uint32_t lvl = geo.lvl;
+    const int w = (int)pyr.w[lvl], h = (int)pyr.h[lvl];
+    const int y0 = (int)band * R, cx0 = (int)ct * TW;
+    const int tw = min(TW, w - cx0);  // columns of this tile that exist
+    const int tid = (int)threadIdx.x;
+    uint16_t* const gray_f = gray + (size_t)frame * pyr.stride;
+    const size_t slot = (size_t)frame * geo.n_slots + geo.slot_base + (size_t)band * geo.n_ct + ct;
+    CornerData* const seg = segments + slot * geo.seg_cap;
+    float* const seg_sc = seg_scores + slot * geo.seg_cap;
+    const uint32_t arc = geo.arc;
+    const int apron = geo.nms ? 1 : 0;  // the NMS needs the scores of the pixels around the tile as well
+    if (tid < 8) counters[tid] = 0u;
+
+    // =========================== A: grey rows [y0-4, y0+R+4) x columns [cx0-8, cx0+tw+8) ===========================
+    if (L0) {
+        // RGBA quads; BT.601 luminance of input(x, y) (IM-1); the tile's own pixels also go to the grey plane (k_gauss)
+        const int q0 = max(cx0 / 4 - 2, 0), q1 = min((cx0 + tw) / 4 + 2, w / 4);
+        const int per_row = q1 - q0;
+        const float inv_per_row = 1.0f / (float)per_row;
+        const int n_items = kIRows * per_row;
+        const uint8_t* src0 = frames + (size_t)frame * frame_bytes;
+        uint16_t* plane0 = gray_f + pyr.off[0];
+        constexpr int U = 4;
+        for (int ib = tid; ib < n_items; ib += NT * U) {
+            uint4 v[U];
+            int dst[U], pix[U];  // LDS half index of the quad (-1: skip); pixel offset in the grey plane (-1: apron)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = ib + u * NT;
+                const int ic = min(i, n_items - 1);
+                const int ly = (int)(((float)ic + 0.5f) * inv_per_row);
+                const int q = q0 + (ic - __mul24(ly, per_row));
+                const int gy = y0 - kIApron + ly;
+                const bool ok = i < n_items && gy >= 0 && gy < h;
+                dst[u] = ok ? __mul24(ly, LS) + kIPad + (q * 4 - cx0) : -1;
+                const bool own = ly >= kIApron && ly < kIApron + R && q * 4 >= cx0 && q * 4 < cx0 + tw;
+                const int gyc = min(max(gy, 0), h - 1);
+                const int off = __mul24(gyc, w) + q * 4;
+                pix[u] = own ? off : -1;
+                v[u] = *reinterpret_cast<const uint4*>(src0 + (size_t)((uint32_t)off * 4u));
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (dst[u] >= 0) {
+                    auto lum = [](uint32_t rgba) {
+                        const float r = unorm8_exact((float)(rgba & 255u));
+                        const float g = unorm8_exact((float)((rgba >> 8) & 255u));
+                        const float b = unorm8_exact((float)((rgba >> 16) & 255u));
+                        const float pr = 0.299f * r;
+                        const float pg = 0.587f * g;
+                        const float pb = 0.114f * b;
+                        return (pr + pg) + pb;
+                    };
+                    uint2 out;
+                    out.x = pack_half2(lum(v[u].x), lum(v[u].y));
+                    out.y = pack_half2(lum(v[u].z), lum(v[u].w));
+                    *reinterpret_cast<uint2*>(grey + dst[u]) = out;
+                    if (pix[u] >= 0) *reinterpret_cast<uint2*>(plane0 + (size_t)(uint32_t)pix[u]) = out;
+                }
+            }
+        }
+    } else {
+        // f16 mip from HBM in 8-texel groups; texels outside the level are never read by a guarded pixel
+        const uint16_t* srcn = gray_f + pyr.off[lvl];
+        const int g0 = cx0 / 8 - 1, per_row = TW / 8 + 2;
+        const float inv_per_row = 1.0f / (float)per_row;
+        const int n_items = kIRows * per_row;
+        const bool vec_ok = (w & 7) == 0;
+        for (int i = tid; i < n_items; i += NT) {
+            const int ly = (int)(((float)i + 0.5f) * inv_per_row);
+            const int x = (g0 + (i - __mul24(ly, per_row))) * 8;
+            const int gy = y0 - kIApron + ly;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (gy >= 0 && gy < h && x >= 0 && x < w) {
+                const uint16_t* row = srcn + (size_t)(uint32_t)__mul24(gy, w);
+                if (vec_ok && x + 8 <= w) {
+                    v = *reinterpret_cast<const uint4*>(row + x);
+                } else {
+                    uint32_t e[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) e[k] = (x + k < w) ? (uint32_t)row[x + k] : 0u;
+                    v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+                }
+            }
+            *reinterpret_cast<uint4*>(grey + __mul24(ly, LS) + kIPad + (x - cx0)) = v;
+        }
+    }
+    __syncthreads();
+
+    // Region of this tile: its own pixels plus (with NMS) a 1-px apron.  Region row r <-> image row y0 - 1 + r,
+    // LDS row r + 3.  IM-4 guard: 16 < x < w - 16, 16 < y < h - 16.
+    const int rx0 = max(cx0 - apron, 17), rx1 = min(cx0 + tw + apron, w - 16);  // [rx0, rx1) columns tested
+    const int ry0 = max(y0 - apron, 17), ry1 = min(min(y0 + R, h) + apron, h - 16);
+    auto in_core = [&](int x, int gy) { return x >= cx0 && x < cx0 + tw && gy >= y0 && gy < y0 + R && gy < h; };
+    auto append = [&](uint32_t x, uint32_t gy, uint32_t angle, float score) {
+        const uint32_t idx = atomicAdd(c_count, 1u);
+        if (idx < geo.seg_cap) {
+            *reinterpret_cast<uint4*>(&seg[idx]) = make_uint4(x, gy, angle, lvl);
+            seg_sc[idx] = score;
+        }
+    };
+    // Direct evaluation of one pixel (used when a queue overflowed): corner?  NMS by re-scoring its neighbours.
+    auto direct_pixel = [&](int x, int gy) {
+        const half_t* ctr = grey + __mul24(gy - y0 + kIApron, LS) + kIPad + (x - cx0);
+        if (!ring_has_arc(ctr, LS, thr, arc)) return;
+        float s;
+        uint32_t ang;
+        ring_score_angle(ctr, LS, thr, arc, &s, &ang);
+        if (geo.nms) {
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    if (dx == 0 && dy == 0) continue;
+                    const int nx = x + dx, ny = gy + dy;
+                    if (!(nx > 16 && nx < w - 16 && ny > 16 && ny < h - 16)) continue;
+                    const half_t* nc = ctr + dy * LS + dx;
+                    if (!ring_has_arc(nc, LS, thr, arc)) continue;
+                    float t;
+                    uint32_t na;
+                    ring_score_angle(nc, LS, thr, arc, &t, &na);
+                    const bool later = dy > 0 || (dy == 0 && dx > 0);
+                    if (t > s || (t == s && !later)) return;
+                }
+        }
+        append((uint32_t)x, (uint32_t)gy, ang, s);
+    };
+
+    // =========================== B1: compass pre-test, 8 px per item ===========================
+    // A run of `arc` ring positions holds at least arc / 4 of the four compass points: 3 for arc >= 12 (the
+    // reference's shortcut), 2 for 9..11.  Conservative packed test as in k_front (selection network on the f16 bit
+    // patterns, packed-f16 compares against a threshold one ulp below RD16(thr)).
+    {
+        const bool need3 = arc >= 12u;
+        const int r_lo = ry0 - (y0 - 1), r_hi = ry1 - (y0 - 1);          // region rows [r_lo, r_hi)
+        const int i_lo = (rx0 - cx0 + 8) >> 3, i_hi = (rx1 - 1 - cx0 + 8) >> 3;  // items: xl = 8 * i - 8
+        const int per_row = i_hi - i_lo + 1;
+        const int n_items = (r_hi > r_lo && per_row > 0) ? (r_hi - r_lo) * per_row : 0;
+        const float inv_per_row = 1.0f / (float)max(per_row, 1);
+        uint32_t tb = half_bits(to_half(thr));
+        if (from_half(bits_half((uint16_t)tb)) > thr) tb--;
+        tb = tb ? tb - 1u : 0x8001u;
+        const half2_t thr_lo2 = __builtin_bit_cast(half2_t, tb | (tb << 16));
+        for (int i = tid; i < n_items; i += NT) {
+            const int rr = (int)(((float)i + 0.5f) * inv_per_row);
+            const int r = r_lo + rr;
+            const int xl = (i_lo + (i - __mul24(rr, per_row))) * 8 - 8;  // column inside the tile of the item's pixel 0
+            const int x = cx0 + xl;
+            const half_t* rowc = grey + __mul24(r + 3, LS) + kIPad + xl;
+            const uint2 qa = *reinterpret_cast<const uint2*>(rowc - 4);
+            const uint4 qb = *reinterpret_cast<const uint4*>(rowc);
+            const uint2 qc = *reinterpret_cast<const uint2*>(rowc + 8);
+            const uint4 qu = *reinterpret_cast<const uint4*>(rowc - 3 * LS);
+            const uint4 qd = *reinterpret_cast<const uint4*>(rowc + 3 * LS);
+            const uint32_t dw[8] = {qa.x, qa.y, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};
+            const uint32_t upw[4] = {qu.x, qu.y, qu.z, qu.w}, dnw[4] = {qd.x, qd.y, qd.z, qd.w};
+            uint32_t e_ovr[4], e_und[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const ushort2_t left = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 1], dw[j], 16));
+                const ushort2_t right = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 4], dw[j + 3], 16));
+                const ushort2_t upp = as_u16x2(upw[j]), dwn = as_u16x2(dnw[j]);
+                const ushort2_t lo1 = __builtin_elementwise_min(left, right), hi1 = __builtin_elementwise_max(left, right);
+                const ushort2_t lo2 = __builtin_elementwise_min(upp, dwn), hi2 = __builtin_elementwise_max(upp, dwn);
+                const ushort2_t m1 = __builtin_elementwise_max(lo1, lo2), m2 = __builtin_elementwise_min(hi1, hi2);
+                const half2_t second_lo = __builtin_bit_cast(half2_t, __builtin_elementwise_min(m1, m2));
+                const half2_t second_hi = __builtin_bit_cast(half2_t, __builtin_elementwise_max(m1, m2));
+                const half2_t c2 = __builtin_bit_cast(half2_t, dw[j + 2]);
+                // >= 3 brighter <=> 2nd smallest beyond thr; >= 2 brighter <=> 2nd largest beyond thr (and mirrored)
+                const half2_t sel_over = need3 ? second_lo : second_hi, sel_under = need3 ? second_hi : second_lo;
+                const half2_t e_over = thr_lo2 - (sel_over - c2);    // negative  <=>  sel_over - c > thr_lo
+                const half2_t e_under = (sel_under - c2) + thr_lo2;  // negative  <=>  sel_under - c < -thr_lo
+                e_ovr[j] = __builtin_bit_cast(uint32_t, e_over);
+                e_und[j] = __builtin_bit_cast(uint32_t, e_under);
+            }
+            auto gather_signs = [](const uint32_t (&e)[4]) {
+                const uint32_t p01 = __builtin_amdgcn_perm(e[1], e[0], 0x07050301u);
+                const uint32_t p23 = __builtin_amdgcn_perm(e[3], e[2], 0x07050301u);
+                return (p01 & 0x80808080u) | ((p23 & 0x80808080u) >> 4);  // pixel k at bit 8*(k&3) + (k<4 ? 7 : 3)
+            };
+            uint32_t c_over = gather_signs(e_ovr), c_under = gather_signs(e_und);
+            {   // pixels of the item outside [rx0, rx1)
+                const int first = rx0 - x, past = rx1 - x;
+                if (first > 0 || past < 8) {
+                    uint32_t keep = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        if (k >= first && k < past) keep |= 1u << (8 * (k & 3) + (k < 4 ? 7 : 3));
+                    c_over &= keep;
+                    c_under &= keep;
+                }
+            }
+            uint32_t cand = c_over | c_under;
+            if (cand) {
+                uint32_t qs = atomicAdd(qa_count, (uint32_t)__builtin_popcount(cand));
+                while (cand) {
+                    const int p = __builtin_ctz(cand);
+                    cand &= cand - 1u;
+                    const int k = (p >> 3) | ((p & 4) ^ 4);
+                    if (qs < (uint32_t)kIQueueA)
+                        queue_a[qs] = (uint16_t)((((c_over >> p) & 1u) << 15) | (((c_under >> p) & 1u) << 14) |
+                                                 ((uint32_t)r << 9) | (uint32_t)(kIPad + xl + k));
+                    else
+                        *overflow = 1u;
+                    qs++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    auto locate = [&](uint32_t e, int* x, int* gy) -> const half_t* {
+        const int r = (int)((e >> 9) & 31u), col = (int)(e & 511u);
+        *x = cx0 + col - kIPad;
+        *gy = y0 - 1 + r;
+        return grey + __mul24(r + 3, LS) + col;
+    };
+    // =========================== S1: even-ring filter, A -> B ===========================
+    {
+        const uint32_t need_even = arc >> 1;
+        const uint32_t n_a = min(*qa_count, (uint32_t)kIQueueA);
+        for (uint32_t i = (uint32_t)tid; i < n_a; i += NT) {
+            const uint32_t e = queue_a[i];
+            int x, gy;
+            const half_t* ctr = locate(e, &x, &gy);
+            if (even_ring_filter(ctr, LS, thr, need_even, (e & 0x8000u) != 0u, (e & 0x4000u) != 0u)) {
+                const uint32_t qs = atomicAdd(qb_count, 1u);
+                if (qs < (uint32_t)kIQueueB)
+                    queue_b[qs] = (uint16_t)e;
+                else
+                    *overflow = 1u;
+            }
+        }
+    }
+    __syncthreads();
+    // =========================== S2: full segment test, B -> C ===========================
+    {
+        const uint32_t n_b = min(*qb_count, (uint32_t)kIQueueB);
+        for (uint32_t i = (uint32_t)tid; i < n_b; i += NT) {
+            const uint32_t e = queue_b[i];
+            int x, gy;
+            const half_t* ctr = locate(e, &x, &gy);
+            if (ring_has_arc(ctr, LS, thr, arc)) {
+                const uint32_t qs = atomicAdd(qc_count, 1u);
+                if (qs < (uint32_t)kIQueueC)
+                    queue_c[qs] = (uint16_t)e;
+                else
+                    *overflow = 1u;
+            }
+        }
+    }
+    __syncthreads();
+    // =========================== S3: score and angle of the corners -> list (A's storage) ===========================
+    {
+        const uint32_t n_c = min(*qc_count, (uint32_t)kIQueueC);
+        for (uint32_t i = (uint32_t)tid; i < n_c; i += NT) {
+            const uint32_t e = queue_c[i];
+            int x, gy;
+            const half_t* ctr = locate(e, &x, &gy);
+            float s;
+            uint32_t ang;
+            ring_score_angle(ctr, LS, thr, arc, &s, &ang);
+            list_pos[i] = (uint16_t)(e & 0x3fffu);
+            list_ang[i] = (uint16_t)ang;
+            list_score[i] = s;
+        }
+        if (tid == 0) *list_count = n_c;
+    }
+    __syncthreads();
+    // =========================== S4: 3x3 NMS inside the tile, survivors -> segment ===========================
+    if (*overflow == 0u) {
+        const uint32_t n = *list_count;
+        for (uint32_t i = (uint32_t)tid; i < n; i += NT) {
+            const uint32_t pi = list_pos[i];
+            const int ri = (int)(pi >> 9), ci = (int)(pi & 511u);
+            const int x = cx0 + ci - kIPad, gy = y0 - 1 + ri;
+            if (!in_core(x, gy)) continue;
+            const float s = list_score[i];
+            bool keep = true;
+            if (geo.nms) {
+                for (uint32_t j = 0; j < n; j++) {
+                    const uint32_t pj = list_pos[j];
+                    const int dy = (int)(pj >> 9) - ri, dx = (int)(pj & 511u) - ci;
+                    if (j != i && dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1) {
+                        const float t = list_score[j];
+                        const bool later = dy > 0 || (dy == 0 && dx > 0);
+                        if (t > s || (t == s && !later)) keep = false;
+                    }
+                }
+            }
+            if (keep) append((uint32_t)x, (uint32_t)gy, (uint32_t)list_ang[i], s);
+        }
+    } else {
+        // some queue was full (a pathologically dense tile): evaluate every pixel of the tile directly
+        const int n_px = R * tw;
+        for (int i = tid; i < n_px; i += NT) {
+            const int r = i / tw, x = cx0 + (i - r * tw), gy = y0 + r;
+            if (gy < h && x > 16 && x < w - 16 && gy > 16 && gy < h - 16) direct_pixel(x, gy);
+        }
+    }
+
+    // =========================== C0: next mip level (exact 2x2 case) ===========================
+    if (geo.write_mip) {
+        const int wd = (int)pyr.w[lvl + 1], hd = (int)pyr.h[lvl + 1];
+        uint16_t* dst = gray_f + pyr.off[lvl + 1];
+        const int g4 = (tw / 2 + 3) >> 2;
+        const float inv_g4 = 1.0f / (float)max(g4, 1);
+        const int n_items = (R / 2) * g4;
+        const bool vec_ok = (wd & 3) == 0;
+        for (int i = tid; i < n_items; i += NT) {
+            const int r = (int)(((float)i + 0.5f) * inv_g4);
+            const int xl = (i - __mul24(r, g4)) * 4;
+            const int xd = cx0 / 2 + xl, yd = (y0 >> 1) + r;
+            if (yd >= hd || xd >= wd) continue;
+            const half_t* top = grey + __mul24(2 * r + kIApron, LS) + kIPad + 2 * xl;
+            const uint4 qt = *reinterpret_cast<const uint4*>(top);
+            const uint4 qb = *reinterpret_cast<const uint4*>(top + LS);
+            const uint32_t tw4[4] = {qt.x, qt.y, qt.z, qt.w}, bw[4] = {qb.x, qb.y, qb.z, qb.w};
+            uint16_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float a = h2f(tw4[k], 0), b = h2f(tw4[k], 1), c = h2f(bw[k], 0), d = h2f(bw[k], 1);
+                const float st = a + b;
+                const float sb = c + d;
+                o[k] = half_bits(to_half((st + sb) * 0.25f));
+            }
+            uint16_t* out = dst + (size_t)(uint32_t)(__mul24(yd, wd) + xd);
+            if (vec_ok && xd + 4 <= wd) {
+                *reinterpret_cast<uint2*>(out) = make_uint2(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (xd + k < wd) out[k] = o[k];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) seg_counts[slot] = *c_count;  // raw count of the tile (may exceed seg_cap)
+}
+
+// 64-bit selection key of a candidate (IM-8): larger = better.  Scores are positive, so their bit patterns order
+// like the values; ties go to the smaller (octave, y, x).
+__device__ __forceinline__ unsigned long long select_key(const uint4 rec, float score) {
+    const uint32_t pos = (rec.w << 28) | (rec.y << 14) | rec.x;  // x, y < 2^14 (checked at create)
+    return ((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xffffffffu - pos);
+}
+
+// Per frame: counts[f] = candidates before the cut; thr_key[f] = smallest key that is kept (0: keep everything);
+// seg_before[slot] = where the slot's kept keypoints start in the frame's final list.  One workgroup per frame.
+__global__ __launch_bounds__(1024) void k_select_i(const uint32_t* __restrict__ seg_counts,
+                                                   const CornerData* __restrict__ segments,
+                                                   const float* __restrict__ seg_scores, uint32_t n_slots,
+                                                   uint32_t seg_cap, uint32_t cap, uint32_t* __restrict__ counts,
+                                                   unsigned long long* __restrict__ thr_key,
+                                                   uint32_t* __restrict__ seg_before) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t red[16];
+    __shared__ unsigned long long sel_prefix;
+    __shared__ uint32_t sel_want;
+    const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t* sc = seg_counts + (size_t)f * n_slots;
+    uint32_t* sb = seg_before + (size_t)f * n_slots;
+    auto block_sum = [&](uint32_t v) {  // sum over the 1024 threads, returned to all
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh);
+        __syncthreads();
+        if (lane == 0u) red[wv] = v;
+        __syncthreads();
+        uint32_t t = 0;
+        for (int k = 0; k < 16; k++) t += red[k];
+        return t;
+    };
+    uint32_t raw = 0, stored = 0;
+    for (uint32_t s = tid; s < n_slots; s += 1024u) {
+        raw += sc[s];
+        stored += min(sc[s], seg_cap);
+    }
+    raw = block_sum(raw);
+    stored = block_sum(stored);
+    if (tid == 0u) counts[f] = raw;
+    unsigned long long kth = 0ull;
+    if (stored > cap) {  // uniform
+        if (tid == 0u) {
+            sel_prefix = 0ull;
+            sel_want = cap;
+        }
+        unsigned long long known = 0ull;
+        for (int pass = 7; pass >= 0; pass--) {
+            if (tid < 256u) hist[tid] = 0u;
+            __syncthreads();
+            const unsigned long long prefix = sel_prefix;
+            for (uint32_t s = wv; s < n_slots; s += 16u) {  // one wave per slot
+                const uint32_t n = min(sc[s], seg_cap);
+                const size_t base = ((size_t)f * n_slots + s) * seg_cap;
+                for (uint32_t j = lane; j < n; j += 64u) {
+                    const unsigned long long k =
+                        select_key(*reinterpret_cast<const uint4*>(&segments[base + j]), seg_scores[base + j]);
+                    if ((k & known) == prefix) atomicAdd(&hist[(uint32_t)(k >> (8 * pass)) & 255u], 1u);
+                }
+            }
+            __syncthreads();
+            if (tid == 0u) {
+                uint32_t acc = 0, want = sel_want, digit = 0;
+                for (int b = 255; b >= 0; b--) {
+                    if (acc + hist[b] >= want) {
+                        digit = (uint32_t)b;
+                        break;
+                    }
+                    acc += hist[b];
+                }
+                sel_want = want - acc;
+                sel_prefix = prefix | ((unsigned long long)digit << (8 * pass));
+            }
+            known |= 0xffull << (8 * pass);
+            __syncthreads();
+        }
+        kth = sel_prefix;  // exactly `cap` keys are >= kth (keys are unique)
+    }
+    if (tid == 0u) thr_key[f] = kth;
+    // kept keypoints per slot -> exclusive prefix over the slots (in slot order)
+    __shared__ uint32_t carry;
+    if (tid == 0u) carry = 0u;
+    __syncthreads();
+    for (uint32_t s0 = 0; s0 < n_slots; s0 += 1024u) {
+        const uint32_t s = s0 + tid;
+        uint32_t kept = 0;
+        if (s < n_slots) {
+            const uint32_t n = min(sc[s], seg_cap);
+            if (kth == 0ull) {
+                kept = n;
+            } else {
+                const size_t base = ((size_t)f * n_slots + s) * seg_cap;
+                for (uint32_t j = 0; j < n; j++)
+                    kept += select_key(*reinterpret_cast<const uint4*>(&segments[base + j]), seg_scores[base + j]) >= kth ? 1u : 0u;
+            }
+        }
+        // block-wide exclusive scan of `kept`
+        uint32_t incl = kept;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += t;
+        }
+        __syncthreads();
+        if (lane == 63u) red[wv] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0, total = 0;
+        for (uint32_t k = 0; k < 16u; k++) {
+            if (k < wv) wave_off += red[k];
+            total += red[k];
+        }
+        if (s < n_slots) sb[s] = carry + wave_off + incl - kept;
+        __syncthreads();
+        if (tid == 0u) carry += total;
+        __syncthreads();
+    }
+}
+
+// Rotated BRIEF-256 of the kept keypoints of one tile (IM-6: R(+theta), full-circle table).  The blur window the
+// tile's keypoints can sample, widened to 16-byte columns ([y0-18, y0+16+18) x [cx0-24, cx0+tw+24), texels outside
+// the level = 0, CRD-6), is staged in LDS with 16-byte loads; the kept keypoints are dealt to the four waves
+// round-robin, one wave64 per keypoint, lane l evaluates tests l, 64+l, 128+l, 192+l.
+struct IBriefGeom {
+    uint32_t n_slots, seg_cap;
+    uint32_t slot_base[kMaxLevels + 1];
+    uint32_t tw[kMaxLevels], n_ct[kMaxLevels];
+    uint32_t pitch;  // LDS row pitch in halfs: kITileW + 2 * kIBriefApronX
+};
+constexpr int kIBriefRows = kFrontRows + 2 * kBriefHalo;  // 52
+constexpr int kIBriefApronX = 24;                         // >= 18, multiple of 8
+
+__global__ __launch_bounds__(256) void k_brief_i(const uint16_t* __restrict__ blur, Pyramid pyr, IBriefGeom bg,
+                                                 const uint32_t* __restrict__ seg_counts,
+                                                 const uint32_t* __restrict__ seg_before,
+                                                 const unsigned long long* __restrict__ thr_key,
+                                                 const CornerData* __restrict__ segments,
+                                                 const float* __restrict__ seg_scores,
+                                                 CornerData* __restrict__ corners, uint32_t cap,
+                                                 CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t win[];  // kIBriefRows x pitch
+    __shared__ uint4 kept_rec[256];
+    __shared__ uint32_t wave_kept[4], kept_base;
+    const uint32_t slot = blockIdx.x, frame = blockIdx.y;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const size_t sidx = (size_t)frame * bg.n_slots + slot;
+    const uint32_t n = min(seg_counts[sidx], bg.seg_cap);
+    if (n == 0u) return;  // uniform
+    uint32_t lvl = 0;
+    for (uint32_t m = 1; m < pyr.depth; m++)
+        if (slot >= bg.slot_base[m]) lvl = m;
+    const uint32_t rel = slot - bg.slot_base[lvl];
+    const int band = (int)(rel / bg.n_ct[lvl]), ct = (int)(rel % bg.n_ct[lvl]);
+    const int w = (int)pyr.w[lvl], h = (int)pyr.h[lvl];
+    const int wy0 = band * kFrontRows - kBriefHalo, wx0 = ct * (int)bg.tw[lvl] - kIBriefApronX;
+    const int tw = min((int)bg.tw[lvl], w - ct * (int)bg.tw[lvl]);
+    const int pitch = (int)bg.pitch;
+    const uint16_t* plane = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
+    {   // stage the window in 8-texel groups
+        const int groups = (tw + 2 * kIBriefApronX + 7) >> 3;
+        const int n_items = kIBriefRows * groups;
+        const float inv_groups = 1.0f / (float)groups;
+        const bool vec_ok = (w & 7) == 0;
+        for (int i = (int)tid; i < n_items; i += 256) {
+            const int r = (int)(((float)i + 0.5f) * inv_groups);
+            const int c = (i - __mul24(r, groups)) * 8;
+            const int gy = wy0 + r, gx = wx0 + c;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (gy >= 0 && gy < h && gx + 8 > 0 && gx < w) {
+                const uint16_t* row = plane + (size_t)(uint32_t)__mul24(gy, w);
+                if (vec_ok && gx >= 0 && gx + 8 <= w) {
+                    v = *reinterpret_cast<const uint4*>(row + gx);
+                } else {
+                    uint32_t e[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) e[k] = (gx + k >= 0 && gx + k < w) ? (uint32_t)row[gx + k] : 0u;
+                    v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+                }
+            }
+            *reinterpret_cast<uint4*>(&win[__mul24(r, pitch) + c]) = v;
+        }
+    }
+    const unsigned long long kth = thr_key[frame];
+    const CornerData* seg = segments + sidx * bg.seg_cap;
+    const float* ssc = seg_scores + sidx * bg.seg_cap;
+    CornerData* out_kp = corners + (size_t)frame * cap;
+    uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)frame * cap);
+    uint32_t pat[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) pat[e] = tab.pattern[64u * (uint32_t)e + lane];
+    if (tid == 0u) kept_base = seg_before[sidx];
+    // chunks of 256 segment entries: kept entries are compacted (in segment order) into kept_rec, then dealt
+    // to the waves round-robin; final index = seg_before[slot] + rank among the kept entries of the tile.
+    for (uint32_t j0 = 0; j0 < n; j0 += 256u) {
+        const uint32_t j = j0 + tid;
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+        bool kept = false;
+        if (j < n) {
+            rec = *reinterpret_cast<const uint4*>(&seg[j]);
+            kept = kth == 0ull || select_key(rec, ssc[j]) >= kth;
+        }
+        const uint64_t mask = __ballot(kept);
+        __syncthreads();  // previous chunk's kept_rec fully consumed; (first chunk) window and kept_base visible
+        if (lane == 0u) wave_kept[wv] = (uint32_t)__builtin_popcountll(mask);
+        __syncthreads();
+        uint32_t off = 0;
+        for (uint32_t k = 0; k < wv; k++) off += wave_kept[k];
+        const uint32_t chunk_total = wave_kept[0] + wave_kept[1] + wave_kept[2] + wave_kept[3];
+        if (kept) kept_rec[off + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = rec;
+        __syncthreads();
+        const uint32_t base = kept_base;
+        for (uint32_t r = wv; r < chunk_total; r += 4u) {
+            const uint32_t k = base + r;
+            if (k >= cap) break;  // indices only grow
+            const uint4 kr = kept_rec[r];
+            const uint32_t code = min(kr.z, (uint32_t)(ORB_ANGLE_STEPS_FULL - 1));
+            const float ct_ = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
+            const int bx = (int)kr.x - wx0, by = (int)kr.y - wy0;  // keypoint inside the window
+            uint64_t bal[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
+                const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
+                // R(+theta) p = (ct*x - st*y, st*x + ct*y), products and sums rounded on their own (IM-6)
+                const float a0 = ct_ * pax, a1 = nst * pay, a2 = st * pax, a3 = ct_ * pay;
+                const float b0 = ct_ * pbx, b1 = nst * pby, b2 = st * pbx, b3 = ct_ * pby;
+                const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+                const uint32_t va = win[__mul24(by + (int)ray, pitch) + bx + (int)rax];
+                const uint32_t vb = win[__mul24(by + (int)rby, pitch) + bx + (int)rbx];
+                bal[e] = __ballot(va > vb);  // non-negative f16: bit patterns order like the values
+            }
+            if (lane < 8u) {
+                const uint64_t srcw = lane < 2u ? bal[0] : (lane < 4u ? bal[1] : (lane < 6u ? bal[2] : bal[3]));
+                out_desc[(size_t)k * 8u + lane] = (uint32_t)(srcw >> ((lane & 1u) * 32u));
+            } else if (lane == 8u) {
+                *reinterpret_cast<uint4*>(&out_kp[k]) = kr;
+            }
+        }
+        __syncthreads();
+        if (tid == 0u) kept_base = base + chunk_total;
+    }
+}
+
+}  // namespace orb
