@@ -71,7 +71,7 @@ __device__ __forceinline__ bool even_ring_filter(const half_t* ctr, int ls, floa
     return (try_over && has_run_bits(m_over, 8u, need)) || (try_under && has_run_bits(m_under, 8u, need));
 }
 
-// Segment test on the full ring (orc_fast_intended): corner <=> run of >= arc in either polarity.
+// Segment test on the full ring: corner <=> run of >= arc in either polarity.
 __device__ __forceinline__ bool ring_has_arc(const half_t* ctr, int ls, float thr, uint32_t arc) {
     const float c = from_half(ctr[0]);
     uint32_t m_over = 0, m_under = 0;
