@@ -220,7 +220,7 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
     for (uint32_t m = 0; m < D; m++) {  // orb.rs:432-466 (both passes)
         LaunchScope ls(p, s, KID_BLUR);
         if (p->intended) {
-            hipLaunchKernelGGL(k_gauss, dim3((pyr.w[m] + 63u) / 64u, (pyr.h[m] + 15u) / 16u, n), dim3(256), 0, s,
+            hipLaunchKernelGGL(k_gauss, dim3((pyr.w[m] + kGaussTW - 1u) / kGaussTW, (pyr.h[m] + kGaussTH - 1u) / kGaussTH, n), dim3(256), 0, s,
                                p->d_gray, p->d_blur, pyr, m);
             continue;
         }
@@ -455,7 +455,7 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
     }
     for (uint32_t m = 0; m < D; m++) {
         LaunchScope ls(p, s, KID_BLUR);
-        hipLaunchKernelGGL(k_gauss, dim3((pyr.w[m] + 63u) / 64u, (pyr.h[m] + 15u) / 16u, n), dim3(256), 0, s, p->d_gray,
+        hipLaunchKernelGGL(k_gauss, dim3((pyr.w[m] + kGaussTW - 1u) / kGaussTW, (pyr.h[m] + kGaussTH - 1u) / kGaussTH, n), dim3(256), 0, s, p->d_gray,
                            p->d_blur, pyr, m);
     }
     {
@@ -466,7 +466,9 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
     {
         LaunchScope ls(p, s, KID_BRIEF_I);
         const size_t lds = (size_t)kIBriefRows * bg.pitch * sizeof(uint16_t);
-        hipLaunchKernelGGL(k_brief_i, dim3(bg.n_slots, n), dim3(256), lds, s, p->d_blur, pyr, bg, p->d_iseg_counts,
+        IBriefGeom bgl = bg;
+        bgl.xcd_swizzle = (n % 8u == 0u) ? 1u : 0u;
+        hipLaunchKernelGGL(k_brief_i, dim3(bg.n_slots * n), dim3(256), lds, s, p->d_blur, pyr, bgl, p->d_iseg_counts,
                            p->d_iseg_before, p->d_thr_key, p->d_iseg, p->d_iseg_scores, p->d_corners, cap, p->d_desc,
                            BriefTables{p->d_pattern, p->d_cos, p->d_sin});
     }

@@ -620,6 +620,7 @@ struct IBriefGeom {
     uint32_t slot_base[kMaxLevels + 1];
     uint32_t tw[kMaxLevels], n_ct[kMaxLevels];
     uint32_t pitch;  // LDS row pitch in halfs: kITileW + 2 * kIBriefApronX
+    uint32_t xcd_swizzle;  // all tiles of a frame on one XCD: its blur planes stay in that L2
 };
 constexpr int kIBriefRows = kFrontRows + 2 * kBriefHalo;  // 52
 constexpr int kIBriefApronX = 24;                         // >= 18, multiple of 8
@@ -635,7 +636,15 @@ __global__ __launch_bounds__(256) void k_brief_i(const uint16_t* __restrict__ bl
     extern __shared__ __attribute__((aligned(16))) uint16_t win[];  // kIBriefRows x pitch
     __shared__ uint4 kept_rec[256];
     __shared__ uint32_t wave_kept[4], kept_base;
-    const uint32_t slot = blockIdx.x, frame = blockIdx.y;
+    uint32_t slot, frame;
+    if (bg.xcd_swizzle) {
+        const uint32_t xcd = blockIdx.x & 7u, s2 = blockIdx.x >> 3;
+        frame = (s2 / bg.n_slots) * 8u + xcd;
+        slot = s2 % bg.n_slots;
+    } else {
+        frame = blockIdx.x / bg.n_slots;
+        slot = blockIdx.x % bg.n_slots;
+    }
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const size_t sidx = (size_t)frame * bg.n_slots + slot;
     const uint32_t n = min(seg_counts[sidx], bg.seg_cap);
@@ -650,28 +659,46 @@ __global__ __launch_bounds__(256) void k_brief_i(const uint16_t* __restrict__ bl
     const int tw = min((int)bg.tw[lvl], w - ct * (int)bg.tw[lvl]);
     const int pitch = (int)bg.pitch;
     const uint16_t* plane = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
-    {   // stage the window in 8-texel groups
+    {   // stage the window in 8-texel groups; five 16-byte loads per thread are in flight (unconditional, from
+        // clamped addresses), groups that straddle the level's edge are patched texel by texel
         const int groups = (tw + 2 * kIBriefApronX + 7) >> 3;
         const int n_items = kIBriefRows * groups;
         const float inv_groups = 1.0f / (float)groups;
-        const bool vec_ok = (w & 7) == 0;
-        for (int i = (int)tid; i < n_items; i += 256) {
-            const int r = (int)(((float)i + 0.5f) * inv_groups);
-            const int c = (i - __mul24(r, groups)) * 8;
-            const int gy = wy0 + r, gx = wx0 + c;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (gy >= 0 && gy < h && gx + 8 > 0 && gx < w) {
-                const uint16_t* row = plane + (size_t)(uint32_t)__mul24(gy, w);
-                if (vec_ok && gx >= 0 && gx + 8 <= w) {
-                    v = *reinterpret_cast<const uint4*>(row + gx);
-                } else {
-                    uint32_t e[8];
+        const bool vec_ok = (w & 7) == 0 && w >= 8;
+        constexpr int U = 5;
+        for (int ib = (int)tid; ib < n_items; ib += 256 * U) {
+            uint4 v[U];
+            int dst[U], gxs[U], gys[U];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) e[k] = (gx + k >= 0 && gx + k < w) ? (uint32_t)row[gx + k] : 0u;
-                    v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-                }
+            for (int u = 0; u < U; u++) {
+                const int i = min(ib + u * 256, n_items - 1);
+                const int r = (int)(((float)i + 0.5f) * inv_groups);
+                const int c = (i - __mul24(r, groups)) * 8;
+                gys[u] = wy0 + r;
+                gxs[u] = wx0 + c;
+                dst[u] = (ib + u * 256) < n_items ? __mul24(r, pitch) + c : -1;
+                const int gyc = min(max(gys[u], 0), h - 1), gxc = vec_ok ? min(max(gxs[u], 0), w - 8) : 0;
+                v[u] = vec_ok ? *reinterpret_cast<const uint4*>(plane + (size_t)(uint32_t)(__mul24(gyc, w) + gxc))
+                              : make_uint4(0u, 0u, 0u, 0u);
             }
-            *reinterpret_cast<uint4*>(&win[__mul24(r, pitch) + c]) = v;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (dst[u] < 0) continue;
+                const int gy = gys[u], gx = gxs[u];
+                uint4 o = make_uint4(0u, 0u, 0u, 0u);
+                if (gy >= 0 && gy < h && gx + 8 > 0 && gx < w) {
+                    if (vec_ok && gx >= 0 && gx + 8 <= w) {
+                        o = v[u];
+                    } else {
+                        const uint16_t* row = plane + (size_t)(uint32_t)__mul24(gy, w);
+                        uint32_t e[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) e[k] = (gx + k >= 0 && gx + k < w) ? (uint32_t)row[gx + k] : 0u;
+                        o = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+                    }
+                }
+                *reinterpret_cast<uint4*>(&win[dst[u]]) = o;
+            }
         }
     }
     const unsigned long long kth = thr_key[frame];

@@ -119,49 +119,105 @@ __global__ __launch_bounds__(256) void k_blur_rows(const uint16_t* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // "intended" mode IM-3 (not in the reference, which runs its X shader twice with UV-unit offsets): separable
-// 7-tap Gaussian, X pass then Y pass, both f16-rounded.  One block = a 64x16 tile: the grey tile with a 3-px
-// halo (clamp-to-edge) goes to LDS, the X pass fills (16+6) x 64 intermediate values in LDS, the Y pass writes.
-// grid: (ceil(w/64), ceil(h/16), frames)
+// 7-tap Gaussian, X pass then Y pass, both f16-rounded.  One block = a 256x16 tile: the grey tile with a 3-px
+// apron (clamp-to-edge) goes to LDS as f16 (16-byte loads inside the level), the X pass (4 outputs per thread
+// from 10 inputs) fills (16+6) x 256 f16 intermediate values in LDS, the Y pass (2 columns x 8 rows per thread
+// from 14 rows) writes 4-byte pairs.
+// grid: (ceil(w/256), ceil(h/16), frames)
 // ---------------------------------------------------------------------------------------------
+constexpr int kGaussTW = 256, kGaussTH = 16, kGaussPad = 8;
+constexpr int kGaussPitch = kGaussTW + 2 * kGaussPad;  // grey tile: LDS column kGaussPad <-> image column bx
+
+__device__ __forceinline__ float gauss7(const float (&t)[7]) {
+    float acc = kGauss[0] * t[3];
+#pragma unroll
+    for (int k = 1; k <= 3; k++) {
+        const float pair = t[3 - k] + t[3 + k];
+        const float term = kGauss[k] * pair;
+        acc = acc + term;
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void k_gauss(const uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                                Pyramid pyr, uint32_t m) {
-    constexpr int TW = 64, TH = 16, R = 3;
-    __shared__ float src[TH + 2 * R][TW + 2 * R + 2];
-    __shared__ float mid[TH + 2 * R][TW];
+    constexpr int TW = kGaussTW, TH = kGaussTH, R = 3, ROWS = TH + 2 * R;
+    __shared__ __attribute__((aligned(16))) uint16_t src[ROWS * kGaussPitch];
+    __shared__ __attribute__((aligned(16))) uint16_t mid[ROWS * TW];
     const int w = (int)pyr.w[m], h = (int)pyr.h[m];
     const size_t base = (size_t)blockIdx.z * pyr.stride + pyr.off[m];
+    const uint16_t* plane = gray + base;
     const int bx = (int)blockIdx.x * TW, by = (int)blockIdx.y * TH;
     const int tid = (int)threadIdx.x;
-    for (int i = tid; i < (TH + 2 * R) * (TW + 2 * R); i += 256) {
-        const int ty = i / (TW + 2 * R), tx = i - ty * (TW + 2 * R);
-        const int gx = min(max(bx + tx - R, 0), w - 1), gy = min(max(by + ty - R, 0), h - 1);
-        src[ty][tx] = from_half(bits_half(gray[base + (size_t)gy * w + gx]));
+    {   // 8-texel groups: columns [bx - 8, bx + TW + 8), rows [by - 3, by + TH + 3), indices clamped to the level
+        constexpr int G = kGaussPitch / 8;
+        const bool vec_ok = (w & 7) == 0;
+        for (int i = tid; i < ROWS * G; i += 256) {
+            const int r = i / G, g = i - r * G;
+            const int gy = min(max(by + r - R, 0), h - 1), gx = bx - kGaussPad + g * 8;
+            const uint16_t* row = plane + (size_t)gy * w;
+            uint4 v;
+            if (vec_ok && gx >= 0 && gx + 8 <= w) {
+                v = *reinterpret_cast<const uint4*>(row + gx);
+            } else {
+                uint32_t e[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) e[k] = row[min(max(gx + k, 0), w - 1)];
+                v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+            }
+            *reinterpret_cast<uint4*>(&src[r * kGaussPitch + g * 8]) = v;
+        }
     }
     __syncthreads();
-    for (int i = tid; i < (TH + 2 * R) * TW; i += 256) {
-        const int ty = i / TW, tx = i - ty * TW;
-        float acc = kGauss[0] * src[ty][tx + R];
+    // X pass: item = 4 consecutive columns of one row; inputs x-3 .. x+6 = 12 halfs from three 8-byte reads
+    for (int i = tid; i < ROWS * (TW / 4); i += 256) {
+        const int r = i / (TW / 4), x = (i - r * (TW / 4)) * 4;
+        const uint16_t* p = &src[r * kGaussPitch + kGaussPad + x - 4];
+        const uint2 q0 = *reinterpret_cast<const uint2*>(p), q1 = *reinterpret_cast<const uint2*>(p + 4),
+                    q2 = *reinterpret_cast<const uint2*>(p + 8);
+        const uint32_t wds[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
+        float f[12];
 #pragma unroll
-        for (int k = 1; k <= R; k++) {
-            const float pair = src[ty][tx + R - k] + src[ty][tx + R + k];
-            const float term = kGauss[k] * pair;
-            acc = acc + term;
+        for (int k = 0; k < 6; k++) {
+            f[2 * k] = from_half(bits_half((uint16_t)(wds[k] & 0xffffu)));
+            f[2 * k + 1] = from_half(bits_half((uint16_t)(wds[k] >> 16)));
         }
-        mid[ty][tx] = from_half(to_half(acc));
+        uint16_t o[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {  // output column x + c: taps f[c + 1 .. c + 7]
+            const float t[7] = {f[c + 1], f[c + 2], f[c + 3], f[c + 4], f[c + 5], f[c + 6], f[c + 7]};
+            o[c] = half_bits(to_half(gauss7(t)));
+        }
+        *reinterpret_cast<uint2*>(&mid[r * TW + x]) = make_uint2(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16));
     }
     __syncthreads();
-    for (int i = tid; i < TH * TW; i += 256) {
-        const int ty = i / TW, tx = i - ty * TW;
-        const int gx = bx + tx, gy = by + ty;
-        if (gx >= w || gy >= h) continue;
-        float acc = kGauss[0] * mid[ty + R][tx];
+    // Y pass: item = 2 columns x 8 rows; 14 intermediate rows per item
+    {
+        const int x = (tid & 127) * 2, r0 = (tid >> 7) * 8;  // 128 column pairs x 2 row groups = 256 threads
+        float lo[14], hi[14];
 #pragma unroll
-        for (int k = 1; k <= R; k++) {
-            const float pair = mid[ty + R - k][tx] + mid[ty + R + k][tx];
-            const float term = kGauss[k] * pair;
-            acc = acc + term;
+        for (int k = 0; k < 14; k++) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(&mid[(r0 + k) * TW + x]);
+            lo[k] = from_half(bits_half((uint16_t)(v & 0xffffu)));
+            hi[k] = from_half(bits_half((uint16_t)(v >> 16)));
         }
-        blur[base + (size_t)gy * w + gx] = half_bits(to_half(acc));
+        const int gx = bx + x;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int gy = by + r0 + k;
+            const float ta[7] = {lo[k], lo[k + 1], lo[k + 2], lo[k + 3], lo[k + 4], lo[k + 5], lo[k + 6]};
+            const float tb[7] = {hi[k], hi[k + 1], hi[k + 2], hi[k + 3], hi[k + 4], hi[k + 5], hi[k + 6]};
+            const uint32_t oa = half_bits(to_half(gauss7(ta))), ob = half_bits(to_half(gauss7(tb)));
+            if (gy < h && gx < w) {
+                uint16_t* out = blur + base + (size_t)gy * w + gx;
+                if (gx + 1 < w && (w & 1) == 0)
+                    *reinterpret_cast<uint32_t*>(out) = oa | (ob << 16);
+                else {
+                    out[0] = (uint16_t)oa;
+                    if (gx + 1 < w) out[1] = (uint16_t)ob;
+                }
+            }
+        }
     }
 }
 
