@@ -66,6 +66,7 @@ struct OrbProgram {
     uint32_t* d_iseg_counts = nullptr;
     uint32_t* d_iseg_before = nullptr;
     unsigned long long* d_thr_key = nullptr;
+    uint32_t ibrief_lds = 0;
     uint32_t* d_prov2_counts = nullptr;
     CornerData* d_prov2 = nullptr;
     float* d_prov2_scores = nullptr;
@@ -465,12 +466,11 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
     }
     {
         LaunchScope ls(p, s, KID_BRIEF_I);
-        const size_t lds = (size_t)kIBriefRows * bg.pitch * sizeof(uint16_t);
         IBriefGeom bgl = bg;
         bgl.xcd_swizzle = (n % 8u == 0u) ? 1u : 0u;
-        hipLaunchKernelGGL(k_brief_i, dim3(bg.n_slots * n), dim3(256), lds, s, p->d_blur, pyr, bgl, p->d_iseg_counts,
-                           p->d_iseg_before, p->d_thr_key, p->d_iseg, p->d_iseg_scores, p->d_corners, cap, p->d_desc,
-                           BriefTables{p->d_pattern, p->d_cos, p->d_sin});
+        hipLaunchKernelGGL(k_brief_i, dim3(bg.group_base[D] * n), dim3(kIBriefThreads), p->ibrief_lds, s, p->d_blur, pyr, bgl,
+                           p->d_iseg_counts, p->d_iseg_before, p->d_thr_key, p->d_iseg, p->d_iseg_scores, p->d_corners, cap,
+                           p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin});
     }
     HIP_TRY(p, hipGetLastError());
     p->planes_valid = true;
@@ -614,9 +614,25 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         }
         bg.slot_base[p->pyr.depth] = slots;
         bg.n_slots = slots;
+        uint32_t groups = 0, max_rows = 0;
+        for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
+            bg.n_bands[lvl] = (p->pyr.h[lvl] + kFrontRows - 1) / kFrontRows;
+            bg.group_base[lvl] = groups;
+            groups += ((bg.n_bands[lvl] + kIBriefStack - 1) / kIBriefStack) * bg.n_ct[lvl];
+            const uint32_t rows = std::min<uint32_t>(bg.n_bands[lvl], kIBriefStack) * kFrontRows + 2u * kBriefHalo;
+            if (rows > max_rows) max_rows = rows;
+        }
+        bg.group_base[p->pyr.depth] = groups;
         const uint64_t tile_px = (uint64_t)kFrontRows * bg.tw[0];
         bg.seg_cap = (uint32_t)(tile_px < config->max_features ? tile_px : config->max_features);
         bg.pitch = (uint32_t)kITileW + 2u * kIBriefApronX;
+        p->ibrief_lds = max_rows * bg.pitch * (uint32_t)sizeof(uint16_t);
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_brief_i),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->ibrief_lds);
+        if (ea != hipSuccess) {
+            fail(p, ORB_EHIP, "hipFuncSetAttribute(k_brief_i): %s", hipGetErrorString(ea));
+            return bail(ORB_EHIP);
+        }
     }
     const size_t B = p->max_batch, cap = config->max_features;
     CREATE_TRY(hipMalloc(&p->d_gray, B * p->pyr.stride * sizeof(uint16_t)));

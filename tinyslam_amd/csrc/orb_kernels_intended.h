@@ -611,72 +611,81 @@ __global__ __launch_bounds__(1024) void k_select_i(const uint32_t* __restrict__ 
     }
 }
 
-// Rotated BRIEF-256 of the kept keypoints of one tile (IM-6: R(+theta), full-circle table).  The blur window the
-// tile's keypoints can sample, widened to 16-byte columns ([y0-18, y0+16+18) x [cx0-24, cx0+tw+24), texels outside
-// the level = 0, CRD-6), is staged in LDS with 16-byte loads; the kept keypoints are dealt to the four waves
-// round-robin, one wave64 per keypoint, lane l evaluates tests l, 64+l, 128+l, 192+l.
+// Rotated BRIEF-256 of the kept keypoints (IM-6: R(+theta), full-circle table).  A workgroup takes a column of
+// kIBriefStack vertically adjacent tiles: the blur window their keypoints can sample, widened to 16-byte columns
+// ([y0-18, y0+16*stack+18) x [cx0-24, cx0+tw+24), texels outside the level = 0, CRD-6), is staged in LDS once with
+// 16-byte loads (a single tile's window would be 3.25x its own rows, the stack's is 1.56x); the kept keypoints of
+// each tile are dealt to the eight waves round-robin, one wave64 per keypoint, lane l evaluates tests l, 64+l,
+// 128+l, 192+l.
+constexpr int kIBriefStack = 4;
+constexpr int kIBriefThreads = 512;
+constexpr int kIBriefRowsMax = kFrontRows * kIBriefStack + 2 * kBriefHalo;  // 100
+constexpr int kIBriefApronX = 24;                                            // >= 18, multiple of 8
 struct IBriefGeom {
     uint32_t n_slots, seg_cap;
     uint32_t slot_base[kMaxLevels + 1];
-    uint32_t tw[kMaxLevels], n_ct[kMaxLevels];
-    uint32_t pitch;  // LDS row pitch in halfs: kITileW + 2 * kIBriefApronX
-    uint32_t xcd_swizzle;  // all tiles of a frame on one XCD: its blur planes stay in that L2
+    uint32_t tw[kMaxLevels], n_ct[kMaxLevels], n_bands[kMaxLevels];
+    uint32_t group_base[kMaxLevels + 1];  // first stack of each level; [depth] = stacks per frame
+    uint32_t pitch;        // LDS row pitch in halfs: kITileW + 2 * kIBriefApronX
+    uint32_t xcd_swizzle;  // all stacks of a frame on one XCD: its blur planes stay in that L2
 };
-constexpr int kIBriefRows = kFrontRows + 2 * kBriefHalo;  // 52
-constexpr int kIBriefApronX = 24;                         // >= 18, multiple of 8
 
-__global__ __launch_bounds__(256) void k_brief_i(const uint16_t* __restrict__ blur, Pyramid pyr, IBriefGeom bg,
-                                                 const uint32_t* __restrict__ seg_counts,
-                                                 const uint32_t* __restrict__ seg_before,
-                                                 const unsigned long long* __restrict__ thr_key,
-                                                 const CornerData* __restrict__ segments,
-                                                 const float* __restrict__ seg_scores,
-                                                 CornerData* __restrict__ corners, uint32_t cap,
-                                                 CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t win[];  // kIBriefRows x pitch
+__global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __restrict__ blur, Pyramid pyr,
+                                                            IBriefGeom bg, const uint32_t* __restrict__ seg_counts,
+                                                            const uint32_t* __restrict__ seg_before,
+                                                            const unsigned long long* __restrict__ thr_key,
+                                                            const CornerData* __restrict__ segments,
+                                                            const float* __restrict__ seg_scores,
+                                                            CornerData* __restrict__ corners, uint32_t cap,
+                                                            CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
+    constexpr int NT = kIBriefThreads, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) uint16_t win[];  // up to kIBriefRowsMax x pitch
     __shared__ uint4 kept_rec[256];
-    __shared__ uint32_t wave_kept[4], kept_base;
-    uint32_t slot, frame;
+    __shared__ uint32_t wave_kept[4];
+    const uint32_t n_groups = bg.group_base[pyr.depth];
+    uint32_t group, frame;
     if (bg.xcd_swizzle) {
         const uint32_t xcd = blockIdx.x & 7u, s2 = blockIdx.x >> 3;
-        frame = (s2 / bg.n_slots) * 8u + xcd;
-        slot = s2 % bg.n_slots;
+        frame = (s2 / n_groups) * 8u + xcd;
+        group = s2 % n_groups;
     } else {
-        frame = blockIdx.x / bg.n_slots;
-        slot = blockIdx.x % bg.n_slots;
+        frame = blockIdx.x / n_groups;
+        group = blockIdx.x % n_groups;
     }
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const size_t sidx = (size_t)frame * bg.n_slots + slot;
-    const uint32_t n = min(seg_counts[sidx], bg.seg_cap);
-    if (n == 0u) return;  // uniform
     uint32_t lvl = 0;
     for (uint32_t m = 1; m < pyr.depth; m++)
-        if (slot >= bg.slot_base[m]) lvl = m;
-    const uint32_t rel = slot - bg.slot_base[lvl];
-    const int band = (int)(rel / bg.n_ct[lvl]), ct = (int)(rel % bg.n_ct[lvl]);
+        if (group >= bg.group_base[m]) lvl = m;
+    const uint32_t rel = group - bg.group_base[lvl];
+    const int band0 = (int)(rel / bg.n_ct[lvl]) * kIBriefStack, ct = (int)(rel % bg.n_ct[lvl]);
+    const int nb = min(kIBriefStack, (int)bg.n_bands[lvl] - band0);  // tiles in this stack
+    const size_t sidx0 = (size_t)frame * bg.n_slots + bg.slot_base[lvl] + (size_t)band0 * bg.n_ct[lvl] + ct;
+    uint32_t total = 0;
+    for (int t = 0; t < nb; t++) total += min(seg_counts[sidx0 + (size_t)t * bg.n_ct[lvl]], bg.seg_cap);
+    if (total == 0u) return;  // uniform
     const int w = (int)pyr.w[lvl], h = (int)pyr.h[lvl];
-    const int wy0 = band * kFrontRows - kBriefHalo, wx0 = ct * (int)bg.tw[lvl] - kIBriefApronX;
+    const int wy0 = band0 * kFrontRows - kBriefHalo, wx0 = ct * (int)bg.tw[lvl] - kIBriefApronX;
     const int tw = min((int)bg.tw[lvl], w - ct * (int)bg.tw[lvl]);
     const int pitch = (int)bg.pitch;
     const uint16_t* plane = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
     {   // stage the window in 8-texel groups; five 16-byte loads per thread are in flight (unconditional, from
         // clamped addresses), groups that straddle the level's edge are patched texel by texel
         const int groups = (tw + 2 * kIBriefApronX + 7) >> 3;
-        const int n_items = kIBriefRows * groups;
+        const int n_items = (nb * kFrontRows + 2 * kBriefHalo) * groups;
         const float inv_groups = 1.0f / (float)groups;
         const bool vec_ok = (w & 7) == 0 && w >= 8;
         constexpr int U = 5;
-        for (int ib = (int)tid; ib < n_items; ib += 256 * U) {
+        for (int ib = (int)tid; ib < n_items; ib += NT * U) {
             uint4 v[U];
             int dst[U], gxs[U], gys[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int i = min(ib + u * 256, n_items - 1);
+                const int i = min(ib + u * NT, n_items - 1);
                 const int r = (int)(((float)i + 0.5f) * inv_groups);
                 const int c = (i - __mul24(r, groups)) * 8;
                 gys[u] = wy0 + r;
                 gxs[u] = wx0 + c;
-                dst[u] = (ib + u * 256) < n_items ? __mul24(r, pitch) + c : -1;
+                dst[u] = (ib + u * NT) < n_items ? __mul24(r, pitch) + c : -1;
                 const int gyc = min(max(gys[u], 0), h - 1), gxc = vec_ok ? min(max(gxs[u], 0), w - 8) : 0;
                 v[u] = vec_ok ? *reinterpret_cast<const uint4*>(plane + (size_t)(uint32_t)(__mul24(gyc, w) + gxc))
                               : make_uint4(0u, 0u, 0u, 0u);
@@ -702,63 +711,65 @@ __global__ __launch_bounds__(256) void k_brief_i(const uint16_t* __restrict__ bl
         }
     }
     const unsigned long long kth = thr_key[frame];
-    const CornerData* seg = segments + sidx * bg.seg_cap;
-    const float* ssc = seg_scores + sidx * bg.seg_cap;
     CornerData* out_kp = corners + (size_t)frame * cap;
     uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)frame * cap);
     uint32_t pat[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) pat[e] = tab.pattern[64u * (uint32_t)e + lane];
-    if (tid == 0u) kept_base = seg_before[sidx];
-    // chunks of 256 segment entries: kept entries are compacted (in segment order) into kept_rec, then dealt
-    // to the waves round-robin; final index = seg_before[slot] + rank among the kept entries of the tile.
-    for (uint32_t j0 = 0; j0 < n; j0 += 256u) {
-        const uint32_t j = j0 + tid;
-        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-        bool kept = false;
-        if (j < n) {
-            rec = *reinterpret_cast<const uint4*>(&seg[j]);
-            kept = kth == 0ull || select_key(rec, ssc[j]) >= kth;
-        }
-        const uint64_t mask = __ballot(kept);
-        __syncthreads();  // previous chunk's kept_rec fully consumed; (first chunk) window and kept_base visible
-        if (lane == 0u) wave_kept[wv] = (uint32_t)__builtin_popcountll(mask);
-        __syncthreads();
-        uint32_t off = 0;
-        for (uint32_t k = 0; k < wv; k++) off += wave_kept[k];
-        const uint32_t chunk_total = wave_kept[0] + wave_kept[1] + wave_kept[2] + wave_kept[3];
-        if (kept) kept_rec[off + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = rec;
-        __syncthreads();
-        const uint32_t base = kept_base;
-        for (uint32_t r = wv; r < chunk_total; r += 4u) {
-            const uint32_t k = base + r;
-            if (k >= cap) break;  // indices only grow
-            const uint4 kr = kept_rec[r];
-            const uint32_t code = min(kr.z, (uint32_t)(ORB_ANGLE_STEPS_FULL - 1));
-            const float ct_ = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
-            const int bx = (int)kr.x - wx0, by = (int)kr.y - wy0;  // keypoint inside the window
-            uint64_t bal[4];
+    for (int t = 0; t < nb; t++) {  // tile by tile: final index = seg_before[tile] + rank among its kept entries
+        const size_t sidx = sidx0 + (size_t)t * bg.n_ct[lvl];
+        const uint32_t n = min(seg_counts[sidx], bg.seg_cap);
+        const CornerData* seg = segments + sidx * bg.seg_cap;
+        const float* ssc = seg_scores + sidx * bg.seg_cap;
+        uint32_t base = seg_before[sidx];
+        // chunks of 256 entries: the first four waves decide "kept" and compact the records (in segment order)
+        // into kept_rec, then all eight waves describe them
+        for (uint32_t j0 = 0; j0 < n; j0 += 256u) {
+            const uint32_t j = j0 + tid;
+            uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+            bool kept = false;
+            if (tid < 256u && j < n) {
+                rec = *reinterpret_cast<const uint4*>(&seg[j]);
+                kept = kth == 0ull || select_key(rec, ssc[j]) >= kth;
+            }
+            const uint64_t mask = __ballot(kept);
+            __syncthreads();  // previous chunk's kept_rec consumed; (first chunk) the window is complete
+            if (lane == 0u && wv < 4u) wave_kept[wv] = (uint32_t)__builtin_popcountll(mask);
+            __syncthreads();
+            uint32_t off = 0;
+            for (uint32_t k = 0; k < wv && k < 4u; k++) off += wave_kept[k];
+            const uint32_t chunk_total = wave_kept[0] + wave_kept[1] + wave_kept[2] + wave_kept[3];
+            if (kept) kept_rec[off + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = rec;
+            __syncthreads();
+            for (uint32_t r = wv; r < chunk_total; r += NW) {
+                const uint32_t k = base + r;
+                if (k >= cap) break;  // indices only grow
+                const uint4 kr = kept_rec[r];
+                const uint32_t code = min(kr.z, (uint32_t)(ORB_ANGLE_STEPS_FULL - 1));
+                const float ct_ = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
+                const int bx = (int)kr.x - wx0, by = (int)kr.y - wy0;  // keypoint inside the window
+                uint64_t bal[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
-                const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
-                // R(+theta) p = (ct*x - st*y, st*x + ct*y), products and sums rounded on their own (IM-6)
-                const float a0 = ct_ * pax, a1 = nst * pay, a2 = st * pax, a3 = ct_ * pay;
-                const float b0 = ct_ * pbx, b1 = nst * pby, b2 = st * pbx, b3 = ct_ * pby;
-                const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
-                const uint32_t va = win[__mul24(by + (int)ray, pitch) + bx + (int)rax];
-                const uint32_t vb = win[__mul24(by + (int)rby, pitch) + bx + (int)rbx];
-                bal[e] = __ballot(va > vb);  // non-negative f16: bit patterns order like the values
+                for (int e = 0; e < 4; e++) {
+                    const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
+                    const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
+                    // R(+theta) p = (ct*x - st*y, st*x + ct*y), products and sums rounded on their own (IM-6)
+                    const float a0 = ct_ * pax, a1 = nst * pay, a2 = st * pax, a3 = ct_ * pay;
+                    const float b0 = ct_ * pbx, b1 = nst * pby, b2 = st * pbx, b3 = ct_ * pby;
+                    const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+                    const uint32_t va = win[__mul24(by + (int)ray, pitch) + bx + (int)rax];
+                    const uint32_t vb = win[__mul24(by + (int)rby, pitch) + bx + (int)rbx];
+                    bal[e] = __ballot(va > vb);  // non-negative f16: bit patterns order like the values
+                }
+                if (lane < 8u) {
+                    const uint64_t srcw = lane < 2u ? bal[0] : (lane < 4u ? bal[1] : (lane < 6u ? bal[2] : bal[3]));
+                    out_desc[(size_t)k * 8u + lane] = (uint32_t)(srcw >> ((lane & 1u) * 32u));
+                } else if (lane == 8u) {
+                    *reinterpret_cast<uint4*>(&out_kp[k]) = kr;
+                }
             }
-            if (lane < 8u) {
-                const uint64_t srcw = lane < 2u ? bal[0] : (lane < 4u ? bal[1] : (lane < 6u ? bal[2] : bal[3]));
-                out_desc[(size_t)k * 8u + lane] = (uint32_t)(srcw >> ((lane & 1u) * 32u));
-            } else if (lane == 8u) {
-                *reinterpret_cast<uint4*>(&out_kp[k]) = kr;
-            }
+            base += chunk_total;
         }
-        __syncthreads();
-        if (tid == 0u) kept_base = base + chunk_total;
     }
 }
 
