@@ -138,6 +138,24 @@ int orb_batch_select_output(OrbProgram *p, uint32_t set);
  * counts[max_batch] u32, corners[max_batch][max_features], descriptors[max_batch][max_features]. */
 int orb_batch_device_buffers(OrbProgram *p, void **counts, void **corners, void **descriptors);
 
+/* ---- descriptor matching (the SLAM stage that consumes this path's output; NOT in the
+ * reference, definition is the build's own) ----
+ * Brute-force Hamming matching between consecutive frames of the last batch: for every stored keypoint i of frame
+ * f (query) the stored keypoint j of frame f+1 with the smallest popcount(desc_f[i] ^ desc_f+1[j]); ties go to the
+ * smallest j.  `second` is the smallest distance over all other j (for a ratio test).  Without candidates:
+ * index = ORB_MATCH_NONE, distance = second = 0xffff; with one candidate second = 0xffff. */
+typedef struct {
+    uint32_t index;
+    uint16_t distance;
+    uint16_t second;
+} OrbMatch;
+#define ORB_MATCH_NONE 0xffffffffu
+/* Matches frame f against f+1 for f in [0, n_frames - 1) of the last batch, asynchronously on `stream` (NULL: the
+ * program's stream; it is ordered after the batch that produced the descriptors when that ran on the same stream). */
+int orb_match_consecutive(OrbProgram *p, uint32_t n_frames, void *stream);
+/* Copy up to n matches of the queries of `frame` to the host (synchronises). */
+int orb_match_read(OrbProgram *p, uint32_t frame, OrbMatch *dst, size_t n);
+
 /* ---- inspection (parity tests) ---- */
 #define ORB_PLANE_GRAY 0
 #define ORB_PLANE_BLUR 1
@@ -151,7 +169,7 @@ int orb_debug_f32_to_f16(OrbProgram *p, const float *src, uint16_t *dst, size_t 
 int orb_debug_angle_code(OrbProgram *p, const float *cy, const float *cx, uint32_t *dst, size_t n);
 
 /* ---- measurement ---- */
-#define ORB_KERNEL_COUNT 13
+#define ORB_KERNEL_COUNT 14
 /* When enabled every kernel launch is bracketed by hipEvents on its stream. */
 int orb_profile_enable(OrbProgram *p, int enable);
 int orb_profile_reset(OrbProgram *p);

@@ -551,3 +551,28 @@ def extract_intended(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, a
     total = kps.shape[0]
     kps = topk(kps, scores, max_features)
     return dict(total=total, corners=kps, descriptors=brief_intended(blur, kps), gray=gray, blur=blur)
+
+
+# ------------------------------------------------------------------ descriptor matching (definition: include/tinyorb.h)
+def match(desc_a, desc_b):
+    """Brute-force Hamming match of every row of desc_a (u32 (n, 8)) against desc_b; ties to the smallest index.
+    Returns (index u32, distance u16, second u16)."""
+    desc_a = np.asarray(desc_a, dtype=np.uint32).reshape(-1, 8)
+    desc_b = np.asarray(desc_b, dtype=np.uint32).reshape(-1, 8)
+    na, nb = desc_a.shape[0], desc_b.shape[0]
+    index = np.full(na, 0xFFFFFFFF, dtype=np.uint32)
+    dist = np.full(na, 0xFFFF, dtype=np.uint16)
+    second = np.full(na, 0xFFFF, dtype=np.uint16)
+    if nb == 0:
+        return index, dist, second
+    bits_b = np.unpackbits(desc_b.view(np.uint8), axis=1)
+    for i0 in range(0, na, 256):
+        bits_a = np.unpackbits(desc_a[i0:i0 + 256].view(np.uint8), axis=1)
+        d = (bits_a[:, None, :] != bits_b[None, :, :]).sum(axis=2).astype(np.int64)
+        j = d.argmin(axis=1)  # first minimum
+        index[i0:i0 + 256] = j
+        dist[i0:i0 + 256] = d[np.arange(d.shape[0]), j]
+        if nb > 1:
+            d[np.arange(d.shape[0]), j] = 1 << 20
+            second[i0:i0 + 256] = d.min(axis=1)
+    return index, dist, second

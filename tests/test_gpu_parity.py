@@ -408,3 +408,30 @@ def test_intended_pathological_dense_tile(tinyorb, oracle):
             for k in ("octave", "y", "x", "angle"):
                 assert np.array_equal(c[k], rc[k]), k
             assert np.array_equal(d, rd)
+
+
+# ---------------------------------------------------------------------------------------------
+# Hamming matcher between consecutive frames (not in the reference): GPU vs NumPy brute force
+# ---------------------------------------------------------------------------------------------
+def test_match_consecutive_frames(tinyorb, oracle):
+    from oracle import orb_numpy
+    W, H, cap = 320, 240, 600
+    base = oracle.synth_frame(W + 8, H + 6, 300)
+    frames = np.stack([np.ascontiguousarray(base[dy:dy + H, dx:dx + W]) for dx, dy in ((0, 0), (3, 2), (8, 6))]
+                      + [np.zeros((H, W, 4), np.uint8)])  # three shifted views of one scene, then an empty frame
+    with _program(tinyorb, W, H, 2, max_features=cap, max_batch=4) as prog:
+        prog.extract_batch_host(frames)
+        counts = np.minimum(prog.batch_counts(4), cap)
+        assert counts[0] > 200 and counts[3] == 0
+        desc = [prog.batch_read(f, int(counts[f]))[1] for f in range(4)]
+        prog.match_consecutive(4)
+        for f in range(3):
+            got = prog.match_read(f, int(counts[f]))
+            idx, dist, second = orb_numpy.match(desc[f], desc[f + 1])
+            assert np.array_equal(got["index"], idx) and np.array_equal(got["distance"], dist)
+            assert np.array_equal(got["second"], second)
+        m01 = prog.match_read(0, int(counts[0]))
+        assert float(np.mean(m01["distance"] < 40)) > 0.1  # a shifted scene: a good share of close matches
+        assert (prog.match_read(2, int(counts[2]))["index"] == tinyorb.ORB_MATCH_NONE).all()
+        with pytest.raises(tinyorb.OrbError):
+            prog.match_consecutive(5)

@@ -24,10 +24,10 @@ using namespace orb;
 
 namespace {
 
-enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I };
+enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I, KID_MATCH };
 const char* const kKernelNames[ORB_KERNEL_COUNT] = {"k_grayscale", "k_mip",      "k_blur_rows", "k_fast",       "k_brief",
                                                     "k_front_l0",  "k_front_ln", "k_synth",     "k_brief_rows", "k_slot_prefix",
-                                                    "k_front_i",   "k_select_i", "k_brief_i"};
+                                                    "k_front_i",   "k_select_i", "k_brief_i",   "k_match"};
 
 thread_local std::string g_create_error;
 
@@ -67,6 +67,7 @@ struct OrbProgram {
     uint32_t* d_iseg_before = nullptr;
     unsigned long long* d_thr_key = nullptr;
     uint32_t ibrief_lds = 0;
+    MatchRecord* d_matches = nullptr;  // [max_batch][max_features], allocated by the first orb_match_consecutive
     uint32_t* d_prov2_counts = nullptr;
     CornerData* d_prov2 = nullptr;
     float* d_prov2_scores = nullptr;
@@ -733,6 +734,7 @@ void orb_program_destroy(OrbProgram* p) {
     (void)hipFree(p->d_prov_counts);
     (void)hipFree(p->d_prov);
     (void)hipFree(p->d_prov_scores);
+    (void)hipFree(p->d_matches);
     (void)hipFree(p->d_iseg);
     (void)hipFree(p->d_iseg_scores);
     (void)hipFree(p->d_iseg_counts);
@@ -906,6 +908,36 @@ int orb_batch_read(OrbProgram* p, uint32_t frame, CornerData* corners, CornerDes
     if (descriptors)
         HIP_TRY(p, hipMemcpy(descriptors, p->d_desc + (size_t)frame * cap, n * sizeof(CornerDescriptor),
                              hipMemcpyDeviceToHost));
+    return ORB_OK;
+}
+
+int orb_match_consecutive(OrbProgram* p, uint32_t n_frames, void* stream) {
+    if (!p) return ORB_EINVAL;
+    if (n_frames < 2u || n_frames > p->last_batch)
+        return fail(p, ORB_EINVAL, "match_consecutive: need 2..%u frames of the last batch", p->last_batch);
+    if (p->cfg.max_features > (1u << 23)) return fail(p, ORB_EINVAL, "match_consecutive: max_features must be <= 2^23");
+    HIP_TRY(p, hipSetDevice(p->device));
+    const size_t cap = p->cfg.max_features;
+    if (!p->d_matches) HIP_TRY(p, hipMalloc(&p->d_matches, (size_t)p->max_batch * cap * sizeof(MatchRecord)));
+    hipStream_t s = stream ? (hipStream_t)stream : (p->last_stream ? p->last_stream : p->stream);
+    {
+        LaunchScope ls(p, s, KID_MATCH);
+        hipLaunchKernelGGL(k_match, dim3(n_frames - 1u, (unsigned)((cap + 64u * kMatchQ - 1u) / (64u * kMatchQ))), dim3(64), 0, s, p->d_counts,
+                           p->d_desc, (uint32_t)cap, p->d_matches);
+    }
+    HIP_TRY(p, hipGetLastError());
+    p->last_stream = s;
+    return ORB_OK;
+}
+
+int orb_match_read(OrbProgram* p, uint32_t frame, OrbMatch* dst, size_t n) {
+    if (!p || !dst) return ORB_EINVAL;
+    if (!p->d_matches || frame + 1u >= p->last_batch) return fail(p, ORB_EINVAL, "match_read: no matches for frame %u", frame);
+    if (int rc = orb_batch_sync(p)) return rc;
+    const size_t cap = p->cfg.max_features;
+    if (n > cap) n = cap;
+    static_assert(sizeof(OrbMatch) == sizeof(MatchRecord), "OrbMatch layout");
+    HIP_TRY(p, hipMemcpy(dst, p->d_matches + (size_t)frame * cap, n * sizeof(OrbMatch), hipMemcpyDeviceToHost));
     return ORB_OK;
 }
 

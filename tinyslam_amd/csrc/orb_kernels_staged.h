@@ -541,6 +541,96 @@ __global__ __launch_bounds__(256) void k_brief(const uint16_t* __restrict__ blur
 }
 
 // ---------------------------------------------------------------------------------------------
+// Brute-force Hamming matcher (not in the reference).  Pair p = (frame p, frame p+1).
+// A wave holds kMatchQ x 64 query descriptors in registers (8 VGPRs each); the candidate is the same for every lane,
+// so its descriptor is read with one scalar load (8 SGPRs, the next one issued before the current is used) and
+// shared by the kMatchQ queries of a lane: per pair 8 x (xor, popcount) + key + max/min/min, no LDS.
+// grid: (n_pairs, ceil(cap / (64 * kMatchQ))), block 64.  The pair is the fast grid index: workgroups past a frame's
+// keypoint count exit at once, and with the chunk as the fast index their regular pattern (15 busy, 17 idle, ...)
+// lands on the same CUs every time -- half the chip then idles (measured: 4.8 ms against 2.3 ms).
+// ---------------------------------------------------------------------------------------------
+struct MatchRecord {
+    uint32_t index;
+    uint32_t dist;  // distance | second << 16
+};
+constexpr int kMatchQ = 2;
+constexpr int kMatchG = 3;
+
+__global__ __launch_bounds__(64) void k_match(const uint32_t* __restrict__ counts,
+                                              const CornerDescriptor* __restrict__ descriptors, uint32_t cap,
+                                              MatchRecord* __restrict__ matches) {
+    const uint32_t pair = blockIdx.x, lane = threadIdx.x;
+    const uint32_t na = min(counts[pair], cap), nb = min(counts[pair + 1u], cap);
+    const uint32_t i0 = blockIdx.y * (64u * kMatchQ);
+    if (i0 >= na) return;  // uniform
+    const uint4* qa = reinterpret_cast<const uint4*>(descriptors + (size_t)pair * cap);
+    const uint4* qb = reinterpret_cast<const uint4*>(descriptors + (size_t)(pair + 1u) * cap);
+    uint4 a0[kMatchQ], a1[kMatchQ];
+    uint32_t k1[kMatchQ], k2[kMatchQ];
+#pragma unroll
+    for (int q = 0; q < kMatchQ; q++) {
+        const uint32_t i = min(i0 + (uint32_t)q * 64u + lane, na - 1u);
+        a0[q] = qa[2u * i];
+        a1[q] = qa[2u * i + 1u];
+        k1[q] = k2[q] = 0xffffffffu;
+    }
+    // key = distance << 23 | candidate index (distance <= 256, index < 2^23): the two smallest keys are the best match
+    // with ties to the smallest index, and the runner-up
+    // candidates in groups of kMatchG: the scalar loads of the next group are issued before the current group is
+    // used (a scalar load under load takes well over a thousand cycles; one wait per group instead of per candidate)
+    uint4 n0[kMatchG], n1[kMatchG];
+#pragma unroll
+    for (int g = 0; g < kMatchG; g++) {
+        const uint32_t jc = nb ? min((uint32_t)g, nb - 1u) : 0u;
+        n0[g] = nb ? qb[2u * jc] : make_uint4(0u, 0u, 0u, 0u);
+        n1[g] = nb ? qb[2u * jc + 1u] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    for (uint32_t j0 = 0; j0 < nb; j0 += kMatchG) {
+        uint4 b0[kMatchG], b1[kMatchG];
+#pragma unroll
+        for (int g = 0; g < kMatchG; g++) {
+            b0[g] = n0[g];
+            b1[g] = n1[g];
+        }
+#pragma unroll
+        for (int g = 0; g < kMatchG; g++) {
+            const uint32_t jn = min(j0 + kMatchG + (uint32_t)g, nb - 1u);
+            n0[g] = qb[2u * jn];
+            n1[g] = qb[2u * jn + 1u];
+        }
+#pragma unroll
+        for (int g = 0; g < kMatchG; g++) {
+            const uint32_t j = j0 + (uint32_t)g;
+            if (j >= nb) break;  // uniform
+#pragma unroll
+            for (int q = 0; q < kMatchQ; q++) {
+                uint32_t d = __builtin_popcount(a0[q].x ^ b0[g].x);
+                d += __builtin_popcount(a0[q].y ^ b0[g].y);
+                d += __builtin_popcount(a0[q].z ^ b0[g].z);
+                d += __builtin_popcount(a0[q].w ^ b0[g].w);
+                d += __builtin_popcount(a1[q].x ^ b1[g].x);
+                d += __builtin_popcount(a1[q].y ^ b1[g].y);
+                d += __builtin_popcount(a1[q].z ^ b1[g].z);
+                d += __builtin_popcount(a1[q].w ^ b1[g].w);
+                const uint32_t key = (d << 23) | j;
+                k2[q] = min(k2[q], max(k1[q], key));
+                k1[q] = min(k1[q], key);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kMatchQ; q++) {
+        const uint32_t i = i0 + (uint32_t)q * 64u + lane;
+        if (i < na) {
+            MatchRecord r;
+            r.index = k1[q] == 0xffffffffu ? 0xffffffffu : (k1[q] & 0x7fffffu);
+            r.dist = (k1[q] == 0xffffffffu ? 0xffffu : (k1[q] >> 23)) | ((k2[q] == 0xffffffffu ? 0xffffu : (k2[q] >> 23)) << 16);
+            matches[(size_t)pair * cap + i] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic frames: frame i of the launch uses seed0 + i.  One thread = 4 pixels.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t synth_pixel(uint32_t x, uint32_t y, uint32_t W, uint32_t H, uint32_t seed,

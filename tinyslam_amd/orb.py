@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_PKG, "libtinyorb.so")
 
 ORB_OK, ORB_EINVAL, ORB_EHIP, ORB_ECAPACITY, ORB_ESTATE = 0, 1, 2, 3, 4
 ORB_PLANE_GRAY, ORB_PLANE_BLUR = 0, 1
-ORB_KERNEL_COUNT = 13
+ORB_KERNEL_COUNT = 14
 ORB_FLAG_STAGED = 1
 ORB_FLAG_DOUBLE_OUTPUT = 2
 ORB_FLAG_NMS = 4
@@ -30,6 +30,8 @@ SYN_ALL = 15
 
 # orb.rs:10-17 / orb.rs:19-23 as numpy record layouts (16 B / 32 B)
 CORNER_DTYPE = np.dtype([("x", "<u4"), ("y", "<u4"), ("angle", "<u4"), ("octave", "<u4")])
+MATCH_DTYPE = np.dtype([("index", "<u4"), ("distance", "<u2"), ("second", "<u2")])
+ORB_MATCH_NONE = 0xFFFFFFFF
 DESCRIPTOR_DTYPE = np.dtype([("bits", "u1", (32,))])
 
 # Names every build of libtinyorb.so must export (checked by tests against include/tinyorb.h).
@@ -40,6 +42,7 @@ EXPORTS = [
     "orb_batch_counts", "orb_batch_read", "orb_batch_select_output", "orb_batch_device_buffers", "orb_level_size",
     "orb_debug_read_plane", "orb_debug_f32_to_f16", "orb_debug_angle_code", "orb_profile_enable",
     "orb_profile_reset", "orb_profile_get", "orb_synth_frames_device", "orb_copy_to_host", "orb_debug_stamps",
+    "orb_match_consecutive", "orb_match_read",
 ]
 
 
@@ -121,6 +124,8 @@ def load_library(path=None):
     L.orb_debug_read_plane.argtypes = [vp, u32, ctypes.c_int, u32, vp, sz]
     L.orb_debug_f32_to_f16.argtypes = [vp, vp, vp, sz]
     L.orb_debug_angle_code.argtypes = [vp, vp, vp, vp, sz]
+    L.orb_match_consecutive.argtypes = [vp, u32, vp]
+    L.orb_match_read.argtypes = [vp, u32, vp, ctypes.c_size_t]
     L.orb_profile_enable.argtypes = [vp, ctypes.c_int]
     L.orb_profile_reset.argtypes = [vp]
     L.orb_profile_get.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
@@ -277,6 +282,15 @@ class OrbProgram:
         desc = np.zeros((n, 8), dtype=np.uint32)
         self._check(self._lib.orb_batch_read(self._handle(), frame, _ptr(corners), _ptr(desc), n))
         return corners, desc
+
+    def match_consecutive(self, n_frames, stream=None):
+        """Hamming-match frame f against f+1 for the first n_frames of the last batch (not in the reference)."""
+        self._check(self._lib.orb_match_consecutive(self._handle(), n_frames, ctypes.c_void_p(stream) if stream else None))
+
+    def match_read(self, frame, n):
+        out = np.zeros(n, dtype=MATCH_DTYPE)
+        self._check(self._lib.orb_match_read(self._handle(), frame, _ptr(out), n))
+        return out
 
     def batch_select_output(self, slot):
         self._check(self._lib.orb_batch_select_output(self._handle(), slot))
