@@ -331,7 +331,6 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
     return g;
 }
 
-// The fused pipeline: one k_front launch per level + BRIEF.
 // The fused pipeline for frames [f0, f0 + n) of the batch on stream s: one k_front launch per level + BRIEF.
 int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint32_t n, hipStream_t s) {
     const Pyramid& pyr = p->pyr;
@@ -347,7 +346,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
     CornerData* const d_corners = p->d_corners + (size_t)f0 * cap;
     CornerDescriptor* const d_desc = p->d_desc + (size_t)f0 * cap;
     // orb.rs:475 clear_buffer(counter): every band slot's count is rewritten by its k_front block and
-    // counts[] by k_brief_bands, so nothing needs clearing here.
+    // counts[] by k_slot_prefix, so nothing needs clearing here.
     uint32_t width = pyr.w[0], height = pyr.h[0];  // orb.rs:501-519
     for (uint32_t lvl = 0; lvl < D; lvl++) {
         const uint32_t gw = ((width + 7u) / 8u) * 8u, gh = ((height + 7u) / 8u) * 8u;

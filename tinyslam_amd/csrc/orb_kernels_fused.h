@@ -210,8 +210,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
 
     // =========================== A: stage grey rows [y0-3, y0+R+3) ===========================
     // Thread -> (column group tx, row phase ty): a thread keeps its column group and walks down the
-    // rows, so per item there is one address increment instead of a division; up to eight 16-byte
-    // loads are in flight per thread before the first is consumed.
+    // rows, so per item there is one address increment instead of a division; four 16-byte loads are
+    // in flight per thread before the first is consumed.
     {
         const int per_row = L0 ? (w >> 2) : ((LS - kLdsPad) >> 3);  // 16-byte items per row (RGBA quads / half8 groups)
         const int rpp = NT / per_row;                                 // rows covered per pass (>= 1: W <= 2048)
