@@ -443,6 +443,8 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
         g.seg_cap = bg.seg_cap;
         g.arc = p->arc;
         g.nms = (p->opt.flags & ORB_FLAG_NMS) ? 1u : 0u;
+        g.phase_mask = 31u;
+        if (const char* e = getenv("TINYORB_PHASE_MASK")) g.phase_mask = (uint32_t)atoi(e);
         if (g.n_bands * g.n_ct != bg.slot_base[lvl + 1] - bg.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: tile count mismatch at level %u", lvl);
         const dim3 grid(g.n_bands * g.n_ct * n);

@@ -39,6 +39,7 @@ struct IGeom {
     uint32_t seg_cap;    // records per tile segment
     uint32_t arc;        // 9..16
     uint32_t nms;        // 0 / 1
+    uint32_t phase_mask; // timing experiments only: bit0 B1, bit1 S1, bit2 S2, bit3 S3+S4, bit4 C0
 };
 
 __host__ __device__ inline uint32_t ifront_lds_bytes(const IGeom& g) {
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     };
 
     // =========================== B1: compass pre-test, 8 px per item ===========================
+    if (geo.phase_mask & 1u)
     // A run of `arc` ring positions holds at least arc / 4 of the four compass points: 3 for arc >= 12 (the
     // reference's shortcut), 2 for 9..11.  Conservative packed test as in k_front (selection network on the f16 bit
     // patterns, packed-f16 compares against a threshold one ulp below RD16(thr)).
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
         return grey + __mul24(r + 3, LS) + col;
     };
     // =========================== S1: even-ring filter, A -> B ===========================
-    {
+    if (geo.phase_mask & 2u) {
         const uint32_t need_even = arc >> 1;
         const uint32_t n_a = min(*qa_count, (uint32_t)kIQueueA);
         for (uint32_t i = (uint32_t)tid; i < n_a; i += NT) {
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     }
     __syncthreads();
     // =========================== S2: full segment test, B -> C ===========================
-    {
+    if (geo.phase_mask & 4u) {
         const uint32_t n_b = min(*qb_count, (uint32_t)kIQueueB);
         for (uint32_t i = (uint32_t)tid; i < n_b; i += NT) {
             const uint32_t e = queue_b[i];
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     }
     __syncthreads();
     // =========================== S3: score and angle of the corners -> list (A's storage) ===========================
-    {
+    if (geo.phase_mask & 8u) {
         const uint32_t n_c = min(*qc_count, (uint32_t)kIQueueC);
         for (uint32_t i = (uint32_t)tid; i < n_c; i += NT) {
             const uint32_t e = queue_c[i];
@@ -425,25 +427,36 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     // =========================== S4: 3x3 NMS inside the tile, survivors -> segment ===========================
     if (*overflow == 0u) {
         const uint32_t n = *list_count;
-        for (uint32_t i = (uint32_t)tid; i < n; i += NT) {
-            const uint32_t pi = list_pos[i];
-            const int ri = (int)(pi >> 9), ci = (int)(pi & 511u);
-            const int x = cx0 + ci - kIPad, gy = y0 - 1 + ri;
-            if (!in_core(x, gy)) continue;
-            const float s = list_score[i];
-            bool keep = true;
-            if (geo.nms) {
-                for (uint32_t j = 0; j < n; j++) {
-                    const uint32_t pj = list_pos[j];
-                    const int dy = (int)(pj >> 9) - ri, dx = (int)(pj & 511u) - ci;
-                    if (j != i && dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1) {
-                        const float t = list_score[j];
-                        const bool later = dy > 0 || (dy == 0 && dx > 0);
-                        if (t > s || (t == s && !later)) keep = false;
-                    }
+        if (geo.nms && n > 1u) {
+            // all n * n ordered pairs spread over the workgroup: pair p = (i, j) clears keep[i] (queue C's storage,
+            // C is in the list by now) when corner j is an 8-neighbour of corner i that beats it
+            uint16_t* const keep = queue_c;
+            for (uint32_t i = (uint32_t)tid; i < n; i += NT) keep[i] = 1u;
+            __syncthreads();
+            const uint32_t n_pairs = n * n;
+            const float inv_n = 1.0f / (float)n;
+            for (uint32_t p = (uint32_t)tid; p < n_pairs; p += NT) {
+                const uint32_t i = (uint32_t)(((float)p + 0.5f) * inv_n), j = p - i * n;
+                const uint32_t pi = list_pos[i], pj = list_pos[j];
+                const int dy = (int)(pj >> 9) - (int)(pi >> 9), dx = (int)(pj & 511u) - (int)(pi & 511u);
+                if (j != i && dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1) {
+                    const float s = list_score[i], t = list_score[j];
+                    const bool later = dy > 0 || (dy == 0 && dx > 0);
+                    if (t > s || (t == s && !later)) keep[i] = 0u;
                 }
             }
-            if (keep) append((uint32_t)x, (uint32_t)gy, (uint32_t)list_ang[i], s);
+            __syncthreads();
+            for (uint32_t i = (uint32_t)tid; i < n; i += NT) {
+                const uint32_t pi = list_pos[i];
+                const int x = cx0 + (int)(pi & 511u) - kIPad, gy = y0 - 1 + (int)(pi >> 9);
+                if (keep[i] && in_core(x, gy)) append((uint32_t)x, (uint32_t)gy, (uint32_t)list_ang[i], list_score[i]);
+            }
+        } else {
+            for (uint32_t i = (uint32_t)tid; i < n; i += NT) {
+                const uint32_t pi = list_pos[i];
+                const int x = cx0 + (int)(pi & 511u) - kIPad, gy = y0 - 1 + (int)(pi >> 9);
+                if (in_core(x, gy)) append((uint32_t)x, (uint32_t)gy, (uint32_t)list_ang[i], list_score[i]);
+            }
         }
     } else {
         // some queue was full (a pathologically dense tile): evaluate every pixel of the tile directly
@@ -455,7 +468,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     }
 
     // =========================== C0: next mip level (exact 2x2 case) ===========================
-    if (geo.write_mip) {
+    if (geo.write_mip && (geo.phase_mask & 16u)) {
         const int wd = (int)pyr.w[lvl + 1], hd = (int)pyr.h[lvl + 1];
         uint16_t* dst = gray_f + pyr.off[lvl + 1];
         const int g4 = (tw / 2 + 3) >> 2;
