@@ -403,3 +403,21 @@ def test_intended_descriptors_follow_a_half_turn(oracle):
         ham.append(int(np.unpackbits((a["descriptors"][i] ^ b["descriptors"][j]).view(np.uint8)).sum()))
     assert n > 0.9 * len(a["corners"]) and max(dang) <= 2
     assert float(np.median(ham)) <= 4 and float(np.mean(ham)) < 12
+
+
+def test_match_oracle_known_answers():
+    """The NumPy matcher (checker of orb_match_consecutive): ties to the smallest index, runner-up distance."""
+    a = np.zeros((3, 8), dtype=np.uint32)
+    a[1, 0] = 0b1111
+    a[2, 7] = 0xFFFFFFFF
+    b = np.zeros((4, 8), dtype=np.uint32)
+    b[0, 0] = 0b0011          # distances to a[0]: 2, a[1]: 2, a[2]: 34 (the runner-up of a[2])
+    b[1, 0] = 0b0011          # duplicate of b[0]: ties go to index 0
+    b[2, 7] = 0xFFFFFFFE      # distance to a[2]: 1
+    b[3, 3] = 0xFFFFFFFF
+    idx, dist, second = orb_numpy.match(a, b)
+    assert idx.tolist() == [0, 0, 2] and dist.tolist() == [2, 2, 1] and second.tolist() == [2, 2, 34]
+    idx, dist, second = orb_numpy.match(a, b[:1])
+    assert idx.tolist() == [0, 0, 0] and second.tolist() == [0xFFFF] * 3
+    idx, dist, second = orb_numpy.match(a, b[:0])
+    assert idx.tolist() == [0xFFFFFFFF] * 3 and dist.tolist() == [0xFFFF] * 3
