@@ -12,8 +12,9 @@ import sys
 import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = os.path.join(ROOT, "gpurun_out", tag)
+src_tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else src_tag  # name of the committed files (one set per round)
+src = os.path.join(ROOT, "gpurun_out", src_tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
