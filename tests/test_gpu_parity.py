@@ -327,7 +327,8 @@ def _intended_program(tinyorb, W, H, depth, cap, arc, nms, max_batch=1, staged=F
                                                    (640, 480, 2, 9, False, 777), (36, 40, 2, 9, False, 64),
                                                    (70, 34, 1, 9, True, 64), (1280, 720, 2, 9, True, 8192),
                                                    (1284, 250, 4, 9, True, 8192), (648, 100, 3, 16, True, 8192),
-                                                   (322, 202, 2, 9, False, 8192), (1920, 120, 2, 11, True, 50)])
+                                                   (322, 202, 2, 9, False, 8192), (1920, 120, 2, 11, True, 50),
+                                                   (320, 240, 2, 9, False, 8), (640, 360, 1, 9, True, 3)])
 @pytest.mark.parametrize("staged", [False, True])
 def test_intended_mode_matches_oracle(tinyorb, oracle, W, H, depth, arc, nms, cap, staged):
     rgba = oracle.synth_frame(W, H, 90 + depth)

@@ -625,8 +625,9 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
             if (rows > max_rows) max_rows = rows;
         }
         bg.group_base[p->pyr.depth] = groups;
-        const uint64_t tile_px = (uint64_t)kFrontRows * bg.tw[0];
-        bg.seg_cap = (uint32_t)(tile_px < config->max_features ? tile_px : config->max_features);
+        // a tile's segment holds every keypoint the tile can have (one per pixel), whatever max_features is: the
+        // top-K cut (IM-8) must see all candidates, not the ones that happened to be appended first
+        bg.seg_cap = (uint32_t)kFrontRows * bg.tw[0];
         bg.pitch = (uint32_t)kITileW + 2u * kIBriefApronX;
         p->ibrief_lds = max_rows * bg.pitch * (uint32_t)sizeof(uint16_t);
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_brief_i),
