@@ -436,3 +436,21 @@ def test_match_consecutive_frames(tinyorb, oracle):
         assert (prog.match_read(2, int(counts[2]))["index"] == tinyorb.ORB_MATCH_NONE).all()
         with pytest.raises(tinyorb.OrbError):
             prog.match_consecutive(5)
+
+
+def test_large_frames_take_the_fused_pipelines(tinyorb, oracle):
+    """Frames beyond 2^22 pixels (4 K): both fused pipelines, against the oracle."""
+    W, H = 2048, 2200
+    rgba = oracle.synth_frame(W, H, 31)
+    ref = oracle.extract(rgba, depth=2, threshold=THR, max_features=1 << 16)
+    with _program(tinyorb, W, H, 2, max_features=1 << 16) as prog:
+        assert prog.pipeline() == "fused"
+        total, corners, desc = prog.extract(rgba)
+        _assert_frame_equal(oracle, ref, total, corners, desc)
+    W, H = 3840, 2160
+    rgba = oracle.synth_frame(W, H, 32)
+    ref = oracle.extract_intended(rgba, depth=3, threshold=THR, max_features=1 << 17, arc=9, nms=True)
+    with _intended_program(tinyorb, W, H, 3, 1 << 17, 9, True) as prog:
+        assert prog.pipeline() == "fused"
+        total, corners, desc = prog.extract(rgba)
+        _assert_frame_equal(oracle, ref, total, corners, desc)

@@ -291,7 +291,9 @@ bool fused_eligible(const OrbProgram* p) {
     if (p->opt.flags & (ORB_FLAG_STAGED | ORB_FLAG_NMS | ORB_FLAG_INTENDED)) return false;
     if (p->arc != 12u) return false;  // the fused FAST phase is specialised for the reference's 12-run
     const Pyramid& pyr = p->pyr;
-    if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 22)) return false;  // 24-bit index products in k_front
+    // index arithmetic: v_mul_i32_i24 takes 24-bit operands (rows, widths < 2^14 here) and returns 32 bits; RGBA byte
+    // offsets inside a frame are 4 * W * H < 2^32
+    if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 26) || pyr.h[0] > 16384u) return false;
     if ((pyr.w[0] & 3u) != 0u || pyr.w[0] > (uint32_t)(kFrontMaxCols * 512) || pyr.w[0] < 8u) return false;
     if (pyr.depth > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) return false;
     return true;
@@ -413,7 +415,7 @@ uint32_t itile_width(uint32_t w) {
 bool fused_i_eligible(const OrbProgram* p) {
     if (!p->intended || (p->opt.flags & ORB_FLAG_STAGED)) return false;
     const Pyramid& pyr = p->pyr;
-    if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 22)) return false;  // 24-bit index products
+    if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 26)) return false;  // 32-bit byte offsets; W, H <= 16384 (create)
     if ((pyr.w[0] & 3u) != 0u || pyr.w[0] < 8u) return false;       // level 0 is read as RGBA quads
     return true;
 }

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 if (L0) {
                     // rows outside the image are never read by a pixel that passes the guard (fast.wgsl:77);
                     // the input row is the vertically mirrored one (grayscale.wgsl:16-25).  24-bit multiplies:
-                    // pixel offsets inside a frame are < 2^22 (checked at create).  The load itself is
+                    // rows and widths are < 2^14, byte offsets inside a frame < 2^32 (checked at create).  The load itself is
                     // unconditional (clamped address) so that all eight are issued back to back.
                     const bool ok = in_band && gy >= 0 && gy < h;
                     dst[u] = ok ? __mul24(ly, LS) + kLdsPad + tx * 4 : -1;
