@@ -454,3 +454,40 @@ def test_large_frames_take_the_fused_pipelines(tinyorb, oracle):
         assert prog.pipeline() == "fused"
         total, corners, desc = prog.extract(rgba)
         _assert_frame_equal(oracle, ref, total, corners, desc)
+
+
+def test_intended_full_size_batch(tinyorb, oracle):
+    """BASELINE.json's frame size in the intended mode: a 64-frame batch on both output sets, fused against staged on
+    every frame's counter, the oracle on a few frames, matches between consecutive frames, a second run."""
+    W, H, B, cap = 1280, 720, 64, 8192
+    flags = tinyorb.ORB_FLAG_INTENDED | tinyorb.ORB_FLAG_NMS
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=cap, hierarchy_depth=2, initial_threshold=THR,
+                            max_batch=B, flags=flags | tinyorb.ORB_FLAG_DOUBLE_OUTPUT, fast_arc=9)
+    cfg_s = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=cap, hierarchy_depth=2, initial_threshold=THR,
+                              max_batch=8, flags=flags | tinyorb.ORB_FLAG_STAGED, fast_arc=9)
+    with tinyorb.OrbProgram(cfg) as fused, tinyorb.OrbProgram(cfg_s) as staged:
+        assert fused.pipeline() == "fused" and staged.pipeline() == "staged"
+        dev = fused.synth_frames_device(B, 5000)
+        fused.extract_batch_device(dev, B)
+        counts = fused.batch_counts(B)
+        assert counts.min() > 3000 and counts.max() <= cap
+        for i0 in range(0, B, 8):
+            staged.extract_batch_device(dev + i0 * W * H * 4, 8)
+            assert np.array_equal(staged.batch_counts(8), counts[i0:i0 + 8])
+        for i in (0, 37, 63):
+            frame = fused.copy_to_host(dev + i * W * H * 4, W * H * 4).reshape(H, W, 4)
+            ref = oracle.extract_intended(frame, depth=2, threshold=THR, max_features=cap, arc=9, nms=True)
+            corners, desc = fused.batch_read(i, int(counts[i]))
+            _assert_frame_equal(oracle, ref, int(counts[i]), corners, desc)
+            assert int(corners["angle"].max()) > 3141 and int(corners["angle"].max()) <= 6283
+        fused.match_consecutive(B)
+        m = fused.match_read(10, int(counts[10]))
+        assert (m["index"] < counts[11]).all() and (m["distance"] <= m["second"]).all()
+        # the other output set, then the first again: same counters, nothing leaks between batches or sets
+        fused.batch_select_output(1)
+        fused.extract_batch_device(dev, B)
+        assert np.array_equal(fused.batch_counts(B), counts)
+        c1, d1 = _sorted(*fused.batch_read(37, int(counts[37])))
+        fused.batch_select_output(0)
+        c0, d0 = _sorted(*fused.batch_read(37, int(counts[37])))
+        assert np.array_equal(c0, c1) and np.array_equal(d0, d1)
