@@ -29,7 +29,7 @@ SEED0 = 1000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(n_sample):
+def cpu_baseline(n_sample, intended=False):
     """Times oracle/ (the CPU restatement) on the first n_sample frames of the workload."""
     import numpy as np
     from oracle import orb_oracle
@@ -42,8 +42,12 @@ def cpu_baseline(n_sample):
     cores = min(cores, 16)  # the CPU share of a one-GPU box
     frames = np.stack([orb_oracle.synth_frame(W, H, SEED0 + i) for i in range(n_sample)])
     t0 = time.perf_counter()
-    totals, _, _ = orb_oracle.extract_batch(frames, depth=DEPTH, threshold=THRESHOLD, max_features=MAX_FEATURES,
-                                            n_threads=cores)
+    if intended:
+        totals, _, _ = orb_oracle.extract_intended_batch(frames, depth=DEPTH, threshold=THRESHOLD, max_features=MAX_FEATURES,
+                                                         arc=9, nms=True, n_threads=cores)
+    else:
+        totals, _, _ = orb_oracle.extract_batch(frames, depth=DEPTH, threshold=THRESHOLD, max_features=MAX_FEATURES,
+                                                n_threads=cores)
     dt = time.perf_counter() - t0
     return {"value": n_sample / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d of the bench's 1280x720 frames (seeds %d..), oracle/orb_oracle.c frame-parallel over %d "
@@ -59,6 +63,9 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--staged", action="store_true", help="force the one-kernel-per-stage pipeline")
+    ap.add_argument("--mode", choices=("literal", "intended"), default="literal",
+                    help="literal = the reference's algorithm (the headline, BASELINE.json); intended = the opt-in "
+                         "repaired algorithm with FAST-9 + NMS (DESIGN.md section 8; not in the reference)")
     args = ap.parse_args()
 
     import numpy as np
@@ -90,7 +97,9 @@ def main():
     B = args.frames
     cfg = orb.OrbConfig(orb.Extent3d(W, H), max_features=MAX_FEATURES, hierarchy_depth=DEPTH,
                         initial_threshold=THRESHOLD, device=dev_index, max_batch=B,
-                        flags=(orb.ORB_FLAG_STAGED if args.staged else 0) | (orb.ORB_FLAG_DOUBLE_OUTPUT if world > 1 else 0))
+                        flags=(orb.ORB_FLAG_STAGED if args.staged else 0) | (orb.ORB_FLAG_DOUBLE_OUTPUT if world > 1 else 0)
+                        | ((orb.ORB_FLAG_INTENDED | orb.ORB_FLAG_NMS) if args.mode == "intended" else 0),
+                        fast_arc=9 if args.mode == "intended" else 0)
     prog = orb.OrbProgram(cfg).init()
     frames_dev = prog.synth_frames_device(B, SEED0 + rank * B)  # rank g owns frames [g*B, (g+1)*B)
     n_sets = 2 if world > 1 else 1
@@ -202,9 +211,12 @@ def main():
             "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (gradient+blobs+wedges+noise, seeds %d.., generated on device)" % SEED0,
             "config": {"workload": "BASELINE.json configs[3]: batch of %d independent 1280x720 RGBA frames per GPU, "
-                                   "device-resident, full ORB (FAST-12 + orientation + blur + BRIEF-256)" % B,
+                                   "device-resident, full ORB (%s)"
+                                   % (B, "FAST-12 + orientation + blur + BRIEF-256" if args.mode == "literal" else
+                                      "opt-in intended mode, NOT the reference's algorithm: FAST-9 + NMS + full-circle "
+                                      "orientation + separable Gaussian + BRIEF-256"),
                        "frames_per_gpu": B, "width": W, "height": H, "hierarchy_depth": DEPTH,
-                       "max_features": MAX_FEATURES, "threshold": THRESHOLD, "mode": "literal",
+                       "max_features": MAX_FEATURES, "threshold": THRESHOLD, "mode": args.mode,
                        "pipeline": "staged" if args.staged else "default",
                        "collate": "RCCL gather of every batch to rank 0, overlapped with the next batch's kernels" if world > 1 else "none (1 GPU)"},
             "mkeypoints_per_s": kp_per_step * args.steps / elapsed / 1e6,
@@ -215,7 +227,7 @@ def main():
         if world == 1:
             n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 128
             if n_cpu > 0:
-                out["cpu_baseline"] = cpu_baseline(n_cpu)
+                out["cpu_baseline"] = cpu_baseline(n_cpu, intended=args.mode == "intended")
         print(json.dumps(out), flush=True)
     prog.close()
     if world > 1:

@@ -766,6 +766,25 @@ int orc_extract_intended(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t d
     return 0;
 }
 
+int orc_extract_intended_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth,
+                               float threshold, uint32_t max_features, const orc_options_t *opt, orc_corner_t *corners,
+                               orc_descriptor_t *descriptors, uint32_t *totals, int n_threads) {
+    int rc = 0;
+    size_t frame_bytes = (size_t)W * H * 4;
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int64_t f = 0; f < (int64_t)n_frames; f++) {
+        int r = orc_extract_intended(rgba + (size_t)f * frame_bytes, W, H, depth, threshold, max_features, opt,
+                                     corners + (size_t)f * max_features,
+                                     descriptors ? descriptors + (size_t)f * max_features : NULL, &totals[f], NULL, NULL);
+        if (r) {
+#pragma omp critical
+            rc = r;
+        }
+    }
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Synthetic frames.  Counter-based so that C, NumPy and a GPU generator
  * produce identical bytes without sharing a sequential random stream.

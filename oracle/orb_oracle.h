@@ -123,6 +123,11 @@ int orc_extract_intended(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t d
                          uint32_t max_features, const orc_options_t *opt, orc_corner_t *corners,
                          orc_descriptor_t *descriptors, uint32_t *total, uint16_t *gray_pyr, uint16_t *blur_pyr);
 
+/* Frame-parallel batch of orc_extract_intended (CPU baseline of `bench.py --mode intended`). */
+int orc_extract_intended_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth,
+                               float threshold, uint32_t max_features, const orc_options_t *opt, orc_corner_t *corners,
+                               orc_descriptor_t *descriptors, uint32_t *totals, int n_threads);
+
 /* Frame-parallel batch for the CPU baseline leg of bench.py: n_frames contiguous RGBA frames,
  * outputs strided by max_features.  n_threads <= 1 runs serially. */
 int orc_extract_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth, float threshold,

@@ -79,6 +79,8 @@ def lib():
         L.orc_grayscale_intended.argtypes = [vp, u32, u32, vp]
         L.orc_angle_code_signed.argtypes = [f32, f32]
         L.orc_angle_code_signed.restype = u32
+        L.orc_extract_intended_batch.argtypes = [vp, u32, u32, u32, u32, f32, u32, vp, vp, vp, vp, ctypes.c_int]
+        L.orc_extract_intended_batch.restype = ctypes.c_int
         L.orc_extract_batch.argtypes = [vp, u32, u32, u32, u32, f32, u32, vp, vp, vp, ctypes.c_int]
         L.orc_extract_batch.restype = ctypes.c_int
         L.orc_synth_frame.argtypes = [vp, u32, u32, u32, u32]
@@ -234,6 +236,21 @@ def extract_batch(frames, depth=2, threshold=20.0 / 255.0, max_features=8192, n_
                                  _ptr(corners), _ptr(desc), _ptr(totals), int(n_threads))
     if rc != 0:
         raise ValueError("orc_extract_batch failed")
+    return totals, corners, desc
+
+
+def extract_intended_batch(frames, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=9, nms=False, n_threads=1):
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    F, H, W = frames.shape[:3]
+    corners = np.zeros((F, max_features), dtype=CORNER_DTYPE)
+    desc = np.zeros((F, max_features, 8), dtype=np.uint32)
+    totals = np.zeros(F, dtype=np.uint32)
+    opt = (ctypes.c_uint32 * 2)(int(arc), 1 if nms else 0)
+    rc = lib().orc_extract_intended_batch(_ptr(frames), F, W, H, depth, ctypes.c_float(np.float32(threshold)),
+                                          max_features, ctypes.cast(opt, ctypes.c_void_p), _ptr(corners), _ptr(desc),
+                                          _ptr(totals), int(n_threads))
+    if rc != 0:
+        raise ValueError("orc_extract_intended_batch failed")
     return totals, corners, desc
 
 
