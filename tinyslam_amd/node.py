@@ -53,11 +53,17 @@ def collate_to_root(counts: torch.Tensor, corners: torch.Tensor, descriptors: to
     counts_all = torch.cat(all_counts)
     mx = int(torch.clamp(counts_all, max=cap).max().item()) if counts_all.numel() else 0
     mx = max(mx, 1)
-    # one payload per rank: corners and descriptors of a frame side by side -> a single gather
+    # one payload per rank: corners and descriptors of a frame side by side -> a single gather, received straight
+    # into the root's frame-ordered buffer (no concatenation or re-split afterwards: the returned corner and
+    # descriptor tensors are views of it)
     payload = torch.cat([corners[:, :mx], descriptors[:, :mx]], dim=2).contiguous()  # (B, mx, 12)
-    bufs = [torch.empty_like(payload) for _ in range(world)] if rank == dst else None
+    merged = None
+    bufs = None
+    if rank == dst:
+        merged = torch.empty((world * payload.shape[0],) + tuple(payload.shape[1:]), dtype=payload.dtype,
+                             device=payload.device)
+        bufs = list(merged.chunk(world, dim=0))  # contiguous slices, one per rank
     dist.gather(payload, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    merged = torch.cat(bufs, dim=0)
-    return counts_all, merged[:, :, :4].contiguous(), merged[:, :, 4:].contiguous()
+    return counts_all, merged[:, :, :4], merged[:, :, 4:]
