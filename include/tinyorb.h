@@ -159,6 +159,11 @@ int orb_match_consecutive(OrbProgram *p, uint32_t n_frames, void *stream);
 /* Copy up to n matches of the queries of `frame` to the host (synchronises). */
 int orb_match_read(OrbProgram *p, uint32_t frame, OrbMatch *dst, size_t n);
 
+/* Keypoint coordinates are in the octave's own pixel grid (fast.wgsl:143-150).  Centre of that pixel in level-0
+ * pixel units, for consumers that work across octaves: a level-m texel covers 2^m level-0
+ * pixels (exact halving; for odd sizes the blit's own mapping, blit.wgsl:17-36, differs by less than a pixel). */
+void orb_corner_level0_xy(const CornerData *c, float *x0, float *y0);
+
 /* ---- inspection (parity tests) ---- */
 #define ORB_PLANE_GRAY 0
 #define ORB_PLANE_BLUR 1

@@ -915,6 +915,13 @@ int orb_batch_read(OrbProgram* p, uint32_t frame, CornerData* corners, CornerDes
     return ORB_OK;
 }
 
+void orb_corner_level0_xy(const CornerData* c, float* x0, float* y0) {
+    if (!c || !x0 || !y0) return;
+    const float s = (float)(1u << (c->octave & 31u));
+    *x0 = ((float)c->x + 0.5f) * s - 0.5f;
+    *y0 = ((float)c->y + 0.5f) * s - 0.5f;
+}
+
 int orb_match_consecutive(OrbProgram* p, uint32_t n_frames, void* stream) {
     if (!p) return ORB_EINVAL;
     if (n_frames < 2u || n_frames > p->last_batch)

@@ -42,8 +42,15 @@ EXPORTS = [
     "orb_batch_counts", "orb_batch_read", "orb_batch_select_output", "orb_batch_device_buffers", "orb_level_size",
     "orb_debug_read_plane", "orb_debug_f32_to_f16", "orb_debug_angle_code", "orb_profile_enable",
     "orb_profile_reset", "orb_profile_get", "orb_synth_frames_device", "orb_copy_to_host", "orb_debug_stamps",
-    "orb_match_consecutive", "orb_match_read",
+    "orb_match_consecutive", "orb_match_read", "orb_corner_level0_xy",
 ]
+
+
+def level0_xy(corners):
+    """Centres of the keypoints' pixels in level-0 pixel units (orb_corner_level0_xy of include/tinyorb.h)."""
+    s = np.left_shift(1, corners["octave"].astype(np.int64)).astype(np.float32)
+    return ((corners["x"].astype(np.float32) + np.float32(0.5)) * s - np.float32(0.5),
+            (corners["y"].astype(np.float32) + np.float32(0.5)) * s - np.float32(0.5))
 
 
 class OrbError(RuntimeError):
