@@ -81,8 +81,7 @@ typedef struct OrbOptions {
 #define ORB_FLAG_DOUBLE_OUTPUT 2u /* two sets of output slabs: batch k+1 computes while batch k is collated */
 #define ORB_FLAG_NMS 4u           /* opt-in, NOT in the reference: 3x3 non-maximum suppression per
                                    * octave on the arc score sum(|v - c| - threshold); the counter is then the number
-                                   * of survivors.  Without ORB_FLAG_INTENDED, fast_arc != 12 or NMS run on the staged
-                                   * pipeline. */
+                                   * of survivors. */
 #define ORB_FLAG_INTENDED 8u      /* opt-in, NOT in the reference: the algorithm the reference's
                                    * README describes, with the shaders' accidents repaired -- BT.601 luminance (0.299),
                                    * no vertical mirror, a true separable 7-tap Gaussian (X then Y), the octave's own
@@ -101,8 +100,7 @@ void orb_program_destroy(OrbProgram *p);
 const char *orb_last_error(const OrbProgram *p);
 uint32_t orb_abi_version(void);
 /* "fused" (one kernel per pyramid level + BRIEF) or "staged" (one kernel per reference stage;
- * taken with ORB_FLAG_STAGED, with fast_arc != 12 or ORB_FLAG_NMS on the reference's algorithm, or
- * for shapes the fused kernels do not cover: width not a multiple of 4, more than 2^26 pixels;
+ * taken with ORB_FLAG_STAGED or for shapes the fused kernels do not cover: width not a multiple of 4, more than 2^26 pixels;
  * the reference's algorithm also: width > 2048, odd level-0 size with depth > 1). */
 const char *orb_pipeline(const OrbProgram *p);
 

@@ -292,18 +292,46 @@ def test_double_output_sets(tinyorb, oracle):
 # the definitions are the build's own (oracle/orb_oracle.h) -- GPU vs C oracle, bit for bit.
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("arc,nms", [(9, False), (9, True), (12, True), (10, False), (16, True), (12, False)])
-def test_arc_length_and_nms_extensions(tinyorb, oracle, arc, nms):
-    W, H = 320, 240
+@pytest.mark.parametrize("W,H,depth", [(320, 240, 2), (332, 202, 4), (1284, 96, 3), (642, 120, 2)])
+@pytest.mark.parametrize("staged", [False, True])
+def test_arc_length_and_nms_extensions(tinyorb, oracle, arc, nms, W, H, depth, staged):
     rgba = oracle.synth_frame(W, H, 77)
-    ref = oracle.extract_ex(rgba, depth=2, threshold=THR, max_features=1 << 15, arc=arc, nms=nms)
-    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=1 << 15, hierarchy_depth=2, initial_threshold=THR,
-                            flags=tinyorb.ORB_FLAG_NMS if nms else 0, fast_arc=arc)
+    ref = oracle.extract_ex(rgba, depth=depth, threshold=THR, max_features=1 << 15, arc=arc, nms=nms)
+    planes = oracle.extract(rgba, depth=depth, threshold=THR, planes=True)  # grey and blur do not depend on the detector
+    flags = (tinyorb.ORB_FLAG_NMS if nms else 0) | (tinyorb.ORB_FLAG_STAGED if staged else 0)
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=1 << 15, hierarchy_depth=depth, initial_threshold=THR,
+                            flags=flags, fast_arc=arc)
     with tinyorb.OrbProgram(cfg) as prog:
-        assert prog.pipeline() == ("fused" if arc == 12 and not nms else "staged")
+        fused_ok = W % 4 == 0 and W % 2 == 0 and H % 2 == 0
+        assert prog.pipeline() == ("fused" if fused_ok and not staged else "staged")
         total, corners, desc = prog.extract(rgba)
         _assert_frame_equal(oracle, ref, total, corners, desc)
-    if arc == 9 and not nms:
-        assert ref["total"] > oracle.extract(rgba, depth=2, threshold=THR)["total"]  # FAST-9 finds more than FAST-12
+        dims, _ = oracle.level_dims(W, H, depth)
+        for m, (w, h, off) in enumerate(dims):
+            assert np.array_equal(prog.read_plane(tinyorb.ORB_PLANE_BLUR, m).ravel(), planes["blur"][off:off + w * h])
+            plain_fused = arc == 12 and not nms and prog.pipeline() == "fused"  # keeps the level-0 grey plane in LDS only
+            if m > 0 or not plain_fused:
+                assert np.array_equal(prog.read_plane(tinyorb.ORB_PLANE_GRAY, m).ravel(), planes["gray"][off:off + w * h])
+    if arc == 9 and not nms and (W, H) == (320, 240) and not staged:
+        assert ref["total"] > oracle.extract(rgba, depth=depth, threshold=THR)["total"]  # FAST-9 finds more than FAST-12
+
+
+def test_extensions_dense_frame_on_tiles(tinyorb, oracle):
+    """Bright dots everywhere: the tile queues of the fused detector overflow, its direct path must agree."""
+    W, H = 640, 128
+    rng = np.random.default_rng(6)
+    rgba = np.zeros((H, W, 4), dtype=np.uint8)
+    rgba[..., :3] = (rng.random((H, W, 1)) < 0.2) * 255
+    rgba[..., 3] = 255
+    for nms in (False, True):
+        ref = oracle.extract_ex(rgba, depth=2, threshold=THR, max_features=1 << 16, arc=9, nms=nms)
+        assert ref["total"] > 4000
+        cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=1 << 16, hierarchy_depth=2, initial_threshold=THR,
+                                flags=tinyorb.ORB_FLAG_NMS if nms else 0, fast_arc=9)
+        with tinyorb.OrbProgram(cfg) as prog:
+            assert prog.pipeline() == "fused"
+            total, corners, desc = prog.extract(rgba)
+            _assert_frame_equal(oracle, ref, total, corners, desc)
 
 
 def test_bad_arc_is_rejected(tinyorb):

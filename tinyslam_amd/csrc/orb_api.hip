@@ -60,6 +60,10 @@ struct OrbProgram {
     bool intended = false;
     // fused "intended" pipeline (orb_kernels_intended.h): tile slots, their segments (record + score), the cut
     bool fused_i = false;
+    bool fused_x = false;  // the reference's algorithm with the opt-in arc / NMS on the tile kernels
+    uint32_t* d_xband_counts = nullptr;  // band-slot counters written by the blur-only k_front launches (unused)
+    RowsGeom xrows{};
+    uint32_t xband_slots = 0;  // 16-row bands per frame over all levels (grid of the blur-only launches)
     IBriefGeom itiles{};
     CornerData* d_iseg = nullptr;
     float* d_iseg_scores = nullptr;
@@ -447,6 +451,11 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
         g.nms = (p->opt.flags & ORB_FLAG_NMS) ? 1u : 0u;
         g.phase_mask = 31u;
         if (const char* e = getenv("TINYORB_PHASE_MASK")) g.phase_mask = (uint32_t)atoi(e);
+        g.literal = 0u;
+        g.dw = pyr.w[lvl];
+        g.dh = pyr.h[lvl];
+        g.gx1 = (uint32_t)((int)pyr.w[lvl] - 16);
+        g.gy1 = (uint32_t)((int)pyr.h[lvl] - 16);
         if (g.n_bands * g.n_ct != bg.slot_base[lvl + 1] - bg.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: tile count mismatch at level %u", lvl);
         const dim3 grid(g.n_bands * g.n_ct * n);
@@ -481,8 +490,114 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
     return ORB_OK;
 }
 
+// Dispatch grid of octave `lvl` in the reference (orb.rs:501-519: halved and 8-rounded per octave).
+void reference_grid(const Pyramid& pyr, uint32_t lvl, uint32_t* gw, uint32_t* gh) {
+    uint32_t width = pyr.w[0], height = pyr.h[0];
+    for (uint32_t m = 0; m < lvl; m++) {
+        width /= 2u;
+        height /= 2u;
+    }
+    *gw = ((width + 7u) / 8u) * 8u;
+    *gh = ((height + 7u) / 8u) * 8u;
+}
+
+bool fused_x_eligible(const OrbProgram* p) {
+    if (p->intended || (p->opt.flags & ORB_FLAG_STAGED)) return false;
+    if (p->arc == 12u && !(p->opt.flags & ORB_FLAG_NMS)) return false;  // that is the plain fused pipeline
+    const Pyramid& pyr = p->pyr;
+    if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 26) || pyr.h[0] > 16384u) return false;
+    if ((pyr.w[0] & 3u) != 0u || pyr.w[0] > (uint32_t)(kFrontMaxCols * 512) || pyr.w[0] < 8u) return false;
+    if (pyr.depth > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) return false;
+    return true;
+}
+
+// The reference's algorithm with the opt-in arc length / NMS, fused: k_front_i per level
+// in its literal setting (grey plane, detector, NMS, mip), k_front<false> per level with only its blur phase (row
+// constants + stored tail from the grey plane), k_slot_prefix, k_brief_rows over the tile slots.
+int run_fused_x(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
+    const Pyramid& pyr = p->pyr;
+    const uint32_t D = pyr.depth, cap = p->cfg.max_features;
+    const IBriefGeom& bg = p->itiles;
+    uint32_t band_base = 0;
+    for (uint32_t lvl = 0; lvl < D; lvl++) {
+        if (lvl > 0 && !(pyr.w[lvl - 1] == 2u * pyr.w[lvl] && pyr.h[lvl - 1] == 2u * pyr.h[lvl])) {
+            LaunchScope ls(p, s, KID_MIP);
+            dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 3u) / 4u, n);
+            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, p->d_gray, pyr, lvl);
+        }
+        uint32_t gw, gh;
+        reference_grid(pyr, lvl, &gw, &gh);
+        IGeom g{};
+        g.lvl = lvl;
+        g.tw = bg.tw[lvl];
+        g.n_ct = bg.n_ct[lvl];
+        g.n_bands = bg.n_bands[lvl];
+        g.ls = kIPad + g.tw + 16u;
+        g.write_mip = (lvl + 1 < D && pyr.w[lvl] == 2u * pyr.w[lvl + 1] && pyr.h[lvl] == 2u * pyr.h[lvl + 1]) ? 1u : 0u;
+        g.xcd_swizzle = (n % 8u == 0u) ? 1u : 0u;
+        g.slot_base = bg.slot_base[lvl];
+        g.n_slots = bg.n_slots;
+        g.seg_cap = bg.seg_cap;
+        g.arc = p->arc;
+        g.nms = (p->opt.flags & ORB_FLAG_NMS) ? 1u : 0u;
+        g.phase_mask = 31u;
+        g.literal = 1u;
+        g.dw = std::max(pyr.w[lvl], gw);
+        g.dh = std::max(pyr.h[lvl], gh);
+        g.gx1 = std::min<uint32_t>(gw, pyr.w[0] > 16u ? pyr.w[0] - 16u : 0u);  // fast.wgsl:77 with level-0 dimensions (Q8)
+        g.gy1 = std::min<uint32_t>(gh, pyr.h[0] > 16u ? pyr.h[0] - 16u : 0u);
+        if (g.n_bands * g.n_ct != bg.slot_base[lvl + 1] - bg.slot_base[lvl])
+            return fail(p, ORB_EINVAL, "internal: tile count mismatch at level %u", lvl);
+        if (gw && gh) {
+            LaunchScope ls(p, s, KID_FRONT_I);
+            const dim3 grid(g.n_bands * g.n_ct * n);
+            if (lvl == 0)
+                hipLaunchKernelGGL(k_front_i<true>, grid, dim3(kIThreads), ifront_lds_bytes(g), s, frames, p->frame_bytes,
+                                   p->d_gray, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
+            else
+                hipLaunchKernelGGL(k_front_i<false>, grid, dim3(kIThreads), ifront_lds_bytes(g), s, frames, p->frame_bytes,
+                                   p->d_gray, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
+        } else {  // no FAST dispatch at this octave (orb.rs:511-515 with width 0): its tiles hold nothing
+            HIP_TRY(p, hipMemsetAsync(p->d_iseg_counts, 0, sizeof(uint32_t) * (size_t)n * bg.n_slots, s));
+        }
+        {   // literal blur of this level from its grey plane: k_front's staging + phase C, nothing else
+            FrontGeom fg = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n);
+            fg.phase_mask = 8u;
+            fg.write_mip = 0u;
+            fg.slot_base = band_base;
+            fg.n_slots = p->xband_slots;
+            fg.seg_cap = 1u;
+            fg.stamps = nullptr;
+            band_base += fg.n_bands;
+            const uint32_t lds = front_lds_bytes(fg);
+            if (lds > p->max_lds) return fail(p, ORB_EINVAL, "level %u needs %u bytes of LDS", lvl, lds);
+            LaunchScope ls(p, s, KID_FUSED_LN);
+            hipLaunchKernelGGL(k_front<false>, dim3(fg.n_bands * n), dim3(kFrontThreadsLN), lds, s, frames, p->frame_bytes,
+                               p->d_gray, p->d_blur, p->d_blur_rowc, pyr, fg, p->threshold, p->d_xband_counts, p->d_iseg);
+        }
+    }
+    {
+        LaunchScope ls(p, s, KID_PREFIX);
+        hipLaunchKernelGGL(k_slot_prefix, dim3(n), dim3(64), 0, s, p->d_iseg_counts, p->d_iseg_before, p->d_counts, bg.n_slots,
+                           bg.seg_cap);
+    }
+    {
+        LaunchScope ls(p, s, KID_BRIEF_ROWS);
+        RowsGeom rg = p->xrows;
+        rg.split = 1u;
+        while (rg.split < 16u && rg.n_slots * n * rg.split < 2048u) rg.split *= 2u;
+        hipLaunchKernelGGL(k_brief_rows, dim3(rg.n_slots * rg.split, n), dim3(256), 0, s, p->d_blur, p->d_blur_rowc, pyr, rg,
+                           p->d_iseg_counts, p->d_iseg_before, p->d_iseg, p->d_corners, cap, p->d_desc,
+                           BriefTables{p->d_pattern, p->d_cos, p->d_sin});
+    }
+    HIP_TRY(p, hipGetLastError());
+    p->planes_valid = true;
+    return ORB_OK;
+}
+
 int run_pipeline(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
     if (p->fused_i) return run_fused_i(p, frames, n, s);
+    if (p->fused_x) return run_fused_x(p, frames, n, s);
     return p->fused ? run_fused(p, frames, n, s) : run_staged(p, frames, n, s);
 }
 
@@ -499,7 +614,7 @@ uint32_t orb_abi_version(void) { return TINYORB_ABI_VERSION; }
 
 const char* orb_last_error(const OrbProgram* p) { return p ? p->err.c_str() : g_create_error.c_str(); }
 
-const char* orb_pipeline(const OrbProgram* p) { return p ? ((p->fused || p->fused_i) ? "fused" : "staged") : ""; }
+const char* orb_pipeline(const OrbProgram* p) { return p ? ((p->fused || p->fused_i || p->fused_x) ? "fused" : "staged") : ""; }
 
 const char* orb_kernel_name(int id) { return (id >= 0 && id < ORB_KERNEL_COUNT) ? kKernelNames[id] : ""; }
 
@@ -639,6 +754,48 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
             return bail(ORB_EHIP);
         }
     }
+    p->fused_x = fused_x_eligible(p);
+    if (p->fused_x) {
+        // tiles over the reference's dispatch grid of every octave; blur-only k_front launches over 16-row bands
+        IBriefGeom& bg = p->itiles;
+        RowsGeom& rg = p->xrows;
+        uint32_t slots = 0, bands = 0, need = 0;
+        for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
+            uint32_t gw, gh;
+            reference_grid(p->pyr, lvl, &gw, &gh);
+            const uint32_t dw = std::max(p->pyr.w[lvl], gw), dh = std::max(p->pyr.h[lvl], gh);
+            bg.tw[lvl] = itile_width(dw);
+            bg.n_ct[lvl] = (dw + bg.tw[lvl] - 1u) / bg.tw[lvl];
+            bg.n_bands[lvl] = (dh + kFrontRows - 1) / kFrontRows;
+            bg.slot_base[lvl] = slots;
+            rg.slot_base[lvl] = slots;
+            slots += bg.n_bands[lvl] * bg.n_ct[lvl];
+            const FrontGeom fg = front_geometry(p->pyr, lvl, gw ? gw : 8u, gh, 1);
+            bands += fg.n_bands;
+            need = std::max(need, front_lds_bytes(fg));
+            const uint32_t qa = fg.blur_q & ~7u;
+            p->blur_qa[lvl] = qa;
+            rg.qa[lvl] = qa;
+            rg.flat_end[lvl] = qa > (uint32_t)kBriefHalo ? qa - kBriefHalo : 0u;
+        }
+        bg.slot_base[p->pyr.depth] = slots;
+        rg.slot_base[p->pyr.depth] = slots;
+        bg.n_slots = slots;
+        bg.seg_cap = (uint32_t)kFrontRows * bg.tw[0];
+        rg.n_slots = slots;
+        rg.seg_cap = bg.seg_cap;
+        p->xband_slots = bands;
+        if (need > p->max_lds) {
+            p->fused_x = false;
+        } else {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            if (ea != hipSuccess) {
+                fail(p, ORB_EHIP, "hipFuncSetAttribute(k_front): %s", hipGetErrorString(ea));
+                return bail(ORB_EHIP);
+            }
+        }
+    }
     const size_t B = p->max_batch, cap = config->max_features;
     CREATE_TRY(hipMalloc(&p->d_gray, B * p->pyr.stride * sizeof(uint16_t)));
     CREATE_TRY(hipMalloc(&p->d_blur, B * p->pyr.stride * sizeof(uint16_t)));
@@ -661,7 +818,12 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         CREATE_TRY(hipMemset(p->d_seg_counts, 0, B * p->bands.n_slots * sizeof(uint32_t)));
         CREATE_TRY(hipMalloc(&p->d_seg_before, B * p->bands.n_slots * sizeof(uint32_t)));
     }
-    if (p->fused_i) {
+    if (p->fused_x) {
+        CREATE_TRY(hipMalloc(&p->d_blur_rowc, B * p->pyr.row_stride * sizeof(uint16_t)));
+        CREATE_TRY(hipMemset(p->d_blur_rowc, 0, B * p->pyr.row_stride * sizeof(uint16_t)));
+        CREATE_TRY(hipMalloc(&p->d_xband_counts, B * (size_t)p->xband_slots * sizeof(uint32_t)));
+    }
+    if (p->fused_i || p->fused_x) {
         const size_t n_seg = B * (size_t)p->itiles.n_slots;
         CREATE_TRY(hipMalloc(&p->d_iseg, n_seg * p->itiles.seg_cap * sizeof(CornerData)));
         CREATE_TRY(hipMalloc(&p->d_iseg_scores, n_seg * p->itiles.seg_cap * sizeof(float)));
@@ -739,6 +901,7 @@ void orb_program_destroy(OrbProgram* p) {
     (void)hipFree(p->d_prov);
     (void)hipFree(p->d_prov_scores);
     (void)hipFree(p->d_matches);
+    (void)hipFree(p->d_xband_counts);
     (void)hipFree(p->d_iseg);
     (void)hipFree(p->d_iseg_scores);
     (void)hipFree(p->d_iseg_counts);
@@ -988,7 +1151,7 @@ int orb_debug_read_plane(OrbProgram* p, uint32_t frame, int kind, uint32_t level
     if (int rc = orb_batch_sync(p)) return rc;
     const uint16_t* base = (kind == ORB_PLANE_GRAY ? p->d_gray : p->d_blur) + (size_t)frame * p->pyr.stride + p->pyr.off[level];
     HIP_TRY(p, hipMemcpy(dst, base, texels * sizeof(uint16_t), hipMemcpyDeviceToHost));
-    if (p->fused && kind == ORB_PLANE_BLUR && p->blur_qa[level] > 0) {
+    if ((p->fused || p->fused_x) && kind == ORB_PLANE_BLUR && p->blur_qa[level] > 0) {
         // the fused path keeps columns [0, qa) of a blur level as one constant per row (k_front, phase C)
         const uint32_t w = p->pyr.w[level], h = p->pyr.h[level], qa = p->blur_qa[level];
         std::vector<uint16_t> rowc(h);

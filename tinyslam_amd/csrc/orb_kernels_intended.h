@@ -40,6 +40,13 @@ struct IGeom {
     uint32_t arc;        // 9..16
     uint32_t nms;        // 0 / 1
     uint32_t phase_mask; // timing experiments only: bit0 B1, bit1 S1, bit2 S2, bit3 S3+S4, bit4 C0
+    // Detector domain and guard.  intended (IM-4): the level itself, 16 < x < w - 16, 16 < y < h - 16.
+    // literal == 1 (the reference's algorithm with the opt-in arc / NMS): the reference's
+    // dispatch grid of the octave (8-rounded, may exceed the level) and its level-0 guard at every octave (fast.wgsl:77,
+    // Q8); grey = 0.229 r + ..., mirrored rows (Q1, Q2); angle codes 0..3141 (Q7).
+    uint32_t literal;
+    uint32_t dw, dh;        // domain: columns / rows covered by tiles
+    uint32_t gx1, gy1;      // guard: 16 < x < gx1, 16 < y < gy1
 };
 
 __host__ __device__ inline uint32_t ifront_lds_bytes(const IGeom& g) {
@@ -86,8 +93,8 @@ __device__ __forceinline__ bool ring_has_arc(const half_t* ctr, int ls, float th
 }
 
 // Score (sum over the run's polarity of |diff| - thr, ring order, binary32) and full-circle angle of a corner.
-__device__ __forceinline__ void ring_score_angle(const half_t* ctr, int ls, float thr, uint32_t arc, float* score,
-                                                 uint32_t* angle) {
+__device__ __forceinline__ void ring_score_angle(const half_t* ctr, int ls, float thr, uint32_t arc, bool literal,
+                                                 float* score, uint32_t* angle) {
     const float c = from_half(ctr[0]);
     uint32_t m_over = 0;
     float cx = 0.0f, cy = 0.0f, s_over = 0.0f, s_under = 0.0f;
@@ -110,7 +117,7 @@ __device__ __forceinline__ void ring_score_angle(const half_t* ctr, int ls, floa
         }
     }
     *score = has_run_16(m_over, arc) ? s_over : s_under;
-    *angle = angle_code_signed(cy, cx);
+    *angle = literal ? angle_code(cy, cx) : angle_code_signed(cy, cx);
 }
 
 template <bool L0>
@@ -159,7 +166,9 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     const uint32_t lvl = geo.lvl;
     const int w = (int)pyr.w[lvl], h = (int)pyr.h[lvl];
     const int y0 = (int)band * R, cx0 = (int)ct * TW;
-    const int tw = min(TW, w - cx0);  // columns of this tile that exist
+    const bool lit = geo.literal != 0u;
+    const int dw = (int)geo.dw, dh = (int)geo.dh, gx1 = (int)geo.gx1, gy1 = (int)geo.gy1;
+    const int tw = min(TW, dw - cx0);  // columns of this tile inside the detector's domain
     const int tid = (int)threadIdx.x;
     uint16_t* const gray_f = gray + (size_t)frame * pyr.stride;
     const size_t slot = (size_t)frame * geo.n_slots + geo.slot_base + (size_t)band * geo.n_ct + ct;
@@ -171,7 +180,9 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
 
     // =========================== A: grey rows [y0-4, y0+R+4) x columns [cx0-8, cx0+tw+8) ===========================
     if (L0) {
-        // RGBA quads; BT.601 luminance of input(x, y) (IM-1); the tile's own pixels also go to the grey plane (k_gauss)
+        // RGBA quads; BT.601 luminance of input(x, y) (IM-1) -- or the reference's 0.229 weight on the mirrored row
+        // (grayscale.wgsl:16-38); the tile's own pixels also go to the grey plane (for the blur kernel)
+        const float w_red = lit ? 0.229f : 0.299f;
         const int q0 = max(cx0 / 4 - 2, 0), q1 = min((cx0 + tw) / 4 + 2, w / 4);
         const int per_row = q1 - q0;
         const float inv_per_row = 1.0f / (float)per_row;
@@ -193,18 +204,19 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
                 dst[u] = ok ? __mul24(ly, LS) + kIPad + (q * 4 - cx0) : -1;
                 const bool own = ly >= kIApron && ly < kIApron + R && q * 4 >= cx0 && q * 4 < cx0 + tw;
                 const int gyc = min(max(gy, 0), h - 1);
-                const int off = __mul24(gyc, w) + q * 4;
+                const int off = __mul24(gyc, w) + q * 4;                      // grey plane: row gy
+                const int src = __mul24(lit ? h - 1 - gyc : gyc, w) + q * 4;  // input: mirrored row in the literal mode
                 pix[u] = own ? off : -1;
-                v[u] = *reinterpret_cast<const uint4*>(src0 + (size_t)((uint32_t)off * 4u));
+                v[u] = *reinterpret_cast<const uint4*>(src0 + (size_t)((uint32_t)src * 4u));
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (dst[u] >= 0) {
-                    auto lum = [](uint32_t rgba) {
+                    auto lum = [w_red](uint32_t rgba) {
                         const float r = unorm8_exact((float)(rgba & 255u));
                         const float g = unorm8_exact((float)((rgba >> 8) & 255u));
                         const float b = unorm8_exact((float)((rgba >> 16) & 255u));
-                        const float pr = 0.299f * r;
+                        const float pr = w_red * r;
                         const float pg = 0.587f * g;
                         const float pb = 0.114f * b;
                         return (pr + pg) + pb;
@@ -247,9 +259,9 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
 
     // Region of this tile: its own pixels plus (with NMS) a 1-px apron.  Region row r <-> image row y0 - 1 + r,
     // LDS row r + 3.  IM-4 guard: 16 < x < w - 16, 16 < y < h - 16.
-    const int rx0 = max(cx0 - apron, 17), rx1 = min(cx0 + tw + apron, w - 16);  // [rx0, rx1) columns tested
-    const int ry0 = max(y0 - apron, 17), ry1 = min(min(y0 + R, h) + apron, h - 16);
-    auto in_core = [&](int x, int gy) { return x >= cx0 && x < cx0 + tw && gy >= y0 && gy < y0 + R && gy < h; };
+    const int rx0 = max(cx0 - apron, 17), rx1 = min(cx0 + tw + apron, gx1);  // [rx0, rx1) columns tested
+    const int ry0 = max(y0 - apron, 17), ry1 = min(min(y0 + R, dh) + apron, gy1);
+    auto in_core = [&](int x, int gy) { return x >= cx0 && x < cx0 + tw && gy >= y0 && gy < y0 + R && gy < dh; };
     auto append = [&](uint32_t x, uint32_t gy, uint32_t angle, float score) {
         const uint32_t idx = atomicAdd(c_count, 1u);
         if (idx < geo.seg_cap) {
@@ -263,18 +275,18 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
         if (!ring_has_arc(ctr, LS, thr, arc)) return;
         float s;
         uint32_t ang;
-        ring_score_angle(ctr, LS, thr, arc, &s, &ang);
+        ring_score_angle(ctr, LS, thr, arc, lit, &s, &ang);
         if (geo.nms) {
             for (int dy = -1; dy <= 1; dy++)
                 for (int dx = -1; dx <= 1; dx++) {
                     if (dx == 0 && dy == 0) continue;
                     const int nx = x + dx, ny = gy + dy;
-                    if (!(nx > 16 && nx < w - 16 && ny > 16 && ny < h - 16)) continue;
+                    if (!(nx > 16 && nx < gx1 && ny > 16 && ny < gy1)) continue;
                     const half_t* nc = ctr + dy * LS + dx;
                     if (!ring_has_arc(nc, LS, thr, arc)) continue;
                     float t;
                     uint32_t na;
-                    ring_score_angle(nc, LS, thr, arc, &t, &na);
+                    ring_score_angle(nc, LS, thr, arc, lit, &t, &na);
                     const bool later = dy > 0 || (dy == 0 && dx > 0);
                     if (t > s || (t == s && !later)) return;
                 }
@@ -416,7 +428,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
             const half_t* ctr = locate(e, &x, &gy);
             float s;
             uint32_t ang;
-            ring_score_angle(ctr, LS, thr, arc, &s, &ang);
+            ring_score_angle(ctr, LS, thr, arc, lit, &s, &ang);
             list_pos[i] = (uint16_t)(e & 0x3fffu);
             list_ang[i] = (uint16_t)ang;
             list_score[i] = s;
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
         const int n_px = R * tw;
         for (int i = tid; i < n_px; i += NT) {
             const int r = i / tw, x = cx0 + (i - r * tw), gy = y0 + r;
-            if (gy < h && x > 16 && x < w - 16 && gy > 16 && gy < h - 16) direct_pixel(x, gy);
+            if (gy < dh && x > 16 && x < gx1 && gy > 16 && gy < gy1) direct_pixel(x, gy);
         }
     }
 
