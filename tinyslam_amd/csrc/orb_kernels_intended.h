@@ -69,6 +69,17 @@ __device__ __forceinline__ bool has_run_bits(uint32_t mask, uint32_t n_bits, uin
 __device__ __forceinline__ bool even_ring_filter(const half_t* ctr, int ls, float thr, uint32_t need, bool try_over,
                                                  bool try_under) {
     const float c = from_half(ctr[0]);
+    if (try_over != try_under) {
+        // one polarity to test (the usual case): d = +-(v - c) is exact, one compare per ring point
+        const float sgn = try_over ? 1.0f : -1.0f;
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float diff = from_half(ctr[kRingDy[2 * i] * ls + kRingDx[2 * i]]) - c;
+            m |= (diff * sgn > thr) ? (1u << i) : 0u;
+        }
+        return has_run_bits(m, 8u, need);
+    }
     uint32_t m_over = 0, m_under = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
