@@ -90,9 +90,21 @@ __device__ __forceinline__ bool even_ring_filter(const half_t* ctr, int ls, floa
     return (try_over && has_run_bits(m_over, 8u, need)) || (try_under && has_run_bits(m_under, 8u, need));
 }
 
-// Segment test on the full ring: corner <=> run of >= arc in either polarity.
-__device__ __forceinline__ bool ring_has_arc(const half_t* ctr, int ls, float thr, uint32_t arc) {
+// Segment test on the full ring: corner <=> run of >= arc in either polarity.  try_over / try_under: polarities whose
+// compass pre-test passed (a run of `arc` implies it, so the other polarity cannot have one).
+__device__ __forceinline__ bool ring_has_arc(const half_t* ctr, int ls, float thr, uint32_t arc, bool try_over = true,
+                                             bool try_under = true) {
     const float c = from_half(ctr[0]);
+    if (try_over != try_under) {
+        const float sgn = try_over ? 1.0f : -1.0f;
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float diff = from_half(ctr[kRingDy[i] * ls + kRingDx[i]]) - c;
+            m |= (diff * sgn > thr) ? (1u << i) : 0u;
+        }
+        return has_run_16(m, arc);
+    }
     uint32_t m_over = 0, m_under = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
             const uint32_t e = queue_b[i];
             int x, gy;
             const half_t* ctr = locate(e, &x, &gy);
-            if (ring_has_arc(ctr, LS, thr, arc)) {
+            if (ring_has_arc(ctr, LS, thr, arc, (e & 0x8000u) != 0u, (e & 0x4000u) != 0u)) {
                 const uint32_t qs = atomicAdd(qc_count, 1u);
                 if (qs < (uint32_t)kIQueueC)
                     queue_c[qs] = (uint16_t)e;
