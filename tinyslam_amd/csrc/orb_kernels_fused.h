@@ -100,6 +100,19 @@ __device__ __forceinline__ bool ring_is_corner(const half_t* ctr, int ls, float 
     }
     return (detect_streak_16(m_over) | detect_streak_16(m_under)) != 0u;  // fast.wgsl:117-121
 }
+// The same for a pixel whose compass pre-test passed with the given polarity: a 12-run holds three of the four
+// compass points, so a run of the other polarity is impossible and one mask is enough (+-(v - c) is exact).
+__device__ __forceinline__ bool ring_is_corner_polar(const half_t* ctr, int ls, float thr, bool over) {
+    const float c = from_half(ctr[0]);
+    const float sgn = over ? 1.0f : -1.0f;
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float diff = from_half(ctr[kRingDy[i] * ls + kRingDx[i]]) - c;
+        m |= (diff * sgn > thr) ? (1u << i) : 0u;
+    }
+    return detect_streak_16(m) != 0u;
+}
 // ring centroid -> milliradian code (fast.wgsl:106,115,153; CRD-8: ring order, unfused)
 __device__ __forceinline__ uint32_t ring_angle(const half_t* ctr, int ls) {
     float cx = 0.0f, cy = 0.0f;
@@ -443,7 +456,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 const uint32_t e = queue_b[i];
                 uint32_t x, gy;
                 const half_t* ctr = locate(e, &x, &gy);
-                if (ring_is_corner(ctr, LS, thr)) {
+                if (ring_is_corner_polar(ctr, LS, thr, (e & 0x8000u) != 0u)) {
                     const uint32_t qs = atomicAdd(qc_count, 1u);
                     if (qs < cap_c)
                         queue_c[qs] = (uint16_t)e;
