@@ -135,15 +135,16 @@ __device__ __forceinline__ bool fast_full_test(const half_t* ctr, int ls, float 
 // 2, 6, 10, 14 are four apart), with the run's polarity.  Cheap necessary condition used to thin the
 // pre-test survivors (9.4 % of the pixels of a noisy frame) before the 16-point test (-> 2.7 %).
 __device__ __forceinline__ bool diagonal_filter(const half_t* ctr, int ls, float thr, bool over) {
-    const float c = from_half(ctr[0]);
-    const float a = from_half(ctr[-2 * ls - 2]), b = from_half(ctr[-2 * ls + 2]);
-    const float d = from_half(ctr[2 * ls - 2]), e = from_half(ctr[2 * ls + 2]);
-    const float lo1 = fminf(a, b), hi1 = fmaxf(a, b), lo2 = fminf(d, e), hi2 = fmaxf(d, e);
-    const float m1 = fmaxf(lo1, lo2), m2 = fminf(hi1, hi2);
+    // grey values are non-negative f16: their bit patterns order like the values, so the selection runs on 16-bit
+    // integers (v_min_u16 / v_max_u16 issue at twice the rate of v_min_f32) and only the selected value is converted
+    const uint16_t a = half_bits(ctr[-2 * ls - 2]), b = half_bits(ctr[-2 * ls + 2]);
+    const uint16_t d = half_bits(ctr[2 * ls - 2]), e = half_bits(ctr[2 * ls + 2]);
+    const uint16_t lo1 = min(a, b), hi1 = max(a, b), lo2 = min(d, e), hi2 = max(d, e);
+    const uint16_t m1 = max(lo1, lo2), m2 = min(hi1, hi2);
     // 2nd smallest / 2nd largest of the four; v -> fl(v - c) is monotone, so ">= 3 diffs beyond thr"
     // is decided by that one value
-    const float sel = over ? fminf(m1, m2) : fmaxf(m1, m2);
-    const float diff = sel - c;
+    const uint16_t sel = over ? min(m1, m2) : max(m1, m2);
+    const float diff = from_half(bits_half(sel)) - from_half(ctr[0]);
     return over ? diff > thr : diff < -thr;
 }
 
