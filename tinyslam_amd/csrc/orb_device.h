@@ -31,6 +31,14 @@ __device__ __forceinline__ float from_half(half_t h) { return (float)h; }
 __device__ __forceinline__ uint16_t half_bits(half_t h) { return __builtin_bit_cast(uint16_t, h); }
 __device__ __forceinline__ half_t bits_half(uint16_t b) { return __builtin_bit_cast(half_t, b); }
 
+// fl32(v * s + a) with v a binary16 in the low half of a register, s and a binary32: one v_fma_mix_f32 instead of
+// a conversion and the arithmetic.  With s = +-1 and a = -+c the result is +-(v - c), which is exact (CRD-7).
+__device__ __forceinline__ float fma_mix_h(uint32_t v_half_bits, float s, float a) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(v_half_bits), "v"(s), "v"(a));
+    return d;
+}
+
 // CRD-1 + CRD-2: grayscale.wgsl:31-38 for one RGBA8 texel (little-endian packed word).
 __device__ __forceinline__ float luminance(uint32_t rgba) {
     float r = (float)(rgba & 255u) / 255.0f;

@@ -104,12 +104,12 @@ __device__ __forceinline__ bool ring_is_corner(const half_t* ctr, int ls, float 
 // compass points, so a run of the other polarity is impossible and one mask is enough (+-(v - c) is exact).
 __device__ __forceinline__ bool ring_is_corner_polar(const half_t* ctr, int ls, float thr, bool over) {
     const float c = from_half(ctr[0]);
-    const float sgn = over ? 1.0f : -1.0f;
+    const float sgn = over ? 1.0f : -1.0f, cneg = over ? -c : c;
     uint32_t m = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const float diff = from_half(ctr[kRingDy[i] * ls + kRingDx[i]]) - c;
-        m |= (diff * sgn > thr) ? (1u << i) : 0u;
+        const float diff = fma_mix_h(half_bits(ctr[kRingDy[i] * ls + kRingDx[i]]), sgn, cneg);  // +-(v - c), exact
+        m |= (diff > thr) ? (1u << i) : 0u;
     }
     return detect_streak_16(m) != 0u;
 }
