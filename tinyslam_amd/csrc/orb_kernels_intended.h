@@ -70,13 +70,13 @@ __device__ __forceinline__ bool even_ring_filter(const half_t* ctr, int ls, floa
                                                  bool try_under) {
     const float c = from_half(ctr[0]);
     if (try_over != try_under) {
-        // one polarity to test (the usual case): d = +-(v - c) is exact, one compare per ring point
-        const float sgn = try_over ? 1.0f : -1.0f;
+        // one polarity to test (the usual case): d = +-(v - c) is exact (one v_fma_mix_f32), one compare per ring point
+        const float sgn = try_over ? 1.0f : -1.0f, cneg = try_over ? -c : c;
         uint32_t m = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float diff = from_half(ctr[kRingDy[2 * i] * ls + kRingDx[2 * i]]) - c;
-            m |= (diff * sgn > thr) ? (1u << i) : 0u;
+            const float diff = fma_mix_h(half_bits(ctr[kRingDy[2 * i] * ls + kRingDx[2 * i]]), sgn, cneg);
+            m |= (diff > thr) ? (1u << i) : 0u;
         }
         return has_run_bits(m, 8u, need);
     }
@@ -96,12 +96,12 @@ __device__ __forceinline__ bool ring_has_arc(const half_t* ctr, int ls, float th
                                              bool try_under = true) {
     const float c = from_half(ctr[0]);
     if (try_over != try_under) {
-        const float sgn = try_over ? 1.0f : -1.0f;
+        const float sgn = try_over ? 1.0f : -1.0f, cneg = try_over ? -c : c;
         uint32_t m = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const float diff = from_half(ctr[kRingDy[i] * ls + kRingDx[i]]) - c;
-            m |= (diff * sgn > thr) ? (1u << i) : 0u;
+            const float diff = fma_mix_h(half_bits(ctr[kRingDy[i] * ls + kRingDx[i]]), sgn, cneg);
+            m |= (diff > thr) ? (1u << i) : 0u;
         }
         return has_run_16(m, arc);
     }
