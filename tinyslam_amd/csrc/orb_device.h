@@ -39,6 +39,13 @@ __device__ __forceinline__ float fma_mix_h(uint32_t v_half_bits, float s, float 
     return d;
 }
 
+// fl32(lo + hi) of the two binary16 halves of a register (one rounding, as the binary32 sum of the converted values).
+__device__ __forceinline__ float add_halves(uint32_t packed) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(packed));
+    return d;
+}
+
 // CRD-1 + CRD-2: grayscale.wgsl:31-38 for one RGBA8 texel (little-endian packed word).
 __device__ __forceinline__ float luminance(uint32_t rgba) {
     float r = (float)(rgba & 255u) / 255.0f;

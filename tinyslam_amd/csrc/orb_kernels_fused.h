@@ -501,9 +501,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 uint16_t o[4];
     #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const float a = h2f(tw[k], 0), b = h2f(tw[k], 1), c = h2f(bw[k], 0), d = h2f(bw[k], 1);
-                    const float st = a + b;
-                    const float sb = c + d;
+                    const float st = add_halves(tw[k]);  // a + b, c + d: the two texels of a row share a register (CRD-4)
+                    const float sb = add_halves(bw[k]);
                     o[k] = half_bits(to_half((st + sb) * 0.25f));
                 }
                 uint16_t* out = dst + (size_t)(uint32_t)(__mul24(yd, wd) + xd);
