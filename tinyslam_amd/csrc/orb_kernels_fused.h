@@ -576,9 +576,10 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
             }
         }
     };
-    phase_B();
+    __syncthreads();  // blur row constants published
     phase_C();
     stamp(11);  // C
+    phase_B();
     __syncthreads();
     stamp(12);
     if (tid == 0) seg_counts[slot] = *c_count;  // raw count of the band (may exceed seg_cap)
