@@ -280,6 +280,42 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     }
     __syncthreads();
 
+    // =========================== C0: next mip level (exact 2x2 case) ===========================
+    // (before the detector: its stores drain while the detector runs)
+    if (geo.write_mip && (geo.phase_mask & 16u)) {
+        const int wd = (int)pyr.w[lvl + 1], hd = (int)pyr.h[lvl + 1];
+        uint16_t* dst = gray_f + pyr.off[lvl + 1];
+        const int g4 = (tw / 2 + 3) >> 2;
+        const float inv_g4 = 1.0f / (float)max(g4, 1);
+        const int n_items = (R / 2) * g4;
+        const bool vec_ok = (wd & 3) == 0;
+        for (int i = tid; i < n_items; i += NT) {
+            const int r = (int)(((float)i + 0.5f) * inv_g4);
+            const int xl = (i - __mul24(r, g4)) * 4;
+            const int xd = cx0 / 2 + xl, yd = (y0 >> 1) + r;
+            if (yd >= hd || xd >= wd) continue;
+            const half_t* top = grey + __mul24(2 * r + kIApron, LS) + kIPad + 2 * xl;
+            const uint4 qt = *reinterpret_cast<const uint4*>(top);
+            const uint4 qb = *reinterpret_cast<const uint4*>(top + LS);
+            const uint32_t tw4[4] = {qt.x, qt.y, qt.z, qt.w}, bw[4] = {qb.x, qb.y, qb.z, qb.w};
+            uint16_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float st = add_halves(tw4[k]);  // a + b, c + d: the two texels of a row share a register (CRD-4)
+                const float sb = add_halves(bw[k]);
+                o[k] = half_bits(to_half((st + sb) * 0.25f));
+            }
+            uint16_t* out = dst + (size_t)(uint32_t)(__mul24(yd, wd) + xd);
+            if (vec_ok && xd + 4 <= wd) {
+                *reinterpret_cast<uint2*>(out) = make_uint2(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (xd + k < wd) out[k] = o[k];
+            }
+        }
+    }
+
     // Region of this tile: its own pixels plus (with NMS) a 1-px apron.  Region row r <-> image row y0 - 1 + r,
     // LDS row r + 3.  IM-4 guard: 16 < x < w - 16, 16 < y < h - 16.
     const int rx0 = max(cx0 - apron, 17), rx1 = min(cx0 + tw + apron, gx1);  // [rx0, rx1) columns tested
@@ -502,40 +538,6 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
         }
     }
 
-    // =========================== C0: next mip level (exact 2x2 case) ===========================
-    if (geo.write_mip && (geo.phase_mask & 16u)) {
-        const int wd = (int)pyr.w[lvl + 1], hd = (int)pyr.h[lvl + 1];
-        uint16_t* dst = gray_f + pyr.off[lvl + 1];
-        const int g4 = (tw / 2 + 3) >> 2;
-        const float inv_g4 = 1.0f / (float)max(g4, 1);
-        const int n_items = (R / 2) * g4;
-        const bool vec_ok = (wd & 3) == 0;
-        for (int i = tid; i < n_items; i += NT) {
-            const int r = (int)(((float)i + 0.5f) * inv_g4);
-            const int xl = (i - __mul24(r, g4)) * 4;
-            const int xd = cx0 / 2 + xl, yd = (y0 >> 1) + r;
-            if (yd >= hd || xd >= wd) continue;
-            const half_t* top = grey + __mul24(2 * r + kIApron, LS) + kIPad + 2 * xl;
-            const uint4 qt = *reinterpret_cast<const uint4*>(top);
-            const uint4 qb = *reinterpret_cast<const uint4*>(top + LS);
-            const uint32_t tw4[4] = {qt.x, qt.y, qt.z, qt.w}, bw[4] = {qb.x, qb.y, qb.z, qb.w};
-            uint16_t o[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float st = add_halves(tw4[k]);  // a + b, c + d: the two texels of a row share a register (CRD-4)
-                const float sb = add_halves(bw[k]);
-                o[k] = half_bits(to_half((st + sb) * 0.25f));
-            }
-            uint16_t* out = dst + (size_t)(uint32_t)(__mul24(yd, wd) + xd);
-            if (vec_ok && xd + 4 <= wd) {
-                *reinterpret_cast<uint2*>(out) = make_uint2(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16));
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (xd + k < wd) out[k] = o[k];
-            }
-        }
-    }
     __syncthreads();
     if (tid == 0) seg_counts[slot] = *c_count;  // raw count of the tile (may exceed seg_cap)
 }
