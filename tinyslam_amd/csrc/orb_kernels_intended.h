@@ -762,9 +762,16 @@ __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __re
     const unsigned long long kth = thr_key[frame];
     CornerData* out_kp = corners + (size_t)frame * cap;
     uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)frame * cap);
-    uint32_t pat[4];
+    // this lane's four tests (l, 64+l, 128+l, 192+l) of the pattern, as binary32 once per workgroup
+    float pfx[8], pfy[8];  // [2e] = point a, [2e+1] = point b of test e
 #pragma unroll
-    for (int e = 0; e < 4; e++) pat[e] = tab.pattern[64u * (uint32_t)e + lane];
+    for (int e = 0; e < 4; e++) {
+        const uint32_t pk = tab.pattern[64u * (uint32_t)e + lane];
+        pfx[2 * e] = (float)(int8_t)(pk & 255u);
+        pfy[2 * e] = (float)(int8_t)((pk >> 8) & 255u);
+        pfx[2 * e + 1] = (float)(int8_t)((pk >> 16) & 255u);
+        pfy[2 * e + 1] = (float)(int8_t)(pk >> 24);
+    }
     for (int t = 0; t < nb; t++) {  // tile by tile: final index = seg_before[tile] + rank among its kept entries
         const size_t sidx = sidx0 + (size_t)t * bg.n_ct[lvl];
         const uint32_t n = min(seg_counts[sidx], bg.seg_cap);
@@ -796,19 +803,21 @@ __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __re
                 const uint4 kr = kept_rec[r];
                 const uint32_t code = min(kr.z, (uint32_t)(ORB_ANGLE_STEPS_FULL - 1));
                 const float ct_ = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
-                const int bx = (int)kr.x - wx0, by = (int)kr.y - wy0;  // keypoint inside the window
+                // LDS index of the keypoint inside the window (wave-uniform); a sample adds dy * pitch + dx
+                const int kbase = __builtin_amdgcn_readfirstlane(((int)kr.y - wy0) * pitch + ((int)kr.x - wx0));
                 uint64_t bal[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
-                    const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
-                    // R(+theta) p = (ct*x - st*y, st*x + ct*y), products and sums rounded on their own (IM-6)
-                    const float a0 = ct_ * pax, a1 = nst * pay, a2 = st * pax, a3 = ct_ * pay;
-                    const float b0 = ct_ * pbx, b1 = nst * pby, b2 = st * pbx, b3 = ct_ * pby;
-                    const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
-                    const uint32_t va = win[__mul24(by + (int)ray, pitch) + bx + (int)rax];
-                    const uint32_t vb = win[__mul24(by + (int)rby, pitch) + bx + (int)rbx];
-                    bal[e] = __ballot(va > vb);  // non-negative f16: bit patterns order like the values
+                    int idx[2];
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        // R(+theta) p = (ct*x - st*y, st*x + ct*y), products and sums rounded on their own (IM-6)
+                        const float p0 = ct_ * pfx[2 * e + q], p1 = nst * pfy[2 * e + q];
+                        const float p2 = st * pfx[2 * e + q], p3 = ct_ * pfy[2 * e + q];
+                        const float rx = p0 + p1, ry = p2 + p3;
+                        idx[q] = kbase + __mul24((int)ry, pitch) + (int)rx;
+                    }
+                    bal[e] = __ballot((uint32_t)win[idx[0]] > (uint32_t)win[idx[1]]);  // non-negative f16: bit patterns order like the values
                 }
                 if (lane < 8u) {
                     const uint64_t srcw = lane < 2u ? bal[0] : (lane < 4u ? bal[1] : (lane < 6u ? bal[2] : bal[3]));
