@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- ORB extract throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B] [--total-frames T] [--repeats R]
 
-One "step" = one pass of the hot path (RGBA frames in -> keypoints + BRIEF-256 descriptors out)
-over one batch of B synthetic 1280x720 frames that are already resident in HBM (generated on the
-device).  BASELINE.json configs[3]: B = 256 frames on one GPU.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank processes its own B frames (weak scaling:
-configs[4] is 2048 frames over 8 GPUs = 256 per GPU) and each step ends with the collate of all
-results to rank 0 over RCCL.
+One "step" = one pass of the hot path (RGBA frames in -> keypoints + BRIEF-256 descriptors out) over one batch of
+synthetic 1280x720 frames that are already resident in HBM (generated on the device).
 
-Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against HBM bandwidth with
-the algorithmic bytes of SURVEY.md 8(d); `cpu_baseline` is the CPU restatement (oracle/, "port")
-timed on the host cores on a bounded sample of the same frames -- it is never the thing shipped.
+* default (weak scaling): every GPU processes its own B = 256 frames per step -- BASELINE.json configs[3] at N = 1,
+  configs[4] (2048 frames over 8 GPUs = 256 per GPU) at N = 8;
+* --total-frames T (strong scaling, e.g. 2048): a step is the whole T-frame job, sharded in contiguous ranges over the
+  N GPUs, every rank working through its shard in B-frame batches.
+With N > 1 every batch is collated on rank 0 over RCCL inside the timed region (the gather of one batch overlaps the
+kernels of the next).
+
+`python bench.py --gpus N` launches its own N rank processes (tinyslam_amd/launch.py) when it was not started by
+torch.distributed.run; the launcher never touches the GPU.
+
+The timed region is EXACTLY K steps between barrier + synchronize on both sides, max over ranks; it is repeated R
+times and `value` / `ms_per_step` are the median repeat (all repeats in `repeats_ms_per_step`).  Kernel durations for
+`roofline` come from a further pass of the same K steps with every launch bracketed by HIP events on its stream, so the
+events are outside the timed repeats.  `cpu_baseline` is the CPU restatement (oracle/, "port") timed on the host cores
+on a bounded sample of the same frames -- it is never the thing shipped.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -29,8 +37,28 @@ SEED0 = 1000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(n_sample, intended=False):
-    """Times oracle/ (the CPU restatement) on the first n_sample frames of the workload."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per batch")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="strong scaling: a step is this many frames in all (BASELINE.json configs[4]: 2048), sharded "
+                         "over the GPUs; 0 = weak scaling, --frames per GPU per step")
+    ap.add_argument("--repeats", type=int, default=5, help="how often the K-step timed region is repeated (median reported)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="frames for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-host-out", action="store_true", help="skip the device-in -> host-out measurement (N = 1)")
+    ap.add_argument("--staged", action="store_true", help="force the one-kernel-per-stage pipeline")
+    ap.add_argument("--mode", choices=("literal", "intended"), default="literal",
+                    help="literal = the reference's algorithm (the headline, BASELINE.json); intended = the opt-in "
+                         "repaired algorithm with FAST-9 + NMS (DESIGN.md section 8; not in the reference)")
+    return ap.parse_args(argv)
+
+
+def cpu_baseline(n_sample, gpu_counts, intended=False):
+    """Times oracle/ (the CPU restatement) on the first n_sample frames of the workload and checks that its per-frame
+    counters equal the GPU's on those frames."""
     import numpy as np
     from oracle import orb_oracle
     orb_oracle.build()
@@ -49,25 +77,17 @@ def cpu_baseline(n_sample, intended=False):
         totals, _, _ = orb_oracle.extract_batch(frames, depth=DEPTH, threshold=THRESHOLD, max_features=MAX_FEATURES,
                                                 n_threads=cores)
     dt = time.perf_counter() - t0
+    m = min(n_sample, len(gpu_counts))
     return {"value": n_sample / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d of the bench's 1280x720 frames (seeds %d..), oracle/orb_oracle.c frame-parallel over %d "
                       "threads, %.1f s wall" % (n_sample, SEED0, cores, dt),
-            "keypoints_per_frame": float(np.minimum(totals, MAX_FEATURES).mean())}
+            "keypoints_per_frame": float(np.minimum(totals, MAX_FEATURES).mean()),
+            "counts_equal_gpu": bool(np.array_equal(np.asarray(totals[:m], dtype=np.int64),
+                                                    np.asarray(gpu_counts[:m], dtype=np.int64))),
+            "counts_compared": int(m)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="frames for the CPU baseline (0 = skip)")
-    ap.add_argument("--staged", action="store_true", help="force the one-kernel-per-stage pipeline")
-    ap.add_argument("--mode", choices=("literal", "intended"), default="literal",
-                    help="literal = the reference's algorithm (the headline, BASELINE.json); intended = the opt-in "
-                         "repaired algorithm with FAST-9 + NMS (DESIGN.md section 8; not in the reference)")
-    args = ap.parse_args()
-
+def run_rank(args):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -77,14 +97,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     n_dev = torch.cuda.device_count()
     dev_index = local_rank if local_rank < n_dev else local_rank % max(n_dev, 1)  # rehearsal: ranks share a GPU
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend = None
     if world > 1:
         # "nccl" is RCCL on ROCm.  TINYORB_DIST_BACKEND=gloo only exists to rehearse the N > 1 code path
         # on a one-GPU box (several ranks sharing device 0, which RCCL refuses).
@@ -95,54 +115,73 @@ def main():
             dist.init_process_group(backend)
 
     B = args.frames
+    strong = args.total_frames > 0
+    if strong:
+        lo, hi = node.shard_range(args.total_frames, world, rank)
+    else:
+        lo, hi = rank * B, (rank + 1) * B  # rank g owns frames [g*B, (g+1)*B)
+    n_local = hi - lo
+    batches = [(b0, min(B, n_local - b0)) for b0 in range(0, n_local, B)]  # (first local frame, frames)
+    job_frames = args.total_frames if strong else B * world
+
     cfg = orb.OrbConfig(orb.Extent3d(W, H), max_features=MAX_FEATURES, hierarchy_depth=DEPTH,
                         initial_threshold=THRESHOLD, device=dev_index, max_batch=B,
-                        flags=(orb.ORB_FLAG_STAGED if args.staged else 0) | (orb.ORB_FLAG_DOUBLE_OUTPUT if world > 1 else 0)
+                        flags=(orb.ORB_FLAG_STAGED if args.staged else 0) | orb.ORB_FLAG_DOUBLE_OUTPUT
                         | ((orb.ORB_FLAG_INTENDED | orb.ORB_FLAG_NMS) if args.mode == "intended" else 0),
                         fast_arc=9 if args.mode == "intended" else 0)
     prog = orb.OrbProgram(cfg).init()
-    frames_dev = prog.synth_frames_device(B, SEED0 + rank * B)  # rank g owns frames [g*B, (g+1)*B)
-    n_sets = 2 if world > 1 else 1
+    frame_bytes = W * H * 4
+    frames_t = torch.empty(max(n_local, 1) * frame_bytes, dtype=torch.uint8, device=dev)  # this rank's shard, in HBM
+    for b0, nb in batches:
+        prog.synth_frames_device(nb, SEED0 + lo + b0, frames_dev_ptr=frames_t.data_ptr() + b0 * frame_bytes)
     views = []
-    for s_ in range(n_sets):
+    for s_ in range(2):
         prog.batch_select_output(s_)
         d_counts, d_corners, d_desc = prog.batch_device_buffers()
         views.append((node.as_tensor(d_counts, (B,), "<i4", dev), node.as_tensor(d_corners, (B, MAX_FEATURES, 4), "<i4", dev),
                       node.as_tensor(d_desc, (B, MAX_FEATURES, 8), "<i4", dev)))
     prog.batch_select_output(0)
-    state = {"k": 0, "pending": None}
+    state = {"k": 0, "pending": None, "gathered_bytes": 0}
     free = [None, None]
     compute_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
 
     def collate(pending):
-        slot, done = pending
+        slot, done, nb = pending
         counts_t, corners_t, desc_t = views[slot]
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(done)  # the kernels that wrote this output set
-            node.collate_to_root(counts_t, corners_t, desc_t, MAX_FEATURES)
+            out = node.collate_to_root(counts_t, corners_t, desc_t, MAX_FEATURES)
+            if out is not None:
+                state["gathered_bytes"] += out[1].numel() * 4 + out[2].numel() * 4
             free[slot] = torch.cuda.Event()
             free[slot].record(comm_stream)  # the gather has read this output set
 
     def step():
-        """N = 1: extract.  N > 1: launch batch k into output set k%2 on the compute stream, then collate
-        batch k-1 on the communication stream (it waits on the event recorded behind batch k-1's kernels):
-        the RCCL gather of one batch overlaps the kernels of the next.  Every batch is collated inside the
-        timed region (flush() drains the last one)."""
-        if world == 1:
-            prog.extract_batch_device(frames_dev, B)
-            return
-        slot = state["k"] & 1
-        prog.batch_select_output(slot)
-        if free[slot] is not None:
-            compute_stream.wait_event(free[slot])  # do not overwrite a set that is still being gathered
-        prog.extract_batch_device(frames_dev, B, stream=compute_stream.cuda_stream)
-        done = torch.cuda.Event()
-        done.record(compute_stream)
-        if state["pending"] is not None:
-            collate(state["pending"])
-        state["pending"] = (slot, done)
-        state["k"] += 1
+        """One pass over this rank's frames.  N = 1: extract, batch by batch.  N > 1: batch k goes into output set k%2 on
+        the compute stream, then batch k-1 is collated on the communication stream (it waits on the event recorded
+        behind batch k-1's kernels): the RCCL gather of one batch overlaps the kernels of the next.  Every batch is
+        collated inside the timed region (flush() drains the last one).  In the strong-scaling mode every rank runs the
+        same number of collates (an empty shard tail still takes part with zero counts)."""
+        for b0, nb in batches:
+            ptr = frames_t.data_ptr() + b0 * frame_bytes
+            if world == 1:
+                prog.extract_batch_device(ptr, nb)
+                continue
+            slot = state["k"] & 1
+            prog.batch_select_output(slot)
+            if free[slot] is not None:
+                compute_stream.wait_event(free[slot])  # do not overwrite a set that is still being gathered
+            if nb < B:  # ragged last batch: frames past nb must read as empty in the gather
+                with torch.cuda.stream(compute_stream):
+                    views[slot][0][nb:].zero_()
+            prog.extract_batch_device(ptr, nb, stream=compute_stream.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(compute_stream)
+            if state["pending"] is not None:
+                collate(state["pending"])
+            state["pending"] = (slot, done, nb)
+            state["k"] += 1
 
     def flush():
         if world > 1 and state["pending"] is not None:
@@ -157,47 +196,138 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n_steps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if strong and world > 1:
+        n_b = torch.tensor([len(batches)], device=dev)
+        mx_b = n_b.clone()
+        dist.all_reduce(mx_b, op=dist.ReduceOp.MAX)
+        if int(mx_b.item()) != len(batches):
+            raise SystemExit("--total-frames %d does not split into the same number of %d-frame batches on every rank"
+                             % (args.total_frames, B))
+
     for _ in range(args.warmup):
         step()
-    fence()
+    repeats = [timed(args.steps) for _ in range(max(1, args.repeats))]
+    state["gathered_bytes"] = 0
     prog.profile_enable(True)
     prog.profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    profiled = timed(args.steps)  # same K steps with HIP events around every launch
+    prof = prog.profile()
     prog.profile_enable(False)
+    gathered_per_step = state["gathered_bytes"] / max(1, args.steps)
+    elapsed = sorted(repeats)[len(repeats) // 2]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    # keypoints of this rank's shard (last batch's counters stand for all of them only in the weak mode; in the
+    # strong mode every batch is visited once more, outside any timed region)
+    stored_local, counts_first = 0.0, None
+    for b0, nb in batches:
+        if len(batches) > 1 or world > 1:
+            prog.batch_select_output(0)
+            prog.extract_batch_device(frames_t.data_ptr() + b0 * frame_bytes, nb)
+        c = prog.batch_counts(nb)
+        if counts_first is None:
+            counts_first = c.copy()
+        stored_local += float(np.minimum(c, MAX_FEATURES).sum())
+    kp = torch.tensor([stored_local], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        dist.all_reduce(kp, op=dist.ReduceOp.SUM)
+    kp_per_step = float(kp.item())
 
-    counts = prog.batch_counts(B)
-    stored = np.minimum(counts, MAX_FEATURES)
-    kp_local = torch.tensor([float(stored.sum())], dtype=torch.float64, device=dev)
+    # collate alone (N > 1): the same gather, serialised, to price the links into rank 0
+    collate_info = None
     if world > 1:
-        dist.all_reduce(kp_local, op=dist.ReduceOp.SUM)
-    kp_per_step = float(kp_local.item())
+        fence()
+        prog.batch_select_output(0)
+        prog.extract_batch_device(frames_t.data_ptr(), batches[0][1] if batches else 0, stream=compute_stream.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(compute_stream)
+        fence()
+        state["gathered_bytes"] = 0
+        n_rep = 10
+        t0 = time.perf_counter()
+        for _ in range(n_rep):
+            collate((0, done, batches[0][1]))
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        per = state["gathered_bytes"] / n_rep
+        from_peers = per * (world - 1) / world
+        collate_info = {"bytes_gathered_per_batch": per, "bytes_from_peers_per_batch": from_peers,
+                        "ms_alone_per_batch": dt / n_rep * 1e3, "gbs_into_root": from_peers / (dt / n_rep) / 1e9,
+                        "gbs_per_link": from_peers / (dt / n_rep) / 1e9 / (world - 1),
+                        "bytes_gathered_per_step_timed": gathered_per_step, "backend": backend}
+
+    # device-resident in -> host-resident out (N = 1): every batch is packed and written to pinned host memory by
+    # orb_batch_read_all on a second stream while the next batch computes
+    host_out = None
+    if world == 1 and not args.no_host_out and batches:
+        copy_stream = torch.cuda.Stream(device=dev)
+        hbs = [orb.HostBatch(B, B * MAX_FEATURES) for _ in range(2)]
+        ev_free = [None, None]
+        k = 0
+
+        def host_step():
+            nonlocal k
+            for b0, nb in batches:
+                slot = k & 1
+                prog.batch_select_output(slot)
+                if ev_free[slot] is not None:
+                    torch.cuda.current_stream(dev).wait_event(ev_free[slot])
+                prog.extract_batch_device(frames_t.data_ptr() + b0 * frame_bytes, nb,
+                                          stream=torch.cuda.current_stream(dev).cuda_stream)
+                prog.batch_read_all(nb, out=hbs[slot], stream=copy_stream.cuda_stream, sync=False)
+                ev_free[slot] = torch.cuda.Event()
+                ev_free[slot].record(copy_stream)
+                k += 1
+        for _ in range(2):
+            host_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            host_step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        total_rec = int(hbs[(k - 1) & 1].offsets[batches[-1][1]])
+        host_out = {"frames_per_s": job_frames * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                    "bytes_to_host_per_batch": total_rec * 48 + batches[-1][1] * 12,
+                    "how": "orb_batch_read_all: k_compact writes the packed records of a batch straight into pinned host "
+                           "memory over PCIe on a second stream, double buffered against the next batch's kernels"}
+        host_out["pcie_gbs"] = host_out["bytes_to_host_per_batch"] * len(batches) * args.steps / dt / 1e9
+        prog.batch_select_output(0)
+        for hb in hbs:
+            hb.close()
 
     if rank == 0:
-        prof = prog.profile()
-        total_frames = B * world * args.steps
+        total_frames = job_frames * args.steps
         fps = total_frames / elapsed
-        # dominant kernel = largest accumulated device time inside the timed region
-        dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else (None, (0.0, 0))
-        n_mean = float(stored.mean())
+        launches_frames = n_local * args.steps  # frames this rank pushed through each kernel in the profiled pass
+        prof_k = {k_: v for k_, v in prof.items() if k_ != "k_compact"}
+        dom = max(prof_k.items(), key=lambda kv: kv[1][0]) if prof_k else (None, (0.0, 0))
+        n_mean = kp_per_step / job_frames
         bytes_per_frame = 4 * W * H + 48 * n_mean + 4  # RGBA read once + records + counter
         roofline = None
         if dom[0]:
             avg_ms = dom[1][0] / dom[1][1]
-            frames_per_launch = B * args.steps / dom[1][1]
+            frames_per_launch = launches_frames / dom[1][1]
             achieved = bytes_per_frame * frames_per_launch / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
                         "algorithmic_bytes_per_launch": bytes_per_frame * frames_per_launch,
-                        "all_kernels_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()}}
+                        "frames_per_launch": frames_per_launch,
+                        "measured": "HIP events around every launch on the launch stream, in a pass of the same %d steps "
+                                    "right after the timed repeats (%.4f ms per step with the events in)"
+                                    % (args.steps, profiled / args.steps * 1e3),
+                        "all_kernels_ms_per_step": {k_: v[0] / args.steps for k_, v in prof.items()}}
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
@@ -207,32 +337,52 @@ def main():
         out = {
             "metric": "ORB extract throughput, 1280x720 (frames/sec; Mkeypoints/sec alongside)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (gradient+blobs+wedges+noise, seeds %d.., generated on device)" % SEED0,
-            "config": {"workload": "BASELINE.json configs[3]: batch of %d independent 1280x720 RGBA frames per GPU, "
-                                   "device-resident, full ORB (%s)"
-                                   % (B, "FAST-12 + orientation + blur + BRIEF-256" if args.mode == "literal" else
+            "config": {"workload": ("BASELINE.json configs[4]: one job of %d independent 1280x720 RGBA frames sharded over "
+                                    "%d GPU(s), %d-frame batches" % (args.total_frames, world, B)) if strong else
+                                   ("BASELINE.json configs[3]: batch of %d independent 1280x720 RGBA frames per GPU"
+                                    % B) + ", device-resident, full ORB (%s)"
+                                   % ("FAST-12 + orientation + blur + BRIEF-256" if args.mode == "literal" else
                                       "opt-in intended mode, NOT the reference's algorithm: FAST-9 + NMS + full-circle "
                                       "orientation + separable Gaussian + BRIEF-256"),
-                       "frames_per_gpu": B, "width": W, "height": H, "hierarchy_depth": DEPTH,
-                       "max_features": MAX_FEATURES, "threshold": THRESHOLD, "mode": args.mode,
+                       "frames_per_gpu_per_batch": B, "frames_per_step": job_frames, "width": W, "height": H,
+                       "hierarchy_depth": DEPTH, "max_features": MAX_FEATURES, "threshold": THRESHOLD, "mode": args.mode,
                        "pipeline": "staged" if args.staged else "default",
                        "collate": "RCCL gather of every batch to rank 0, overlapped with the next batch's kernels" if world > 1 else "none (1 GPU)"},
+            "repeats_ms_per_step": [r / args.steps * 1e3 for r in repeats],
+            "min_ms_per_step": min(repeats) / args.steps * 1e3, "max_ms_per_step": max(repeats) / args.steps * 1e3,
             "mkeypoints_per_s": kp_per_step * args.steps / elapsed / 1e6,
             "keypoints_per_frame": n_mean,
             "hbm_algorithmic_gbs": bytes_per_frame * fps / 1e9,
             "roofline": roofline,
         }
+        if collate_info:
+            out["collate"] = collate_info
+        if host_out:
+            out["host_out_frames_per_s"] = host_out["frames_per_s"]
+            out["host_out"] = host_out
         if world == 1:
             n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 128
             if n_cpu > 0:
-                out["cpu_baseline"] = cpu_baseline(n_cpu, intended=args.mode == "intended")
+                out["cpu_baseline"] = cpu_baseline(n_cpu, counts_first, intended=args.mode == "intended")
         print(json.dumps(out), flush=True)
     prog.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not started by torch.distributed.run: spawn the ranks ourselves -- before torch, libtinyorb or anything else
+        # that could initialise the GPU is imported into this process (a process that holds a HIP context must not fork
+        # or exec workers; this one only waits and relays the exit status)
+        from tinyslam_amd import launch
+        sys.exit(launch.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TINYORB_ABI_VERSION 1
+#define TINYORB_ABI_VERSION 2
 
 /* status codes (the reference panics instead: orb.rs:553 unwrap, label look-ups) */
 #define ORB_OK 0
@@ -139,6 +139,58 @@ int orb_batch_select_output(OrbProgram *p, uint32_t set);
  * counts[max_batch] u32, corners[max_batch][max_features], descriptors[max_batch][max_features]. */
 int orb_batch_device_buffers(OrbProgram *p, void **counts, void **corners, void **descriptors);
 
+/* ---- bulk read-back (orb.rs:537-565: the reference copies counter + corners + descriptors to host staging after
+ * every frame; the batched mode returns a whole batch in one go) ----
+ * Packs the STORED records (min(counter, max_features) per frame) of the first n_frames frames of the last batch
+ * back to back, in frame order, into caller-allocated buffers:
+ *   counts[n_frames]       raw per-frame counters (may be NULL)
+ *   offsets[n_frames + 1]  exclusive prefix of the stored counts; offsets[n_frames] = total records (may be NULL)
+ *   corners / descriptors  [capacity] records; records past `capacity` are dropped (compare offsets[n_frames]).
+ * orb_batch_read_all: HOST buffers.  With pinned memory (orb_host_alloc, or registered with the HIP runtime by the
+ * caller) the device writes them directly over PCIe, asynchronously on `stream` (NULL: the stream of the batch; then
+ * orb_batch_sync() waits for it; another stream is ordered behind the batch and waited for with orb_stream_sync()).
+ * Pageable buffers are pinned for the duration of the call, which then blocks.
+ * orb_batch_compact_device: the same into DEVICE buffers (payload of a device-side collate). */
+int orb_batch_read_all(OrbProgram *p, uint32_t n_frames, uint32_t *counts, uint64_t *offsets, CornerData *corners,
+                       CornerDescriptor *descriptors, size_t capacity, void *stream);
+int orb_batch_compact_device(OrbProgram *p, uint32_t n_frames, uint32_t *counts_dev, uint64_t *offsets_dev,
+                             CornerData *corners_dev, CornerDescriptor *descriptors_dev, size_t capacity, void *stream);
+/* Pinned, device-visible host memory for callers without a HIP binding of their own. */
+int orb_host_alloc(size_t nbytes, void **out);
+void orb_host_free(void *ptr);
+/* Waits for `stream` (a hipStream_t; NULL: the program's own stream) on the program's device. */
+int orb_stream_sync(OrbProgram *p, void *stream);
+/* The program's own stream (a hipStream_t), for callers that order their own work behind it. */
+void *orb_program_stream(OrbProgram *p);
+
+/* ---- one node, several GPUs (BASELINE.json configs[4]).  NOT in the reference, which drives one wgpu
+ * device (orb.rs:47-51): an OrbNode owns one OrbProgram per listed device of this process and shards a batch of
+ * independent frames over them in contiguous ranges (rank r gets frames [F*r/n, F*(r+1)/n) -- no data-path
+ * collective).  The only exchange is the collate to the first device: per-frame counters by ncclAllGather, then the
+ * packed records of every other device by grouped ncclSend/ncclRecv of their EXACT sizes (RCCL over xGMI; librccl is
+ * loaded on first use, a single-GPU program never needs it). ---- */
+typedef struct OrbNode OrbNode;
+/* options->device is ignored (devices[] decides); options->max_batch is the largest shard of one device. */
+int orb_node_create(const int *devices, int n_devices, const OrbConfig *config, const OrbOptions *options, OrbNode **out);
+void orb_node_destroy(OrbNode *node);
+const char *orb_node_last_error(const OrbNode *node);
+int orb_node_device_count(const OrbNode *node);
+/* The program of rank `rank` (borrowed; e.g. for orb_synth_frames_device or orb_set_threshold on every rank). */
+OrbProgram *orb_node_program(OrbNode *node, int rank);
+/* Frame range [*lo, *hi) of rank `rank` for a job of n_frames frames. */
+int orb_node_shard(const OrbNode *node, uint32_t n_frames, int rank, uint32_t *lo, uint32_t *hi);
+/* frames_dev[r]: rank r's shard, resident on ITS device (frames lo_r.. of the job, contiguous RGBA8).  Asynchronous:
+ * every device runs its shard on its own stream. */
+int orb_node_extract_batch(OrbNode *node, const uint8_t *const *frames_dev, uint32_t n_frames);
+/* The same from one host array of n_frames frames (each shard is uploaded to its device first). */
+int orb_node_extract_batch_host(OrbNode *node, const uint8_t *frames_host, uint32_t n_frames);
+/* Collates the last job on the first device and blocks until it is there.  counts[n_frames] and offsets[n_frames + 1]
+ * are HOST arrays (as in orb_batch_read_all; either may be NULL); *corners_dev / *descriptors_dev receive the
+ * addresses of the packed records on the first device (frame order, valid until the next collate). */
+int orb_node_collate(OrbNode *node, uint32_t *counts, uint64_t *offsets, void **corners_dev, void **descriptors_dev);
+/* Copies the collated records to the host (after orb_node_collate); capacity in records. */
+int orb_node_read_collated(OrbNode *node, CornerData *corners, CornerDescriptor *descriptors, size_t capacity);
+
 /* ---- descriptor matching (the SLAM stage that consumes this path's output; NOT in the
  * reference, definition is the build's own) ----
  * Brute-force Hamming matching between consecutive frames of the last batch: for every stored keypoint i of frame
@@ -175,7 +227,7 @@ int orb_debug_f32_to_f16(OrbProgram *p, const float *src, uint16_t *dst, size_t 
 int orb_debug_angle_code(OrbProgram *p, const float *cy, const float *cx, uint32_t *dst, size_t n);
 
 /* ---- measurement ---- */
-#define ORB_KERNEL_COUNT 14
+#define ORB_KERNEL_COUNT 15
 /* When enabled every kernel launch is bracketed by hipEvents on its stream. */
 int orb_profile_enable(OrbProgram *p, int enable);
 int orb_profile_reset(OrbProgram *p);

@@ -1,0 +1,268 @@
+"""GPU parity, round 2: the surfaces round 1 left untested (chunked host ingest, a non-Python caller of the C ABI,
+orb_corner_level0_xy, wide literal frames, two programs alive at once, octaves without a FAST dispatch) and the new
+entries (bulk read-back, node-level API).  Everything is compared with the CPU oracle, bit for bit."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+THR = 20.0 / 255.0
+
+
+def _program(tinyorb, W, H, depth=2, max_features=8192, max_batch=1, flags=0, thr=THR, fast_arc=0):
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=max_features, hierarchy_depth=depth,
+                            initial_threshold=thr, max_batch=max_batch, flags=flags, fast_arc=fast_arc)
+    return tinyorb.OrbProgram(cfg).init()
+
+
+def _sorted(corners, desc):
+    order = np.lexsort((corners["x"], corners["y"], corners["octave"]))
+    return corners[order], desc[order]
+
+
+def _assert_frame_equal(oracle, ref, total, corners, desc):
+    assert total == ref["total"]
+    c, d = _sorted(corners, desc)
+    rc, rd = oracle.sort_keypoints(ref["corners"], ref["descriptors"])
+    assert len(c) == len(rc)
+    for k in ("octave", "y", "x", "angle"):
+        assert np.array_equal(c[k], rc[k]), k
+    assert np.array_equal(d, rd), "descriptors differ"
+
+
+def _compile(src, out):
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", src),
+                           "-L" + os.path.join(ROOT, "tinyslam_amd"), "-ltinyorb",
+                           "-Wl,-rpath," + os.path.join(ROOT, "tinyslam_amd"), "-o", out])
+
+
+def test_chunked_host_ingest_equals_per_frame_oracle(tinyorb, oracle):
+    """orb_extract_batch_host with more frames than one upload chunk (16) and a ragged last chunk: the copy stream, the
+    per-chunk events and run_fused_range with f0 > 0 (orb_api.hip)."""
+    W, H, B = 160, 120, 40
+    frames = np.stack([oracle.synth_frame(W, H, 500 + i) for i in range(B)])
+    keep = frames.copy()
+    with _program(tinyorb, W, H, 2, max_batch=B) as prog:
+        assert prog.pipeline() == "fused"
+        prog.extract_batch_host(frames)
+        assert np.array_equal(frames, keep), "the caller's frames were modified"
+        counts = prog.batch_counts(B)
+        for i in range(B):
+            ref = oracle.extract(frames[i], depth=2, threshold=THR)
+            corners, desc = prog.batch_read(i, int(counts[i]))
+            _assert_frame_equal(oracle, ref, int(counts[i]), corners, desc)
+        # the bulk read-back of the same batch says the same (pinned destination, written by the device)
+        hb = prog.batch_read_all(B)
+        assert np.array_equal(hb.counts, counts)
+        assert np.array_equal(hb.offsets, np.concatenate([[0], np.cumsum(np.minimum(counts, 8192))]).astype(np.uint64))
+        for i in (0, 15, 16, 17, 39):
+            c, d = hb.frame(i)
+            c2, d2 = prog.batch_read(i, int(counts[i]))
+            assert np.array_equal(c, c2) and np.array_equal(d, d2)
+        hb.close()
+
+
+def test_read_all_capacity_and_pageable_buffers(tinyorb, oracle):
+    W, H, B, cap = 160, 120, 5, 64  # cap below the per-frame count: stored = min(raw, cap)
+    frames = np.stack([oracle.synth_frame(W, H, 900 + i) for i in range(B)])
+    with _program(tinyorb, W, H, 2, max_batch=B, max_features=cap) as prog:
+        prog.extract_batch_host(frames)
+        counts = prog.batch_counts(B)
+        assert counts.max() > cap  # the raw counter is reported (orb.rs:550-556), records are capped
+        stored = np.minimum(counts, cap)
+        total = int(stored.sum())
+        # pageable numpy destinations: pinned for the duration of the call
+        c_counts = np.zeros(B, np.uint32)
+        c_off = np.zeros(B + 1, np.uint64)
+        c_kp = np.zeros(total, tinyorb.CORNER_DTYPE)
+        c_d = np.zeros((total, 8), np.uint32)
+        L = prog._lib
+        rc = L.orb_batch_read_all(prog._handle(), B, c_counts.ctypes.data, c_off.ctypes.data, c_kp.ctypes.data, c_d.ctypes.data,
+                                  total, None)
+        assert rc == 0
+        assert np.array_equal(c_counts, counts) and int(c_off[B]) == total
+        for i in range(B):
+            kp, d = prog.batch_read(i, int(stored[i]))
+            lo, hi = int(c_off[i]), int(c_off[i + 1])
+            assert np.array_equal(c_kp[lo:hi], kp) and np.array_equal(c_d[lo:hi], d)
+        # a destination that is too small: records past the capacity are dropped, the total still reports them
+        small = total - int(stored[-1]) - 3
+        s_kp = np.full(small + 8, 0xEE, np.uint8).view(np.uint8)
+        s_kp = np.zeros(small + 8, tinyorb.CORNER_DTYPE)
+        s_kp["x"] = 0xEEEEEEEE
+        s_d = np.zeros((small + 8, 8), np.uint32)
+        rc = L.orb_batch_read_all(prog._handle(), B, None, c_off.ctypes.data, s_kp.ctypes.data, s_d.ctypes.data, small, None)
+        assert rc == 0 and int(c_off[B]) == total
+        assert np.array_equal(s_kp[:small], c_kp[:small]) and np.all(s_kp["x"][small:] == 0xEEEEEEEE)
+
+
+def test_c_caller_matches_oracle(tinyorb, oracle, tmp_path):
+    """examples/minimal.c, compiled here with gcc against include/tinyorb.h and libtinyorb.so: a non-Python caller of
+    the six reference methods (stands in for the Rust shim, which cannot be built in this image)."""
+    exe = str(tmp_path / "minimal")
+    _compile("minimal.c", exe)
+    # 1. the built-in checker frame
+    dump = str(tmp_path / "dump.bin")
+    out = subprocess.run([exe, dump], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    i = np.arange(640 * 480)
+    v = np.where(((i % 640) // 3 % 5 == 0) & ((i // 640) // 3 % 5 == 0), 255, 0).astype(np.uint8)
+    rgba = np.stack([v, v, v, np.full_like(v, 255)], axis=1).reshape(480, 640, 4)
+    for frame_path, frame in ((None, rgba), (str(tmp_path / "frame.rgba"), oracle.synth_frame(640, 480, 1))):
+        if frame_path:
+            frame.tofile(frame_path)
+            out = subprocess.run([exe, dump, frame_path], capture_output=True, text=True, timeout=300)
+            assert out.returncode == 0, out.stderr
+        raw = open(dump, "rb").read()
+        total, n = np.frombuffer(raw[:8], np.uint32)
+        kp = np.frombuffer(raw[8:8 + 16 * n], tinyorb.CORNER_DTYPE)
+        desc = np.frombuffer(raw[8 + 16 * n:8 + 48 * n], np.uint32).reshape(n, 8)
+        ref = oracle.extract(frame, depth=2, threshold=THR, max_features=4096)
+        assert int(total) == ref["total"] and ("%d keypoints (fused pipeline)" % total) in out.stdout
+        if total <= 4096:
+            _assert_frame_equal(oracle, ref, int(total), kp, desc)
+        else:  # more corners than max_features: which ones are kept is unspecified (Q9/Q10); every kept one must be real
+            full = oracle.extract(frame, depth=2, threshold=THR, max_features=1 << 20)
+            want = {(int(c["octave"]), int(c["y"]), int(c["x"])): (int(c["angle"]), d.tobytes())
+                    for c, d in zip(full["corners"], full["descriptors"])}
+            assert n == 4096
+            for c, d in zip(kp, desc):
+                assert want[(int(c["octave"]), int(c["y"]), int(c["x"]))] == (int(c["angle"]), d.tobytes())
+
+
+def test_c_node_caller_one_device(tinyorb, oracle, tmp_path):
+    """examples/node_batch.c: orb_node_* (n = 1: RCCL communicator of one rank, degenerate collate) against the
+    single-device bulk read-back, and both against the oracle."""
+    exe = str(tmp_path / "node_batch")
+    _compile("node_batch.c", exe)
+    W, H, F = 160, 120, 7
+    frames = np.stack([oracle.synth_frame(W, H, 300 + i) for i in range(F)])
+    fpath, opath = str(tmp_path / "frames.rgba"), str(tmp_path / "out.bin")
+    frames.tofile(fpath)
+    out = subprocess.run([exe, fpath, str(W), str(H), str(F), opath, "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "node collate == single-device read-back" in out.stdout
+    raw = open(opath, "rb").read()
+    assert np.frombuffer(raw[:4], np.uint32)[0] == F
+    counts = np.frombuffer(raw[4:4 + 4 * F], np.uint32)
+    offsets = np.frombuffer(raw[4 + 4 * F:4 + 4 * F + 8 * (F + 1)], np.uint64)
+    base = 4 + 4 * F + 8 * (F + 1)
+    total = int(offsets[F])
+    kp = np.frombuffer(raw[base:base + 16 * total], tinyorb.CORNER_DTYPE)
+    desc = np.frombuffer(raw[base + 16 * total:base + 48 * total], np.uint32).reshape(total, 8)
+    for i in range(F):
+        ref = oracle.extract(frames[i], depth=2, threshold=THR, max_features=2048)
+        lo, hi = int(offsets[i]), int(offsets[i + 1])
+        assert hi - lo == min(ref["total"], 2048)
+        _assert_frame_equal(oracle, ref, int(counts[i]), kp[lo:hi], desc[lo:hi])
+
+
+def test_node_api_one_device_equals_plain_batch(tinyorb, oracle):
+    """orb_node_* through the Python mirror: device-resident shards, collate, read-back; bit-equal to the plain batched
+    call on the same frames."""
+    W, H, F = 320, 240, 6
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=4096, hierarchy_depth=2, initial_threshold=THR, max_batch=F)
+    with tinyorb.OrbNode(cfg, [0]) as node:
+        assert node.device_count() == 1 and node.shard(F, 0) == (0, F)
+        prog = node.program(0)
+        dev = prog.synth_frames_device(F, 700)
+        node.extract_batch([dev], F)
+        counts, offsets, c_dev, d_dev = node.collate(F)
+        kp, desc = node.read_collated(int(offsets[F]))
+        # the node's own program still holds the padded slabs of the same batch
+        for i in range(F):
+            c2, d2 = prog.batch_read(i, int(min(counts[i], 4096)))
+            lo, hi = int(offsets[i]), int(offsets[i + 1])
+            assert np.array_equal(kp[lo:hi], c2) and np.array_equal(desc[lo:hi], d2)
+            ref = oracle.extract(oracle.synth_frame(W, H, 700 + i), depth=2, threshold=THR, max_features=4096)
+            _assert_frame_equal(oracle, ref, int(counts[i]), kp[lo:hi], desc[lo:hi])
+        # a second job on the same node (buffers are reused), from host frames this time
+        frames = np.stack([oracle.synth_frame(W, H, 800 + i) for i in range(4)])
+        node.extract_batch_host(frames)
+        counts, offsets, _, _ = node.collate(4)
+        kp, desc = node.read_collated(int(offsets[4]))
+        for i in range(4):
+            ref = oracle.extract(frames[i], depth=2, threshold=THR, max_features=4096)
+            lo, hi = int(offsets[i]), int(offsets[i + 1])
+            _assert_frame_equal(oracle, ref, int(counts[i]), kp[lo:hi], desc[lo:hi])
+    with pytest.raises(tinyorb.OrbError):
+        tinyorb.OrbNode(cfg, [0, 0]).init()  # a device listed twice
+
+
+def test_corner_level0_xy_matches_python_mirror(tinyorb):
+    L = tinyorb.load_library()
+    rng = np.random.default_rng(3)
+    c = np.zeros(512, tinyorb.CORNER_DTYPE)
+    c["x"] = rng.integers(0, 4000, 512)
+    c["y"] = rng.integers(0, 3000, 512)
+    c["octave"] = rng.integers(0, 10, 512)
+    wx, wy = tinyorb.level0_xy(c)
+    for i in range(512):
+        x0, y0 = ctypes.c_float(), ctypes.c_float()
+        L.orb_corner_level0_xy(c[i:i + 1].ctypes.data, ctypes.byref(x0), ctypes.byref(y0))
+        assert np.float32(x0.value) == wx[i] and np.float32(y0.value) == wy[i]
+    # octave 0 is the identity, octave m scales the pixel centre by 2^m
+    one = np.zeros(1, tinyorb.CORNER_DTYPE)
+    one["x"], one["y"], one["octave"] = 7, 9, 2
+    x0, y0 = ctypes.c_float(), ctypes.c_float()
+    L.orb_corner_level0_xy(one.ctypes.data, ctypes.byref(x0), ctypes.byref(y0))
+    assert (x0.value, y0.value) == (29.5, 37.5)
+
+
+@pytest.mark.parametrize("W,H,depth", [(3840, 96, 2), (2560, 64, 3), (2050, 48, 2)])
+def test_wide_literal_frames(tinyorb, oracle, W, H, depth):
+    """Literal mode on frames wider than one LDS band can hold (W > 2048) or with a width that is not a multiple of 4:
+    whichever pipeline takes them, the results are the oracle's."""
+    rgba = oracle.synth_frame(W, H, 21)
+    ref = oracle.extract(rgba, depth=depth, threshold=THR, planes=True)
+    with _program(tinyorb, W, H, depth) as prog:
+        total, corners, desc = prog.extract(rgba)
+        _assert_frame_equal(oracle, ref, total, corners, desc)
+        dims, _ = oracle.level_dims(W, H, depth)
+        for m, (w, h, off) in enumerate(dims):
+            b = prog.read_plane(tinyorb.ORB_PLANE_BLUR, m)
+            assert np.array_equal(b.ravel(), ref["blur"][off:off + w * h]), "blur level %d" % m
+
+
+def test_two_programs_of_different_size_alive(tinyorb, oracle):
+    """The dynamic-LDS attribute of k_front belongs to the function, not to a program: a small program created while a
+    large one is alive must not break the large one's launches."""
+    big_f = oracle.synth_frame(1280, 96, 5)
+    small_f = oracle.synth_frame(64, 48, 6)
+    big_ref = oracle.extract(big_f, depth=2, threshold=THR)
+    small_ref = oracle.extract(small_f, depth=2, threshold=THR)
+    with _program(tinyorb, 1280, 96, 2) as big:
+        t, c, d = big.extract(big_f)
+        _assert_frame_equal(oracle, big_ref, t, c, d)
+        with _program(tinyorb, 64, 48, 2) as small:
+            for _ in range(2):
+                t, c, d = small.extract(small_f)
+                _assert_frame_equal(oracle, small_ref, t, c, d)
+                t, c, d = big.extract(big_f)
+                _assert_frame_equal(oracle, big_ref, t, c, d)
+
+
+@pytest.mark.parametrize("flags,arc", [(4, 0), (0, 9), (4, 9), (0, 0)])
+def test_octaves_without_a_fast_dispatch(tinyorb, oracle, flags, arc):
+    """64x48 with depth 7: level 6 is 1 texel wide and 0 rows of dispatch (48 >> 6 == 0, orb.rs:511-519).  The fused
+    arc/NMS pipeline, the staged one and the oracle must agree (the earlier levels' counts must survive)."""
+    W, H, depth = 64, 48, 7
+    rgba = oracle.synth_frame(W, H, 17)
+    nms = bool(flags & 4)
+    if nms or arc:
+        ref = oracle.extract_ex(rgba, depth=depth, threshold=THR, arc=arc or 12, nms=nms)
+    else:
+        ref = oracle.extract(rgba, depth=depth, threshold=THR)
+    assert ref["total"] > 0
+    results = []
+    for staged in (0, 1):
+        with _program(tinyorb, W, H, depth, flags=flags | staged, fast_arc=arc) as prog:
+            total, corners, desc = prog.extract(rgba)
+            _assert_frame_equal(oracle, ref, total, corners, desc)
+            results.append(total)
+    assert results[0] == results[1]

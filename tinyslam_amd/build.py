@@ -13,7 +13,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libtinyorb.so")
-SOURCES = ["orb_api.hip"]
+SOURCES = ["orb_api.hip", "orb_node.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
@@ -51,7 +51,7 @@ def build_lib(force=False, verbose=False):
     flags = list(HIPCC_FLAGS)
     if os.environ.get("TINYORB_BUILD_STAMPS"):  # diagnostic build: in-kernel cycle stamps (tools/stamps.py)
         flags.append("-DTINYORB_STAMPS")
-    cmd = [_hipcc()] + flags + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [_hipcc()] + flags + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -19,15 +19,16 @@
 #include "orb_kernels_fused.h"
 #include "orb_kernels_intended.h"
 #include "orb_kernels_staged.h"
+#include "orb_kernels_collate.h"
 
 using namespace orb;
 
 namespace {
 
-enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I, KID_MATCH };
+enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I, KID_MATCH, KID_COMPACT };
 const char* const kKernelNames[ORB_KERNEL_COUNT] = {"k_grayscale", "k_mip",      "k_blur_rows", "k_fast",       "k_brief",
                                                     "k_front_l0",  "k_front_ln", "k_synth",     "k_brief_rows", "k_slot_prefix",
-                                                    "k_front_i",   "k_select_i", "k_brief_i",   "k_match"};
+                                                    "k_front_i",   "k_select_i", "k_brief_i",   "k_match",      "k_compact"};
 
 thread_local std::string g_create_error;
 
@@ -44,6 +45,7 @@ struct OrbProgram {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // chunked uploads of orb_extract_batch_host
+    hipEvent_t order_event = nullptr;   // orders work on a caller's stream behind the last batch
     Pyramid pyr{};
     size_t frame_bytes = 0;
     uint32_t max_batch = 1;
@@ -371,7 +373,8 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         g.stamps = p->d_stamps;
         if (g.n_bands != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: band count mismatch at level %u", lvl);
-        const uint32_t lds = front_lds_bytes(g);
+        uint32_t lds = front_lds_bytes(g);
+        if (const char* e = getenv("TINYORB_LDS_PAD")) lds += (uint32_t)atoi(e);  // occupancy experiments only
         if (lds > p->max_lds) return fail(p, ORB_EINVAL, "level %u needs %u bytes of LDS", lvl, lds);
         const dim3 grid(g.n_bands * n);
         if (lvl == 0) {
@@ -557,9 +560,10 @@ int run_fused_x(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
             else
                 hipLaunchKernelGGL(k_front_i<false>, grid, dim3(kIThreads), ifront_lds_bytes(g), s, frames, p->frame_bytes,
                                    p->d_gray, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
-        } else {  // no FAST dispatch at this octave (orb.rs:511-515 with width 0): its tiles hold nothing
-            HIP_TRY(p, hipMemsetAsync(p->d_iseg_counts, 0, sizeof(uint32_t) * (size_t)n * bg.n_slots, s));
         }
+        // else: no FAST dispatch at this octave (orb.rs:511-515 with width 0).  Its tile slots were zeroed at create and
+        // no kernel of this program ever writes them, so there is nothing to clear (clearing the whole counter array
+        // here would erase the counts the earlier levels have just produced).
         {   // literal blur of this level from its grey plane: k_front's staging + phase C, nothing else
             FrontGeom fg = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n);
             fg.phase_mask = 8u;
@@ -714,10 +718,12 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                     rg.qa[lvl] = qa;
                     rg.flat_end[lvl] = qa > (uint32_t)kBriefHalo ? qa - kBriefHalo : 0u;
                 }
+                // The attribute belongs to the function on this device, not to the program: always raise it to the
+                // device's limit, so that a later, smaller program never lowers it under a live, larger one.
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
             }
         }
     }
@@ -747,8 +753,12 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         bg.seg_cap = (uint32_t)kFrontRows * bg.tw[0];
         bg.pitch = (uint32_t)kITileW + 2u * kIBriefApronX;
         p->ibrief_lds = max_rows * bg.pitch * (uint32_t)sizeof(uint16_t);
+        if (p->ibrief_lds > p->max_lds) {
+            fail(p, ORB_EINVAL, "k_brief_i needs %u bytes of LDS", p->ibrief_lds);
+            return bail(ORB_EINVAL);
+        }
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_brief_i),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->ibrief_lds);
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds);
         if (ea != hipSuccess) {
             fail(p, ORB_EHIP, "hipFuncSetAttribute(k_brief_i): %s", hipGetErrorString(ea));
             return bail(ORB_EHIP);
@@ -789,7 +799,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
             p->fused_x = false;
         } else {
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds);
             if (ea != hipSuccess) {
                 fail(p, ORB_EHIP, "hipFuncSetAttribute(k_front): %s", hipGetErrorString(ea));
                 return bail(ORB_EHIP);
@@ -919,6 +929,7 @@ void orb_program_destroy(OrbProgram* p) {
     if (p->h_desc) (void)hipHostFree(p->h_desc);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
+    if (p->order_event) (void)hipEventDestroy(p->order_event);
     delete p;
 }
 
@@ -1077,6 +1088,113 @@ int orb_batch_read(OrbProgram* p, uint32_t frame, CornerData* corners, CornerDes
                              hipMemcpyDeviceToHost));
     return ORB_OK;
 }
+
+}  // extern "C"
+
+namespace {
+
+// Launches k_compact for the first n frames of the last batch on `stream` (NULL: the batch's own stream); a foreign
+// stream is first ordered behind the batch with an event.
+int launch_compact(OrbProgram* p, uint32_t n, uint32_t* counts, uint64_t* offsets, CornerData* corners,
+                   CornerDescriptor* desc, size_t capacity, void* stream, hipStream_t* used) {
+    hipStream_t batch = p->last_stream ? p->last_stream : p->stream;
+    hipStream_t s = stream ? (hipStream_t)stream : batch;
+    if (s != batch) {
+        if (!p->order_event) HIP_TRY(p, hipEventCreateWithFlags(&p->order_event, hipEventDisableTiming));
+        HIP_TRY(p, hipEventRecord(p->order_event, batch));
+        HIP_TRY(p, hipStreamWaitEvent(s, p->order_event, 0));
+    }
+    const uint32_t cap = p->cfg.max_features;
+    {
+        LaunchScope ls(p, s, KID_COMPACT);
+        hipLaunchKernelGGL(k_compact, dim3((cap + kCompactChunk - 1u) / kCompactChunk, n), dim3(256), 0, s, p->d_counts,
+                           p->d_corners, p->d_desc, cap, n, counts, reinterpret_cast<unsigned long long*>(offsets), corners, desc,
+                           (unsigned long long)capacity);
+    }
+    HIP_TRY(p, hipGetLastError());
+    if (used) *used = s;
+    return ORB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orb_batch_compact_device(OrbProgram* p, uint32_t n_frames, uint32_t* counts_dev, uint64_t* offsets_dev,
+                             CornerData* corners_dev, CornerDescriptor* descriptors_dev, size_t capacity, void* stream) {
+    if (!p) return ORB_EINVAL;
+    if (n_frames == 0 || n_frames > p->last_batch) return fail(p, ORB_EINVAL, "compact: n_frames %u not in the last batch (%u)", n_frames, p->last_batch);
+    if (!corners_dev || !descriptors_dev) return fail(p, ORB_EINVAL, "compact: destination is NULL");
+    HIP_TRY(p, hipSetDevice(p->device));
+    return launch_compact(p, n_frames, counts_dev, offsets_dev, corners_dev, descriptors_dev, capacity, stream, nullptr);
+}
+
+int orb_batch_read_all(OrbProgram* p, uint32_t n_frames, uint32_t* counts, uint64_t* offsets, CornerData* corners,
+                       CornerDescriptor* descriptors, size_t capacity, void* stream) {
+    if (!p) return ORB_EINVAL;
+    if (n_frames == 0 || n_frames > p->last_batch) return fail(p, ORB_EINVAL, "read_all: n_frames %u not in the last batch (%u)", n_frames, p->last_batch);
+    if (!corners || !descriptors) return fail(p, ORB_EINVAL, "read_all: destination is NULL");
+    HIP_TRY(p, hipSetDevice(p->device));
+    // Device-visible addresses of the host buffers.  Pinned memory (orb_host_alloc / hipHostRegister by the caller)
+    // resolves directly; anything else is registered for the duration of the call, which then has to block.
+    struct Buf { void* host; size_t bytes; void* dev; bool registered; };
+    Buf bufs[4] = {{counts, sizeof(uint32_t) * n_frames, nullptr, false},
+                   {offsets, sizeof(uint64_t) * ((size_t)n_frames + 1u), nullptr, false},
+                   {corners, sizeof(CornerData) * capacity, nullptr, false},
+                   {descriptors, sizeof(CornerDescriptor) * capacity, nullptr, false}};
+    bool blocking = false;
+    int rc = ORB_OK;
+    for (Buf& b : bufs) {
+        if (!b.host || b.bytes == 0) continue;
+        if (hipHostGetDevicePointer(&b.dev, b.host, 0) == hipSuccess && b.dev) continue;
+        (void)hipGetLastError();
+        hipError_t e = hipHostRegister(b.host, b.bytes, hipHostRegisterMapped);
+        if (e == hipSuccess) {
+            b.registered = true;
+            e = hipHostGetDevicePointer(&b.dev, b.host, 0);
+        }
+        if (e != hipSuccess) {
+            rc = fail(p, ORB_EHIP, "read_all: host buffer cannot be made device-visible: %s", hipGetErrorString(e));
+            break;
+        }
+        blocking = true;
+    }
+    hipStream_t used = nullptr;
+    if (!rc)
+        rc = launch_compact(p, n_frames, (uint32_t*)bufs[0].dev, (uint64_t*)bufs[1].dev, (CornerData*)bufs[2].dev,
+                            (CornerDescriptor*)bufs[3].dev, capacity, stream, &used);
+    if (blocking || rc) {
+        if (used && hipStreamSynchronize(used) != hipSuccess && !rc) rc = fail(p, ORB_EHIP, "read_all: stream sync failed");
+        for (Buf& b : bufs)
+            if (b.registered) (void)hipHostUnregister(b.host);
+    }
+    return rc;
+}
+
+int orb_host_alloc(size_t nbytes, void** out) {
+    if (!out || nbytes == 0) return ORB_EINVAL;
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, nbytes, hipHostMallocMapped | hipHostMallocPortable);
+    if (e != hipSuccess) return fail(nullptr, ORB_EHIP, "hipHostMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e));
+    return ORB_OK;
+}
+
+void orb_host_free(void* ptr) {
+    if (ptr) (void)hipHostFree(ptr);
+}
+
+int orb_stream_sync(OrbProgram* p, void* stream) {
+    if (!p) return ORB_EINVAL;
+    HIP_TRY(p, hipSetDevice(p->device));
+    HIP_TRY(p, hipStreamSynchronize(stream ? (hipStream_t)stream : p->stream));
+    return ORB_OK;
+}
+
+void* orb_program_stream(OrbProgram* p) { return p ? (void*)p->stream : nullptr; }
+
+}  // extern "C"
+
+extern "C" {
 
 void orb_corner_level0_xy(const CornerData* c, float* x0, float* y0) {
     if (!c || !x0 || !y0) return;

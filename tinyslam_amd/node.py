@@ -47,6 +47,7 @@ def collate_to_root(counts: torch.Tensor, corners: torch.Tensor, descriptors: to
     rank = dist.get_rank(group)
     if world == 1:
         mx = int(torch.clamp(counts, max=cap).max().item()) if counts.numel() else 0
+        mx = max(mx, 1)  # same shape rule as the gathered case: at least one (possibly unused) record per frame
         return counts, corners[:, :mx].contiguous(), descriptors[:, :mx].contiguous()
     all_counts = [torch.empty_like(counts) for _ in range(world)]
     dist.all_gather(all_counts, counts, group=group)

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_PKG, "libtinyorb.so")
 
 ORB_OK, ORB_EINVAL, ORB_EHIP, ORB_ECAPACITY, ORB_ESTATE = 0, 1, 2, 3, 4
 ORB_PLANE_GRAY, ORB_PLANE_BLUR = 0, 1
-ORB_KERNEL_COUNT = 14
+ORB_KERNEL_COUNT = 15
 ORB_FLAG_STAGED = 1
 ORB_FLAG_DOUBLE_OUTPUT = 2
 ORB_FLAG_NMS = 4
@@ -43,6 +43,11 @@ EXPORTS = [
     "orb_debug_read_plane", "orb_debug_f32_to_f16", "orb_debug_angle_code", "orb_profile_enable",
     "orb_profile_reset", "orb_profile_get", "orb_synth_frames_device", "orb_copy_to_host", "orb_debug_stamps",
     "orb_match_consecutive", "orb_match_read", "orb_corner_level0_xy",
+    "orb_batch_read_all", "orb_batch_compact_device", "orb_host_alloc", "orb_host_free", "orb_stream_sync",
+    "orb_program_stream",
+    "orb_node_create", "orb_node_destroy", "orb_node_last_error", "orb_node_device_count", "orb_node_program",
+    "orb_node_shard", "orb_node_extract_batch", "orb_node_extract_batch_host", "orb_node_collate",
+    "orb_node_read_collated",
 ]
 
 
@@ -139,11 +144,86 @@ def load_library(path=None):
     L.orb_synth_frames_device.argtypes = [vp, vp, u32, u32, u32, ctypes.POINTER(vp)]
     L.orb_copy_to_host.argtypes = [vp, vp, vp, sz]
     L.orb_debug_stamps.argtypes = [vp, vp, sz]
-    if L.orb_abi_version() != 1:
+    L.orb_corner_level0_xy.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    L.orb_corner_level0_xy.restype = None
+    L.orb_batch_read_all.argtypes = [vp, u32, vp, vp, vp, vp, sz, vp]
+    L.orb_batch_compact_device.argtypes = [vp, u32, vp, vp, vp, vp, sz, vp]
+    L.orb_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
+    L.orb_host_free.argtypes = [vp]
+    L.orb_host_free.restype = None
+    L.orb_stream_sync.argtypes = [vp, vp]
+    L.orb_program_stream.argtypes = [vp]
+    L.orb_program_stream.restype = vp
+    L.orb_node_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(_Config), ctypes.POINTER(_Options),
+                                  ctypes.POINTER(vp)]
+    L.orb_node_destroy.argtypes = [vp]
+    L.orb_node_destroy.restype = None
+    L.orb_node_last_error.argtypes = [vp]
+    L.orb_node_last_error.restype = ctypes.c_char_p
+    L.orb_node_device_count.argtypes = [vp]
+    L.orb_node_program.argtypes = [vp, ctypes.c_int]
+    L.orb_node_program.restype = vp
+    L.orb_node_shard.argtypes = [vp, u32, ctypes.c_int, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.orb_node_extract_batch.argtypes = [vp, ctypes.POINTER(vp), u32]
+    L.orb_node_extract_batch_host.argtypes = [vp, vp, u32]
+    L.orb_node_collate.argtypes = [vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.orb_node_read_collated.argtypes = [vp, vp, vp, sz]
+    if L.orb_abi_version() != 2:
         raise OrbError(ORB_EINVAL, "libtinyorb ABI version mismatch")
     if path == LIB_PATH:
         _lib = L
     return L
+
+
+class PinnedArray:
+    """A numpy array over pinned, device-visible host memory from orb_host_alloc (freed with the object)."""
+
+    def __init__(self, shape, dtype):
+        L = load_library()
+        self._lib = L
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape))
+        self.nbytes = max(n * dtype.itemsize, 1)
+        ptr = ctypes.c_void_p()
+        rc = L.orb_host_alloc(self.nbytes, ctypes.byref(ptr))
+        if rc != ORB_OK:
+            raise OrbError(rc, (L.orb_last_error(None) or b"").decode())
+        self.ptr = ptr
+        buf = (ctypes.c_uint8 * self.nbytes).from_address(ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+    def close(self):
+        if self.ptr is not None:
+            self.array = None
+            self._lib.orb_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HostBatch:
+    """Pinned host destination of orb_batch_read_all: counts[n], offsets[n+1], corners[capacity], descriptors[capacity]."""
+
+    def __init__(self, n_frames, capacity):
+        self.n_frames, self.capacity = n_frames, capacity
+        self._c = PinnedArray((n_frames,), np.uint32)
+        self._o = PinnedArray((n_frames + 1,), np.uint64)
+        self._k = PinnedArray((capacity,), CORNER_DTYPE)
+        self._d = PinnedArray((capacity, 8), np.uint32)
+        self.counts, self.offsets, self.corners, self.descriptors = self._c.array, self._o.array, self._k.array, self._d.array
+
+    def frame(self, f):
+        lo, hi = int(self.offsets[f]), int(self.offsets[f + 1])
+        return self.corners[lo:hi], self.descriptors[lo:hi]
+
+    def close(self):
+        self.counts = self.offsets = self.corners = self.descriptors = None
+        for a in (self._c, self._o, self._k, self._d):
+            a.close()
 
 
 @dataclass
@@ -203,7 +283,8 @@ class OrbProgram:
 
     def close(self):
         if self._h is not None:
-            self._lib.orb_program_destroy(self._h)
+            if not getattr(self, "_borrowed", False):  # programs of an OrbNode belong to the node
+                self._lib.orb_program_destroy(self._h)
             self._h = None
 
     def __enter__(self):
@@ -290,6 +371,26 @@ class OrbProgram:
         self._check(self._lib.orb_batch_read(self._handle(), frame, _ptr(corners), _ptr(desc), n))
         return corners, desc
 
+    def batch_read_all(self, n_frames, out=None, stream=None, sync=True):
+        """Bulk read-back of the last batch (orb_batch_read_all): returns a `HostBatch` whose arrays live in pinned host
+        memory (reused when `out` is passed).  The stored records of all frames are packed back to back in frame
+        order; frame f owns records [offsets[f], offsets[f+1])."""
+        cap = self.config.max_features
+        hb = out if out is not None else HostBatch(n_frames, n_frames * cap)
+        assert hb.n_frames >= n_frames
+        self._check(self._lib.orb_batch_read_all(self._handle(), n_frames, hb.counts.ctypes.data, hb.offsets.ctypes.data,
+                                                 hb.corners.ctypes.data, hb.descriptors.ctypes.data, hb.capacity,
+                                                 ctypes.c_void_p(stream) if stream else None))
+        if sync:
+            if stream:
+                self.stream_sync(stream)
+            else:
+                self.batch_sync()
+        return hb
+
+    def stream_sync(self, stream=None):
+        self._check(self._lib.orb_stream_sync(self._handle(), ctypes.c_void_p(stream) if stream else None))
+
     def match_consecutive(self, n_frames, stream=None):
         """Hamming-match frame f against f+1 for the first n_frames of the last batch (not in the reference)."""
         self._check(self._lib.orb_match_consecutive(self._handle(), n_frames, ctypes.c_void_p(stream) if stream else None))
@@ -367,3 +468,82 @@ class OrbProgram:
         out = np.zeros(nbytes, dtype=np.uint8)
         self._check(self._lib.orb_copy_to_host(self._handle(), _ptr(out), ctypes.c_void_p(dev_ptr), nbytes))
         return out
+
+
+class OrbNode:
+    """One process, several GPUs of one node (include/tinyorb.h, orb_node_*): one OrbProgram per device, contiguous
+    frame shards, collate on the first device over RCCL.  Not in the reference (single wgpu device, orb.rs:47-51)."""
+
+    def __init__(self, config: OrbConfig, devices):
+        self.config = config
+        self.devices = list(devices)
+        self._h = None
+        self._lib = None
+
+    def init(self):
+        L = load_library()
+        c = self.config
+        cfg = _Config(_Extent3d(c.image_size.width, c.image_size.height, c.image_size.depth_or_array_layers),
+                      c.max_features, c.hierarchy_depth, float(np.float32(c.initial_threshold)))
+        opt = _Options(0, c.max_batch, c.flags, c.fast_arc)
+        devs = (ctypes.c_int * len(self.devices))(*self.devices)
+        h = ctypes.c_void_p()
+        rc = L.orb_node_create(devs, len(self.devices), ctypes.byref(cfg), ctypes.byref(opt), ctypes.byref(h))
+        if rc != ORB_OK:
+            raise OrbError(rc, (L.orb_node_last_error(None) or b"").decode())
+        self._h, self._lib = h, L
+        return self
+
+    def close(self):
+        if self._h is not None:
+            self._lib.orb_node_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self if self._h is not None else self.init()
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != ORB_OK:
+            raise OrbError(rc, (self._lib.orb_node_last_error(self._h) or b"").decode())
+
+    def device_count(self):
+        return self._lib.orb_node_device_count(self._h)
+
+    def program(self, rank):
+        """Borrowed OrbProgram of one rank (do not close it)."""
+        h = self._lib.orb_node_program(self._h, rank)
+        if not h:
+            raise OrbError(ORB_EINVAL, "no such rank")
+        p = OrbProgram(self.config)
+        p._h, p._lib_obj, p._borrowed = ctypes.c_void_p(h), self._lib, True
+        return p
+
+    def shard(self, n_frames, rank):
+        lo, hi = ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self._lib.orb_node_shard(self._h, n_frames, rank, ctypes.byref(lo), ctypes.byref(hi)))
+        return lo.value, hi.value
+
+    def extract_batch(self, frames_dev_ptrs, n_frames):
+        arr = (ctypes.c_void_p * len(frames_dev_ptrs))(*[ctypes.c_void_p(x) for x in frames_dev_ptrs])
+        self._check(self._lib.orb_node_extract_batch(self._h, arr, n_frames))
+
+    def extract_batch_host(self, frames):
+        a = np.ascontiguousarray(frames, dtype=np.uint8)
+        self._check(self._lib.orb_node_extract_batch_host(self._h, _ptr(a), a.shape[0]))
+
+    def collate(self, n_frames):
+        """-> counts (n,), offsets (n+1,), device addresses of the packed corners / descriptors on the first device."""
+        counts = np.zeros(n_frames, dtype=np.uint32)
+        offsets = np.zeros(n_frames + 1, dtype=np.uint64)
+        c, d = ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self._lib.orb_node_collate(self._h, _ptr(counts), _ptr(offsets), ctypes.byref(c), ctypes.byref(d)))
+        return counts, offsets, c.value, d.value
+
+    def read_collated(self, total):
+        corners = np.zeros(total, dtype=CORNER_DTYPE)
+        desc = np.zeros((total, 8), dtype=np.uint32)
+        self._check(self._lib.orb_node_read_collated(self._h, _ptr(corners), _ptr(desc), total))
+        return corners, desc
