@@ -252,7 +252,10 @@ def test_octaves_without_a_fast_dispatch(tinyorb, oracle, flags, arc):
     """64x48 with depth 7: level 6 is 1 texel wide and 0 rows of dispatch (48 >> 6 == 0, orb.rs:511-519).  The fused
     arc/NMS pipeline, the staged one and the oracle must agree (the earlier levels' counts must survive)."""
     W, H, depth = 64, 48, 7
-    rgba = oracle.synth_frame(W, H, 17)
+    rgba = oracle.synth_frame(W, H, 17).copy()
+    rgba[:, :, :3] //= 4  # dim background + bright blobs inside the 16-px guard, so that FAST-12 fires on this tiny frame
+    for (x, y, s) in ((22, 21, 2), (30, 25, 3), (40, 22, 1), (26, 27, 2), (36, 26, 3), (44, 24, 2)):
+        rgba[y:y + s, x:x + s, :3] = 255
     nms = bool(flags & 4)
     if nms or arc:
         ref = oracle.extract_ex(rgba, depth=depth, threshold=THR, arc=arc or 12, nms=nms)

@@ -332,6 +332,7 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
         if (P > 0) while (Q < w && (uint32_t)blur_tap(Q, w, kBlurOffHost).i1 < P) Q++;
         g.blur_p = P;
         g.blur_q = Q;
+        g.n_var = w - Q;
     }
     g.phase_mask = 15u;
     if (const char* e = getenv("TINYORB_PHASE_MASK")) g.phase_mask = (uint32_t)atoi(e);
@@ -753,12 +754,16 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         bg.seg_cap = (uint32_t)kFrontRows * bg.tw[0];
         bg.pitch = (uint32_t)kITileW + 2u * kIBriefApronX;
         p->ibrief_lds = max_rows * bg.pitch * (uint32_t)sizeof(uint16_t);
-        if (p->ibrief_lds > p->max_lds) {
-            fail(p, ORB_EINVAL, "k_brief_i needs %u bytes of LDS", p->ibrief_lds);
+        // as for k_front: raise to the device limit (less the kernel's static LDS), never to this program's own need
+        hipFuncAttributes fa{};
+        hipError_t ea = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_brief_i));
+        if (ea == hipSuccess && p->ibrief_lds + (uint32_t)fa.sharedSizeBytes > p->max_lds) {
+            fail(p, ORB_EINVAL, "k_brief_i needs %u bytes of LDS", p->ibrief_lds + (uint32_t)fa.sharedSizeBytes);
             return bail(ORB_EINVAL);
         }
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_brief_i),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds);
+        if (ea == hipSuccess)
+            ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_brief_i), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(p->max_lds - (uint32_t)fa.sharedSizeBytes));
         if (ea != hipSuccess) {
             fail(p, ORB_EHIP, "hipFuncSetAttribute(k_brief_i): %s", hipGetErrorString(ea));
             return bail(ORB_EHIP);

@@ -47,12 +47,25 @@ struct FrontGeom {
     uint32_t seg_cap;     // CornerData records per band segment
     uint32_t blur_p;      // columns [0, blur_p) of blur pass 1 are one constant per row (tap 1 clamps to column 0)
     uint32_t blur_q;      // columns [0, blur_q) of the final blur are one constant per row
+    uint32_t n_var;       // w - blur_q: columns whose blur varies along the row (one BlurCol table entry each)
     unsigned long long* stamps;  // diagnostic runs only: 16 cycle sums per kernel flavour (else null)
 };
 
+// Tap positions of one column x >= blur_q of the literal blur (phase C): pass 2 at x lerps pass 1 at columns j0, j1
+// with fraction f2; pass 1 at j0 (j1) lerps the grey texels a0, a1 (b0, b1) with fraction fa (fb).  a0 (b0) == 0xffff:
+// that pass-1 column lies in the stretch that is one constant per row.  A function of x and the level's width only,
+// so a band evaluates blur_tap() once per column instead of three times per pixel.
+struct __attribute__((aligned(8))) BlurCol {
+    uint16_t a0, a1, b0, b1;
+    float fa, fb, f2;
+    uint32_t pad;
+};
+static_assert(sizeof(BlurCol) == 24, "BlurCol layout");
+
 __host__ __device__ inline uint32_t front_lds_bytes(const FrontGeom& g) {
-    // grey rows + queues B/C + queue A + 4 counters + blur row constants (2 x 16 float4)
-    return ((kFrontRows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + kFrontQueue * 2u + 16u + 32u * 16u;
+    // grey rows + queues B/C + queue A + 4 counters + blur row constants (2 x 16 float4) + blur column table
+    return ((kFrontRows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + kFrontQueue * 2u + 16u + 32u * 16u +
+           (uint32_t)sizeof(BlurCol) * g.n_var;
 }
 
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
@@ -184,6 +197,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     uint32_t* const c_count = qa_count + 3;  // corners found by this band
     float4* const blur_k1 = reinterpret_cast<float4*>(qa_count + 4);  // per band row: taps 0, 2, 3 of blur pass 1
     float4* const blur_k2 = blur_k1 + R;                              // per band row: the same for pass 2, and c2
+    BlurCol* const blur_cols = reinterpret_cast<BlurCol*>(blur_k2 + R);  // per column >= blur_q: tap positions
 
     // ---- which band of which frame: keep all bands of a frame on one XCD so halo rows hit its L2
     uint32_t frame, band;
@@ -324,6 +338,29 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
         const float base2 = 0.0f + b0;
         blur_k1[tid] = make_float4(base, a2, a3, c1);
         blur_k2[tid] = make_float4(base2, b2, b3, finish(base2, c1, b2, b3));
+    }
+
+    // ---- blur column table (the last threads of the workgroup, so that wave 0 is not doing both) ----
+    if ((geo.phase_mask & 8u) && tid >= NT - (int)geo.n_var) {
+        const int c = NT - 1 - tid;
+        const int x = (int)geo.blur_q + c, P = (int)geo.blur_p;
+        const BlurTap t2 = blur_tap((uint32_t)x, (uint32_t)w, kBlurOff[1]);
+        BlurCol e;
+        e.f2 = t2.f;
+        e.pad = 0u;
+        if (t2.i0 < P) {
+            e.a0 = 0xffffu, e.a1 = 0u, e.fa = 0.0f;
+        } else {
+            const BlurTap t = blur_tap((uint32_t)t2.i0, (uint32_t)w, kBlurOff[1]);
+            e.a0 = (uint16_t)t.i0, e.a1 = (uint16_t)t.i1, e.fa = t.f;
+        }
+        if (t2.i1 < P) {
+            e.b0 = 0xffffu, e.b1 = 0u, e.fb = 0.0f;
+        } else {
+            const BlurTap t = blur_tap((uint32_t)t2.i1, (uint32_t)w, kBlurOff[1]);
+            e.b0 = (uint16_t)t.i0, e.b1 = (uint16_t)t.i1, e.fb = t.f;
+        }
+        blur_cols[c] = e;
     }
 
     // Phases B (FAST) and C (mip + blur) only share the read-only grey rows.
@@ -524,7 +561,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
         // orb.rs:291-304) -- no intermediate plane, no barrier.  Pass 1 at any other column is never read.
         if (geo.phase_mask & 8u) {
             const int rows = min(R, h - y0);  // band rows that exist in this level (uniform per block)
-            const int P = (int)geo.blur_p, Q = (int)geo.blur_q;
+            const int Q = (int)geo.blur_q;
             if (rows > 0) {
                 // constant stretch: one f16 per row in the row-constant array covers columns [0, Qa), Qa = Q rounded
                 // down to a multiple of 8 (the plane itself is only written from column Qa on: k_brief_rows
@@ -537,40 +574,46 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     const int r = i / (Q - Qa), x = Qa + i % (Q - Qa);
                     blur_lvl[(size_t)(uint32_t)(__mul24(y0 + r, w) + x)] = half_bits(to_half(blur_k2[r].w));
                 }
-                // per-pixel stretch [Q, w)
+                // per-pixel stretch [Q, w): a thread takes one column and kBlurRowsPerItem rows of the band; the
+                // column's tap positions come from the band's table, so no blur_tap() (a division and a floor) runs here
                 const int nvar = w - Q;
                 if (nvar > 0) {
+                    constexpr int RPI = 4;
                     const float inv_nvar = 1.0f / (float)nvar;
-                    const int n_items = rows * nvar;
+                    const int n_items = ((rows + RPI - 1) / RPI) * nvar;
                     for (int i = tid; i < n_items; i += NT) {
-                        const int r = (int)(((float)i + 0.5f) * inv_nvar);
-                        const int x = Q + (i - __mul24(r, nvar));
-                        const half_t* row = grey + (r + 3) * LS + kLdsPad;
-                        const float4 k1 = blur_k1[r], k2 = blur_k2[r];
-                        auto pass1_at = [&](int j) {  // pass 1 at column j of this row, as stored (f16)
-                            if (j < P) return k1.w;
-                            const BlurTap t = blur_tap((uint32_t)j, (uint32_t)w, kBlurOff[1]);
-                            const float v0 = from_half(row[t.i0]), v1 = from_half(row[t.i1]);
-                            const float d = v1 - v0;
-                            const float fd = t.f * d;
-                            const float lerp = v0 + fd;
+                        const int rg = (int)(((float)i + 0.5f) * inv_nvar);
+                        const int c = i - __mul24(rg, nvar);
+                        const BlurCol e = blur_cols[c];
+#pragma unroll
+                        for (int k = 0; k < RPI; k++) {
+                            const int r = rg * RPI + k;
+                            if (r >= rows) break;
+                            const half_t* row = grey + (r + 3) * LS + kLdsPad;
+                            const float4 k1 = blur_k1[r], k2 = blur_k2[r];
+                            auto pass1 = [&](uint32_t i0, uint32_t i1, float f) {  // pass 1 as stored (f16, orb.rs:291-304)
+                                if (i0 == 0xffffu) return k1.w;
+                                const float v0 = from_half(row[i0]), v1 = from_half(row[i1]);
+                                const float d = v1 - v0;
+                                const float fd = f * d;
+                                const float lerp = v0 + fd;
+                                const float ws = lerp * kBlurWgt[1];
+                                float acc = k1.x + ws;
+                                acc = acc + k1.y;
+                                acc = acc + k1.z;
+                                return from_half(to_half(acc));
+                            };
+                            const float u0 = pass1(e.a0, e.a1, e.fa);
+                            const float u1 = pass1(e.b0, e.b1, e.fb);
+                            const float d = u1 - u0;
+                            const float fd = e.f2 * d;
+                            const float lerp = u0 + fd;
                             const float ws = lerp * kBlurWgt[1];
-                            float acc = k1.x + ws;
-                            acc = acc + k1.y;
-                            acc = acc + k1.z;
-                            return from_half(to_half(acc));
-                        };
-                        const BlurTap t2 = blur_tap((uint32_t)x, (uint32_t)w, kBlurOff[1]);
-                        const float u0 = pass1_at(t2.i0);
-                        const float u1 = t2.i1 == t2.i0 ? u0 : pass1_at(t2.i1);
-                        const float d = u1 - u0;
-                        const float fd = t2.f * d;
-                        const float lerp = u0 + fd;
-                        const float ws = lerp * kBlurWgt[1];
-                        float acc = k2.x + ws;
-                        acc = acc + k2.y;
-                        acc = acc + k2.z;
-                        blur_lvl[(size_t)(uint32_t)(__mul24(y0 + r, w) + x)] = half_bits(to_half(acc));
+                            float acc = k2.x + ws;
+                            acc = acc + k2.y;
+                            acc = acc + k2.z;
+                            blur_lvl[(size_t)(uint32_t)(__mul24(y0 + r, w) + Q + c)] = half_bits(to_half(acc));
+                        }
                     }
                 }
             }
