@@ -17,6 +17,7 @@
 
 #include "../../include/tinyorb.h"
 #include "orb_kernels_fused.h"
+#include "orb_kernels_brief.h"
 #include "orb_kernels_intended.h"
 #include "orb_kernels_staged.h"
 #include "orb_kernels_collate.h"
@@ -25,10 +26,11 @@ using namespace orb;
 
 namespace {
 
-enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I, KID_MATCH, KID_COMPACT };
+enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I, KID_MATCH, KID_COMPACT, KID_BRIEF_T, KID_BRIEF_NF };
 const char* const kKernelNames[ORB_KERNEL_COUNT] = {"k_grayscale", "k_mip",      "k_blur_rows", "k_fast",       "k_brief",
                                                     "k_front_l0",  "k_front_ln", "k_synth",     "k_brief_rows", "k_slot_prefix",
-                                                    "k_front_i",   "k_select_i", "k_brief_i",   "k_match",      "k_compact"};
+                                                    "k_front_i",   "k_select_i", "k_brief_i",   "k_match",      "k_compact",
+                                                    "k_brief_t",   "k_brief_nf"};
 
 thread_local std::string g_create_error;
 
@@ -94,6 +96,8 @@ struct OrbProgram {
     uint32_t* d_seg_before = nullptr;  // [max_batch][n_slots] exclusive prefix of the stored counts
     BandGeom bands{};
     RowsGeom rows{};
+    BriefTGeom brieft{};       // thread-per-keypoint BRIEF of the fused literal pipelines (plain and arc/NMS)
+    bool use_brief_t = false;
     uint32_t* d_pattern = nullptr;
     float* d_cos = nullptr;
     float* d_sin = nullptr;
@@ -340,6 +344,62 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
     return g;
 }
 
+// Geometry of k_brief_t over the band (or tile) slots described by `rg`; false when the frame is too large for its LDS
+// staging (then k_brief_rows does the work).
+bool brieft_geometry(const OrbProgram* p, const RowsGeom& rg, BriefTGeom* out) {
+    BriefTGeom g{};
+    g.n_slots = rg.n_slots;
+    g.seg_cap = rg.seg_cap;
+    uint32_t rows = 0;
+    for (uint32_t m = 0; m < p->pyr.depth; m++) {
+        g.flat_end[m] = rg.flat_end[m];
+        g.qa[m] = rg.qa[m];
+        // 18 zero rows in front of a level and 26 behind it: the patch reaches 18 rows past the keypoint, and at
+        // octaves >= 1 a keypoint may sit up to 7 rows below the level's last row (8-rounded dispatch, Q8)
+        g.row_base[m] = rows + (uint32_t)kBriefHalo;
+        rows += p->pyr.h[m] + 2u * (uint32_t)kBriefHalo + 8u;
+    }
+    g.rows_padded = rows;
+    *out = g;
+    if (getenv("TINYORB_BRIEF_ROWS")) return false;  // A/B and cross-check: the wave-per-keypoint kernel
+    return rg.n_slots >= 1u && rg.n_slots <= kBriefTMaxSlots && rows <= kBriefTMaxRows;
+}
+
+// k_slot_prefix + BRIEF over the band (or tile) slots `rows_geom` of frames [f0, f0 + n).
+int launch_brief(OrbProgram* p, hipStream_t s, uint32_t n, const RowsGeom& rows_geom, const uint16_t* d_blur,
+                 const uint16_t* d_blur_rowc, const uint32_t* seg_counts, uint32_t* seg_before, const CornerData* seg,
+                 uint32_t* d_counts, CornerData* d_corners, CornerDescriptor* d_desc) {
+    const uint32_t cap = p->cfg.max_features;
+    const BriefTables tab{p->d_pattern, p->d_cos, p->d_sin};
+    const bool use_t = p->use_brief_t;
+    {
+        LaunchScope ls(p, s, KID_PREFIX);
+        hipLaunchKernelGGL(k_slot_prefix, dim3(n), dim3(64), 0, s, seg_counts, seg_before, d_counts, rows_geom.n_slots,
+                           rows_geom.seg_cap);
+    }
+    if (use_t) {
+        const BriefTGeom& tg = p->brieft;
+        const dim3 grid(n, (cap + 255u) / 256u);
+        {
+            LaunchScope ls(p, s, KID_BRIEF_T);
+            hipLaunchKernelGGL(k_brief_t<kBriefTWaves>, dim3(n, (cap + kBriefTThreads - 1u) / kBriefTThreads), dim3(kBriefTThreads),
+                               brieft_lds_bytes(tg), s, d_blur_rowc, p->pyr, tg, seg_counts, seg_before, seg, d_corners, cap,
+                               d_desc, tab);
+        }
+        LaunchScope ls(p, s, KID_BRIEF_NF);
+        hipLaunchKernelGGL(k_brief_nf, grid, dim3(256), 0, s, d_blur, d_blur_rowc, p->pyr, tg, seg_counts, seg_before, d_corners,
+                           cap, d_desc, tab);
+    } else {
+        LaunchScope ls(p, s, KID_BRIEF_ROWS);
+        RowsGeom rg = rows_geom;
+        rg.split = 1u;  // small batches: several workgroups per band slot so that the chip still sees ~2000 of them
+        while (rg.split < 16u && rg.n_slots * n * rg.split < 2048u) rg.split *= 2u;
+        hipLaunchKernelGGL(k_brief_rows, dim3(rg.n_slots * rg.split, n), dim3(256), 0, s, d_blur, d_blur_rowc, p->pyr, rg,
+                           seg_counts, seg_before, seg, d_corners, cap, d_desc, tab);
+    }
+    return ORB_OK;
+}
+
 // The fused pipeline for frames [f0, f0 + n) of the batch on stream s: one k_front launch per level + BRIEF.
 int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint32_t n, hipStream_t s) {
     const Pyramid& pyr = p->pyr;
@@ -389,19 +449,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         }
     }
     // orb.rs:523-534, plus the compaction of the band segments into the final lists
-    {
-        LaunchScope ls(p, s, KID_PREFIX);
-        hipLaunchKernelGGL(k_slot_prefix, dim3(n), dim3(64), 0, s, d_seg_counts, d_seg_before, d_counts,
-                           p->bands.n_slots, p->bands.seg_cap);
-    }
-    {
-        LaunchScope ls(p, s, KID_BRIEF_ROWS);
-        RowsGeom rg = p->rows;
-        rg.split = 1u;  // small batches: several workgroups per band slot so that the chip still sees ~2000 of them
-        while (rg.split < 16u && rg.n_slots * n * rg.split < 2048u) rg.split *= 2u;
-        hipLaunchKernelGGL(k_brief_rows, dim3(rg.n_slots * rg.split, n), dim3(256), 0, s, d_blur, d_blur_rowc, pyr, rg, d_seg_counts,
-                           d_seg_before, d_seg, d_corners, cap, d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin});
-    }
+    launch_brief(p, s, n, p->rows, d_blur, d_blur_rowc, d_seg_counts, d_seg_before, d_seg, d_counts, d_corners, d_desc);
     HIP_TRY(p, hipGetLastError());
     return ORB_OK;
 }
@@ -520,7 +568,7 @@ bool fused_x_eligible(const OrbProgram* p) {
 // constants + stored tail from the grey plane), k_slot_prefix, k_brief_rows over the tile slots.
 int run_fused_x(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
     const Pyramid& pyr = p->pyr;
-    const uint32_t D = pyr.depth, cap = p->cfg.max_features;
+    const uint32_t D = pyr.depth;
     const IBriefGeom& bg = p->itiles;
     uint32_t band_base = 0;
     for (uint32_t lvl = 0; lvl < D; lvl++) {
@@ -581,20 +629,8 @@ int run_fused_x(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
                                p->d_gray, p->d_blur, p->d_blur_rowc, pyr, fg, p->threshold, p->d_xband_counts, p->d_iseg);
         }
     }
-    {
-        LaunchScope ls(p, s, KID_PREFIX);
-        hipLaunchKernelGGL(k_slot_prefix, dim3(n), dim3(64), 0, s, p->d_iseg_counts, p->d_iseg_before, p->d_counts, bg.n_slots,
-                           bg.seg_cap);
-    }
-    {
-        LaunchScope ls(p, s, KID_BRIEF_ROWS);
-        RowsGeom rg = p->xrows;
-        rg.split = 1u;
-        while (rg.split < 16u && rg.n_slots * n * rg.split < 2048u) rg.split *= 2u;
-        hipLaunchKernelGGL(k_brief_rows, dim3(rg.n_slots * rg.split, n), dim3(256), 0, s, p->d_blur, p->d_blur_rowc, pyr, rg,
-                           p->d_iseg_counts, p->d_iseg_before, p->d_iseg, p->d_corners, cap, p->d_desc,
-                           BriefTables{p->d_pattern, p->d_cos, p->d_sin});
-    }
+    launch_brief(p, s, n, p->xrows, p->d_blur, p->d_blur_rowc, p->d_iseg_counts, p->d_iseg_before, p->d_iseg, p->d_counts,
+                 p->d_corners, p->d_desc);
     HIP_TRY(p, hipGetLastError());
     p->planes_valid = true;
     return ORB_OK;
@@ -721,6 +757,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 }
                 // The attribute belongs to the function on this device, not to the program: always raise it to the
                 // device's limit, so that a later, smaller program never lowers it under a live, larger one.
+                p->use_brief_t = brieft_geometry(p, rg, &p->brieft);
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<false>),
@@ -803,6 +840,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         if (need > p->max_lds) {
             p->fused_x = false;
         } else {
+            p->use_brief_t = brieft_geometry(p, rg, &p->brieft);
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<false>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds);
             if (ea != hipSuccess) {
@@ -1112,7 +1150,7 @@ int launch_compact(OrbProgram* p, uint32_t n, uint32_t* counts, uint64_t* offset
     const uint32_t cap = p->cfg.max_features;
     {
         LaunchScope ls(p, s, KID_COMPACT);
-        hipLaunchKernelGGL(k_compact, dim3((cap + kCompactChunk - 1u) / kCompactChunk, n), dim3(256), 0, s, p->d_counts,
+        hipLaunchKernelGGL(k_compact, dim3(n, (cap + kCompactChunk - 1u) / kCompactChunk), dim3(256), 0, s, p->d_counts,
                            p->d_corners, p->d_desc, cap, n, counts, reinterpret_cast<unsigned long long*>(offsets), corners, desc,
                            (unsigned long long)capacity);
     }

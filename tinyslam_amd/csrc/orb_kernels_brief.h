@@ -1,0 +1,301 @@
+// orb_kernels_brief.h -- rotated BRIEF-256 (brief.wgsl:20-68) for the fused literal pipeline, one THREAD per keypoint.
+//
+// The literal blur is one value per row for every column below qa (88 % of the width, k_front phase C), so for a
+// keypoint with 18 <= x < qa - 18 ("flat", 88 % of them) a sample is the row constant of the rotated point's row and
+// only the y component of brief.wgsl:50-57's rotation matters.  A workgroup is ONE wave and takes 64 consecutive
+// keypoints of a frame's final list (the band segments back to back): it stages the frame's slot prefix and row
+// constants in LDS (2.3 KB at 720p, zero rows around every level: texels outside the level read 0, CRD-6), finds each
+// lane's band slot by binary search, copies the record to the final list and, for flat keypoints, runs the 256 tests
+// as straight-line code: the pattern's coordinates are literals, so a test is two products and a sum per point (equal
+// ones shared inside a word), a truncation, two ds_read_u16, one subtraction and one v_alignbit that shifts its sign
+// into the descriptor word.  Neighbouring lanes mostly come from the same band, so the rows a wave reads in one
+// instruction lie within ~52 consecutive halfs (fewer than 32 dwords): conflict-free reads with broadcasts.
+// Keypoints that are not flat (within 18 px of the left border or of the stored tail of the plane) are left to a launch
+// of k_brief_rows in its non-flat-only mode.
+// Against the wave-per-keypoint form (k_brief_rows: 85 VALU + 58 SALU per keypoint): ~31 vector instructions per
+// keypoint, next to no scalar work, no barrier between waves.
+#pragma once
+#include "orb_kernels_fused.h"
+
+namespace orb {
+
+constexpr int kBriefTThreads = 64;   // one wave per workgroup: no barrier couples the waves, the dispatcher refills SIMDs one wave at a time
+constexpr int kBriefTWaves = 6;       // waves per SIMD the register allocation aims at
+constexpr uint32_t kBriefTMaxSlots = 8192;  // seg_before of a frame is staged in LDS
+constexpr uint32_t kBriefTMaxRows = 12288;  // rows (all levels) + 36 per level, staged in LDS as f16
+
+struct BriefTGeom {
+    uint32_t n_slots, seg_cap;
+    uint32_t flat_end[kMaxLevels];  // qa - 18
+    uint32_t qa[kMaxLevels];
+    uint32_t row_base[kMaxLevels];  // index of row 0 of the level in the padded LDS row array
+    uint32_t rows_padded;           // entries of that array
+};
+
+__host__ __device__ inline uint32_t brieft_lds_bytes(const BriefTGeom& g) {
+    return (g.n_slots + 1u) * 4u + ((g.rows_padded + 1u) & ~1u) * 2u;
+}
+
+// pattern as compile-time constants (orb_tables.h is generated from brief.wgsl:70-327)
+__device__ __forceinline__ constexpr int pat_ax(int j) { return ORB_BRIEF_PATTERN[4 * j + 0]; }
+__device__ __forceinline__ constexpr int pat_ay(int j) { return ORB_BRIEF_PATTERN[4 * j + 1]; }
+__device__ __forceinline__ constexpr int pat_bx(int j) { return ORB_BRIEF_PATTERN[4 * j + 2]; }
+__device__ __forceinline__ constexpr int pat_by(int j) { return ORB_BRIEF_PATTERN[4 * j + 3]; }
+
+// word = (word << 1) | (a > b), a and b non-negative f16 bit patterns (they order like the values, brief.wgsl:62)
+__device__ __forceinline__ uint32_t push_gt(uint32_t word, uint32_t a, uint32_t b) {
+    return __builtin_amdgcn_alignbit(word, b - a, 31);  // bit 31 of (b - a) is set iff a > b
+}
+
+template <int kWavesPerSimd>
+__global__ __launch_bounds__(kBriefTThreads, kWavesPerSimd) void k_brief_t(const uint16_t* __restrict__ blur_rowc, Pyramid pyr, BriefTGeom bg,
+                                                                const uint32_t* __restrict__ seg_counts,
+                                                                const uint32_t* __restrict__ seg_before,
+                                                                const CornerData* __restrict__ segments,
+                                                                CornerData* __restrict__ corners, uint32_t cap,
+                                                                CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint32_t* const before = reinterpret_cast<uint32_t*>(lds_raw);                    // [n_slots + 1]
+    uint16_t* const rows = reinterpret_cast<uint16_t*>(before + bg.n_slots + 1u);     // [rows_padded]
+    __shared__ uint32_t lv[kMaxLevels][2];  // flat_end, row_base (a run-time index into kernel arguments is a global load)
+
+    // The frame is the FAST grid index: chunks past a frame's keypoint count exit at once, and with the chunk as the fast
+    // index their regular pattern (15 busy, 17 idle, ...) lands every busy workgroup on the same half of the CUs.
+    const uint32_t frame = blockIdx.x, tid = threadIdx.x;
+    const size_t sbase = (size_t)frame * bg.n_slots;
+    const uint32_t last = bg.n_slots - 1u;
+    const uint32_t stored_total = seg_before[sbase + last] + min(seg_counts[sbase + last], bg.seg_cap);
+    const uint32_t n_frame = min(stored_total, cap);
+    const uint32_t k0 = blockIdx.y * (uint32_t)kBriefTThreads;
+    if (k0 >= n_frame) return;  // uniform for the workgroup
+
+    // ---- stage the frame's slot prefix and row constants (zeros around every level)
+    for (uint32_t s = tid; s < bg.n_slots; s += kBriefTThreads) before[s] = seg_before[sbase + s];
+    if (tid == 0) before[bg.n_slots] = stored_total;
+    if (tid < pyr.depth) lv[tid][0] = bg.flat_end[tid], lv[tid][1] = bg.row_base[tid];
+    {
+        const uint16_t* src = blur_rowc + (size_t)frame * pyr.row_stride;
+        uint32_t m = 0;
+        for (uint32_t i = tid; i < bg.rows_padded; i += kBriefTThreads) {
+            while (m + 1u < pyr.depth && i + (uint32_t)kBriefHalo >= bg.row_base[m + 1u]) m++;  // level whose padded range holds i
+            const uint32_t y = i - bg.row_base[m];  // wraps for the zero rows in front of the level
+            rows[i] = y < pyr.h[m] ? src[pyr.row_off[m] + y] : (uint16_t)0;
+        }
+    }
+    __syncthreads();
+
+    // ---- this thread's keypoint: slot by binary search in the prefix, record from the band segment
+    const uint32_t k = k0 + tid;
+    if (k >= n_frame) return;
+    uint32_t lo = 0, hi = bg.n_slots;  // largest s with before[s] <= k (empty slots repeat the value: take the last)
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (before[mid] <= k)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint4 rec = *reinterpret_cast<const uint4*>(&segments[(sbase + lo) * bg.seg_cap + (k - before[lo])]);
+    *reinterpret_cast<uint4*>(&corners[(size_t)frame * cap + k]) = rec;  // final list = band segments back to back
+    const uint32_t lvl = min(rec.w, pyr.depth - 1u);
+    if (!(rec.x >= (uint32_t)kBriefHalo && rec.x < lv[lvl][0])) return;  // not flat: k_brief_nf takes it
+
+    const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
+    const float ct = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;  // CRD-10 table (code 0: ct = 1, st = 0)
+    const uint16_t* base = rows + lv[lvl][1] + rec.y;  // the keypoint's own row
+    uint32_t d[8];
+#pragma unroll
+    for (int wd = 0; wd < 8; wd++) {
+        // The pattern's coordinates are literals, so equal products and sums are shared.  Sharing them across the whole
+        // descriptor keeps hundreds of values alive (255 VGPRs, two waves per SIMD): ct and -st are made opaque once per
+        // word, which confines the sharing to the word's 64 points.
+        float ctw = ct, nstw = nst;
+        asm volatile("" : "+v"(ctw), "+v"(nstw));
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 31; i >= 0; i--) {
+            const int j = wd * 32 + i;
+            // mat2x2f(ct,-st, st,ct) * p (column-major): y' = -st*x + ct*y, every product and the sum rounded (CRD-10)
+            const float a2 = nstw * (float)pat_ax(j), a3 = ctw * (float)pat_ay(j);
+            const float b2 = nstw * (float)pat_bx(j), b3 = ctw * (float)pat_by(j);
+            const float ray = a2 + a3, rby = b2 + b3;
+            acc = push_gt(acc, base[(int)ray], base[(int)rby]);  // vec2i() truncates
+        }
+        d[wd] = acc;
+    }
+    uint4* o = reinterpret_cast<uint4*>(descriptors + (size_t)frame * cap + k);
+    o[0] = make_uint4(d[0], d[1], d[2], d[3]);
+    o[1] = make_uint4(d[4], d[5], d[6], d[7]);
+}
+
+// The keypoints k_brief_t leaves (not flat, 12 %: a sample may come from the stored tail of the blur plane, or lie left
+// of the level).  A workgroup scans 256 consecutive keypoints of a frame's final list, compacts the ones that are not
+// flat (ballots, no atomics) and deals them to its four waves, one wave per keypoint: lane l evaluates tests l, 64+l,
+// 128+l, 192+l (brief.wgsl:47,63,67).
+// Scattered 2-byte gathers from the plane are what this path used to spend its time on: the vector L1 looks up one
+// cache line per cycle, and 512 samples of one keypoint are 512 look-ups although they all fall into the same 37 x 37
+// patch.  So the wave first builds that patch in LDS -- 37 rows x 48 columns from the 8-aligned column left of x - 18,
+// 16-byte pieces, each piece composed of 0 (outside the level, CRD-6), the row constant (columns < qa) or the stored
+// texels (columns >= qa): ~120 line look-ups -- and then samples it with ds_read_u16.  Levels of odd width (2-byte
+// aligned rows) keep the direct gathers.
+constexpr int kNfPatchCols = 48, kNfPatchRows = 2 * kBriefHalo + 1;                       // halfs, rows
+constexpr int kNfPatchHalfs = kNfPatchRows * kNfPatchCols;
+
+__global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ blur, const uint16_t* __restrict__ blur_rowc,
+                                                  Pyramid pyr, BriefTGeom bg, const uint32_t* __restrict__ seg_counts,
+                                                  const uint32_t* __restrict__ seg_before,
+                                                  const CornerData* __restrict__ corners, uint32_t cap,
+                                                  CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
+    __shared__ __attribute__((aligned(16))) uint16_t patches[4][kNfPatchHalfs];
+    __shared__ uint4 recs[256];
+    __shared__ float2 rot[256];  // (cos, sin) of the keypoint's angle code (CRD-10 table), fetched during the scan
+    __shared__ uint16_t list[256];
+    __shared__ uint32_t wave_n[4];
+    // per-level geometry: indexing the by-value kernel arguments with a run-time level is a global load from the
+    // kernarg segment (a memory round trip in front of every keypoint); from LDS it is 64 cycles
+    __shared__ uint32_t lv[kMaxLevels][6];  // w, h, qa, row_off, off, flat_end
+    const uint32_t frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;  // frame = fast index, as above
+    if (tid < pyr.depth) {
+        lv[tid][0] = pyr.w[tid], lv[tid][1] = pyr.h[tid], lv[tid][2] = bg.qa[tid], lv[tid][3] = pyr.row_off[tid];
+        lv[tid][4] = pyr.off[tid], lv[tid][5] = bg.flat_end[tid];
+    }
+    const size_t sbase = (size_t)frame * bg.n_slots;
+    const uint32_t last = bg.n_slots - 1u;
+    const uint32_t n_frame = min(seg_before[sbase + last] + min(seg_counts[sbase + last], bg.seg_cap), cap);
+    const uint32_t k0 = blockIdx.y * 256u;
+    if (k0 >= n_frame) return;  // uniform for the workgroup
+    __syncthreads();
+    // ---- scan: which of this chunk's keypoints are not flat (k_brief_t has written the final list)
+    const uint32_t kk = k0 + tid;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    bool mine = false;
+    if (kk < n_frame) {
+        rec = *reinterpret_cast<const uint4*>(&corners[(size_t)frame * cap + kk]);
+        const uint32_t l = min(rec.w, pyr.depth - 1u);
+        mine = !(rec.x >= (uint32_t)kBriefHalo && rec.x < lv[l][5]);
+        if (mine) {
+            const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
+            rot[tid] = make_float2(tab.cos_tab[code], tab.sin_tab[code]);
+        }
+    }
+    const uint64_t m = __ballot(mine);
+    if (lane == 0u) wave_n[wave] = (uint32_t)__popcll(m);
+    recs[tid] = rec;
+    __syncthreads();
+    uint32_t start = 0, n_nf = 0;
+#pragma unroll
+    for (uint32_t w2 = 0; w2 < 4u; w2++) {
+        if (w2 < wave) start += wave_n[w2];
+        n_nf += wave_n[w2];
+    }
+    if (mine) list[start + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+    __syncthreads();
+    if (wave >= n_nf) return;
+
+    uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)frame * cap + k0);
+    uint16_t* const patch = patches[wave];
+    uint32_t pat[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) pat[e] = tab.pattern[64u * (uint32_t)e + lane];
+    for (uint32_t i = wave; i < n_nf; i += 4u) {
+        const uint32_t idx = list[i];
+        const uint4 r = recs[idx];  // x, y, angle, octave
+        const uint32_t lvl = min(r.w, pyr.depth - 1u);
+        const int w = (int)lv[lvl][0], h = (int)lv[lvl][1], qa = (int)lv[lvl][2];
+        const uint16_t* rowc = blur_rowc + (size_t)frame * pyr.row_stride + lv[lvl][3];
+        const uint16_t* plane = blur + (size_t)frame * pyr.stride + lv[lvl][4];
+        const float ct = rot[idx].x, st = rot[idx].y, nst = -st;
+        int dxa[4], dya[4], dxb[4], dyb[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
+            const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
+            // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y), brief.wgsl:38-54
+            const float a0 = ct * pax, a1 = st * pay, a2 = nst * pax, a3 = ct * pay;
+            const float b0 = ct * pbx, b1 = st * pby, b2 = nst * pbx, b3 = ct * pby;
+            const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+            dxa[e] = (int)rax, dya[e] = (int)ray, dxb[e] = (int)rbx, dyb[e] = (int)rby;  // vec2i() truncates
+        }
+        uint64_t bal[4];
+        if ((w & 1) == 0) {
+            // ---- patch in LDS: rows y-18..y+18, columns c0..c0+47 with c0 = (x - 18) rounded down to 8.  A piece
+            //      (8 columns) lies entirely left of the level (zeros), below qa (the row constant) or in the stored
+            //      tail (one 16-byte load); the four pieces of a lane are loaded back to back from addresses that are
+            //      always valid (the plane's first texels where none is needed) and composed afterwards.
+            const int c0 = ((int)r.x - kBriefHalo) & ~7;
+            constexpr int kPiecesPerRow = kNfPatchCols / 8, kPieces = kNfPatchRows * kPiecesPerRow;
+            constexpr int kRounds = (kPieces + 63) / 64;
+            uint4 tv[kRounds];
+            uint32_t rcv[kRounds];
+            int kind[kRounds], where[kRounds];  // 0: zeros, 1: row constant, 2: loaded, 3: the level ends inside the piece
+#pragma unroll
+            for (int rr = 0; rr < kRounds; rr++) {
+                const int p = (int)lane + 64 * rr;
+                const int pr = (int)(((float)p + 0.5f) * (1.0f / (float)kPiecesPerRow));
+                const int pc = p - pr * kPiecesPerRow;
+                const int gy = (int)r.y - kBriefHalo + pr, cx = c0 + 8 * pc;
+                const bool in = p < kPieces && gy >= 0 && gy < h && cx >= 0 && cx < w;
+                kind[rr] = !in ? 0 : (cx < qa ? 1 : (cx + 8 <= w ? 2 : 3));
+                where[rr] = p < kPieces ? pr * kNfPatchCols + 8 * pc : -1;
+                rcv[rr] = rowc[min(max(gy, 0), h - 1)];
+                // 4-byte aligned: even width, cx a multiple of 8
+                tv[rr] = *reinterpret_cast<const uint4*>(plane + (kind[rr] == 2 ? (size_t)(uint32_t)(__mul24(gy, w) + cx) : (size_t)0));
+            }
+#pragma unroll
+            for (int rr = 0; rr < kRounds; rr++) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (kind[rr] == 1) {
+                    const uint32_t c2 = rcv[rr] | (rcv[rr] << 16);
+                    v = make_uint4(c2, c2, c2, c2);
+                } else if (kind[rr] == 2) {
+                    v = tv[rr];
+                } else if (kind[rr] == 3) {  // width not a multiple of 8: the last piece of a row, texel by texel
+                    const int p = (int)lane + 64 * rr;
+                    const int pr = (int)(((float)p + 0.5f) * (1.0f / (float)kPiecesPerRow));
+                    const int gy = (int)r.y - kBriefHalo + pr, cx = c0 + 8 * (p - pr * kPiecesPerRow);
+                    const uint16_t* src = plane + (size_t)(uint32_t)(__mul24(gy, w) + cx);
+                    uint32_t t[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) t[q] = cx + q < w ? (uint32_t)src[q] : 0u;
+                    v = make_uint4(t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16));
+                }
+                if (where[rr] >= 0) *reinterpret_cast<uint4*>(&patch[where[rr]]) = v;
+            }
+            const int xo = (int)r.x - c0;  // 18..25
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t va = patch[(dya[e] + kBriefHalo) * kNfPatchCols + xo + dxa[e]];
+                const uint32_t vb = patch[(dyb[e] + kBriefHalo) * kNfPatchCols + xo + dxb[e]];
+                bal[e] = __ballot(va > vb);  // non-negative f16: bit patterns order like the values (brief.wgsl:62)
+            }
+        } else {
+            // ---- odd width: rows of the plane are only 2-byte aligned; gather sample by sample
+            const int gy = (int)r.y - kBriefHalo + (int)lane;  // lanes 0..36 are the patch rows
+            const uint32_t rowv = (gy >= 0 && gy < h && lane < 37u) ? (uint32_t)rowc[gy] : 0u;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int xa = (int)r.x + dxa[e], ya = (int)r.y + dya[e];
+                const int xb = (int)r.x + dxb[e], yb = (int)r.y + dyb[e];
+                uint32_t va = (uint32_t)__shfl((int)rowv, dya[e] + kBriefHalo);  // 0 when the row is outside the level
+                uint32_t vb = (uint32_t)__shfl((int)rowv, dyb[e] + kBriefHalo);
+                const bool ina = xa >= 0 && xa < w && ya >= 0 && ya < h;
+                const bool inb = xb >= 0 && xb < w && yb >= 0 && yb < h;
+                if (!ina)
+                    va = 0u;
+                else if (xa >= qa)
+                    va = plane[(size_t)(uint32_t)(__mul24(ya, w) + xa)];
+                if (!inb)
+                    vb = 0u;
+                else if (xb >= qa)
+                    vb = plane[(size_t)(uint32_t)(__mul24(yb, w) + xb)];
+                bal[e] = __ballot(va > vb);
+            }
+        }
+        if (lane < 8u) {
+            const uint64_t src = lane < 2u ? bal[0] : (lane < 4u ? bal[1] : (lane < 6u ? bal[2] : bal[3]));
+            out_desc[(size_t)idx * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
+        }
+    }
+}
+
+}  // namespace orb

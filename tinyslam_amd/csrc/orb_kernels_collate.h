@@ -12,7 +12,8 @@ namespace orb {
 
 constexpr uint32_t kCompactChunk = 1024;  // records per workgroup
 
-// grid (chunks_per_frame, n_frames), 256 threads.
+// grid (n_frames, chunks_per_frame), 256 threads; the frame is the fast index so that the chunks past a frame's count
+// (which exit at once) do not leave half of the XCDs without work.
 //   counts[f]             raw per-frame counters of the batch (orb.rs:550-556)
 //   corners/descriptors   [n_frames][cap] slabs
 //   out_counts[f]         raw counter again (may be null)
@@ -24,7 +25,7 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ co
                                                  unsigned long long* __restrict__ out_offsets, CornerData* __restrict__ out_c,
                                                  CornerDescriptor* __restrict__ out_d, unsigned long long capacity) {
     __shared__ unsigned long long wave_sum[4];
-    const uint32_t frame = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const uint32_t frame = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
     // offset of this frame = stored records of the frames before it (<= a few thousand counts, L2 hits)
     unsigned long long part = 0;
     for (uint32_t f = tid; f < frame; f += 256u) part += (unsigned long long)min(counts[f], cap);

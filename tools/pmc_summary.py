@@ -8,7 +8,7 @@ import sys
 import pandas as pd
 
 src = sys.argv[1]
-KERNELS = ("k_front<true>", "k_front<false>", "k_brief_rows", "k_slot_prefix", "k_front_y", "k_compact")
+KERNELS = ("k_front<true>", "k_front<false>", "k_brief_rows", "k_slot_prefix", "k_front_y", "k_compact", "k_brief_t", "k_brief_nf")
 
 
 def short(name):
