@@ -98,6 +98,25 @@ __device__ __forceinline__ float luminance_fast(uint32_t rgba) {
 __device__ __forceinline__ uint32_t pack_half2(float lo, float hi) {
     return (uint32_t)half_bits(to_half(lo)) | ((uint32_t)half_bits(to_half(hi)) << 16);
 }
+// Luminance (CRD-1, CRD-2) of two neighbouring texels as f16 in one word.  Written on two-element vectors so that the
+// packed binary32 instructions (v_pk_mul/fma/add_f32) work on the pair that v_cvt_pk_f16_f32 then rounds into one
+// register: left to itself the vectoriser pairs texels 0/2 and 1/3 and spends four more instructions re-interleaving.
+__device__ __forceinline__ uint32_t luminance_pair_f16(uint32_t rgba0, uint32_t rgba1) {
+    const float2_t rc_hi = {0x1.010102p-8f, 0x1.010102p-8f}, rc_lo = {-0x1.fdfdfep-33f, -0x1.fdfdfep-33f};
+    const float2_t R = {(float)(rgba0 & 255u), (float)(rgba1 & 255u)};
+    const float2_t G = {(float)((rgba0 >> 8) & 255u), (float)((rgba1 >> 8) & 255u)};
+    const float2_t B = {(float)((rgba0 >> 16) & 255u), (float)((rgba1 >> 16) & 255u)};
+    const float2_t tr = R * rc_lo, tg = G * rc_lo, tb = B * rc_lo;
+    const float2_t r = __builtin_elementwise_fma(R, rc_hi, tr);  // exact byte/255, see unorm8_exact
+    const float2_t g = __builtin_elementwise_fma(G, rc_hi, tg);
+    const float2_t b = __builtin_elementwise_fma(B, rc_hi, tb);
+    const float2_t pr = r * 0.229f, pg = g * 0.587f, pb = b * 0.114f;
+    const float2_t s = pr + pg;
+    const float2_t l = s + pb;
+    uint32_t d;  // the instruction hipcc itself uses for two (half) casts (RNE, CRD-3); as asm so that the pairing stays
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(l.x), "v"(l.y));
+    return d;
+}
 
 // ---- FAST on one pixel; `ctr` points at it inside the LDS grey rows (row stride `ls` halfs) ----
 // 16-point masks (fast.wgsl:102-113).  thr >= 0, so `diff > thr` and `diff < -thr` exclude each other
@@ -292,8 +311,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 if (dst[u] >= 0) {
                     if (L0) {
                         uint2 out;
-                        out.x = pack_half2(luminance_fast(v[u].x), luminance_fast(v[u].y));
-                        out.y = pack_half2(luminance_fast(v[u].z), luminance_fast(v[u].w));
+                        out.x = luminance_pair_f16(v[u].x, v[u].y);
+                        out.y = luminance_pair_f16(v[u].z, v[u].w);
                         *reinterpret_cast<uint2*>(grey + dst[u]) = out;
                     } else {
                         *reinterpret_cast<uint4*>(grey + dst[u]) = v[u];
@@ -438,7 +457,16 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 }
                 if (cand) {  // one LDS atomic for all survivors of this item
                     const uint32_t cand_over = gather_signs(e_ovr);
-                    uint32_t qs = atomicAdd(qa_count, (uint32_t)__builtin_popcount(cand));
+                    // Every lane adds its own count with the LDS's returning add.  Lanes of a wave hit the same
+                    // address and the LDS serialises them (64 of its cycles at most, and it is 23 % busy), which costs
+                    // the vector unit one instruction; hipcc's wave-aggregated form of atomicAdd() with lane-varying
+                    // amounts is a 20-instruction DPP scan in front of its single add.
+                    uint32_t qs;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=v"(qs)
+                                 : "v"((uint32_t)(reinterpret_cast<const uint8_t*>(qa_count) - lds_raw)),
+                                   "v"((uint32_t)__builtin_popcount(cand))
+                                 : "memory");
                     while (cand) {
                         const int p = __builtin_ctz(cand);
                         cand &= cand - 1u;
