@@ -91,6 +91,13 @@ typedef struct OrbOptions {
                                    * x).  Definitions IM-1..IM-8 in DESIGN.md section 8; has its own fused kernels (widths that are a
                                    * multiple of 4), ORB_FLAG_STAGED selects the per-stage cross-check. */
 
+#define ORB_FLAG_INPUT_Y8 16u     /* opt-in, NOT in the reference's code (its roadmap: README.md:42 "Use Y channel of YUV
+                                   * stream directly"): frames are ONE byte per pixel (W*H bytes,
+                                   * tightly packed) and the grey image is that sample, gray(x,y) = f16(Y(x, H-1-y)/255)
+                                   * -- the vertical mirror of the reference's full-screen pass is kept, everything
+                                   * downstream is the literal path, unchanged.  Not combined with ORB_FLAG_INTENDED, ORB_FLAG_NMS
+                                   * or a fast_arc other than 12 (those have no Y8 definition to check against). */
+
 typedef struct OrbProgram OrbProgram; /* opaque; replaces orb.rs:47-51 `OrbProgram` */
 
 /* ---- lifetime: replaces the struct literal + OrbProgram::init (orb.rs:107-219) ---- */
@@ -105,7 +112,7 @@ uint32_t orb_abi_version(void);
 const char *orb_pipeline(const OrbProgram *p);
 
 /* ---- single-frame API, one call per reference method ---- */
-/* orb.rs:567-583 write_input_image: tightly packed RGBA8, rows of 4*width bytes. */
+/* orb.rs:567-583 write_input_image: tightly packed RGBA8, rows of 4*width bytes (ORB_FLAG_INPUT_Y8: rows of width bytes). */
 int orb_write_input_image(OrbProgram *p, const uint8_t *bytes, size_t len);
 /* orb.rs:585-589 set_threshold */
 int orb_set_threshold(OrbProgram *p, float threshold);
@@ -240,6 +247,7 @@ const char *orb_kernel_name(int id);
 #define ORB_SYN_BLOBS 2u
 #define ORB_SYN_WEDGES 4u
 #define ORB_SYN_NOISE 8u
+#define ORB_SYN_Y8 16u /* one byte per pixel: the green channel of the recipe (for ORB_FLAG_INPUT_Y8 programs) */
 /* Frame i gets seed seed0+i.  frames_dev == NULL allocates/uses the program's own input slab
  * (max_batch frames) and returns its address in *out_dev. */
 int orb_synth_frames_device(OrbProgram *p, uint8_t *frames_dev, uint32_t n_frames, uint32_t seed0, uint32_t flags,

@@ -61,6 +61,12 @@ def grayscale(rgba):
     return to_f16_bits(lum)
 
 
+def grayscale_y8(y8):
+    """Y8 input variant (not in the reference's code): the Y sample of the vertically mirrored texel as R16Float."""
+    img = np.asarray(y8, dtype=np.uint8)[::-1, :]
+    return to_f16_bits(img.astype(np.float32) / F(255.0))
+
+
 def _lerp_axis_coords(n_dst, n_src):
     s = (np.arange(n_dst, dtype=np.float32) + F(0.5)) * (F(n_src) / F(n_dst)) - F(0.5)
     s0 = np.floor(s)
@@ -233,9 +239,9 @@ def brief(blur_levels_bits, corners):
     return out
 
 
-def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192):
-    """orb.rs:469-557 stage order."""
-    gray = [grayscale(rgba)]
+def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, y8=False):
+    """orb.rs:469-557 stage order (y8: the frame is a one-byte-per-pixel Y plane)."""
+    gray = [grayscale_y8(rgba) if y8 else grayscale(rgba)]
     for _ in range(1, depth):
         gray.append(mip(gray[-1]))
     tmp = [blur_pass(g) for g in gray]

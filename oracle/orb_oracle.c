@@ -362,9 +362,37 @@ void orc_brief(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_cor
  * whole frame, orb.rs:469-557: grayscale -> mips -> blur A (all levels) -> blur B (all levels)
  * -> FAST per octave -> BRIEF.
  * ---------------------------------------------------------------------------------------- */
+/* Y8 input variant -- NOT in the reference's code; its README lists "Use Y channel of YUV stream directly" as a roadmap
+ * item (README.md:42).  Definition of the build: the grey image is the Y plane itself, gray(x,y) = f16(Y(x, H-1-y)/255):
+ * the luminance dot product of grayscale.wgsl:31-38 is replaced by the sample (CRD-1 for the byte, CRD-3 for the store)
+ * and the vertical mirror of the full-screen pass (Q2, grayscale.wgsl:16-25) is kept, so that everything downstream --
+ * mips, blur, detector, descriptors and every keypoint coordinate -- is the literal path's, unchanged. */
+void orc_grayscale_y8(const uint8_t *y8, uint32_t W, uint32_t H, uint16_t *gray) {
+    for (uint32_t y = 0; y < H; y++) {
+        const uint8_t *src = y8 + (size_t)(H - 1 - y) * W;
+        for (uint32_t x = 0; x < W; x++) gray[(size_t)y * W + x] = orc_f32_to_f16(orc_unorm8(src[x]));
+    }
+}
+
+static int extract_impl(const uint8_t *frame, int y8, uint32_t W, uint32_t H, uint32_t depth, float threshold,
+                        uint32_t max_features, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total,
+                        uint16_t *gray_pyr, uint16_t *blur_pyr);
+
 int orc_extract(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, float threshold, uint32_t max_features,
                 orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total, uint16_t *gray_pyr,
                 uint16_t *blur_pyr) {
+    return extract_impl(rgba, 0, W, H, depth, threshold, max_features, corners, descriptors, total, gray_pyr, blur_pyr);
+}
+
+int orc_extract_y8(const uint8_t *y8, uint32_t W, uint32_t H, uint32_t depth, float threshold, uint32_t max_features,
+                   orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total, uint16_t *gray_pyr,
+                   uint16_t *blur_pyr) {
+    return extract_impl(y8, 1, W, H, depth, threshold, max_features, corners, descriptors, total, gray_pyr, blur_pyr);
+}
+
+static int extract_impl(const uint8_t *rgba, int y8, uint32_t W, uint32_t H, uint32_t depth, float threshold,
+                        uint32_t max_features, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total,
+                        uint16_t *gray_pyr, uint16_t *blur_pyr) {
     if (!rgba || !W || !H || depth < 1 || depth > ORC_MAX_LEVELS || !total) return -1;
     orc_pyramid_t lay;
     orc_pyramid_layout(W, H, depth, &lay);
@@ -377,7 +405,10 @@ int orc_extract(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, flo
         free(blur);
         return -1;
     }
-    orc_grayscale(rgba, W, H, gray);
+    if (y8)
+        orc_grayscale_y8(rgba, W, H, gray);
+    else
+        orc_grayscale(rgba, W, H, gray);
     for (uint32_t m = 1; m < depth; m++)
         orc_mip(gray + lay.offset[m - 1], lay.w[m - 1], lay.h[m - 1], gray + lay.offset[m], lay.w[m], lay.h[m]);
     for (uint32_t m = 0; m < depth; m++) orc_blur_pass(gray + lay.offset[m], lay.w[m], lay.h[m], tmp + lay.offset[m]);

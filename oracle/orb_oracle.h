@@ -58,6 +58,11 @@ float orc_unorm8(uint8_t b); /* CRD-1 */
 
 /* stages */
 void orc_grayscale(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray); /* grayscale.wgsl:12-38 */
+/* Y8 input variant (NOT in the reference's code; its roadmap item README.md:42): gray(x,y) = f16(Y(x, H-1-y)/255) */
+void orc_grayscale_y8(const uint8_t *y8, uint32_t W, uint32_t H, uint16_t *gray);
+int orc_extract_y8(const uint8_t *y8, uint32_t W, uint32_t H, uint32_t depth, float threshold, uint32_t max_features,
+                   orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total, uint16_t *gray_pyr,
+                   uint16_t *blur_pyr);
 void orc_mip(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint32_t wd, uint32_t hd); /* blit.wgsl:17-36 */
 void orc_blur_pass(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst); /* gaussian_blur_x.wgsl:32-60 */
 /* fast.wgsl:62-159 over every octave in dispatch order (orb.rs:504-520).  Appends in raster

@@ -65,11 +65,13 @@ def lib():
         L.orc_unorm8.argtypes = [ctypes.c_uint8]
         L.orc_unorm8.restype = f32
         L.orc_grayscale.argtypes = [vp, u32, u32, vp]
+        L.orc_grayscale_y8.argtypes = [vp, u32, u32, vp]
         L.orc_mip.argtypes = [vp, u32, u32, vp, u32, u32]
         L.orc_blur_pass.argtypes = [vp, u32, u32, vp]
         L.orc_fast.argtypes = [vp, ctypes.POINTER(_Pyramid), f32, vp, u32, u32p]
         L.orc_brief.argtypes = [vp, ctypes.POINTER(_Pyramid), vp, u32, vp]
         L.orc_extract.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, u32p, vp, vp]
+        L.orc_extract_y8.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, u32p, vp, vp]
         L.orc_extract.restype = ctypes.c_int
         L.orc_extract_ex.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, vp, u32p]
         L.orc_extract_ex.restype = ctypes.c_int
@@ -174,6 +176,33 @@ def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=Fal
                            _ptr(gray) if planes else None, _ptr(blur) if planes else None)
     if rc != 0:
         raise ValueError("orc_extract: invalid arguments")
+    n = min(total.value, max_features)
+    return dict(total=total.value, corners=corners[:n], descriptors=desc[:n], gray=gray, blur=blur)
+
+
+def grayscale_y8(y8):
+    y8 = np.ascontiguousarray(y8, dtype=np.uint8)
+    H, W = y8.shape[:2]
+    out = np.empty((H, W), dtype=np.uint16)
+    lib().orc_grayscale_y8(_ptr(y8), W, H, _ptr(out))
+    return out
+
+
+def extract_y8(y8, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=False):
+    """Y8 input variant (one byte per pixel; not in the reference's code, see orb_oracle.c)."""
+    y8 = np.ascontiguousarray(y8, dtype=np.uint8)
+    H, W = y8.shape[:2]
+    corners = np.zeros(max_features, dtype=CORNER_DTYPE)
+    desc = np.zeros((max_features, 8), dtype=np.uint32)
+    total = ctypes.c_uint32(0)
+    _, ntex = level_dims(W, H, depth)
+    gray = np.zeros(ntex, dtype=np.uint16) if planes else None
+    blur = np.zeros(ntex, dtype=np.uint16) if planes else None
+    rc = lib().orc_extract_y8(_ptr(y8), W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
+                              _ptr(corners), _ptr(desc), ctypes.byref(total),
+                              _ptr(gray) if planes else None, _ptr(blur) if planes else None)
+    if rc != 0:
+        raise ValueError("orc_extract_y8: invalid arguments")
     n = min(total.value, max_features)
     return dict(total=total.value, corners=corners[:n], descriptors=desc[:n], gray=gray, blur=blur)
 

@@ -42,6 +42,14 @@ INTENDED_CASES = [
 ]
 
 
+# Y8 input variant (ORB_FLAG_INPUT_Y8; not in the reference's code, see oracle/orb_oracle.c): name, W, H, depth, seed,
+# flags.  The frame is the green channel of the synthetic RGBA frame.  Kept in tests/golden/y8/.
+Y8_CASES = [
+    ("y160x120_d3", 160, 120, 3, 31, 15),
+    ("y640x480_d2", 640, 480, 2, 32, 15),
+]
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -67,6 +75,30 @@ def main():
             os.path.join(HERE, name + ".npz"),
             params=np.array([W, H, depth, seed, flags, 8192], dtype=np.int64), threshold=THR,
             rgba_sha256=sha(rgba), gray_sha256=np.array(gray_sha), blur_sha256=np.array(blur_sha),
+            total=np.int64(ref["total"]),
+            corners=np.stack([corners[k] for k in ("x", "y", "angle", "octave")], 1).astype(np.uint32),
+            descriptors=desc.astype(np.uint32))
+        print(name, "total", ref["total"])
+    os.makedirs(os.path.join(HERE, "y8"), exist_ok=True)
+    for name, W, H, depth, seed, flags in Y8_CASES:
+        y8 = np.ascontiguousarray(orb_oracle.synth_frame(W, H, seed, flags)[:, :, 1])
+        ref = orb_oracle.extract_y8(y8, depth=depth, threshold=THR, max_features=8192, planes=True)
+        alt = orb_numpy.extract(y8, depth=depth, threshold=THR, max_features=8192, y8=True)
+        kc = np.stack([ref["corners"][k] for k in ("x", "y", "angle", "octave")], 1)
+        assert ref["total"] == alt["total"] and np.array_equal(kc, alt["corners"])
+        assert np.array_equal(ref["descriptors"], alt["descriptors"])
+        dims, _ = orb_oracle.level_dims(W, H, depth)
+        gray_sha, blur_sha = [], []
+        for m, (w, h, off) in enumerate(dims):
+            g, b = ref["gray"][off:off + w * h], ref["blur"][off:off + w * h]
+            assert np.array_equal(g, alt["gray"][m].ravel()) and np.array_equal(b, alt["blur"][m].ravel())
+            gray_sha.append(sha(g))
+            blur_sha.append(sha(b))
+        corners, desc = orb_oracle.sort_keypoints(ref["corners"], ref["descriptors"])
+        np.savez_compressed(
+            os.path.join(HERE, "y8", name + ".npz"),
+            params=np.array([W, H, depth, seed, flags, 8192], dtype=np.int64), threshold=THR,
+            y8_sha256=sha(y8), gray_sha256=np.array(gray_sha), blur_sha256=np.array(blur_sha),
             total=np.int64(ref["total"]),
             corners=np.stack([corners[k] for k in ("x", "y", "angle", "octave")], 1).astype(np.uint32),
             descriptors=desc.astype(np.uint32))

@@ -269,3 +269,84 @@ def test_octaves_without_a_fast_dispatch(tinyorb, oracle, flags, arc):
             _assert_frame_equal(oracle, ref, total, corners, desc)
             results.append(total)
     assert results[0] == results[1]
+
+
+# ---------------------------------------------------------------------------------------------
+# Y8 input variant (ORB_FLAG_INPUT_Y8; SURVEY.md 8f rank 3, the reference's roadmap README.md:42)
+# ---------------------------------------------------------------------------------------------
+import glob
+import hashlib
+
+_Y8_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "y8", "*.npz")))
+
+
+@pytest.mark.parametrize("W,H,depth,seed", [(64, 48, 2, 3), (160, 120, 3, 1), (1280, 96, 2, 4), (332, 202, 4, 9),
+                                            (2052, 40, 1, 6), (200, 97, 3, 7)])
+@pytest.mark.parametrize("staged", [0, 1])
+def test_y8_matches_oracle(tinyorb, oracle, W, H, depth, seed, staged):
+    y8 = np.ascontiguousarray(oracle.synth_frame(W, H, seed)[:, :, 1])
+    ref = oracle.extract_y8(y8, depth=depth, threshold=THR, planes=True)
+    with _program(tinyorb, W, H, depth, flags=tinyorb.ORB_FLAG_INPUT_Y8 | staged) as prog:
+        total, corners, desc = prog.extract(y8)
+        _assert_frame_equal(oracle, ref, total, corners, desc)
+        dims, _ = oracle.level_dims(W, H, depth)
+        for m, (w, h, off) in enumerate(dims):
+            if m > 0 or prog.pipeline() == "staged":
+                g = prog.read_plane(tinyorb.ORB_PLANE_GRAY, m)
+                assert np.array_equal(g.ravel(), ref["gray"][off:off + w * h]), "gray level %d" % m
+            b = prog.read_plane(tinyorb.ORB_PLANE_BLUR, m)
+            assert np.array_equal(b.ravel(), ref["blur"][off:off + w * h]), "blur level %d" % m
+        # an RGBA-sized buffer is refused: a Y8 program takes W*H bytes
+        with pytest.raises(tinyorb.OrbError):
+            prog.write_input_image(np.zeros((H, W, 4), np.uint8))
+
+
+@pytest.mark.parametrize("path", _Y8_GOLDEN, ids=[os.path.basename(p) for p in _Y8_GOLDEN])
+@pytest.mark.parametrize("staged", [0, 1])
+def test_y8_golden_fixture_on_gpu(tinyorb, path, staged):
+    g = np.load(path)
+    W, H, depth, seed, syn_flags, cap = (int(v) for v in g["params"])
+    with _program(tinyorb, W, H, depth, max_features=cap, flags=tinyorb.ORB_FLAG_INPUT_Y8 | staged,
+                  thr=float(g["threshold"])) as prog:
+        dev = prog.synth_frames_device(1, seed, syn_flags)  # a Y8 program generates one byte per pixel (green channel)
+        y8 = prog.copy_to_host(dev, W * H)
+        assert hashlib.sha256(y8.tobytes()).hexdigest() == str(g["y8_sha256"])
+        prog.extract_batch_device(dev, 1)
+        total = int(prog.batch_counts(1)[0])
+        assert total == int(g["total"])
+        corners, desc = prog.batch_read(0, total)
+        c, d = _sorted(corners, desc)
+        assert np.array_equal(np.stack([c[k] for k in ("x", "y", "angle", "octave")], 1), g["corners"])
+        assert np.array_equal(d, g["descriptors"])
+        for m in range(depth):
+            b = prog.read_plane(tinyorb.ORB_PLANE_BLUR, m)
+            assert hashlib.sha256(b.tobytes()).hexdigest() == str(g["blur_sha256"][m])
+
+
+def test_y8_batch_and_rejections(tinyorb, oracle):
+    W, H, B = 320, 240, 5
+    with _program(tinyorb, W, H, 2, max_batch=B, flags=tinyorb.ORB_FLAG_INPUT_Y8) as prog:
+        frames = np.stack([np.ascontiguousarray(oracle.synth_frame(W, H, 60 + i)[:, :, 1]) for i in range(B)])
+        prog.extract_batch_host(frames)
+        counts = prog.batch_counts(B)
+        for i in range(B):
+            ref = oracle.extract_y8(frames[i], depth=2, threshold=THR)
+            corners, desc = prog.batch_read(i, int(counts[i]))
+            _assert_frame_equal(oracle, ref, int(counts[i]), corners, desc)
+    # the opt-in detectors have no Y8 definition to check against: refused, not guessed
+    for kw in (dict(flags=tinyorb.ORB_FLAG_INPUT_Y8 | tinyorb.ORB_FLAG_INTENDED),
+               dict(flags=tinyorb.ORB_FLAG_INPUT_Y8 | tinyorb.ORB_FLAG_NMS), dict(flags=tinyorb.ORB_FLAG_INPUT_Y8, fast_arc=9)):
+        with pytest.raises(tinyorb.OrbError):
+            _program(tinyorb, W, H, 2, **kw)
+
+
+def test_forced_wave_per_keypoint_brief(tinyorb, oracle, monkeypatch):
+    """TINYORB_BRIEF_ROWS=1 keeps k_brief_rows (the fallback of frames too large for k_brief_t's LDS staging) in use: it
+    must still agree with the oracle."""
+    monkeypatch.setenv("TINYORB_BRIEF_ROWS", "1")
+    for (W, H, depth, seed) in ((640, 480, 2, 1), (332, 202, 5, 11), (1280, 96, 2, 4)):
+        rgba = oracle.synth_frame(W, H, seed)
+        ref = oracle.extract(rgba, depth=depth, threshold=THR)
+        with _program(tinyorb, W, H, depth) as prog:
+            total, corners, desc = prog.extract(rgba)
+            _assert_frame_equal(oracle, ref, total, corners, desc)

@@ -252,6 +252,47 @@ def test_golden_fixture(oracle, path):
     assert np.array_equal(d, g["descriptors"])
 
 
+Y8_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "y8", "*.npz")))
+
+
+@pytest.mark.parametrize("path", Y8_GOLDEN, ids=[os.path.basename(p) for p in Y8_GOLDEN])
+def test_y8_golden_fixture(oracle, path):
+    """Y8 input variant (one byte per pixel; not in the reference's code): C oracle against its committed fixture."""
+    g = np.load(path)
+    W, H, depth, seed, flags, cap = (int(v) for v in g["params"])
+    y8 = np.ascontiguousarray(oracle.synth_frame(W, H, seed, flags)[:, :, 1])
+    assert _sha(y8) == str(g["y8_sha256"])
+    r = oracle.extract_y8(y8, depth=depth, threshold=g["threshold"], max_features=cap, planes=True)
+    assert r["total"] == int(g["total"])
+    dims, _ = oracle.level_dims(W, H, depth)
+    for m, (w, h, off) in enumerate(dims):
+        assert _sha(r["gray"][off:off + w * h]) == str(g["gray_sha256"][m])
+        assert _sha(r["blur"][off:off + w * h]) == str(g["blur_sha256"][m])
+    c, d = oracle.sort_keypoints(r["corners"], r["descriptors"])
+    assert np.array_equal(np.stack([c[k] for k in ("x", "y", "angle", "octave")], 1), g["corners"])
+    assert np.array_equal(d, g["descriptors"])
+
+
+def test_y8_definition(oracle):
+    """The Y8 grey image is f16(byte/255) of the vertically mirrored sample; a grey RGBA frame run through the literal
+    luminance gives a DIFFERENT image (its weights sum to 0.93, Q1), so the two inputs are not interchangeable; C and
+    NumPy restatements agree; everything downstream of the grey image is shared with the literal path."""
+    from oracle import orb_numpy
+    rng = np.random.default_rng(11)
+    y8 = rng.integers(0, 256, size=(40, 52), dtype=np.uint8)
+    g = oracle.grayscale_y8(y8)
+    want = (y8[::-1].astype(np.float32) / np.float32(255.0)).astype(np.float16).view(np.uint16)
+    assert np.array_equal(g, want) and np.array_equal(g, orb_numpy.grayscale_y8(y8))
+    grey_rgba = np.stack([y8, y8, y8, np.full_like(y8, 255)], axis=2)
+    assert not np.array_equal(oracle.grayscale(grey_rgba), g)
+    frame = np.ascontiguousarray(oracle.synth_frame(96, 80, 5)[:, :, 1])
+    a = oracle.extract_y8(frame, depth=3, threshold=THR, planes=True)
+    b = orb_numpy.extract(frame, depth=3, threshold=THR, y8=True)
+    ka = np.stack([a["corners"][k] for k in ("x", "y", "angle", "octave")], 1)
+    assert a["total"] == b["total"] > 0 and np.array_equal(ka, b["corners"])
+    assert np.array_equal(a["descriptors"], b["descriptors"])
+
+
 def test_batch_threads_equal_serial(oracle):
     frames = np.stack([oracle.synth_frame(96, 64, 50 + i) for i in range(5)])
     t1, c1, d1 = oracle.extract_batch(frames, depth=2, threshold=THR, max_features=512, n_threads=1)

@@ -62,6 +62,7 @@ struct OrbProgram {
     ScoreLayout score_layout{};
     // "intended" mode: survivors of the NMS with their scores, input of the top-K cut
     bool intended = false;
+    bool input_y8 = false;  // ORB_FLAG_INPUT_Y8: frames are one byte per pixel
     // fused "intended" pipeline (orb_kernels_intended.h): tile slots, their segments (record + score), the cut
     bool fused_i = false;
     bool fused_x = false;  // the reference's algorithm with the opt-in arc / NMS on the tile kernels
@@ -219,7 +220,9 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
     {
         LaunchScope ls(p, s, KID_GRAY);
         dim3 grid((W + 1023u) / 1024u, H, n);
-        if (p->intended)
+        if (p->input_y8)
+            hipLaunchKernelGGL(k_grayscale_y8, grid, dim3(256), 0, s, frames, p->frame_bytes, p->d_gray, pyr);
+        else if (p->intended)
             hipLaunchKernelGGL(k_grayscale<true>, grid, dim3(256), 0, s, frames, p->frame_bytes, p->d_gray, pyr);
         else
             hipLaunchKernelGGL(k_grayscale<false>, grid, dim3(256), 0, s, frames, p->frame_bytes, p->d_gray, pyr);
@@ -440,8 +443,12 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         const dim3 grid(g.n_bands * n);
         if (lvl == 0) {
             LaunchScope ls(p, s, KID_FUSED_L0);
-            hipLaunchKernelGGL(k_front<true>, grid, dim3(kFrontThreadsL0), lds, s, frames, p->frame_bytes, d_gray,
-                               d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg);
+            if (p->input_y8)
+                hipLaunchKernelGGL((k_front<true, true>), grid, dim3(kFrontThreadsL0), lds, s, frames, p->frame_bytes, d_gray,
+                                   d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg);
+            else
+                hipLaunchKernelGGL(k_front<true>, grid, dim3(kFrontThreadsL0), lds, s, frames, p->frame_bytes, d_gray,
+                                   d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg);
         } else {
             LaunchScope ls(p, s, KID_FUSED_LN);
             hipLaunchKernelGGL(k_front<false>, grid, dim3(kFrontThreadsLN), lds, s, frames, p->frame_bytes, d_gray,
@@ -554,7 +561,7 @@ void reference_grid(const Pyramid& pyr, uint32_t lvl, uint32_t* gw, uint32_t* gh
 }
 
 bool fused_x_eligible(const OrbProgram* p) {
-    if (p->intended || (p->opt.flags & ORB_FLAG_STAGED)) return false;
+    if (p->intended || p->input_y8 || (p->opt.flags & ORB_FLAG_STAGED)) return false;  // the tile kernel reads RGBA
     if (p->arc == 12u && !(p->opt.flags & ORB_FLAG_NMS)) return false;  // that is the plain fused pipeline
     const Pyramid& pyr = p->pyr;
     if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 26) || pyr.h[0] > 16384u) return false;
@@ -674,6 +681,10 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     if (!(config->initial_threshold >= 0.f)) return fail(nullptr, ORB_EINVAL, "initial_threshold must be >= 0");
     if (options && options->fast_arc != 0 && (options->fast_arc < 9 || options->fast_arc > 16))
         return fail(nullptr, ORB_EINVAL, "fast_arc must be 0 (= 12) or 9..16");
+    if (options && (options->flags & ORB_FLAG_INPUT_Y8) &&
+        ((options->flags & (ORB_FLAG_INTENDED | ORB_FLAG_NMS)) || (options->fast_arc != 0 && options->fast_arc != 12)))
+        return fail(nullptr, ORB_EINVAL, "ORB_FLAG_INPUT_Y8 is defined for the reference's detector only (no "
+                                         "ORB_FLAG_INTENDED, ORB_FLAG_NMS or fast_arc other than 12)");
     if (options && (options->flags & ORB_FLAG_INTENDED) && (W > 16384u || H > 16384u))
         return fail(nullptr, ORB_EINVAL, "ORB_FLAG_INTENDED needs W, H <= 16384 (14-bit coordinates in the top-K key)");
 
@@ -685,8 +696,9 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     p->max_batch = p->opt.max_batch ? p->opt.max_batch : 1u;
     p->threshold = config->initial_threshold;  // orb.rs:178
     p->intended = (p->opt.flags & ORB_FLAG_INTENDED) != 0u;
+    p->input_y8 = (p->opt.flags & ORB_FLAG_INPUT_Y8) != 0u;
     p->arc = p->opt.fast_arc ? p->opt.fast_arc : (p->intended ? 9u : 12u);
-    p->frame_bytes = (size_t)W * H * 4u;
+    p->frame_bytes = (size_t)W * H * (p->input_y8 ? 1u : 4u);
     layout_pyramid(W, H, config->hierarchy_depth, &p->pyr);
 
     auto bail = [&](int code) {
@@ -761,6 +773,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
+                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<true, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
             }
         }
@@ -1404,6 +1418,8 @@ int orb_synth_frames_device(OrbProgram* p, uint8_t* frames_dev, uint32_t n_frame
         frames_dev = p->d_input;
     }
     const uint32_t W = p->pyr.w[0], H = p->pyr.h[0];
+    if (p->input_y8) flags |= ORB_SYN_Y8;  // a Y8 program's frames are one byte per pixel
+    if ((flags & ORB_SYN_Y8) && !p->input_y8) return fail(p, ORB_EINVAL, "ORB_SYN_Y8 needs a program created with ORB_FLAG_INPUT_Y8");
     {
         LaunchScope ls(p, p->stream, KID_SYNTH);
         hipLaunchKernelGGL(k_synth, dim3((W + 255u) / 256u, H, n_frames), dim3(256), 0, p->stream, frames_dev,

@@ -191,7 +191,8 @@ __device__ __forceinline__ void segment_append(bool is_corner, uint32_t x, uint3
     }
 }
 
-template <bool L0>
+// Y8: level 0 reads a one-byte-per-pixel Y plane instead of RGBA (ORB_FLAG_INPUT_Y8), grey = f16(byte/255).
+template <bool L0, bool Y8 = false>
 __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                          uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                                          uint16_t* __restrict__ blur_rowc, Pyramid pyr,
@@ -286,7 +287,10 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     dst[u] = ok ? __mul24(ly, LS) + kLdsPad + tx * 4 : -1;
                     const int gyc = min(max(gy, 0), h - 1);
                     const int txc = lane_ok ? tx : 0;
-                    v[u] = *reinterpret_cast<const uint4*>(src0 + (size_t)((uint32_t)(__mul24(h - 1 - gyc, w) + txc * 4) * 4u));
+                    if (Y8)  // four texels = four bytes
+                        v[u].x = *reinterpret_cast<const uint32_t*>(src0 + (size_t)(uint32_t)(__mul24(h - 1 - gyc, w) + txc * 4));
+                    else
+                        v[u] = *reinterpret_cast<const uint4*>(src0 + (size_t)((uint32_t)(__mul24(h - 1 - gyc, w) + txc * 4) * 4u));
                 } else {
                     // f16 mip from HBM; texels outside the level are stored as 0 (CRD-6): at octaves >= 1 the
                     // reference's guard and dispatch size let pixels near/over the level edge through (Q8).
@@ -311,8 +315,14 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 if (dst[u] >= 0) {
                     if (L0) {
                         uint2 out;
-                        out.x = luminance_pair_f16(v[u].x, v[u].y);
-                        out.y = luminance_pair_f16(v[u].z, v[u].w);
+                        if (Y8) {
+                            const uint32_t b = v[u].x;
+                            out.x = pack_half2(unorm8_exact((float)(b & 255u)), unorm8_exact((float)((b >> 8) & 255u)));
+                            out.y = pack_half2(unorm8_exact((float)((b >> 16) & 255u)), unorm8_exact((float)(b >> 24)));
+                        } else {
+                            out.x = luminance_pair_f16(v[u].x, v[u].y);
+                            out.y = luminance_pair_f16(v[u].z, v[u].w);
+                        }
                         *reinterpret_cast<uint2*>(grey + dst[u]) = out;
                     } else {
                         *reinterpret_cast<uint4*>(grey + dst[u]) = v[u];

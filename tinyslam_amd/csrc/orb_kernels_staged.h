@@ -42,6 +42,19 @@ __global__ __launch_bounds__(256) void k_grayscale(const uint8_t* __restrict__ f
     }
 }
 
+// Y8 input variant (ORB_FLAG_INPUT_Y8; not in the reference's code, its roadmap item README.md:42): the frame is one
+// byte per pixel and the grey image is that sample, gray(x,y) = f16(Y(x, H-1-y)/255) -- same mirror as above (Q2).
+__global__ __launch_bounds__(256) void k_grayscale_y8(const uint8_t* __restrict__ frames, size_t frame_bytes,
+                                                      uint16_t* __restrict__ gray, Pyramid pyr) {
+    const uint32_t W = pyr.w[0], H = pyr.h[0];
+    const uint32_t y = blockIdx.y, f = blockIdx.z;
+    const uint32_t x0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (x0 >= W) return;
+    const uint8_t* src_row = frames + (size_t)f * frame_bytes + (size_t)(H - 1u - y) * W;
+    uint16_t* dst_row = gray + (size_t)f * pyr.stride + pyr.off[0] + (size_t)y * W;
+    for (uint32_t x = x0; x < W && x < x0 + 4u; x++) dst_row[x] = half_bits(to_half((float)src_row[x] / 255.0f));
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2  blit.wgsl:17-36 -- mip m from mip m-1 (CRD-4).  One thread per target texel.
 // grid: (ceil(wd/64), ceil(hd/4), frames), block (64,4)
@@ -679,8 +692,13 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ frames, siz
     const uint32_t y = blockIdx.y, f = blockIdx.z;
     const uint32_t x = blockIdx.x * 256u + threadIdx.x;
     if (x >= W) return;
-    uint32_t* row = reinterpret_cast<uint32_t*>(frames + (size_t)f * frame_bytes + (size_t)y * W * 4u);
-    row[x] = synth_pixel(x, y, W, H, seed0 + f, flags);
+    const uint32_t px = synth_pixel(x, y, W, H, seed0 + f, flags & 15u);
+    if (flags & 16u) {  // ORB_SYN_Y8: one byte per pixel, the green channel of the RGBA recipe
+        frames[(size_t)f * frame_bytes + (size_t)y * W + x] = (uint8_t)((px >> 8) & 255u);
+    } else {
+        uint32_t* row = reinterpret_cast<uint32_t*>(frames + (size_t)f * frame_bytes + (size_t)y * W * 4u);
+        row[x] = px;
+    }
 }
 
 // scalar probes for the tests (CRD-3, CRD-9 on the device)

@@ -25,6 +25,7 @@ ORB_FLAG_STAGED = 1
 ORB_FLAG_DOUBLE_OUTPUT = 2
 ORB_FLAG_NMS = 4
 ORB_FLAG_INTENDED = 8
+ORB_FLAG_INPUT_Y8 = 16
 SYN_GRADIENT, SYN_BLOBS, SYN_WEDGES, SYN_NOISE = 1, 2, 4, 8
 SYN_ALL = 15
 

@@ -31,15 +31,15 @@ for name in ("bench.json", "bench_under_rocprof.json"):
 
 
 def short(name):
-    for k in ("k_front<true>", "k_front<false>", "k_brief_rows", "k_slot_prefix", "k_synth", "k_grayscale", "k_mip",
-              "k_blur_rows", "k_fast", "k_brief"):
+    for k in ("k_front<true>", "k_front<false>", "k_brief_rows", "k_brief_t", "k_brief_nf", "k_slot_prefix", "k_compact",
+              "k_synth", "k_grayscale", "k_mip", "k_blur_rows", "k_fast", "k_brief"):
         if k in name:
             return k
     return name[:40]
 
 
 rows = []
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "sq", "sq2", "sq3"):
     f = newest(os.path.join(src, sub, "*", "*_counter_collection.csv"))
     if not f:
         continue
@@ -57,7 +57,7 @@ dom = {"k_front_l0": "k_front<true>", "k_front_ln": "k_front<false>"}.get(
     bench["roofline"]["kernel"], bench["roofline"]["kernel"])
 fetch_kb, write_kb = float(piv.loc[dom, "FETCH_SIZE"]), float(piv.loc[dom, "WRITE_SIZE"])
 traffic = {
-    "kernel": bench["roofline"]["kernel"], "frames_per_launch": bench["config"]["frames_per_gpu"],
+    "kernel": bench["roofline"]["kernel"], "frames_per_launch": bench["roofline"]["frames_per_launch"],
     "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
     "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1` "
