@@ -50,13 +50,16 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=-1, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-host-out", action="store_true", help="skip the device-in -> host-out measurement (N = 1)")
     ap.add_argument("--staged", action="store_true", help="force the one-kernel-per-stage pipeline")
+    ap.add_argument("--input", choices=("rgba", "y8"), default="rgba",
+                    help="rgba = the reference's input (the headline); y8 = the opt-in one-byte-per-pixel variant "
+                         "(ORB_FLAG_INPUT_Y8, the reference's roadmap item; algorithmic bytes W*H + 48 N + 4)")
     ap.add_argument("--mode", choices=("literal", "intended"), default="literal",
                     help="literal = the reference's algorithm (the headline, BASELINE.json); intended = the opt-in "
                          "repaired algorithm with FAST-9 + NMS (DESIGN.md section 8; not in the reference)")
     return ap.parse_args(argv)
 
 
-def cpu_baseline(n_sample, gpu_counts, intended=False):
+def cpu_baseline(n_sample, gpu_counts, intended=False, y8=False):
     """Times oracle/ (the CPU restatement) on the first n_sample frames of the workload and checks that its per-frame
     counters equal the GPU's on those frames."""
     import numpy as np
@@ -68,14 +71,15 @@ def cpu_baseline(n_sample, gpu_counts, intended=False):
     except AttributeError:
         pass
     cores = min(cores, 16)  # the CPU share of a one-GPU box
-    frames = np.stack([orb_oracle.synth_frame(W, H, SEED0 + i) for i in range(n_sample)])
+    gen = orb_oracle.synth_frame_y8 if y8 else orb_oracle.synth_frame  # ORB_SYN_Y8: integer luma of the same recipe
+    frames = np.stack([gen(W, H, SEED0 + i) for i in range(n_sample)])
     t0 = time.perf_counter()
     if intended:
         totals, _, _ = orb_oracle.extract_intended_batch(frames, depth=DEPTH, threshold=THRESHOLD, max_features=MAX_FEATURES,
                                                          arc=9, nms=True, n_threads=cores)
     else:
         totals, _, _ = orb_oracle.extract_batch(frames, depth=DEPTH, threshold=THRESHOLD, max_features=MAX_FEATURES,
-                                                n_threads=cores)
+                                                n_threads=cores, y8=y8)
     dt = time.perf_counter() - t0
     m = min(n_sample, len(gpu_counts))
     return {"value": n_sample / dt, "unit": "frames/s", "cores": cores, "kind": "port",
@@ -127,10 +131,11 @@ def run_rank(args):
     cfg = orb.OrbConfig(orb.Extent3d(W, H), max_features=MAX_FEATURES, hierarchy_depth=DEPTH,
                         initial_threshold=THRESHOLD, device=dev_index, max_batch=B,
                         flags=(orb.ORB_FLAG_STAGED if args.staged else 0) | orb.ORB_FLAG_DOUBLE_OUTPUT
-                        | ((orb.ORB_FLAG_INTENDED | orb.ORB_FLAG_NMS) if args.mode == "intended" else 0),
+                        | ((orb.ORB_FLAG_INTENDED | orb.ORB_FLAG_NMS) if args.mode == "intended" else 0)
+                        | (orb.ORB_FLAG_INPUT_Y8 if args.input == "y8" else 0),
                         fast_arc=9 if args.mode == "intended" else 0)
     prog = orb.OrbProgram(cfg).init()
-    frame_bytes = W * H * 4
+    frame_bytes = W * H * (1 if args.input == "y8" else 4)
     frames_t = torch.empty(max(n_local, 1) * frame_bytes, dtype=torch.uint8, device=dev)  # this rank's shard, in HBM
     for b0, nb in batches:
         prog.synth_frames_device(nb, SEED0 + lo + b0, frames_dev_ptr=frames_t.data_ptr() + b0 * frame_bytes)
@@ -314,7 +319,8 @@ def run_rank(args):
         prof_k = {k_: v for k_, v in prof.items() if k_ != "k_compact"}
         dom = max(prof_k.items(), key=lambda kv: kv[1][0]) if prof_k else (None, (0.0, 0))
         n_mean = kp_per_step / job_frames
-        bytes_per_frame = 4 * W * H + 48 * n_mean + 4  # RGBA read once + records + counter
+        # the frame read once (RGBA: 4 B per pixel, Y8: 1) + records + counter
+        bytes_per_frame = frame_bytes + 48 * n_mean + 4
         roofline = None
         if dom[0]:
             avg_ms = dom[1][0] / dom[1][1]
@@ -331,7 +337,8 @@ def run_rank(args):
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
-                if tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == frames_per_launch:
+                if (tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == frames_per_launch
+                        and tj.get("input", "rgba") == args.input and tj.get("mode", "literal") == args.mode):
                     roofline["traffic"] = tj.get("hbm_bytes_per_launch")
                     roofline["traffic_source"] = tj.get("source")
         out = {
@@ -349,6 +356,7 @@ def run_rank(args):
                                       "orientation + separable Gaussian + BRIEF-256"),
                        "frames_per_gpu_per_batch": B, "frames_per_step": job_frames, "width": W, "height": H,
                        "hierarchy_depth": DEPTH, "max_features": MAX_FEATURES, "threshold": THRESHOLD, "mode": args.mode,
+                       "input": args.input,
                        "pipeline": "staged" if args.staged else "default",
                        "collate": "RCCL gather of every batch to rank 0, overlapped with the next batch's kernels" if world > 1 else "none (1 GPU)"},
             "repeats_ms_per_step": [r / args.steps * 1e3 for r in repeats],
@@ -366,7 +374,7 @@ def run_rank(args):
         if world == 1:
             n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 128
             if n_cpu > 0:
-                out["cpu_baseline"] = cpu_baseline(n_cpu, counts_first, intended=args.mode == "intended")
+                out["cpu_baseline"] = cpu_baseline(n_cpu, counts_first, intended=args.mode == "intended", y8=args.input == "y8")
         print(json.dumps(out), flush=True)
     prog.close()
     if world > 1:

@@ -110,6 +110,10 @@ uint32_t orb_abi_version(void);
  * taken with ORB_FLAG_STAGED or for shapes the fused kernels do not cover: width not a multiple of 4, more than 2^26 pixels;
  * the reference's algorithm also: width > 2048, odd level-0 size with depth > 1). */
 const char *orb_pipeline(const OrbProgram *p);
+/* Empty unless the program runs on the staged kernels WITHOUT having asked for them: then the reason, e.g.
+ * "staged pipeline (...): width 3840 exceeds 2048 (...)".  The same line goes to stderr once per process (silence it
+ * with TINYORB_QUIET=1): the staged kernels run at about 1/7 of the fused rate and nobody should find that out late. */
+const char *orb_pipeline_note(const OrbProgram *p);
 
 /* ---- single-frame API, one call per reference method ---- */
 /* orb.rs:567-583 write_input_image: tightly packed RGBA8, rows of 4*width bytes (ORB_FLAG_INPUT_Y8: rows of width bytes). */
@@ -247,7 +251,7 @@ const char *orb_kernel_name(int id);
 #define ORB_SYN_BLOBS 2u
 #define ORB_SYN_WEDGES 4u
 #define ORB_SYN_NOISE 8u
-#define ORB_SYN_Y8 16u /* one byte per pixel: the green channel of the recipe (for ORB_FLAG_INPUT_Y8 programs) */
+#define ORB_SYN_Y8 16u /* one byte per pixel: (77 R + 150 G + 29 B + 128) >> 8 of the recipe (ORB_FLAG_INPUT_Y8 programs) */
 /* Frame i gets seed seed0+i.  frames_dev == NULL allocates/uses the program's own input slab
  * (max_batch frames) and returns its address in *out_dev. */
 int orb_synth_frames_device(OrbProgram *p, uint8_t *frames_dev, uint32_t n_frames, uint32_t seed0, uint32_t flags,

@@ -589,6 +589,26 @@ int orc_extract_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t W, uint32
     return rc;
 }
 
+/* The same over Y8 frames (one byte per pixel). */
+int orc_extract_batch_y8(const uint8_t *y8, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth, float threshold,
+                         uint32_t max_features, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *totals,
+                         int n_threads) {
+    int rc = 0;
+    size_t frame_bytes = (size_t)W * H;
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int64_t f = 0; f < (int64_t)n_frames; f++) {
+        int r = orc_extract_y8(y8 + (size_t)f * frame_bytes, W, H, depth, threshold, max_features,
+                               corners + (size_t)f * max_features,
+                               descriptors ? descriptors + (size_t)f * max_features : NULL, &totals[f], NULL, NULL);
+        if (r) {
+#pragma omp critical
+            rc = r;
+        }
+    }
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------------------
  * "intended" mode: the algorithm the reference's README describes, with the literal
  * shaders' defects (Q1, Q2, Q7, Q8, Q11, Q12, Q14) repaired.  NOT in the reference: there is no parity target,

@@ -135,6 +135,9 @@ int orc_extract_intended_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t 
 
 /* Frame-parallel batch for the CPU baseline leg of bench.py: n_frames contiguous RGBA frames,
  * outputs strided by max_features.  n_threads <= 1 runs serially. */
+int orc_extract_batch_y8(const uint8_t *y8, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth, float threshold,
+                         uint32_t max_features, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *totals,
+                         int n_threads);
 int orc_extract_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth, float threshold,
                       uint32_t max_features, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *totals,
                       int n_threads);

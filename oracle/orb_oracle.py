@@ -84,6 +84,7 @@ def lib():
         L.orc_extract_intended_batch.argtypes = [vp, u32, u32, u32, u32, f32, u32, vp, vp, vp, vp, ctypes.c_int]
         L.orc_extract_intended_batch.restype = ctypes.c_int
         L.orc_extract_batch.argtypes = [vp, u32, u32, u32, u32, f32, u32, vp, vp, vp, ctypes.c_int]
+        L.orc_extract_batch_y8.argtypes = [vp, u32, u32, u32, u32, f32, u32, vp, vp, vp, ctypes.c_int]
         L.orc_extract_batch.restype = ctypes.c_int
         L.orc_synth_frame.argtypes = [vp, u32, u32, u32, u32]
         _lib = L
@@ -133,6 +134,13 @@ def synth_frame(W, H, seed, flags=SYN_ALL):
     out = np.empty((H, W, 4), dtype=np.uint8)
     lib().orc_synth_frame(_ptr(out), W, H, int(seed) & 0xFFFFFFFF, flags)
     return out
+
+
+def synth_frame_y8(W, H, seed, flags=SYN_ALL):
+    """One-byte-per-pixel test frame for the Y8 input variant: the integer BT.601 luma of the RGBA recipe
+    (ORB_SYN_Y8 of include/tinyorb.h generates the same on the device)."""
+    px = synth_frame(W, H, seed, flags).astype(np.uint32)
+    return ((77 * px[:, :, 0] + 150 * px[:, :, 1] + 29 * px[:, :, 2] + 128) >> 8).astype(np.uint8)
 
 
 def grayscale(rgba):
@@ -255,14 +263,15 @@ def angle_code_signed(cy, cx):
     return int(lib().orc_angle_code_signed(float(np.float32(cy)), float(np.float32(cx))))
 
 
-def extract_batch(frames, depth=2, threshold=20.0 / 255.0, max_features=8192, n_threads=1):
+def extract_batch(frames, depth=2, threshold=20.0 / 255.0, max_features=8192, n_threads=1, y8=False):
     frames = np.ascontiguousarray(frames, dtype=np.uint8)
     F, H, W = frames.shape[:3]
     corners = np.zeros((F, max_features), dtype=CORNER_DTYPE)
     desc = np.zeros((F, max_features, 8), dtype=np.uint32)
     totals = np.zeros(F, dtype=np.uint32)
-    rc = lib().orc_extract_batch(_ptr(frames), F, W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
-                                 _ptr(corners), _ptr(desc), _ptr(totals), int(n_threads))
+    fn = lib().orc_extract_batch_y8 if y8 else lib().orc_extract_batch
+    rc = fn(_ptr(frames), F, W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
+            _ptr(corners), _ptr(desc), _ptr(totals), int(n_threads))
     if rc != 0:
         raise ValueError("orc_extract_batch failed")
     return totals, corners, desc

@@ -43,7 +43,7 @@ INTENDED_CASES = [
 
 
 # Y8 input variant (ORB_FLAG_INPUT_Y8; not in the reference's code, see oracle/orb_oracle.c): name, W, H, depth, seed,
-# flags.  The frame is the green channel of the synthetic RGBA frame.  Kept in tests/golden/y8/.
+# flags.  The frame is the integer BT.601 luma of the synthetic RGBA frame.  Kept in tests/golden/y8/.
 Y8_CASES = [
     ("y160x120_d3", 160, 120, 3, 31, 15),
     ("y640x480_d2", 640, 480, 2, 32, 15),
@@ -81,7 +81,7 @@ def main():
         print(name, "total", ref["total"])
     os.makedirs(os.path.join(HERE, "y8"), exist_ok=True)
     for name, W, H, depth, seed, flags in Y8_CASES:
-        y8 = np.ascontiguousarray(orb_oracle.synth_frame(W, H, seed, flags)[:, :, 1])
+        y8 = orb_oracle.synth_frame_y8(W, H, seed, flags)
         ref = orb_oracle.extract_y8(y8, depth=depth, threshold=THR, max_features=8192, planes=True)
         alt = orb_numpy.extract(y8, depth=depth, threshold=THR, max_features=8192, y8=True)
         kc = np.stack([ref["corners"][k] for k in ("x", "y", "angle", "octave")], 1)

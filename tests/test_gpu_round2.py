@@ -221,12 +221,16 @@ def test_wide_literal_frames(tinyorb, oracle, W, H, depth):
     rgba = oracle.synth_frame(W, H, 21)
     ref = oracle.extract(rgba, depth=depth, threshold=THR, planes=True)
     with _program(tinyorb, W, H, depth) as prog:
+        # the fall to the per-stage kernels is announced, with its reason
+        assert prog.pipeline() == "staged" and ("width %d" % W) in prog.pipeline_note()
         total, corners, desc = prog.extract(rgba)
         _assert_frame_equal(oracle, ref, total, corners, desc)
         dims, _ = oracle.level_dims(W, H, depth)
         for m, (w, h, off) in enumerate(dims):
             b = prog.read_plane(tinyorb.ORB_PLANE_BLUR, m)
             assert np.array_equal(b.ravel(), ref["blur"][off:off + w * h]), "blur level %d" % m
+    with _program(tinyorb, 640, 64, 2) as prog:
+        assert prog.pipeline() == "fused" and prog.pipeline_note() == ""
 
 
 def test_two_programs_of_different_size_alive(tinyorb, oracle):
@@ -284,7 +288,7 @@ _Y8_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", 
                                             (2052, 40, 1, 6), (200, 97, 3, 7)])
 @pytest.mark.parametrize("staged", [0, 1])
 def test_y8_matches_oracle(tinyorb, oracle, W, H, depth, seed, staged):
-    y8 = np.ascontiguousarray(oracle.synth_frame(W, H, seed)[:, :, 1])
+    y8 = oracle.synth_frame_y8(W, H, seed)
     ref = oracle.extract_y8(y8, depth=depth, threshold=THR, planes=True)
     with _program(tinyorb, W, H, depth, flags=tinyorb.ORB_FLAG_INPUT_Y8 | staged) as prog:
         total, corners, desc = prog.extract(y8)
@@ -308,7 +312,7 @@ def test_y8_golden_fixture_on_gpu(tinyorb, path, staged):
     W, H, depth, seed, syn_flags, cap = (int(v) for v in g["params"])
     with _program(tinyorb, W, H, depth, max_features=cap, flags=tinyorb.ORB_FLAG_INPUT_Y8 | staged,
                   thr=float(g["threshold"])) as prog:
-        dev = prog.synth_frames_device(1, seed, syn_flags)  # a Y8 program generates one byte per pixel (green channel)
+        dev = prog.synth_frames_device(1, seed, syn_flags)  # a Y8 program generates one byte per pixel (integer luma)
         y8 = prog.copy_to_host(dev, W * H)
         assert hashlib.sha256(y8.tobytes()).hexdigest() == str(g["y8_sha256"])
         prog.extract_batch_device(dev, 1)
@@ -326,7 +330,7 @@ def test_y8_golden_fixture_on_gpu(tinyorb, path, staged):
 def test_y8_batch_and_rejections(tinyorb, oracle):
     W, H, B = 320, 240, 5
     with _program(tinyorb, W, H, 2, max_batch=B, flags=tinyorb.ORB_FLAG_INPUT_Y8) as prog:
-        frames = np.stack([np.ascontiguousarray(oracle.synth_frame(W, H, 60 + i)[:, :, 1]) for i in range(B)])
+        frames = np.stack([oracle.synth_frame_y8(W, H, 60 + i) for i in range(B)])
         prog.extract_batch_host(frames)
         counts = prog.batch_counts(B)
         for i in range(B):

@@ -260,7 +260,7 @@ def test_y8_golden_fixture(oracle, path):
     """Y8 input variant (one byte per pixel; not in the reference's code): C oracle against its committed fixture."""
     g = np.load(path)
     W, H, depth, seed, flags, cap = (int(v) for v in g["params"])
-    y8 = np.ascontiguousarray(oracle.synth_frame(W, H, seed, flags)[:, :, 1])
+    y8 = oracle.synth_frame_y8(W, H, seed, flags)
     assert _sha(y8) == str(g["y8_sha256"])
     r = oracle.extract_y8(y8, depth=depth, threshold=g["threshold"], max_features=cap, planes=True)
     assert r["total"] == int(g["total"])
@@ -285,7 +285,7 @@ def test_y8_definition(oracle):
     assert np.array_equal(g, want) and np.array_equal(g, orb_numpy.grayscale_y8(y8))
     grey_rgba = np.stack([y8, y8, y8, np.full_like(y8, 255)], axis=2)
     assert not np.array_equal(oracle.grayscale(grey_rgba), g)
-    frame = np.ascontiguousarray(oracle.synth_frame(96, 80, 5)[:, :, 1])
+    frame = oracle.synth_frame_y8(96, 80, 5)
     a = oracle.extract_y8(frame, depth=3, threshold=THR, planes=True)
     b = orb_numpy.extract(frame, depth=3, threshold=THR, y8=True)
     ka = np.stack([a["corners"][k] for k in ("x", "y", "angle", "octave")], 1)

@@ -123,6 +123,7 @@ struct OrbProgram {
     double prof_ms[ORB_KERNEL_COUNT] = {0};
     uint64_t prof_n[ORB_KERNEL_COUNT] = {0};
 
+    std::string pipeline_note;  // why the staged kernels were chosen when nobody asked for them (else empty)
     std::string err;
 };
 
@@ -664,6 +665,8 @@ const char* orb_last_error(const OrbProgram* p) { return p ? p->err.c_str() : g_
 
 const char* orb_pipeline(const OrbProgram* p) { return p ? ((p->fused || p->fused_i || p->fused_x) ? "fused" : "staged") : ""; }
 
+const char* orb_pipeline_note(const OrbProgram* p) { return p ? p->pipeline_note.c_str() : ""; }
+
 const char* orb_kernel_name(int id) { return (id >= 0 && id < ORB_KERNEL_COUNT) ? kKernelNames[id] : ""; }
 
 int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbProgram** out) {
@@ -861,6 +864,31 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 fail(p, ORB_EHIP, "hipFuncSetAttribute(k_front): %s", hipGetErrorString(ea));
                 return bail(ORB_EHIP);
             }
+        }
+    }
+    if (!(p->fused || p->fused_i || p->fused_x) && !(p->opt.flags & ORB_FLAG_STAGED)) {
+        // A silent fall to the per-stage kernels is a 7x performance cliff: say why, once, and keep it readable.
+        const Pyramid& py = p->pyr;
+        char why[256];
+        if ((py.w[0] & 3u) != 0u)
+            snprintf(why, sizeof why, "width %u is not a multiple of 4", py.w[0]);
+        else if (py.w[0] < 8u)
+            snprintf(why, sizeof why, "width %u is below 8", py.w[0]);
+        else if (!p->intended && py.w[0] > (uint32_t)(kFrontMaxCols * 512))
+            snprintf(why, sizeof why, "width %u exceeds %d (a band of 22 full-width rows must fit in LDS)", py.w[0], kFrontMaxCols * 512);
+        else if ((uint64_t)py.w[0] * py.h[0] > (1ull << 26) || py.h[0] > 16384u)
+            snprintf(why, sizeof why, "%ux%u exceeds the fused kernels' 2^26-pixel / 16384-row index range", py.w[0], py.h[0]);
+        else if (!p->intended && py.depth > 1 && !(py.w[0] == 2u * py.w[1] && py.h[0] == 2u * py.h[1]))
+            snprintf(why, sizeof why, "level 0 (%ux%u) does not halve exactly and hierarchy_depth > 1", py.w[0], py.h[0]);
+        else if (p->input_y8 && ((p->opt.flags & ORB_FLAG_NMS) || p->arc != 12u))
+            snprintf(why, sizeof why, "the tile kernels of the arc/NMS extensions read RGBA");
+        else
+            snprintf(why, sizeof why, "the band does not fit in %u bytes of LDS", p->max_lds);
+        p->pipeline_note = std::string("staged pipeline (one kernel per reference stage, about 1/7 of the fused rate): ") + why;
+        static bool warned = false;
+        if (!warned && !getenv("TINYORB_QUIET")) {
+            warned = true;
+            fprintf(stderr, "libtinyorb: %s\n", p->pipeline_note.c_str());
         }
     }
     const size_t B = p->max_batch, cap = config->max_features;

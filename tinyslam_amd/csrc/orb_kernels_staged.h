@@ -693,8 +693,9 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ frames, siz
     const uint32_t x = blockIdx.x * 256u + threadIdx.x;
     if (x >= W) return;
     const uint32_t px = synth_pixel(x, y, W, H, seed0 + f, flags & 15u);
-    if (flags & 16u) {  // ORB_SYN_Y8: one byte per pixel, the green channel of the RGBA recipe
-        frames[(size_t)f * frame_bytes + (size_t)y * W + x] = (uint8_t)((px >> 8) & 255u);
+    if (flags & 16u) {  // ORB_SYN_Y8: one byte per pixel, the integer BT.601 luma of the RGBA recipe
+        const uint32_t r = px & 255u, g = (px >> 8) & 255u, b = (px >> 16) & 255u;
+        frames[(size_t)f * frame_bytes + (size_t)y * W + x] = (uint8_t)((77u * r + 150u * g + 29u * b + 128u) >> 8);
     } else {
         uint32_t* row = reinterpret_cast<uint32_t*>(frames + (size_t)f * frame_bytes + (size_t)y * W * 4u);
         row[x] = px;

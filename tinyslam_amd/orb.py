@@ -45,7 +45,7 @@ EXPORTS = [
     "orb_profile_reset", "orb_profile_get", "orb_synth_frames_device", "orb_copy_to_host", "orb_debug_stamps",
     "orb_match_consecutive", "orb_match_read", "orb_corner_level0_xy",
     "orb_batch_read_all", "orb_batch_compact_device", "orb_host_alloc", "orb_host_free", "orb_stream_sync",
-    "orb_program_stream",
+    "orb_program_stream", "orb_pipeline_note",
     "orb_node_create", "orb_node_destroy", "orb_node_last_error", "orb_node_device_count", "orb_node_program",
     "orb_node_shard", "orb_node_extract_batch", "orb_node_extract_batch_host", "orb_node_collate",
     "orb_node_read_collated",
@@ -117,6 +117,8 @@ def load_library(path=None):
     L.orb_kernel_name.restype = ctypes.c_char_p
     L.orb_pipeline.restype = ctypes.c_char_p
     L.orb_pipeline.argtypes = [vp]
+    L.orb_pipeline_note.restype = ctypes.c_char_p
+    L.orb_pipeline_note.argtypes = [vp]
     L.orb_kernel_name.argtypes = [ctypes.c_int]
     L.orb_program_create.argtypes = [ctypes.POINTER(_Config), ctypes.POINTER(_Options), ctypes.POINTER(vp)]
     L.orb_program_destroy.argtypes = [vp]
@@ -412,6 +414,10 @@ class OrbProgram:
     # ---- inspection / measurement -------------------------------------------------------------
     def pipeline(self):
         return self._lib.orb_pipeline(self._handle()).decode()
+
+    def pipeline_note(self):
+        """Why the staged kernels were chosen although nobody asked for them ('' otherwise)."""
+        return self._lib.orb_pipeline_note(self._handle()).decode()
 
     def level_size(self, level):
         w, h = ctypes.c_uint32(), ctypes.c_uint32()
