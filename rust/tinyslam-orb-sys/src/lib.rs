@@ -145,4 +145,113 @@ pub mod orb {
 
     // One program = one device + its streams; calls on one program must be serialised by the caller.
     unsafe impl Send for OrbProgram {}
+
+    // ------------------------------------------------------------------------------------------------------------
+    // Batched, multi-GPU entry (include/tinyorb.h "one node, several GPUs"; not in the reference, which drives one
+    // wgpu device).  The same calls, in the same order, are exercised from C by examples/node_batch.c, which the
+    // repository's GPU tests compile with gcc and run -- that C program is the verified twin of this block.
+    // ------------------------------------------------------------------------------------------------------------
+    extern "C" {
+        fn orb_node_create(devices: *const c_int, n: c_int, cfg: *const OrbConfigC, opt: *const OrbOptionsC,
+                           out: *mut *mut c_void) -> c_int;
+        fn orb_node_destroy(node: *mut c_void);
+        fn orb_node_last_error(node: *const c_void) -> *const c_char;
+        fn orb_node_device_count(node: *const c_void) -> c_int;
+        fn orb_node_extract_batch_host(node: *mut c_void, frames: *const u8, n_frames: u32) -> c_int;
+        fn orb_node_extract_batch(node: *mut c_void, frames_dev: *const *const u8, n_frames: u32) -> c_int;
+        fn orb_node_collate(node: *mut c_void, counts: *mut u32, offsets: *mut u64, corners_dev: *mut *mut c_void,
+                            descriptors_dev: *mut *mut c_void) -> c_int;
+        fn orb_node_read_collated(node: *mut c_void, corners: *mut CornerData, descriptors: *mut CornerDescriptor,
+                                  capacity: usize) -> c_int;
+    }
+
+    /// Results of one job: the stored records of all frames back to back, frame `f` owns `offsets[f]..offsets[f+1]`.
+    pub struct BatchResult {
+        pub counts: Vec<u32>,   // raw per-frame counters (may exceed max_features, like `extract_corners`)
+        pub offsets: Vec<u64>,  // n_frames + 1
+        pub corners: Vec<CornerData>,
+        pub descriptors: Vec<CornerDescriptor>,
+    }
+
+    /// One process, several GPUs: frames are sharded in contiguous ranges over `devices`, collated on the first.
+    pub struct OrbNode {
+        handle: *mut c_void,
+        frame_bytes: usize,
+    }
+
+    impl OrbNode {
+        /// `max_batch` = the largest shard one device may get (frames per job / devices, rounded up).
+        pub fn new(devices: &[i32], config: &OrbConfig, max_batch: u32) -> Self {
+            let c = OrbConfigC {
+                image_size: Extent3dC {
+                    width: config.image_size.width,
+                    height: config.image_size.height,
+                    depth_or_array_layers: config.image_size.depth_or_array_layers,
+                },
+                max_features: config.max_features,
+                hierarchy_depth: config.hierarchy_depth,
+                initial_threshold: config.initial_threshold,
+            };
+            let opt = OrbOptionsC { max_batch, ..Default::default() };
+            let mut handle = std::ptr::null_mut();
+            let rc = unsafe { orb_node_create(devices.as_ptr(), devices.len() as c_int, &c, &opt, &mut handle) };
+            if rc != ORB_OK {
+                let msg = unsafe { std::ffi::CStr::from_ptr(orb_node_last_error(std::ptr::null())) };
+                panic!("tinyorb: {}", msg.to_string_lossy());
+            }
+            let frame_bytes = config.image_size.width as usize * config.image_size.height as usize * 4;
+            Self { handle, frame_bytes }
+        }
+
+        fn check(&self, rc: c_int) {
+            if rc != ORB_OK {
+                let msg = unsafe { std::ffi::CStr::from_ptr(orb_node_last_error(self.handle)) };
+                panic!("tinyorb: {}", msg.to_string_lossy());
+            }
+        }
+
+        pub fn device_count(&self) -> usize {
+            unsafe { orb_node_device_count(self.handle) as usize }
+        }
+
+        /// `frames`: n tightly packed RGBA8 frames in host memory.  Shards, extracts on every device, collates.
+        pub fn extract(&self, frames: &[u8]) -> BatchResult {
+            let n = (frames.len() / self.frame_bytes) as u32;
+            assert_eq!(frames.len(), n as usize * self.frame_bytes);
+            self.check(unsafe { orb_node_extract_batch_host(self.handle, frames.as_ptr(), n) });
+            self.collate(n)
+        }
+
+        /// The same for shards that are already resident: `frames_dev[r]` points to rank r's frames on ITS device.
+        pub fn extract_device(&self, frames_dev: &[*const u8], n_frames: u32) -> BatchResult {
+            assert_eq!(frames_dev.len(), self.device_count());
+            self.check(unsafe { orb_node_extract_batch(self.handle, frames_dev.as_ptr(), n_frames) });
+            self.collate(n_frames)
+        }
+
+        fn collate(&self, n: u32) -> BatchResult {
+            let mut counts = vec![0u32; n as usize];
+            let mut offsets = vec![0u64; n as usize + 1];
+            self.check(unsafe {
+                orb_node_collate(self.handle, counts.as_mut_ptr(), offsets.as_mut_ptr(), std::ptr::null_mut(),
+                                 std::ptr::null_mut())
+            });
+            let total = offsets[n as usize] as usize;
+            let mut corners = vec![CornerData::default(); total];
+            let mut descriptors = vec![CornerDescriptor::default(); total];
+            self.check(unsafe {
+                orb_node_read_collated(self.handle, corners.as_mut_ptr(), descriptors.as_mut_ptr(), total)
+            });
+            BatchResult { counts, offsets, corners, descriptors }
+        }
+    }
+
+    impl Drop for OrbNode {
+        fn drop(&mut self) {
+            if !self.handle.is_null() {
+                unsafe { orb_node_destroy(self.handle) }
+            }
+        }
+    }
+    unsafe impl Send for OrbNode {}
 }

@@ -92,13 +92,14 @@ struct OrbProgram {
     uint32_t* out_counts[2] = {nullptr, nullptr};
     CornerData* out_corners[2] = {nullptr, nullptr};
     CornerDescriptor* out_desc[2] = {nullptr, nullptr};
-    CornerData* d_seg = nullptr;     // fused path: [max_batch][n_slots][seg_cap] band segments
-    uint32_t* d_seg_counts = nullptr;  // [max_batch][n_slots]
-    uint32_t* d_seg_before = nullptr;  // [max_batch][n_slots] exclusive prefix of the stored counts
+    CornerData* d_seg = nullptr;     // fused path: [max_batch][n_slots][seg_classes][seg_cap] band segments
+    uint32_t* d_seg_counts = nullptr;  // [max_batch][n_slots][seg_classes]
+    uint32_t* d_seg_before = nullptr;  // [max_batch][seg_classes][n_slots] exclusive prefix of the stored counts
     BandGeom bands{};
     RowsGeom rows{};
     BriefTGeom brieft{};       // thread-per-keypoint BRIEF of the fused literal pipelines (plain and arc/NMS)
     bool use_brief_t = false;
+    uint32_t seg_classes = 1;  // lists per band slot of the plain fused path: 2 with k_brief_t (angle code 0 / the rest)
     uint32_t* d_pattern = nullptr;
     float* d_cos = nullptr;
     float* d_sin = nullptr;
@@ -342,6 +343,7 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
         g.blur_q = Q;
         g.n_var = w - Q;
     }
+    g.n_classes = 1u;
     g.phase_mask = 15u;
     if (const char* e = getenv("TINYORB_PHASE_MASK")) g.phase_mask = (uint32_t)atoi(e);
     if (const char* e = getenv("TINYORB_NO_SWIZZLE")) g.xcd_swizzle = atoi(e) ? 0u : g.xcd_swizzle;
@@ -350,10 +352,11 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
 
 // Geometry of k_brief_t over the band (or tile) slots described by `rg`; false when the frame is too large for its LDS
 // staging (then k_brief_rows does the work).
-bool brieft_geometry(const OrbProgram* p, const RowsGeom& rg, BriefTGeom* out) {
+bool brieft_geometry(const OrbProgram* p, const RowsGeom& rg, uint32_t n_classes, BriefTGeom* out) {
     BriefTGeom g{};
     g.n_slots = rg.n_slots;
     g.seg_cap = rg.seg_cap;
+    g.n_classes = n_classes;
     uint32_t rows = 0;
     for (uint32_t m = 0; m < p->pyr.depth; m++) {
         g.flat_end[m] = rg.flat_end[m];
@@ -366,7 +369,7 @@ bool brieft_geometry(const OrbProgram* p, const RowsGeom& rg, BriefTGeom* out) {
     g.rows_padded = rows;
     *out = g;
     if (getenv("TINYORB_BRIEF_ROWS")) return false;  // A/B and cross-check: the wave-per-keypoint kernel
-    return rg.n_slots >= 1u && rg.n_slots <= kBriefTMaxSlots && rows <= kBriefTMaxRows;
+    return rg.n_slots >= 1u && rg.n_slots * n_classes <= kBriefTMaxSlots && rows <= kBriefTMaxRows;
 }
 
 // k_slot_prefix + BRIEF over the band (or tile) slots `rows_geom` of frames [f0, f0 + n).
@@ -379,7 +382,7 @@ int launch_brief(OrbProgram* p, hipStream_t s, uint32_t n, const RowsGeom& rows_
     {
         LaunchScope ls(p, s, KID_PREFIX);
         hipLaunchKernelGGL(k_slot_prefix, dim3(n), dim3(64), 0, s, seg_counts, seg_before, d_counts, rows_geom.n_slots,
-                           rows_geom.seg_cap);
+                           rows_geom.seg_cap, use_t ? p->brieft.n_classes : 1u);
     }
     if (use_t) {
         const BriefTGeom& tg = p->brieft;
@@ -412,9 +415,10 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
     uint16_t* const d_gray = p->d_gray + (size_t)f0 * pyr.stride;
     uint16_t* const d_blur = p->d_blur + (size_t)f0 * pyr.stride;
     uint16_t* const d_blur_rowc = p->d_blur_rowc + (size_t)f0 * pyr.row_stride;
-    uint32_t* const d_seg_counts = p->d_seg_counts + (size_t)f0 * p->bands.n_slots;
-    uint32_t* const d_seg_before = p->d_seg_before + (size_t)f0 * p->bands.n_slots;
-    CornerData* const d_seg = p->d_seg + (size_t)f0 * p->bands.n_slots * p->bands.seg_cap;
+    const size_t lists = (size_t)p->bands.n_slots * p->seg_classes;  // lists per frame
+    uint32_t* const d_seg_counts = p->d_seg_counts + (size_t)f0 * lists;
+    uint32_t* const d_seg_before = p->d_seg_before + (size_t)f0 * lists;
+    CornerData* const d_seg = p->d_seg + (size_t)f0 * lists * p->bands.seg_cap;
     uint32_t* const d_counts = p->d_counts + f0;
     CornerData* const d_corners = p->d_corners + (size_t)f0 * cap;
     CornerDescriptor* const d_desc = p->d_desc + (size_t)f0 * cap;
@@ -435,6 +439,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         g.slot_base = p->bands.slot_base[lvl];
         g.n_slots = p->bands.n_slots;
         g.seg_cap = p->bands.seg_cap;
+        g.n_classes = p->seg_classes;
         g.stamps = p->d_stamps;
         if (g.n_bands != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: band count mismatch at level %u", lvl);
@@ -628,6 +633,7 @@ int run_fused_x(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
             fg.slot_base = band_base;
             fg.n_slots = p->xband_slots;
             fg.seg_cap = 1u;
+            fg.n_classes = 1u;
             fg.stamps = nullptr;
             band_base += fg.n_bands;
             const uint32_t lds = front_lds_bytes(fg);
@@ -772,7 +778,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 }
                 // The attribute belongs to the function on this device, not to the program: always raise it to the
                 // device's limit, so that a later, smaller program never lowers it under a live, larger one.
-                p->use_brief_t = brieft_geometry(p, rg, &p->brieft);
+                p->use_brief_t = brieft_geometry(p, rg, 2u, &p->brieft);
+                p->seg_classes = p->use_brief_t ? 2u : 1u;
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<false>),
@@ -857,7 +864,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         if (need > p->max_lds) {
             p->fused_x = false;
         } else {
-            p->use_brief_t = brieft_geometry(p, rg, &p->brieft);
+            p->use_brief_t = brieft_geometry(p, rg, 1u, &p->brieft);  // the tile kernels keep one list per tile
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<false>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds);
             if (ea != hipSuccess) {
@@ -908,10 +915,11 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     if (p->fused) {
         CREATE_TRY(hipMalloc(&p->d_blur_rowc, B * p->pyr.row_stride * sizeof(uint16_t)));
         CREATE_TRY(hipMemset(p->d_blur_rowc, 0, B * p->pyr.row_stride * sizeof(uint16_t)));
-        CREATE_TRY(hipMalloc(&p->d_seg, B * p->bands.n_slots * (size_t)p->bands.seg_cap * sizeof(CornerData)));
-        CREATE_TRY(hipMalloc(&p->d_seg_counts, B * p->bands.n_slots * sizeof(uint32_t)));
-        CREATE_TRY(hipMemset(p->d_seg_counts, 0, B * p->bands.n_slots * sizeof(uint32_t)));
-        CREATE_TRY(hipMalloc(&p->d_seg_before, B * p->bands.n_slots * sizeof(uint32_t)));
+        const size_t lists = (size_t)p->bands.n_slots * p->seg_classes;
+        CREATE_TRY(hipMalloc(&p->d_seg, B * lists * (size_t)p->bands.seg_cap * sizeof(CornerData)));
+        CREATE_TRY(hipMalloc(&p->d_seg_counts, B * lists * sizeof(uint32_t)));
+        CREATE_TRY(hipMemset(p->d_seg_counts, 0, B * lists * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc(&p->d_seg_before, B * lists * sizeof(uint32_t)));
     }
     if (p->fused_x) {
         CREATE_TRY(hipMalloc(&p->d_blur_rowc, B * p->pyr.row_stride * sizeof(uint16_t)));

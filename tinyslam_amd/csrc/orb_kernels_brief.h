@@ -19,13 +19,14 @@
 
 namespace orb {
 
-constexpr int kBriefTThreads = 64;   // one wave per workgroup: no barrier couples the waves, the dispatcher refills SIMDs one wave at a time
+constexpr int kBriefTThreads = 256;  // four waves share the staging of the frame's prefix and row constants; nothing couples them afterwards
 constexpr int kBriefTWaves = 6;       // waves per SIMD the register allocation aims at
 constexpr uint32_t kBriefTMaxSlots = 8192;  // seg_before of a frame is staged in LDS
 constexpr uint32_t kBriefTMaxRows = 12288;  // rows (all levels) + 36 per level, staged in LDS as f16
 
 struct BriefTGeom {
     uint32_t n_slots, seg_cap;
+    uint32_t n_classes;             // lists per band slot (FrontGeom::n_classes): 2 = angle code 0 / the rest
     uint32_t flat_end[kMaxLevels];  // qa - 18
     uint32_t qa[kMaxLevels];
     uint32_t row_base[kMaxLevels];  // index of row 0 of the level in the padded LDS row array
@@ -33,7 +34,7 @@ struct BriefTGeom {
 };
 
 __host__ __device__ inline uint32_t brieft_lds_bytes(const BriefTGeom& g) {
-    return (g.n_slots + 1u) * 4u + ((g.rows_padded + 1u) & ~1u) * 2u;
+    return (g.n_slots * g.n_classes + 1u) * 4u + ((g.rows_padded + 1u) & ~1u) * 2u;
 }
 
 // pattern as compile-time constants (orb_tables.h is generated from brief.wgsl:70-327)
@@ -55,23 +56,24 @@ __global__ __launch_bounds__(kBriefTThreads, kWavesPerSimd) void k_brief_t(const
                                                                 CornerData* __restrict__ corners, uint32_t cap,
                                                                 CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    uint32_t* const before = reinterpret_cast<uint32_t*>(lds_raw);                    // [n_slots + 1]
-    uint16_t* const rows = reinterpret_cast<uint16_t*>(before + bg.n_slots + 1u);     // [rows_padded]
+    const uint32_t n_ent = bg.n_slots * bg.n_classes;  // lists of a frame, in final order: class-major, slot-minor
+    uint32_t* const before = reinterpret_cast<uint32_t*>(lds_raw);                    // [n_ent + 1]
+    uint16_t* const rows = reinterpret_cast<uint16_t*>(before + n_ent + 1u);          // [rows_padded]
     __shared__ uint32_t lv[kMaxLevels][2];  // flat_end, row_base (a run-time index into kernel arguments is a global load)
 
     // The frame is the FAST grid index: chunks past a frame's keypoint count exit at once, and with the chunk as the fast
     // index their regular pattern (15 busy, 17 idle, ...) lands every busy workgroup on the same half of the CUs.
     const uint32_t frame = blockIdx.x, tid = threadIdx.x;
-    const size_t sbase = (size_t)frame * bg.n_slots;
-    const uint32_t last = bg.n_slots - 1u;
-    const uint32_t stored_total = seg_before[sbase + last] + min(seg_counts[sbase + last], bg.seg_cap);
+    const size_t sbase = (size_t)frame * n_ent;
+    // the last list (last class, last slot): seg_before is [class][slot], seg_counts is [slot][class]
+    const uint32_t stored_total = seg_before[sbase + n_ent - 1u] + min(seg_counts[sbase + n_ent - 1u], bg.seg_cap);
     const uint32_t n_frame = min(stored_total, cap);
     const uint32_t k0 = blockIdx.y * (uint32_t)kBriefTThreads;
     if (k0 >= n_frame) return;  // uniform for the workgroup
 
-    // ---- stage the frame's slot prefix and row constants (zeros around every level)
-    for (uint32_t s = tid; s < bg.n_slots; s += kBriefTThreads) before[s] = seg_before[sbase + s];
-    if (tid == 0) before[bg.n_slots] = stored_total;
+    // ---- stage the frame's list prefix and row constants (zeros around every level)
+    for (uint32_t s = tid; s < n_ent; s += kBriefTThreads) before[s] = seg_before[sbase + s];
+    if (tid == 0) before[n_ent] = stored_total;
     if (tid < pyr.depth) lv[tid][0] = bg.flat_end[tid], lv[tid][1] = bg.row_base[tid];
     {
         const uint16_t* src = blur_rowc + (size_t)frame * pyr.row_stride;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(kBriefTThreads, kWavesPerSimd) void k_brief_t(const
     // ---- this thread's keypoint: slot by binary search in the prefix, record from the band segment
     const uint32_t k = k0 + tid;
     if (k >= n_frame) return;
-    uint32_t lo = 0, hi = bg.n_slots;  // largest s with before[s] <= k (empty slots repeat the value: take the last)
+    uint32_t lo = 0, hi = n_ent;  // largest e with before[e] <= k (empty lists repeat the value: take the last)
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
         if (before[mid] <= k)
@@ -95,15 +97,37 @@ __global__ __launch_bounds__(kBriefTThreads, kWavesPerSimd) void k_brief_t(const
         else
             hi = mid;
     }
-    const uint4 rec = *reinterpret_cast<const uint4*>(&segments[(sbase + lo) * bg.seg_cap + (k - before[lo])]);
-    *reinterpret_cast<uint4*>(&corners[(size_t)frame * cap + k]) = rec;  // final list = band segments back to back
+    const uint32_t cls = lo >= bg.n_slots ? 1u : 0u, slot = lo - cls * bg.n_slots;
+    const uint4 rec = *reinterpret_cast<const uint4*>(
+        &segments[(((size_t)frame * bg.n_slots + slot) * bg.n_classes + cls) * bg.seg_cap + (k - before[lo])]);
+    *reinterpret_cast<uint4*>(&corners[(size_t)frame * cap + k]) = rec;  // final list = the lists back to back
     const uint32_t lvl = min(rec.w, pyr.depth - 1u);
     if (!(rec.x >= (uint32_t)kBriefHalo && rec.x < lv[lvl][0])) return;  // not flat: k_brief_nf takes it
 
+    uint32_t d[8];
+    uint4* const o = reinterpret_cast<uint4*>(descriptors + (size_t)frame * cap + k);
+    if (bg.n_classes == 2u && k0 + (tid & ~63u) + 64u <= before[bg.n_slots]) {
+        // Every keypoint of this wave comes from a first list: angle code 0, R = I (brief.wgsl:50-57 with theta = 0; half
+        // of all keypoints, Q7).  The sample rows are the pattern's y coordinates: compile-time offsets, and hipcc keeps
+        // the 26 distinct rows in registers -- a test is one subtraction and one v_alignbit.
+        const uint16_t* base0 = rows + lv[lvl][1] + rec.y - kBriefHalo;  // non-negative immediate offsets
+#pragma unroll
+        for (int wd = 0; wd < 8; wd++) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int i = 31; i >= 0; i--) {
+                const int j = wd * 32 + i;
+                acc = push_gt(acc, base0[pat_ay(j) + kBriefHalo], base0[pat_by(j) + kBriefHalo]);
+            }
+            d[wd] = acc;
+        }
+        o[0] = make_uint4(d[0], d[1], d[2], d[3]);
+        o[1] = make_uint4(d[4], d[5], d[6], d[7]);
+        return;
+    }
     const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
     const float ct = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;  // CRD-10 table (code 0: ct = 1, st = 0)
     const uint16_t* base = rows + lv[lvl][1] + rec.y;  // the keypoint's own row
-    uint32_t d[8];
 #pragma unroll
     for (int wd = 0; wd < 8; wd++) {
         // The pattern's coordinates are literals, so equal products and sums are shared.  Sharing them across the whole
@@ -123,7 +147,6 @@ __global__ __launch_bounds__(kBriefTThreads, kWavesPerSimd) void k_brief_t(const
         }
         d[wd] = acc;
     }
-    uint4* o = reinterpret_cast<uint4*>(descriptors + (size_t)frame * cap + k);
     o[0] = make_uint4(d[0], d[1], d[2], d[3]);
     o[1] = make_uint4(d[4], d[5], d[6], d[7]);
 }
@@ -159,9 +182,9 @@ __global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ b
         lv[tid][0] = pyr.w[tid], lv[tid][1] = pyr.h[tid], lv[tid][2] = bg.qa[tid], lv[tid][3] = pyr.row_off[tid];
         lv[tid][4] = pyr.off[tid], lv[tid][5] = bg.flat_end[tid];
     }
-    const size_t sbase = (size_t)frame * bg.n_slots;
-    const uint32_t last = bg.n_slots - 1u;
-    const uint32_t n_frame = min(seg_before[sbase + last] + min(seg_counts[sbase + last], bg.seg_cap), cap);
+    const uint32_t n_ent = bg.n_slots * bg.n_classes;
+    const size_t sbase = (size_t)frame * n_ent;
+    const uint32_t n_frame = min(seg_before[sbase + n_ent - 1u] + min(seg_counts[sbase + n_ent - 1u], bg.seg_cap), cap);
     const uint32_t k0 = blockIdx.y * 256u;
     if (k0 >= n_frame) return;  // uniform for the workgroup
     __syncthreads();

@@ -44,7 +44,10 @@ struct FrontGeom {
     uint32_t phase_mask;  // debug: bit0 B1, bit1 B2, bit2 C0, bit3 C (timing experiments only)
     uint32_t slot_base;   // index of this level's band 0 among the frame's band slots
     uint32_t n_slots;     // band slots per frame (all levels)
-    uint32_t seg_cap;     // CornerData records per band segment
+    uint32_t seg_cap;     // CornerData records per band segment (and per class, see n_classes)
+    uint32_t n_classes;   // 1: a band's corners form one list.  2: two lists per band, angle code 0 and the rest (their
+                          // descriptors need no rotation / a rotation: k_brief_t wants its waves to be of one kind);
+                          // the band's memory is then 2 * seg_cap records and it has two counters
     uint32_t blur_p;      // columns [0, blur_p) of blur pass 1 are one constant per row (tap 1 clamps to column 0)
     uint32_t blur_q;      // columns [0, blur_q) of the final blur are one constant per row
     uint32_t n_var;       // w - blur_q: columns whose blur varies along the row (one BlurCol table entry each)
@@ -63,8 +66,8 @@ struct __attribute__((aligned(8))) BlurCol {
 static_assert(sizeof(BlurCol) == 24, "BlurCol layout");
 
 __host__ __device__ inline uint32_t front_lds_bytes(const FrontGeom& g) {
-    // grey rows + queues B/C + queue A + 4 counters + blur row constants (2 x 16 float4) + blur column table
-    return ((kFrontRows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + kFrontQueue * 2u + 16u + 32u * 16u +
+    // grey rows + queues B/C + queue A + 5 counters + blur row constants (2 x 16 float4) + blur column table
+    return ((kFrontRows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + kFrontQueue * 2u + 32u + 32u * 16u +
            (uint32_t)sizeof(BlurCol) * g.n_var;
 }
 
@@ -183,11 +186,14 @@ __device__ __forceinline__ bool diagonal_filter(const half_t* ctr, int ls, float
 // Block-local stream compaction: a band's corners go to its own segment of the scratch list, the
 // slot comes from an LDS counter.  No global atomic is involved: 180 waves per frame bumping one
 // per-frame counter serialise at the memory side and cost more than the rest of the kernel.
+// lds_counter[0] counts the first list, lds_counter[1] the second (two_lists: angle code != 0 goes to the second, which
+// starts seg_cap records into the band's memory).
 __device__ __forceinline__ void segment_append(bool is_corner, uint32_t x, uint32_t y, uint32_t angle, uint32_t oct,
-                                               uint32_t* lds_counter, CornerData* seg, uint32_t seg_cap) {
+                                               uint32_t* lds_counter, CornerData* seg, uint32_t seg_cap, bool two_lists) {
     if (is_corner) {
-        const uint32_t idx = atomicAdd(lds_counter, 1u);  // hipcc turns this into one ds_add per wave
-        if (idx < seg_cap) *reinterpret_cast<uint4*>(&seg[idx]) = make_uint4(x, y, angle, oct);
+        const uint32_t cls = (two_lists && angle != 0u) ? 1u : 0u;
+        const uint32_t idx = atomicAdd(lds_counter + cls, 1u);  // hipcc turns this into one ds_add per wave and list
+        if (idx < seg_cap) *reinterpret_cast<uint4*>(&seg[cls * seg_cap + idx]) = make_uint4(x, y, angle, oct);
     }
 }
 
@@ -214,8 +220,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     uint32_t* const qa_count = reinterpret_cast<uint32_t*>(queue_a + kFrontQueue);
     uint32_t* const qb_count = qa_count + 1;
     uint32_t* const qc_count = qa_count + 2;
-    uint32_t* const c_count = qa_count + 3;  // corners found by this band
-    float4* const blur_k1 = reinterpret_cast<float4*>(qa_count + 4);  // per band row: taps 0, 2, 3 of blur pass 1
+    uint32_t* const c_count = qa_count + 3;  // corners found by this band: [0] first list, [1] second list
+    float4* const blur_k1 = reinterpret_cast<float4*>(qa_count + 8);  // per band row: taps 0, 2, 3 of blur pass 1
     float4* const blur_k2 = blur_k1 + R;                              // per band row: the same for pass 2, and c2
     BlurCol* const blur_cols = reinterpret_cast<BlurCol*>(blur_k2 + R);  // per column >= blur_q: tap positions
 
@@ -239,7 +245,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     uint16_t* const gray_f = gray + (size_t)frame * pyr.stride;
     uint16_t* const blur_lvl = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
     const size_t slot = (size_t)frame * geo.n_slots + geo.slot_base + band;
-    CornerData* const seg = segments + slot * geo.seg_cap;
+    const bool two_lists = geo.n_classes == 2u;
+    CornerData* const seg = segments + slot * geo.seg_cap * geo.n_classes;
 
     // diagnostic stamps (geo.stamps != null): cycles of wave 0 between consecutive marks, summed over workgroups
 #ifdef TINYORB_STAMPS
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
 #else
     auto stamp = [](int) {};  // the shipped build executes no stamp
 #endif
-    if (tid < 4) qa_count[tid] = 0u;
+    if (tid < 5) qa_count[tid] = 0u;
 
     // =========================== A: stage grey rows [y0-3, y0+R+3) ===========================
     // Thread -> (column group tx, row phase ty): a thread keeps its column group and walks down the
@@ -487,7 +494,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                         } else {  // queue full (pathological frame): finish in place
                             uint32_t angle;
                             const bool hit = fast_full_test(rowc + k, LS, thr, &angle);
-                            segment_append(hit, (uint32_t)(x + k), gy, angle, lvl, c_count, seg, geo.seg_cap);
+                            segment_append(hit, (uint32_t)(x + k), gy, angle, lvl, c_count, seg, geo.seg_cap, two_lists);
                         }
                         qs++;
                     }
@@ -519,7 +526,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     } else {
                         uint32_t angle;
                         const bool hit = fast_full_test(ctr, LS, thr, &angle);
-                        segment_append(hit, x, gy, angle, lvl, c_count, seg, geo.seg_cap);
+                        segment_append(hit, x, gy, angle, lvl, c_count, seg, geo.seg_cap, two_lists);
                     }
                 }
             }
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     if (qs < cap_c)
                         queue_c[qs] = (uint16_t)e;
                     else
-                        segment_append(true, x, gy, ring_angle(ctr, LS), lvl, c_count, seg, geo.seg_cap);
+                        segment_append(true, x, gy, ring_angle(ctr, LS), lvl, c_count, seg, geo.seg_cap, two_lists);
                 }
             }
             stamp(6);  // S2
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
             for (uint32_t i = (uint32_t)tid; i < n_c; i += NT) {
                 uint32_t x, gy;
                 const half_t* ctr = locate(queue_c[i], &x, &gy);
-                segment_append(true, x, gy, ring_angle(ctr, LS), lvl, c_count, seg, geo.seg_cap);
+                segment_append(true, x, gy, ring_angle(ctr, LS), lvl, c_count, seg, geo.seg_cap, two_lists);
             }
         }
         stamp(8);  // S3
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     phase_B();
     __syncthreads();
     stamp(12);
-    if (tid == 0) seg_counts[slot] = *c_count;  // raw count of the band (may exceed seg_cap)
+    if (tid < (int)geo.n_classes) seg_counts[slot * geo.n_classes + tid] = c_count[tid];  // raw counts (may exceed seg_cap)
 }
 
 // Band slots of a frame: one per kFrontRows-row band per level, in level order.
@@ -804,31 +811,35 @@ __global__ __launch_bounds__(256) void k_brief_rows(const uint16_t* __restrict__
     }
 }
 
-// Exclusive prefix of the stored keypoints over a frame's band slots (= where each band's keypoints start in
-// the final lists) and the frame's raw counter (orb.rs:550-556).  One wave per frame.
+// Exclusive prefix of the stored keypoints over a frame's band slots (= where each band's keypoints start in the final
+// lists) and the frame's raw counter (orb.rs:550-556).  One wave per frame.  With n_classes == 2 a band has two lists
+// (seg_counts[slot][class]); the final list is all first lists in slot order, then all second lists:
+// seg_before[class * n_slots + slot].
 __global__ __launch_bounds__(64) void k_slot_prefix(const uint32_t* __restrict__ seg_counts,
                                                     uint32_t* __restrict__ seg_before, uint32_t* __restrict__ counts,
-                                                    uint32_t n_slots, uint32_t seg_cap) {
+                                                    uint32_t n_slots, uint32_t seg_cap, uint32_t n_classes) {
     const uint32_t frame = blockIdx.x, lane = threadIdx.x;
-    const uint32_t* sc = seg_counts + (size_t)frame * n_slots;
-    uint32_t* sb = seg_before + (size_t)frame * n_slots;
+    const uint32_t* sc = seg_counts + (size_t)frame * n_slots * n_classes;
+    uint32_t* sb = seg_before + (size_t)frame * n_slots * n_classes;
     uint32_t carry = 0, total = 0;
-    for (uint32_t s0 = 0; s0 < n_slots; s0 += 64u) {
-        const uint32_t s = s0 + lane;
-        const uint32_t raw = s < n_slots ? sc[s] : 0u;
-        const uint32_t stored = min(raw, seg_cap);
-        uint32_t incl = stored;
+    for (uint32_t cls = 0; cls < n_classes; cls++) {
+        for (uint32_t s0 = 0; s0 < n_slots; s0 += 64u) {
+            const uint32_t s = s0 + lane;
+            const uint32_t raw = s < n_slots ? sc[s * n_classes + cls] : 0u;
+            const uint32_t stored = min(raw, seg_cap);
+            uint32_t incl = stored;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d);
-            if ((int)lane >= d) incl += t;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d);
+                if ((int)lane >= d) incl += t;
+            }
+            if (s < n_slots) sb[cls * n_slots + s] = carry + incl - stored;
+            carry += __shfl(incl, 63);
+            uint32_t r = raw;
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) r += __shfl_xor(r, sh);
+            total += r;
         }
-        if (s < n_slots) sb[s] = carry + incl - stored;
-        carry += __shfl(incl, 63);
-        uint32_t r = raw;
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) r += __shfl_xor(r, sh);
-        total += r;
     }
     if (lane == 0u) counts[frame] = total;
 }
