@@ -2,8 +2,8 @@
 //
 // The literal blur is one value per row for every column below qa (88 % of the width, k_front phase C), so for a
 // keypoint with 18 <= x < qa - 18 ("flat", 88 % of them) a sample is the row constant of the rotated point's row and
-// only the y component of brief.wgsl:50-57's rotation matters.  A workgroup is ONE wave and takes 64 consecutive
-// keypoints of a frame's final list (the band segments back to back): it stages the frame's slot prefix and row
+// only the y component of brief.wgsl:50-57's rotation matters.  A workgroup takes 256 consecutive
+// keypoints of a frame's final list (the band lists back to back, angle code 0 first): it stages the frame's slot prefix and row
 // constants in LDS (2.3 KB at 720p, zero rows around every level: texels outside the level read 0, CRD-6), finds each
 // lane's band slot by binary search, copies the record to the final list and, for flat keypoints, runs the 256 tests
 // as straight-line code: the pattern's coordinates are literals, so a test is two products and a sum per point (equal
@@ -221,13 +221,21 @@ __global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ b
 #pragma unroll
     for (int e = 0; e < 4; e++) pat[e] = tab.pattern[64u * (uint32_t)e + lane];
     for (uint32_t i = wave; i < n_nf; i += 4u) {
-        const uint32_t idx = list[i];
-        const uint4 r = recs[idx];  // x, y, angle, octave
+        // the whole wave works on one keypoint: everything derived from its record is wave-uniform -- say so
+        // (readfirstlane), so that it lives in scalar registers and the arithmetic on it runs on the scalar unit
+        const uint32_t idx = __builtin_amdgcn_readfirstlane((uint32_t)list[i]);
+        uint4 r = recs[idx];  // x, y, angle, octave
+        r.x = __builtin_amdgcn_readfirstlane(r.x), r.y = __builtin_amdgcn_readfirstlane(r.y);
+        r.z = __builtin_amdgcn_readfirstlane(r.z), r.w = __builtin_amdgcn_readfirstlane(r.w);
         const uint32_t lvl = min(r.w, pyr.depth - 1u);
-        const int w = (int)lv[lvl][0], h = (int)lv[lvl][1], qa = (int)lv[lvl][2];
-        const uint16_t* rowc = blur_rowc + (size_t)frame * pyr.row_stride + lv[lvl][3];
-        const uint16_t* plane = blur + (size_t)frame * pyr.stride + lv[lvl][4];
-        const float ct = rot[idx].x, st = rot[idx].y, nst = -st;
+        const int w = (int)__builtin_amdgcn_readfirstlane(lv[lvl][0]), h = (int)__builtin_amdgcn_readfirstlane(lv[lvl][1]);
+        const int qa = (int)__builtin_amdgcn_readfirstlane(lv[lvl][2]);
+        const uint16_t* rowc = blur_rowc + (size_t)frame * pyr.row_stride + __builtin_amdgcn_readfirstlane(lv[lvl][3]);
+        const uint16_t* plane = blur + (size_t)frame * pyr.stride + __builtin_amdgcn_readfirstlane(lv[lvl][4]);
+        const float2 cs = rot[idx];
+        const float ct = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, cs.x)));
+        const float st = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, cs.y)));
+        const float nst = -st;
         int dxa[4], dya[4], dxb[4], dyb[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
