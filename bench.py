@@ -272,41 +272,56 @@ def run_rank(args):
                         "gbs_per_link": from_peers / (dt / n_rep) / 1e9 / (world - 1),
                         "bytes_gathered_per_step_timed": gathered_per_step, "backend": backend}
 
-    # device-resident in -> host-resident out (N = 1): every batch is packed and written to pinned host memory by
-    # orb_batch_read_all on a second stream while the next batch computes
+    # device-resident in -> host-resident out (N = 1): every batch is packed on the device (orb_batch_pack) and fetched
+    # into pinned host memory by two exact-size DMA copies on a second stream (orb_batch_fetch) while the next batch
+    # computes; two output sets, two host buffers
     host_out = None
     if world == 1 and not args.no_host_out and batches:
         copy_stream = torch.cuda.Stream(device=dev)
+        cs = torch.cuda.current_stream(dev)
         hbs = [orb.HostBatch(B, B * MAX_FEATURES) for _ in range(2)]
         ev_free = [None, None]
-        k = 0
+        st = {"k": 0, "pending": None}
+
+        def fetch(pending):
+            pslot, pnb = pending
+            prog.batch_fetch(pslot, hbs[pslot], stream=copy_stream.cuda_stream)  # waits for that pack on the host
+            ev_free[pslot] = torch.cuda.Event()
+            ev_free[pslot].record(copy_stream)
 
         def host_step():
-            nonlocal k
             for b0, nb in batches:
-                slot = k & 1
+                slot = st["k"] & 1
                 prog.batch_select_output(slot)
                 if ev_free[slot] is not None:
-                    torch.cuda.current_stream(dev).wait_event(ev_free[slot])
-                prog.extract_batch_device(frames_t.data_ptr() + b0 * frame_bytes, nb,
-                                          stream=torch.cuda.current_stream(dev).cuda_stream)
-                prog.batch_read_all(nb, out=hbs[slot], stream=copy_stream.cuda_stream, sync=False)
-                ev_free[slot] = torch.cuda.Event()
-                ev_free[slot].record(copy_stream)
-                k += 1
+                    cs.wait_event(ev_free[slot])  # the copies of the batch before last have left this set's buffers
+                prog.extract_batch_device(frames_t.data_ptr() + b0 * frame_bytes, nb, stream=cs.cuda_stream)
+                prog.batch_pack(nb, stream=cs.cuda_stream)
+                if st["pending"] is not None:
+                    fetch(st["pending"])
+                st["pending"] = (slot, nb)
+                st["k"] += 1
+
+        def host_flush():
+            if st["pending"] is not None:
+                fetch(st["pending"])
+                st["pending"] = None
+            torch.cuda.synchronize()
         for _ in range(2):
             host_step()
-        torch.cuda.synchronize()
+        host_flush()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             host_step()
-        torch.cuda.synchronize()
+        host_flush()
         dt = time.perf_counter() - t0
-        total_rec = int(hbs[(k - 1) & 1].offsets[batches[-1][1]])
+        last = hbs[(st["k"] - 1) & 1]
+        total_rec = int(last.offsets[batches[-1][1]])
+        host_counts_ok = bool(np.array_equal(last.counts[:batches[-1][1]], prog.batch_counts(batches[-1][1])))
         host_out = {"frames_per_s": job_frames * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
-                    "bytes_to_host_per_batch": total_rec * 48 + batches[-1][1] * 12,
-                    "how": "orb_batch_read_all: k_compact writes the packed records of a batch straight into pinned host "
-                           "memory over PCIe on a second stream, double buffered against the next batch's kernels"}
+                    "bytes_to_host_per_batch": total_rec * 48 + batches[-1][1] * 12, "counts_match_device": host_counts_ok,
+                    "how": "orb_batch_pack packs a batch's records on the device, orb_batch_fetch copies exactly those "
+                           "bytes to pinned host memory (two DMA copies on a second stream) while the next batch computes"}
         host_out["pcie_gbs"] = host_out["bytes_to_host_per_batch"] * len(batches) * args.steps / dt / 1e9
         prog.batch_select_output(0)
         for hb in hbs:

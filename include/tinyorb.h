@@ -166,6 +166,19 @@ int orb_batch_read_all(OrbProgram *p, uint32_t n_frames, uint32_t *counts, uint6
                        CornerDescriptor *descriptors, size_t capacity, void *stream);
 int orb_batch_compact_device(OrbProgram *p, uint32_t n_frames, uint32_t *counts_dev, uint64_t *offsets_dev,
                              CornerData *corners_dev, CornerDescriptor *descriptors_dev, size_t capacity, void *stream);
+/* The same read-back in two steps, for a host that streams batches: the packed records go to program-owned device
+ * memory first and cross PCIe as two exact-size DMA copies (about 56 GB/s on an MI355X box; the device writing pinned
+ * host memory itself, as orb_batch_read_all does, reaches about 31 GB/s).
+ * orb_batch_pack:  enqueues the packing of the first n_frames frames of the last batch (of the selected output set, see
+ *                  orb_batch_select_output) behind that batch; asynchronous.
+ * orb_batch_fetch: waits ON THE HOST until the pack of output set `set` (0 or 1) is done, fills counts / offsets (either
+ *                  may be NULL) and enqueues the copies of min(total, capacity) records on `stream` (NULL: the program's
+ *                  stream); with pinned destinations it returns while they are in flight (orb_stream_sync waits).
+ * With ORB_FLAG_DOUBLE_OUTPUT: pack batch k (set k % 2), then fetch batch k - 1 on another stream -- its copies overlap
+ * batch k's kernels.  A set may be packed again once its fetch has completed. */
+int orb_batch_pack(OrbProgram *p, uint32_t n_frames, void *stream);
+int orb_batch_fetch(OrbProgram *p, uint32_t set, uint32_t *counts, uint64_t *offsets, CornerData *corners,
+                    CornerDescriptor *descriptors, size_t capacity, void *stream);
 /* Pinned, device-visible host memory for callers without a HIP binding of their own. */
 int orb_host_alloc(size_t nbytes, void **out);
 void orb_host_free(void *ptr);

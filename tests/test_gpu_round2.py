@@ -67,6 +67,39 @@ def test_chunked_host_ingest_equals_per_frame_oracle(tinyorb, oracle):
         hb.close()
 
 
+def test_pack_and_fetch_equal_read_all(tinyorb, oracle):
+    """The two-step streaming read-back (orb_batch_pack + orb_batch_fetch: exact-size DMA copies) against the one-call
+    form and the per-frame reads, on both output sets."""
+    W, H, B = 320, 240, 6
+    with _program(tinyorb, W, H, 2, max_batch=B, max_features=1024, flags=tinyorb.ORB_FLAG_DOUBLE_OUTPUT) as prog:
+        outs = []
+        for s_, seed in ((0, 400), (1, 420)):
+            prog.batch_select_output(s_)
+            dev = prog.synth_frames_device(B, seed)
+            prog.extract_batch_device(dev, B)
+            prog.batch_pack(B)
+            outs.append((s_, seed))
+        for s_, seed in outs:
+            hb = tinyorb.HostBatch(B, B * 1024)
+            prog.batch_fetch(s_, hb)
+            prog.stream_sync()
+            prog.batch_select_output(s_)
+            counts = prog.batch_counts(B)
+            assert np.array_equal(hb.counts, counts)
+            assert np.array_equal(hb.offsets, np.concatenate([[0], np.cumsum(np.minimum(counts, 1024))]).astype(np.uint64))
+            for i in range(B):
+                c, d = hb.frame(i)
+                c2, d2 = prog.batch_read(i, int(min(counts[i], 1024)))
+                assert np.array_equal(c, c2) and np.array_equal(d, d2)
+                ref = oracle.extract(oracle.synth_frame(W, H, seed + i), depth=2, threshold=THR, max_features=1024)
+                if counts[i] <= 1024:
+                    _assert_frame_equal(oracle, ref, int(counts[i]), c, d)
+            hb.close()
+        with pytest.raises(tinyorb.OrbError):  # a set that was never packed
+            with _program(tinyorb, 64, 48, 2, max_batch=2) as p2:
+                p2.batch_fetch(0, tinyorb.HostBatch(2, 16))
+
+
 def test_read_all_capacity_and_pageable_buffers(tinyorb, oracle):
     W, H, B, cap = 160, 120, 5, 64  # cap below the per-frame count: stored = min(raw, cap)
     frames = np.stack([oracle.synth_frame(W, H, 900 + i) for i in range(B)])

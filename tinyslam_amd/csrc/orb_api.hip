@@ -48,6 +48,15 @@ struct OrbProgram {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // chunked uploads of orb_extract_batch_host
     hipEvent_t order_event = nullptr;   // orders work on a caller's stream behind the last batch
+    // orb_batch_pack / orb_batch_fetch: packed records of an output set on the device, its counters and offsets in pinned
+    // host memory (written by the packing kernel), and the event that says the pack is done
+    CornerData* d_pack_c[2] = {nullptr, nullptr};
+    CornerDescriptor* d_pack_d[2] = {nullptr, nullptr};
+    uint32_t* h_pack_counts[2] = {nullptr, nullptr};
+    uint64_t* h_pack_offsets[2] = {nullptr, nullptr};
+    hipEvent_t pack_event[2] = {nullptr, nullptr};
+    uint32_t pack_n[2] = {0u, 0u};
+    uint32_t cur_set = 0;
     Pyramid pyr{};
     size_t frame_bytes = 0;
     uint32_t max_batch = 1;
@@ -1023,6 +1032,13 @@ void orb_program_destroy(OrbProgram* p) {
     if (p->stream) (void)hipStreamDestroy(p->stream);
     if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     if (p->order_event) (void)hipEventDestroy(p->order_event);
+    for (int set = 0; set < 2; set++) {
+        (void)hipFree(p->d_pack_c[set]);
+        (void)hipFree(p->d_pack_d[set]);
+        if (p->h_pack_counts[set]) (void)hipHostFree(p->h_pack_counts[set]);
+        if (p->h_pack_offsets[set]) (void)hipHostFree(p->h_pack_offsets[set]);
+        if (p->pack_event[set]) (void)hipEventDestroy(p->pack_event[set]);
+    }
     delete p;
 }
 
@@ -1264,6 +1280,50 @@ int orb_batch_read_all(OrbProgram* p, uint32_t n_frames, uint32_t* counts, uint6
     return rc;
 }
 
+int orb_batch_pack(OrbProgram* p, uint32_t n_frames, void* stream) {
+    if (!p) return ORB_EINVAL;
+    if (n_frames == 0 || n_frames > p->last_batch) return fail(p, ORB_EINVAL, "pack: n_frames %u not in the last batch (%u)", n_frames, p->last_batch);
+    HIP_TRY(p, hipSetDevice(p->device));
+    const uint32_t set = p->cur_set;
+    const size_t B = p->max_batch, cap = p->cfg.max_features;
+    if (!p->d_pack_c[set]) {
+        HIP_TRY(p, hipMalloc(&p->d_pack_c[set], B * cap * sizeof(CornerData)));
+        HIP_TRY(p, hipMalloc(&p->d_pack_d[set], B * cap * sizeof(CornerDescriptor)));
+        HIP_TRY(p, hipHostMalloc(&p->h_pack_counts[set], B * sizeof(uint32_t), hipHostMallocMapped));
+        HIP_TRY(p, hipHostMalloc(&p->h_pack_offsets[set], (B + 1u) * sizeof(uint64_t), hipHostMallocMapped));
+        HIP_TRY(p, hipEventCreateWithFlags(&p->pack_event[set], hipEventDisableTiming));
+    }
+    void *dc = nullptr, *dof = nullptr;
+    HIP_TRY(p, hipHostGetDevicePointer(&dc, p->h_pack_counts[set], 0));
+    HIP_TRY(p, hipHostGetDevicePointer(&dof, p->h_pack_offsets[set], 0));
+    hipStream_t used = nullptr;
+    if (int rc = launch_compact(p, n_frames, (uint32_t*)dc, (uint64_t*)dof, p->d_pack_c[set], p->d_pack_d[set], B * cap, stream, &used))
+        return rc;
+    HIP_TRY(p, hipEventRecord(p->pack_event[set], used));
+    p->pack_n[set] = n_frames;
+    return ORB_OK;
+}
+
+int orb_batch_fetch(OrbProgram* p, uint32_t set, uint32_t* counts, uint64_t* offsets, CornerData* corners,
+                    CornerDescriptor* descriptors, size_t capacity, void* stream) {
+    if (!p) return ORB_EINVAL;
+    if (set > 1u || !p->pack_event[set] || p->pack_n[set] == 0u) return fail(p, ORB_ESTATE, "fetch: output set %u has not been packed", set);
+    if (!corners || !descriptors) return fail(p, ORB_EINVAL, "fetch: destination is NULL");
+    HIP_TRY(p, hipSetDevice(p->device));
+    HIP_TRY(p, hipEventSynchronize(p->pack_event[set]));  // the sizes are on the host now
+    const uint32_t n = p->pack_n[set];
+    if (counts) memcpy(counts, p->h_pack_counts[set], n * sizeof(uint32_t));
+    if (offsets) memcpy(offsets, p->h_pack_offsets[set], ((size_t)n + 1u) * sizeof(uint64_t));
+    const uint64_t total = p->h_pack_offsets[set][n];
+    const size_t m = total < capacity ? (size_t)total : capacity;
+    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+    if (m) {
+        HIP_TRY(p, hipMemcpyAsync(corners, p->d_pack_c[set], m * sizeof(CornerData), hipMemcpyDeviceToHost, s));
+        HIP_TRY(p, hipMemcpyAsync(descriptors, p->d_pack_d[set], m * sizeof(CornerDescriptor), hipMemcpyDeviceToHost, s));
+    }
+    return ORB_OK;
+}
+
 int orb_host_alloc(size_t nbytes, void** out) {
     if (!out || nbytes == 0) return ORB_EINVAL;
     *out = nullptr;
@@ -1333,6 +1393,7 @@ int orb_batch_select_output(OrbProgram* p, uint32_t set) {
     p->d_counts = p->out_counts[set];
     p->d_corners = p->out_corners[set];
     p->d_desc = p->out_desc[set];
+    p->cur_set = set;
     return ORB_OK;
 }
 

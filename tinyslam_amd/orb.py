@@ -45,7 +45,7 @@ EXPORTS = [
     "orb_profile_reset", "orb_profile_get", "orb_synth_frames_device", "orb_copy_to_host", "orb_debug_stamps",
     "orb_match_consecutive", "orb_match_read", "orb_corner_level0_xy",
     "orb_batch_read_all", "orb_batch_compact_device", "orb_host_alloc", "orb_host_free", "orb_stream_sync",
-    "orb_program_stream", "orb_pipeline_note",
+    "orb_program_stream", "orb_pipeline_note", "orb_batch_pack", "orb_batch_fetch",
     "orb_node_create", "orb_node_destroy", "orb_node_last_error", "orb_node_device_count", "orb_node_program",
     "orb_node_shard", "orb_node_extract_batch", "orb_node_extract_batch_host", "orb_node_collate",
     "orb_node_read_collated",
@@ -151,6 +151,8 @@ def load_library(path=None):
     L.orb_corner_level0_xy.restype = None
     L.orb_batch_read_all.argtypes = [vp, u32, vp, vp, vp, vp, sz, vp]
     L.orb_batch_compact_device.argtypes = [vp, u32, vp, vp, vp, vp, sz, vp]
+    L.orb_batch_pack.argtypes = [vp, u32, vp]
+    L.orb_batch_fetch.argtypes = [vp, u32, vp, vp, vp, vp, sz, vp]
     L.orb_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
     L.orb_host_free.argtypes = [vp]
     L.orb_host_free.restype = None
@@ -390,6 +392,17 @@ class OrbProgram:
             else:
                 self.batch_sync()
         return hb
+
+    def batch_pack(self, n_frames, stream=None):
+        """Step 1 of the streaming read-back (orb_batch_pack): pack the last batch of the selected output set on the device."""
+        self._check(self._lib.orb_batch_pack(self._handle(), n_frames, ctypes.c_void_p(stream) if stream else None))
+
+    def batch_fetch(self, out_set, out, stream=None):
+        """Step 2 (orb_batch_fetch): waits for that set's pack, fills out.counts / out.offsets and enqueues the exact-size
+        copies of the records into the pinned HostBatch `out` on `stream`; returns the total record count."""
+        self._check(self._lib.orb_batch_fetch(self._handle(), out_set, out.counts.ctypes.data, out.offsets.ctypes.data,
+                                              out.corners.ctypes.data, out.descriptors.ctypes.data, out.capacity,
+                                              ctypes.c_void_p(stream) if stream else None))
 
     def stream_sync(self, stream=None):
         self._check(self._lib.orb_stream_sync(self._handle(), ctypes.c_void_p(stream) if stream else None))
