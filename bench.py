@@ -349,7 +349,9 @@ def run_rank(args):
                                     "right after the timed repeats (%.4f ms per step with the events in)"
                                     % (args.steps, profiled / args.steps * 1e3),
                         "all_kernels_ms_per_step": {k_: v[0] / args.steps for k_, v in prof.items()}}
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.mode, args.input))
+            if not os.path.exists(tpath):
+                tpath = os.path.join(ROOT, "profiles", "traffic.json")  # the headline: literal mode, RGBA input
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if (tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == frames_per_launch
