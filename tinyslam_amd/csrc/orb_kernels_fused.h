@@ -275,7 +275,17 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
         const bool lane_ok = ty < rpp;
         const uint8_t* src0 = frames + (size_t)frame * frame_bytes;
         const uint16_t* srcn = gray_f + pyr.off[lvl];
-        constexpr int U = 4;  // 16-byte loads in flight per thread (VGPR budget: 64 at 8 waves/SIMD)
+        constexpr int U = L0 ? 8 : 4;  // 16-byte loads in flight per thread (VGPR budget: 64 at 8 waves/SIMD): level 0 issues all of a thread's rows at once
+        // Level 0 walks with increments: the mirrored source offset, the LDS offset and the row of the thread's first
+        // item are computed once; a step of rpp rows is three additions (the multiplies, clamps and selects of a
+        // per-item address are the 4-cycle kind of instruction, and this phase is a third of the kernel's count).
+        const int bpp = Y8 ? 1 : 4;
+        const int txc = lane_ok ? tx : 0;
+        int gy_w = y0 - 3 + ty;                                                        // row of the walking item
+        uint32_t off_w = (uint32_t)(__mul24(h - 1 - gy_w, w) + txc * 4) * (uint32_t)bpp;   // its (mirrored) byte offset
+        int dst_w = __mul24(ty, LS) + kLdsPad + tx * 4;                                // its LDS offset (halfs)
+        const uint32_t off_step = (uint32_t)(rpp * w * bpp);
+        const int dst_step = rpp * LS;
         for (int lyb = ty; lyb < R + 6; lyb += rpp * U) {
             uint4 v[U];
             int dst[U];
@@ -287,17 +297,19 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 v[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (L0) {
                     // rows outside the image are never read by a pixel that passes the guard (fast.wgsl:77);
-                    // the input row is the vertically mirrored one (grayscale.wgsl:16-25).  24-bit multiplies:
-                    // rows and widths are < 2^14, byte offsets inside a frame < 2^32 (checked at create).  The load itself is
-                    // unconditional (clamped address) so that all eight are issued back to back.
-                    const bool ok = in_band && gy >= 0 && gy < h;
-                    dst[u] = ok ? __mul24(ly, LS) + kLdsPad + tx * 4 : -1;
-                    const int gyc = min(max(gy, 0), h - 1);
-                    const int txc = lane_ok ? tx : 0;
+                    // the input row is the vertically mirrored one (grayscale.wgsl:16-25).  Byte offsets inside a frame
+                    // are < 2^32 (checked at create).  The load itself is unconditional (offset 0 where the item does
+                    // not exist) so that all of a thread's loads are issued back to back.
+                    const bool ok = in_band && (uint32_t)gy_w < (uint32_t)h;
+                    dst[u] = ok ? dst_w : -1;
+                    const uint32_t off = ok ? off_w : 0u;
                     if (Y8)  // four texels = four bytes
-                        v[u].x = *reinterpret_cast<const uint32_t*>(src0 + (size_t)(uint32_t)(__mul24(h - 1 - gyc, w) + txc * 4));
+                        v[u].x = *reinterpret_cast<const uint32_t*>(src0 + (size_t)off);
                     else
-                        v[u] = *reinterpret_cast<const uint4*>(src0 + (size_t)((uint32_t)(__mul24(h - 1 - gyc, w) + txc * 4) * 4u));
+                        v[u] = *reinterpret_cast<const uint4*>(src0 + (size_t)off);
+                    gy_w += rpp;
+                    off_w -= off_step;
+                    dst_w += dst_step;
                 } else {
                     // f16 mip from HBM; texels outside the level are stored as 0 (CRD-6): at octaves >= 1 the
                     // reference's guard and dispatch size let pixels near/over the level edge through (Q8).
