@@ -19,12 +19,15 @@ bad = 0
 t0 = time.time()
 for case in range(n_cases):
     W = int(rng.integers(2, 180)) * 4 if rng.random() < 0.8 else int(rng.integers(9, 700))
+    if rng.random() < 0.08:
+        W = int(rng.integers(180, 560)) * 4  # up to 2236 wide: both sides of the fused kernels' 2048 limit
     H = int(rng.integers(8, 400))
-    depth = int(rng.integers(1, 5))
+    depth = int(rng.integers(1, 7))
     thr = float(np.float32(rng.choice([5, 12, 20, 40, 80]) / 255.0))
-    intended = bool(rng.random() < 0.5)
-    nms = bool(rng.random() < 0.5)
-    arc = int(rng.choice([0, 9, 10, 12, 13, 16]))
+    intended = bool(rng.random() < 0.3)
+    nms = bool(rng.random() < 0.35)
+    arc = int(rng.choice([0, 0, 12, 9, 10, 13, 16]))
+    y8 = (not intended) and (not nms) and arc in (0, 12) and bool(rng.random() < 0.3)  # ORB_FLAG_INPUT_Y8: the literal detector only
     cap = int(rng.choice([8192, 8192, 300, 40, 5]))
     staged = bool(rng.random() < 0.25)
     syn = int(rng.choice([15, 15, 7, 14, 9]))
@@ -32,8 +35,13 @@ for case in range(n_cases):
     rgba = oo.synth_frame(W, H, seed, syn)
     if rng.random() < 0.15:  # salt-and-pepper: dense corners
         rgba[..., :3] = ((rng.random((H, W, 1)) < rng.choice([0.05, 0.2])) * 255).astype(np.uint8)
-    flags = (orb.ORB_FLAG_INTENDED if intended else 0) | (orb.ORB_FLAG_NMS if nms else 0) | (orb.ORB_FLAG_STAGED if staged else 0)
-    if intended:
+    if y8:
+        rgba = np.ascontiguousarray(rgba[..., 1])  # any byte plane will do as a Y8 frame
+    flags = (orb.ORB_FLAG_INTENDED if intended else 0) | (orb.ORB_FLAG_NMS if nms else 0) | (orb.ORB_FLAG_STAGED if staged else 0) \
+        | (orb.ORB_FLAG_INPUT_Y8 if y8 else 0)
+    if y8:
+        ref = oo.extract_y8(rgba, depth=depth, threshold=thr, max_features=cap)
+    elif intended:
         ref = oo.extract_intended(rgba, depth=depth, threshold=thr, max_features=cap, arc=arc or 9, nms=nms)
     elif nms or (arc not in (0, 12)):
         ref = oo.extract_ex(rgba, depth=depth, threshold=thr, max_features=cap, arc=arc or 12, nms=nms)
@@ -50,14 +58,15 @@ for case in range(n_cases):
         rc, rd = oo.sort_keypoints(ref["corners"], ref["descriptors"])
         ok = len(c) == len(rc) and all(np.array_equal(c[k], rc[k]) for k in ("x", "y", "angle", "octave")) and np.array_equal(d, rd)
     elif ok:
-        full = oo.extract(rgba, depth=depth, threshold=thr, max_features=1 << 20) if not (nms or arc not in (0, 12)) else \
+        full = oo.extract_y8(rgba, depth=depth, threshold=thr, max_features=1 << 20) if y8 else \
+            oo.extract(rgba, depth=depth, threshold=thr, max_features=1 << 20) if not (nms or arc not in (0, 12)) else \
             oo.extract_ex(rgba, depth=depth, threshold=thr, max_features=1 << 20, arc=arc or 12, nms=nms)
         table = {(int(k["octave"]), int(k["y"]), int(k["x"])): (int(k["angle"]), dd.tobytes()) for k, dd in zip(full["corners"], full["descriptors"])}
         ok = len(corners) == cap and all(table.get((int(k["octave"]), int(k["y"]), int(k["x"]))) == (int(k["angle"]), dd.tobytes())
                                          for k, dd in zip(corners, desc))
     if not ok:
         bad += 1
-        print("MISMATCH", dict(W=W, H=H, depth=depth, thr=thr, intended=intended, nms=nms, arc=arc, cap=cap, staged=staged,
+        print("MISMATCH", dict(W=W, H=H, depth=depth, thr=thr, intended=intended, nms=nms, arc=arc, cap=cap, staged=staged, y8=y8,
                                syn=syn, seed=seed, pipe=pipe, total=total, ref_total=ref["total"]), flush=True)
     if case % 20 == 19:
         print("case %d, %d mismatches, %.0f s" % (case + 1, bad, time.time() - t0), flush=True)
