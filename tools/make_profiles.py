@@ -31,6 +31,10 @@ for name in ("bench.json", "bench_under_rocprof.json"):
 
 
 def short(name):
+    if "k_front<true" in name:   # k_front<true, false> / <true, true> (Y8): level 0
+        return "k_front<true>"
+    if "k_front<false" in name:
+        return "k_front<false>"
     for k in ("k_front<true>", "k_front<false>", "k_brief_rows", "k_brief_t", "k_brief_nf", "k_slot_prefix", "k_compact",
               "k_synth", "k_grayscale", "k_mip", "k_blur_rows", "k_fast", "k_brief"):
         if k in name:

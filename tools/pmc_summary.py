@@ -12,6 +12,10 @@ KERNELS = ("k_front<true>", "k_front<false>", "k_brief_rows", "k_slot_prefix", "
 
 
 def short(name):
+    if "k_front<true" in name:
+        return "k_front<true>"
+    if "k_front<false" in name:
+        return "k_front<false>"
     for k in KERNELS:
         if k in name:
             return k
