@@ -47,7 +47,7 @@ def test_single_frame_matches_oracle(tinyorb, oracle, W, H, depth, seed, flags):
     ref = oracle.extract(rgba, depth=depth, threshold=THR, planes=True)
     with _program(tinyorb, W, H, depth, flags=flags) as prog:
         staged = bool(flags & tinyorb.ORB_FLAG_STAGED)
-        fused_ok = W % 4 == 0 and W <= 2048 and (depth == 1 or (W % 2 == 0 and H % 2 == 0))
+        fused_ok = W % 4 == 0 and W <= 4096 and (depth == 1 or (W % 2 == 0 and H % 2 == 0))
         assert prog.pipeline() == ("fused" if fused_ok and not staged else "staged")
         total, corners, desc = prog.extract(rgba)
         dims, _ = oracle.level_dims(W, H, depth)
@@ -475,7 +475,13 @@ def test_large_frames_take_the_fused_pipelines(tinyorb, oracle):
         assert prog.pipeline() == "fused"
         total, corners, desc = prog.extract(rgba)
         _assert_frame_equal(oracle, ref, total, corners, desc)
-    W, H = 3840, 2160
+    W, H = 3840, 2160  # literal mode at 4K: the 8-row-band kernels
+    rgba = oracle.synth_frame(W, H, 33)
+    ref = oracle.extract(rgba, depth=3, threshold=THR, max_features=1 << 17)
+    with _program(tinyorb, W, H, 3, max_features=1 << 17) as prog:
+        assert prog.pipeline() == "fused"
+        total, corners, desc = prog.extract(rgba)
+        _assert_frame_equal(oracle, ref, total, corners, desc)
     rgba = oracle.synth_frame(W, H, 32)
     ref = oracle.extract_intended(rgba, depth=3, threshold=THR, max_features=1 << 17, arc=9, nms=True)
     with _intended_program(tinyorb, W, H, 3, 1 << 17, 9, True) as prog:

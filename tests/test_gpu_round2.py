@@ -247,23 +247,47 @@ def test_corner_level0_xy_matches_python_mirror(tinyorb):
     assert (x0.value, y0.value) == (29.5, 37.5)
 
 
-@pytest.mark.parametrize("W,H,depth", [(3840, 96, 2), (2560, 64, 3), (2050, 48, 2)])
+@pytest.mark.parametrize("W,H,depth", [(3840, 96, 2), (2560, 64, 3), (4096, 40, 2), (2052, 100, 2), (4100, 24, 1), (2050, 48, 2)])
 def test_wide_literal_frames(tinyorb, oracle, W, H, depth):
-    """Literal mode on frames wider than one LDS band can hold (W > 2048) or with a width that is not a multiple of 4:
-    whichever pipeline takes them, the results are the oracle's."""
+    """Literal mode on frames wider than the 16-row bands take (W > 2048: 8-row bands up to 4096, one workgroup per CU)
+    and on shapes that only the per-stage kernels take (W > 4096, W not a multiple of 4) -- those must say so.  Whichever
+    pipeline runs, the results are the oracle's."""
     rgba = oracle.synth_frame(W, H, 21)
     ref = oracle.extract(rgba, depth=depth, threshold=THR, planes=True)
     with _program(tinyorb, W, H, depth) as prog:
-        # the fall to the per-stage kernels is announced, with its reason
-        assert prog.pipeline() == "staged" and ("width %d" % W) in prog.pipeline_note()
+        if W % 4 == 0 and W <= 4096:
+            assert prog.pipeline() == "fused" and prog.pipeline_note() == ""
+        else:  # the fall to the per-stage kernels is announced, with its reason
+            assert prog.pipeline() == "staged" and ("width %d" % W) in prog.pipeline_note()
         total, corners, desc = prog.extract(rgba)
         _assert_frame_equal(oracle, ref, total, corners, desc)
         dims, _ = oracle.level_dims(W, H, depth)
         for m, (w, h, off) in enumerate(dims):
             b = prog.read_plane(tinyorb.ORB_PLANE_BLUR, m)
             assert np.array_equal(b.ravel(), ref["blur"][off:off + w * h]), "blur level %d" % m
-    with _program(tinyorb, 640, 64, 2) as prog:
-        assert prog.pipeline() == "fused" and prog.pipeline_note() == ""
+            if m > 0:
+                g = prog.read_plane(tinyorb.ORB_PLANE_GRAY, m)
+                assert np.array_equal(g.ravel(), ref["gray"][off:off + w * h]), "gray level %d" % m
+
+
+def test_wide_batch_and_y8(tinyorb, oracle):
+    """The 8-row-band kernels in batched mode (several frames, XCD swizzle on) and with one-byte-per-pixel input."""
+    W, H, B = 2560, 72, 8
+    with _program(tinyorb, W, H, 2, max_batch=B) as prog:
+        assert prog.pipeline() == "fused"
+        dev = prog.synth_frames_device(B, 900)
+        prog.extract_batch_device(dev, B)
+        counts = prog.batch_counts(B)
+        for i in (0, 3, 7):
+            ref = oracle.extract(oracle.synth_frame(W, H, 900 + i), depth=2, threshold=THR)
+            corners, desc = prog.batch_read(i, int(counts[i]))
+            _assert_frame_equal(oracle, ref, int(counts[i]), corners, desc)
+    y8 = oracle.synth_frame_y8(3072, 64, 33)
+    ref = oracle.extract_y8(y8, depth=2, threshold=THR)
+    with _program(tinyorb, 3072, 64, 2, flags=tinyorb.ORB_FLAG_INPUT_Y8) as prog:
+        assert prog.pipeline() == "fused"
+        total, corners, desc = prog.extract(y8)
+        _assert_frame_equal(oracle, ref, total, corners, desc)
 
 
 def test_two_programs_of_different_size_alive(tinyorb, oracle):

@@ -108,6 +108,7 @@ struct OrbProgram {
     RowsGeom rows{};
     BriefTGeom brieft{};       // thread-per-keypoint BRIEF of the fused literal pipelines (plain and arc/NMS)
     bool use_brief_t = false;
+    uint32_t band_rows = kFrontRows;  // band height of the plain fused path (kFrontRowsWide for frames wider than 2048)
     uint32_t seg_classes = 1;  // lists per band slot of the plain fused path: 2 with k_brief_t (angle code 0 / the rest)
     uint32_t* d_pattern = nullptr;
     float* d_cos = nullptr;
@@ -318,25 +319,27 @@ bool fused_eligible(const OrbProgram* p) {
     // index arithmetic: v_mul_i32_i24 takes 24-bit operands (rows, widths < 2^14 here) and returns 32 bits; RGBA byte
     // offsets inside a frame are 4 * W * H < 2^32
     if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 26) || pyr.h[0] > 16384u) return false;
-    if ((pyr.w[0] & 3u) != 0u || pyr.w[0] > (uint32_t)(kFrontMaxCols * 512) || pyr.w[0] < 8u) return false;
+    if ((pyr.w[0] & 3u) != 0u || pyr.w[0] > (uint32_t)kFrontMaxWidthWide || pyr.w[0] < 8u) return false;
     if (pyr.depth > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) return false;
     return true;
 }
 
-uint32_t front_bands(const Pyramid& pyr, uint32_t lvl) {
+uint32_t front_bands(const Pyramid& pyr, uint32_t lvl, uint32_t band_rows) {
     const uint32_t gh = (((pyr.h[0] >> lvl) + 7u) / 8u) * 8u;  // orb.rs:513, 518
     const uint32_t rows = pyr.h[lvl] > gh ? pyr.h[lvl] : gh;
-    return (rows + kFrontRows - 1) / kFrontRows;
+    return (rows + band_rows - 1) / band_rows;
 }
 
-FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t gh, uint32_t n_frames) {
+FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t gh, uint32_t n_frames,
+                         uint32_t band_rows = kFrontRows) {
     FrontGeom g{};
     g.lvl = lvl;
+    g.rows = band_rows;
     g.gw = gw;
     g.gh = gh;
     const uint32_t w = pyr.w[lvl], h = pyr.h[lvl];
     const uint32_t rows = h > gh ? h : gh;
-    g.n_bands = (rows + kFrontRows - 1) / kFrontRows;
+    g.n_bands = (rows + band_rows - 1) / band_rows;
     g.n_frames = n_frames;
     const uint32_t cols = (w > gw ? w : gw) + 4u;
     g.ls = kLdsPad + ((cols + 7u) & ~7u);
@@ -443,7 +446,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
             dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 3u) / 4u, n);
             hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, d_gray, pyr, lvl);
         }
-        FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n);
+        FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n, p->band_rows);
         if (gw == 0) g.gh = 0;  // no FAST dispatch at this octave (orb.rs:511-515 with width 0)
         g.slot_base = p->bands.slot_base[lvl];
         g.n_slots = p->bands.n_slots;
@@ -452,23 +455,34 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         g.stamps = p->d_stamps;
         if (g.n_bands != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: band count mismatch at level %u", lvl);
+        if (sizeof(BlurCol) * (size_t)g.n_var > 8u * (size_t)g.ts)  // the column table borrows the queues' storage
+            return fail(p, ORB_EINVAL, "internal: blur column table of level %u does not fit", lvl);
         uint32_t lds = front_lds_bytes(g);
         if (const char* e = getenv("TINYORB_LDS_PAD")) lds += (uint32_t)atoi(e);  // occupancy experiments only
         if (lds > p->max_lds) return fail(p, ORB_EINVAL, "level %u needs %u bytes of LDS", lvl, lds);
         const dim3 grid(g.n_bands * n);
+        const bool wide = p->band_rows == (uint32_t)kFrontRowsWide;
+#define FRONT_ARGS frames, p->frame_bytes, d_gray, d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg
         if (lvl == 0) {
             LaunchScope ls(p, s, KID_FUSED_L0);
-            if (p->input_y8)
-                hipLaunchKernelGGL((k_front<true, true>), grid, dim3(kFrontThreadsL0), lds, s, frames, p->frame_bytes, d_gray,
-                                   d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg);
+            const dim3 block(kFrontThreadsL0);
+            if (p->input_y8 && wide)
+                hipLaunchKernelGGL((k_front<true, true, kFrontRowsWide>), grid, block, lds, s, FRONT_ARGS);
+            else if (p->input_y8)
+                hipLaunchKernelGGL((k_front<true, true, kFrontRows>), grid, block, lds, s, FRONT_ARGS);
+            else if (wide)
+                hipLaunchKernelGGL((k_front<true, false, kFrontRowsWide>), grid, block, lds, s, FRONT_ARGS);
             else
-                hipLaunchKernelGGL(k_front<true>, grid, dim3(kFrontThreadsL0), lds, s, frames, p->frame_bytes, d_gray,
-                                   d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg);
+                hipLaunchKernelGGL((k_front<true, false, kFrontRows>), grid, block, lds, s, FRONT_ARGS);
         } else {
             LaunchScope ls(p, s, KID_FUSED_LN);
-            hipLaunchKernelGGL(k_front<false>, grid, dim3(kFrontThreadsLN), lds, s, frames, p->frame_bytes, d_gray,
-                               d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg);
+            const dim3 block(kFrontThreadsLN);
+            if (wide)
+                hipLaunchKernelGGL((k_front<false, false, kFrontRowsWide>), grid, block, lds, s, FRONT_ARGS);
+            else
+                hipLaunchKernelGGL((k_front<false, false, kFrontRows>), grid, block, lds, s, FRONT_ARGS);
         }
+#undef FRONT_ARGS
     }
     // orb.rs:523-534, plus the compaction of the band segments into the final lists
     launch_brief(p, s, n, p->rows, d_blur, d_blur_rowc, d_seg_counts, d_seg_before, d_seg, d_counts, d_corners, d_desc);
@@ -580,7 +594,7 @@ bool fused_x_eligible(const OrbProgram* p) {
     if (p->arc == 12u && !(p->opt.flags & ORB_FLAG_NMS)) return false;  // that is the plain fused pipeline
     const Pyramid& pyr = p->pyr;
     if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 26) || pyr.h[0] > 16384u) return false;
-    if ((pyr.w[0] & 3u) != 0u || pyr.w[0] > (uint32_t)(kFrontMaxCols * 512) || pyr.w[0] < 8u) return false;
+    if ((pyr.w[0] & 3u) != 0u || pyr.w[0] > (uint32_t)kFrontMaxWidth || pyr.w[0] < 8u) return false;
     if (pyr.depth > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) return false;
     return true;
 }
@@ -753,13 +767,23 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         p->n_cus = cus > 0 ? (uint32_t)cus : 256u;
         p->fused = fused_eligible(p);
         if (p->fused) {
-            uint32_t need = 0, width = W, height = H;
-            for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
-                FrontGeom g = front_geometry(p->pyr, lvl, ((width + 7u) / 8u) * 8u, ((height + 7u) / 8u) * 8u, 1);
-                width /= 2u;
-                height /= 2u;
-                const uint32_t b = front_lds_bytes(g);
-                if (b > need) need = b;
+            // 16-row bands up to 2048 texels wide (two workgroups per CU at 1280); 8-row bands up to 4096 (one per CU:
+            // 14 full-width rows); whichever fits the CU's LDS
+            auto lds_need = [&](uint32_t band_rows) {
+                uint32_t need = 0, width = W, height = H;
+                for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
+                    FrontGeom g = front_geometry(p->pyr, lvl, ((width + 7u) / 8u) * 8u, ((height + 7u) / 8u) * 8u, 1, band_rows);
+                    width /= 2u;
+                    height /= 2u;
+                    need = std::max(need, front_lds_bytes(g));
+                }
+                return need;
+            };
+            p->band_rows = W <= (uint32_t)kFrontMaxWidth ? (uint32_t)kFrontRows : (uint32_t)kFrontRowsWide;
+            uint32_t need = lds_need(p->band_rows);
+            if (need > p->max_lds && p->band_rows == (uint32_t)kFrontRows) {
+                p->band_rows = kFrontRowsWide;
+                need = lds_need(p->band_rows);
             }
             if (need > p->max_lds) {
                 p->fused = false;
@@ -768,11 +792,11 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 uint32_t slots = 0;
                 for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
                     bg.slot_base[lvl] = slots;
-                    slots += front_bands(p->pyr, lvl);
+                    slots += front_bands(p->pyr, lvl, p->band_rows);
                 }
                 bg.slot_base[p->pyr.depth] = slots;
                 bg.n_slots = slots;
-                const uint64_t band_px = (uint64_t)kFrontRows * (((uint64_t)W + 7u) / 8u * 8u);
+                const uint64_t band_px = (uint64_t)p->band_rows * (((uint64_t)W + 7u) / 8u * 8u);
                 bg.seg_cap = (uint32_t)(band_px < config->max_features ? band_px : config->max_features);
                 RowsGeom& rg = p->rows;
                 rg.n_slots = bg.n_slots;
@@ -789,12 +813,14 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 // device's limit, so that a later, smaller program never lowers it under a live, larger one.
                 p->use_brief_t = brieft_geometry(p, rg, 2u, &p->brieft);
                 p->seg_classes = p->use_brief_t ? 2u : 1u;
-                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
-                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
-                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<true, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
+                const void* fronts[] = {reinterpret_cast<const void*>(&k_front<true, false, kFrontRows>),
+                                        reinterpret_cast<const void*>(&k_front<false, false, kFrontRows>),
+                                        reinterpret_cast<const void*>(&k_front<true, true, kFrontRows>),
+                                        reinterpret_cast<const void*>(&k_front<true, false, kFrontRowsWide>),
+                                        reinterpret_cast<const void*>(&k_front<false, false, kFrontRowsWide>),
+                                        reinterpret_cast<const void*>(&k_front<true, true, kFrontRowsWide>)};
+                for (const void* f : fronts)
+                    CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
             }
         }
     }
@@ -890,8 +916,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
             snprintf(why, sizeof why, "width %u is not a multiple of 4", py.w[0]);
         else if (py.w[0] < 8u)
             snprintf(why, sizeof why, "width %u is below 8", py.w[0]);
-        else if (!p->intended && py.w[0] > (uint32_t)(kFrontMaxCols * 512))
-            snprintf(why, sizeof why, "width %u exceeds %d (a band of 22 full-width rows must fit in LDS)", py.w[0], kFrontMaxCols * 512);
+        else if (!p->intended && py.w[0] > (uint32_t)kFrontMaxWidthWide)
+            snprintf(why, sizeof why, "width %u exceeds %d (a band of 14 full-width rows must fit in LDS)", py.w[0], kFrontMaxWidthWide);
         else if ((uint64_t)py.w[0] * py.h[0] > (1ull << 26) || py.h[0] > 16384u)
             snprintf(why, sizeof why, "%ux%u exceeds the fused kernels' 2^26-pixel / 16384-row index range", py.w[0], py.h[0]);
         else if (!p->intended && py.depth > 1 && !(py.w[0] == 2u * py.w[1] && py.h[0] == 2u * py.h[1]))

@@ -26,14 +26,17 @@ namespace orb {
 
 constexpr int kFrontThreadsL0 = 1024;  // level 0: 16 waves per band, two bands per CU -> 8 waves/SIMD
 constexpr int kFrontThreadsLN = 512;
-constexpr int kFrontRows = 16;       // R: band height (even)
+constexpr int kFrontRows = 16;       // R: band height (even); frames wider than 2048 take kFrontRowsWide
+constexpr int kFrontRowsWide = 8;    // band height of the wide variant: 14 full-width rows of up to 4096 texels fit in LDS
 constexpr int kFrontTmpRows = 2;     // rows per blur chunk (double buffered)
 constexpr int kFrontQueue = 4096;    // pre-test survivor queue, 16-bit entries
-constexpr int kFrontMaxCols = 4;     // blur columns per thread -> level width <= 4 * 512 = 2 * 1024
+constexpr int kFrontMaxWidth = 2048;     // widest level 0 of the 16-row bands (11-bit x in the 16-bit queue entries)
+constexpr int kFrontMaxWidthWide = 4096; // ... of the 8-row bands (12-bit x)
 constexpr int kLdsPad = 8;           // halfs of padding left of column 0
 
 struct FrontGeom {
     uint32_t lvl;       // pyramid level handled by this launch
+    uint32_t rows;      // band height: kFrontRows, or kFrontRowsWide for frames wider than kFrontMaxWidth
     uint32_t gw, gh;    // FAST dispatch domain of this octave (8-rounded, orb.rs:511-515)
     uint32_t n_bands;   // ceil(max(h, gh) / R)
     uint32_t n_frames;
@@ -66,9 +69,9 @@ struct __attribute__((aligned(8))) BlurCol {
 static_assert(sizeof(BlurCol) == 24, "BlurCol layout");
 
 __host__ __device__ inline uint32_t front_lds_bytes(const FrontGeom& g) {
-    // grey rows + queues B/C + queue A + 5 counters + blur row constants (2 x 16 float4) + blur column table
-    return ((kFrontRows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + kFrontQueue * 2u + 32u + 32u * 16u +
-           (uint32_t)sizeof(BlurCol) * g.n_var;
+    // grey rows + queues B/C (the blur column table lives there first: 24 B x n_var <= 8 B x ts, checked on the host)
+    // + queue A + 5 counters + blur row constants (2 x rows float4)
+    return ((g.rows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + kFrontQueue * 2u + 32u + 32u * g.rows;
 }
 
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
@@ -198,13 +201,16 @@ __device__ __forceinline__ void segment_append(bool is_corner, uint32_t x, uint3
 }
 
 // Y8: level 0 reads a one-byte-per-pixel Y plane instead of RGBA (ORB_FLAG_INPUT_Y8), grey = f16(byte/255).
-template <bool L0, bool Y8 = false>
+// RB: band height (kFrontRows, or kFrontRowsWide for frames wider than kFrontMaxWidth: one workgroup per CU then).
+template <bool L0, bool Y8 = false, int RB = kFrontRows>
 __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                          uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                                          uint16_t* __restrict__ blur_rowc, Pyramid pyr,
                                                          FrontGeom geo, float thr, uint32_t* __restrict__ seg_counts,
                                                          CornerData* __restrict__ segments) {
-    constexpr int NT = L0 ? kFrontThreadsL0 : kFrontThreadsLN, R = kFrontRows, TC = kFrontTmpRows;
+    constexpr int NT = L0 ? kFrontThreadsL0 : kFrontThreadsLN, R = RB, TC = kFrontTmpRows;
+    constexpr int XB = RB == kFrontRows ? 11 : 12;  // 16-bit queue entries: [15] polarity, row of the band, [XB-1:0] x
+    static_assert((RB - 1) < (1 << (15 - XB)), "band row does not fit the queue entry");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int LS = (int)geo.ls, TS = (int)geo.ts;
     half_t* const grey = reinterpret_cast<half_t*>(lds_raw);             // (R+6) rows x LS
@@ -223,7 +229,10 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     uint32_t* const c_count = qa_count + 3;  // corners found by this band: [0] first list, [1] second list
     float4* const blur_k1 = reinterpret_cast<float4*>(qa_count + 8);  // per band row: taps 0, 2, 3 of blur pass 1
     float4* const blur_k2 = blur_k1 + R;                              // per band row: the same for pass 2, and c2
-    BlurCol* const blur_cols = reinterpret_cast<BlurCol*>(blur_k2 + R);  // per column >= blur_q: tap positions
+    // per column >= blur_q: tap positions.  Used by phase C only, which runs before the detector: it borrows the storage of
+    // queues B and C, which are first written in stage S1 -- behind the barrier that ends the pre-test, which every wave
+    // reaches after its share of phase C.
+    BlurCol* const blur_cols = reinterpret_cast<BlurCol*>(tmp);
 
     // ---- which band of which frame: keep all bands of a frame on one XCD so halo rows hit its L2
     uint32_t frame, band;
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                         const int k = (p >> 3) | ((p & 4) ^ 4);
                         const bool over = (cand_over >> p) & 1u;
                         if (qs < (uint32_t)kFrontQueue) {
-                            queue_a[qs] = (uint16_t)((over ? 0x8000u : 0u) | ((uint32_t)lyc << 11) | (uint32_t)(x + k));
+                            queue_a[qs] = (uint16_t)((over ? 0x8000u : 0u) | ((uint32_t)lyc << XB) | (uint32_t)(x + k));
                         } else {  // queue full (pathological frame): finish in place
                             uint32_t angle;
                             const bool hit = fast_full_test(rowc + k, LS, thr, &angle);
@@ -520,8 +529,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
         // =========================== B2: thin, test, orient -- each stage on densely packed lanes ===========
         if (geo.phase_mask & 2u) {
             auto locate = [&](uint32_t e, uint32_t* x, uint32_t* gy) -> const half_t* {
-                const int lyc = (int)((e >> 11) & 15u);
-                *x = e & 0x7ffu;
+                const int lyc = (int)((e >> XB) & (uint32_t)(RB - 1));
+                *x = e & ((1u << XB) - 1u);
                 *gy = (uint32_t)(y0 + lyc);
                 return grey + __mul24(lyc + 3, LS) + kLdsPad + (int)*x;
             };
