@@ -19,9 +19,9 @@ bad = 0
 t0 = time.time()
 for case in range(n_cases):
     W = int(rng.integers(2, 180)) * 4 if rng.random() < 0.8 else int(rng.integers(9, 700))
-    if rng.random() < 0.08:
-        W = int(rng.integers(180, 560)) * 4  # up to 2236 wide: both sides of the fused kernels' 2048 limit
-    H = int(rng.integers(8, 400))
+    if rng.random() < 0.12:
+        W = int(rng.integers(180, 1040)) * 4  # up to 4156 wide: 16-row bands, 8-row bands (2049..4096) and beyond
+    H = int(rng.integers(8, 400)) if W <= 720 else int(rng.integers(8, 160))
     depth = int(rng.integers(1, 7))
     thr = float(np.float32(rng.choice([5, 12, 20, 40, 80]) / 255.0))
     intended = bool(rng.random() < 0.3)
