@@ -39,6 +39,19 @@ __device__ __forceinline__ float fma_mix_h(uint32_t v_half_bits, float s, float 
     return d;
 }
 
+// Byte address of an LDS object as the DS instructions want it (generic -> local address space).
+__device__ __forceinline__ uint32_t lds_offset(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// Returning add on an LDS counter with a lane-varying amount, straight on the LDS (`ds_add_rtn_u32`).  Lanes of a wave
+// that hit one address are serialised by the LDS (<= 64 of its cycles), which costs the vector unit one instruction;
+// hipcc's wave-aggregated form of atomicAdd() with lane-varying amounts is a 20-instruction DPP scan in front of its add.
+__device__ __forceinline__ uint32_t lds_add_rtn(uint32_t* counter, uint32_t amount) {
+    uint32_t old;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(lds_offset(counter)), "v"(amount) : "memory");
+    return old;
+}
+
 // fl32(lo + hi) of the two binary16 halves of a register (one rounding, as the binary32 sum of the converted values).
 __device__ __forceinline__ float add_halves(uint32_t packed) {
     float d;

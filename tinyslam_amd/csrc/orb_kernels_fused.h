@@ -107,6 +107,7 @@ __device__ __forceinline__ uint32_t pack_half2(float lo, float hi) {
 // Luminance (CRD-1, CRD-2) of two neighbouring texels as f16 in one word.  Written on two-element vectors so that the
 // packed binary32 instructions (v_pk_mul/fma/add_f32) work on the pair that v_cvt_pk_f16_f32 then rounds into one
 // register: left to itself the vectoriser pairs texels 0/2 and 1/3 and spends four more instructions re-interleaving.
+template <bool BT601 = false>  // false: the reference's 0.229 red weight (Q1); true: 0.299 (the intended mode's IM-1)
 __device__ __forceinline__ uint32_t luminance_pair_f16(uint32_t rgba0, uint32_t rgba1) {
     const float2_t rc_hi = {0x1.010102p-8f, 0x1.010102p-8f}, rc_lo = {-0x1.fdfdfep-33f, -0x1.fdfdfep-33f};
     const float2_t R = {(float)(rgba0 & 255u), (float)(rgba1 & 255u)};
@@ -116,7 +117,7 @@ __device__ __forceinline__ uint32_t luminance_pair_f16(uint32_t rgba0, uint32_t 
     const float2_t r = __builtin_elementwise_fma(R, rc_hi, tr);  // exact byte/255, see unorm8_exact
     const float2_t g = __builtin_elementwise_fma(G, rc_hi, tg);
     const float2_t b = __builtin_elementwise_fma(B, rc_hi, tb);
-    const float2_t pr = r * 0.229f, pg = g * 0.587f, pb = b * 0.114f;
+    const float2_t pr = r * (BT601 ? 0.299f : 0.229f), pg = g * 0.587f, pb = b * 0.114f;
     const float2_t s = pr + pg;
     const float2_t l = s + pb;
     uint32_t d;  // the instruction hipcc itself uses for two (half) casts (RNE, CRD-3); as asm so that the pairing stays
@@ -495,16 +496,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 }
                 if (cand) {  // one LDS atomic for all survivors of this item
                     const uint32_t cand_over = gather_signs(e_ovr);
-                    // Every lane adds its own count with the LDS's returning add.  Lanes of a wave hit the same
-                    // address and the LDS serialises them (64 of its cycles at most, and it is 23 % busy), which costs
-                    // the vector unit one instruction; hipcc's wave-aggregated form of atomicAdd() with lane-varying
-                    // amounts is a 20-instruction DPP scan in front of its single add.
-                    uint32_t qs;
-                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=v"(qs)
-                                 : "v"((uint32_t)(reinterpret_cast<const uint8_t*>(qa_count) - lds_raw)),
-                                   "v"((uint32_t)__builtin_popcount(cand))
-                                 : "memory");
+                    // every lane reserves its own slots with the LDS's returning add (lds_add_rtn, orb_device.h)
+                    uint32_t qs = lds_add_rtn(qa_count, (uint32_t)__builtin_popcount(cand));
                     while (cand) {
                         const int p = __builtin_ctz(cand);
                         cand &= cand - 1u;

@@ -205,7 +205,6 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     if (L0) {
         // RGBA quads; BT.601 luminance of input(x, y) (IM-1) -- or the reference's 0.229 weight on the mirrored row
         // (grayscale.wgsl:16-38); the tile's own pixels also go to the grey plane (for the blur kernel)
-        const float w_red = lit ? 0.229f : 0.299f;
         const int q0 = max(cx0 / 4 - 2, 0), q1 = min((cx0 + tw) / 4 + 2, w / 4);
         const int per_row = q1 - q0;
         const float inv_per_row = 1.0f / (float)per_row;
@@ -235,18 +234,15 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (dst[u] >= 0) {
-                    auto lum = [w_red](uint32_t rgba) {
-                        const float r = unorm8_exact((float)(rgba & 255u));
-                        const float g = unorm8_exact((float)((rgba >> 8) & 255u));
-                        const float b = unorm8_exact((float)((rgba >> 16) & 255u));
-                        const float pr = w_red * r;
-                        const float pg = 0.587f * g;
-                        const float pb = 0.114f * b;
-                        return (pr + pg) + pb;
-                    };
+                    // on texel pairs, as in k_front (packed binary32 instructions, one packed conversion per pair)
                     uint2 out;
-                    out.x = pack_half2(lum(v[u].x), lum(v[u].y));
-                    out.y = pack_half2(lum(v[u].z), lum(v[u].w));
+                    if (lit) {
+                        out.x = luminance_pair_f16<false>(v[u].x, v[u].y);
+                        out.y = luminance_pair_f16<false>(v[u].z, v[u].w);
+                    } else {
+                        out.x = luminance_pair_f16<true>(v[u].x, v[u].y);
+                        out.y = luminance_pair_f16<true>(v[u].z, v[u].w);
+                    }
                     *reinterpret_cast<uint2*>(grey + dst[u]) = out;
                     if (pix[u] >= 0) *reinterpret_cast<uint2*>(plane0 + (size_t)(uint32_t)pix[u]) = out;
                 }
@@ -420,7 +416,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
             }
             uint32_t cand = c_over | c_under;
             if (cand) {
-                uint32_t qs = atomicAdd(qa_count, (uint32_t)__builtin_popcount(cand));
+                uint32_t qs = lds_add_rtn(qa_count, (uint32_t)__builtin_popcount(cand));
                 while (cand) {
                     const int p = __builtin_ctz(cand);
                     cand &= cand - 1u;
