@@ -686,6 +686,7 @@ __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __re
     constexpr int NT = kIBriefThreads, NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) uint16_t win[];  // up to kIBriefRowsMax x pitch
     __shared__ uint4 kept_rec[256];
+    __shared__ float2 kept_rot[256];  // (cos, sin) of the kept keypoint's angle code, fetched by the thread that keeps it
     __shared__ uint32_t wave_kept[4];
     const uint32_t n_groups = bg.group_base[pyr.depth];
     uint32_t group, frame;
@@ -791,14 +792,20 @@ __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __re
             uint32_t off = 0;
             for (uint32_t k = 0; k < wv && k < 4u; k++) off += wave_kept[k];
             const uint32_t chunk_total = wave_kept[0] + wave_kept[1] + wave_kept[2] + wave_kept[3];
-            if (kept) kept_rec[off + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = rec;
+            if (kept) {
+                // the table look-up happens here, 256 at a time, not as a memory round trip in front of every keypoint
+                const uint32_t at = off + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS_FULL - 1));
+                kept_rec[at] = rec;
+                kept_rot[at] = make_float2(tab.cos_tab[code], tab.sin_tab[code]);
+            }
             __syncthreads();
             for (uint32_t r = wv; r < chunk_total; r += NW) {
                 const uint32_t k = base + r;
                 if (k >= cap) break;  // indices only grow
                 const uint4 kr = kept_rec[r];
-                const uint32_t code = min(kr.z, (uint32_t)(ORB_ANGLE_STEPS_FULL - 1));
-                const float ct_ = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
+                const float2 cs = kept_rot[r];
+                const float ct_ = cs.x, st = cs.y, nst = -st;
                 // LDS index of the keypoint inside the window (wave-uniform); a sample adds dy * pitch + dx
                 const int kbase = __builtin_amdgcn_readfirstlane(((int)kr.y - wy0) * pitch + ((int)kr.x - wx0));
                 uint64_t bal[4];
