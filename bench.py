@@ -49,6 +49,9 @@ def parse_args(argv=None):
     ap.add_argument("--repeats", type=int, default=5, help="how often the K-step timed region is repeated (median reported)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-host-out", action="store_true", help="skip the device-in -> host-out measurement (N = 1)")
+    ap.add_argument("--collate", choices=("transport", "padded"), default="transport",
+                    help="N > 1: what the gather to rank 0 carries -- 40-byte transport records packed back to back, or "
+                         "the 48-byte record slabs padded to the fullest frame (round 1's form)")
     ap.add_argument("--staged", action="store_true", help="force the one-kernel-per-stage pipeline")
     ap.add_argument("--input", choices=("rgba", "y8"), default="rgba",
                     help="rgba = the reference's input (the headline); y8 = the opt-in one-byte-per-pixel variant "
@@ -151,14 +154,32 @@ def run_rank(args):
     compute_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
 
+    # N > 1, transport collate: per output set a buffer for this rank's packed 40-byte records
+    transport = world > 1 and args.collate == "transport"
+    tbuf = [torch.empty((B * MAX_FEATURES, node.TRANSPORT_WORDS), dtype=torch.int32, device=dev) for _ in range(2)] if transport else None
+
     def collate(pending):
         slot, done, nb = pending
         counts_t, corners_t, desc_t = views[slot]
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(done)  # the kernels that wrote this output set
-            out = node.collate_to_root(counts_t, corners_t, desc_t, MAX_FEATURES)
-            if out is not None:
-                state["gathered_bytes"] += out[1].numel() * 4 + out[2].numel() * 4
+            if transport:
+                cs = comm_stream.cuda_stream
+                prog.batch_pack_transport(slot, B, tbuf[slot].data_ptr(), B * MAX_FEATURES, stream=cs)
+                out = node.collate_transport_to_root(counts_t, tbuf[slot], MAX_FEATURES)
+                if out is not None:  # rank 0: back to the reference's two record arrays, all frames of the job in order
+                    counts_all, totals, merged = out
+                    s_max, first = merged.shape[1], np.concatenate([[0], np.cumsum(totals)])
+                    corners_all = torch.empty((max(int(first[-1]), 1), 4), dtype=torch.int32, device=dev)
+                    desc_all = torch.empty((max(int(first[-1]), 1), 8), dtype=torch.int32, device=dev)
+                    prog.unpack_transport(merged.data_ptr(), [r * s_max for r in range(world)], totals, first[:-1],
+                                          corners_all.data_ptr(), desc_all.data_ptr(), stream=cs)
+                    state["gathered_bytes"] += merged.numel() * 4
+                    state["last"] = (slot, counts_all, first, corners_all, desc_all)
+            else:
+                out = node.collate_to_root(counts_t, corners_t, desc_t, MAX_FEATURES)
+                if out is not None:
+                    state["gathered_bytes"] += out[1].numel() * 4 + out[2].numel() * 4
             free[slot] = torch.cuda.Event()
             free[slot].record(comm_stream)  # the gather has read this output set
 
@@ -267,7 +288,19 @@ def run_rank(args):
         dt = time.perf_counter() - t0
         per = state["gathered_bytes"] / n_rep
         from_peers = per * (world - 1) / world
-        collate_info = {"bytes_gathered_per_batch": per, "bytes_from_peers_per_batch": from_peers,
+        root_check = None
+        if transport and rank == 0 and state.get("last"):
+            # rank 0's own frames must have come through pack -> gather -> unpack unchanged (device-side compare, untimed)
+            slot_l, counts_all, first, corners_all, desc_all = state["last"]
+            own = torch.clamp(views[slot_l][0], max=MAX_FEATURES).tolist()
+            root_check = int(first[-1]) == int(torch.clamp(counts_all, max=MAX_FEATURES).sum().item())
+            at = 0
+            for f in range(0, B, max(B // 8, 1)):
+                at = int(sum(own[:f]))
+                root_check = root_check and torch.equal(corners_all[at:at + own[f]], views[slot_l][1][f, :own[f]]) \
+                    and torch.equal(desc_all[at:at + own[f]], views[slot_l][2][f, :own[f]])
+        collate_info = {"form": args.collate, "bytes_per_keypoint": 40 if transport else 48, "root_check": root_check,
+                        "bytes_gathered_per_batch": per, "bytes_from_peers_per_batch": from_peers,
                         "ms_alone_per_batch": dt / n_rep * 1e3, "gbs_into_root": from_peers / (dt / n_rep) / 1e9,
                         "gbs_per_link": from_peers / (dt / n_rep) / 1e9 / (world - 1),
                         "bytes_gathered_per_step_timed": gathered_per_step, "backend": backend}

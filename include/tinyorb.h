@@ -180,6 +180,23 @@ int orb_batch_compact_device(OrbProgram *p, uint32_t n_frames, uint32_t *counts_
 int orb_batch_pack(OrbProgram *p, uint32_t n_frames, void *stream);
 int orb_batch_fetch(OrbProgram *p, uint32_t set, uint32_t *counts, uint64_t *offsets, CornerData *corners,
                     CornerDescriptor *descriptors, size_t capacity, void *stream);
+/* ---- transport records (multi-GPU collate; not in the reference, which has one device).  On the wire between GPUs a
+ * keypoint is ORB_TRANSPORT_RECORD_BYTES = 40 bytes instead of 16 + 32: ten u32 words {x | y << 16, angle | octave << 16,
+ * descriptor[8]} (angle code < 6284, octave < 8; frames of 65536 or more texels in either direction are refused with
+ * ORB_EINVAL), records of a batch back to back in frame order.  Lossless.
+ * orb_batch_pack_transport:  packs the stored records of the first n_frames frames of the batch in output set `set` into
+ *     dst_dev[capacity_records] and writes offsets_dev[n_frames + 1] (exclusive prefix of min(counter, max_features);
+ *     device memory, may be NULL).  Enqueued on `stream` (NULL: the program's stream) WITHOUT implicit ordering: the caller
+ *     orders `stream` behind the batch's kernels (an event, or the same stream).
+ * orb_unpack_transport:      n_segments runs of records in src_dev (run i: count[i] records from record src_first[i]) are
+ *     expanded into corners_dev / descriptors_dev from record dst_first[i] on; the three arrays are HOST memory, read
+ *     during the call.  Enqueued on `stream` (NULL: the program's stream), no implicit ordering. */
+#define ORB_TRANSPORT_RECORD_BYTES 40
+int orb_batch_pack_transport(OrbProgram *p, uint32_t set, uint32_t n_frames, void *dst_dev, size_t capacity_records,
+                             uint64_t *offsets_dev, void *stream);
+int orb_unpack_transport(OrbProgram *p, const void *src_dev, uint32_t n_segments, const uint64_t *src_first,
+                         const uint64_t *count, const uint64_t *dst_first, CornerData *corners_dev,
+                         CornerDescriptor *descriptors_dev, void *stream);
 /* Pinned, device-visible host memory for callers without a HIP binding of their own. */
 int orb_host_alloc(size_t nbytes, void **out);
 void orb_host_free(void *ptr);
@@ -211,7 +228,8 @@ int orb_node_extract_batch(OrbNode *node, const uint8_t *const *frames_dev, uint
 int orb_node_extract_batch_host(OrbNode *node, const uint8_t *frames_host, uint32_t n_frames);
 /* Collates the last job on the first device and blocks until it is there.  counts[n_frames] and offsets[n_frames + 1]
  * are HOST arrays (as in orb_batch_read_all; either may be NULL); *corners_dev / *descriptors_dev receive the
- * addresses of the packed records on the first device (frame order, valid until the next collate). */
+ * addresses of the packed records on the first device (frame order, valid until the next collate).  Between devices
+ * the records travel as transport records of their exact number (see orb_batch_pack_transport). */
 int orb_node_collate(OrbNode *node, uint32_t *counts, uint64_t *offsets, void **corners_dev, void **descriptors_dev);
 /* Copies the collated records to the host (after orb_node_collate); capacity in records. */
 int orb_node_read_collated(OrbNode *node, CornerData *corners, CornerDescriptor *descriptors, size_t capacity);
@@ -252,7 +270,7 @@ int orb_debug_f32_to_f16(OrbProgram *p, const float *src, uint16_t *dst, size_t 
 int orb_debug_angle_code(OrbProgram *p, const float *cy, const float *cx, uint32_t *dst, size_t n);
 
 /* ---- measurement ---- */
-#define ORB_KERNEL_COUNT 17
+#define ORB_KERNEL_COUNT 19
 /* When enabled every kernel launch is bracketed by hipEvents on its stream. */
 int orb_profile_enable(OrbProgram *p, int enable);
 int orb_profile_reset(OrbProgram *p);

@@ -411,3 +411,61 @@ def test_forced_wave_per_keypoint_brief(tinyorb, oracle, monkeypatch):
         with _program(tinyorb, W, H, depth) as prog:
             total, corners, desc = prog.extract(rgba)
             _assert_frame_equal(oracle, ref, total, corners, desc)
+
+
+def test_transport_records_round_trip(tinyorb, oracle):
+    """orb_batch_pack_transport -> orb_unpack_transport (the multi-GPU collate's wire format: 40-byte records back to
+    back) reproduces the per-frame reads, on both output sets, with a capacity cut (count > max_features), an empty
+    frame, two runs placed out of order (as the records of two ranks would be) and a destination that is too small."""
+    import torch
+    W, H, B, CAP = 320, 240, 6, 256
+    dev = torch.device("cuda", 0)
+    with _program(tinyorb, W, H, 2, max_batch=B, max_features=CAP, flags=tinyorb.ORB_FLAG_DOUBLE_OUTPUT) as prog:
+        for s_, seed in ((0, 500), (1, 530)):
+            prog.batch_select_output(s_)
+            frames = np.stack([oracle.synth_frame(W, H, seed + i) for i in range(B)])
+            frames[2] = 90  # a flat frame: no keypoints
+            frames[4] = frames[4] // 3 + 80  # low contrast: few keypoints (the others are around the capacity)
+            prog.extract_batch_host(frames)
+            prog.batch_sync()
+        for s_ in (0, 1):
+            prog.batch_select_output(s_)
+            counts = prog.batch_counts(B)
+            stored = np.minimum(counts, CAP).astype(np.int64)
+            assert counts[2] == 0 and (counts > CAP).any() and (counts[counts > 0] <= CAP).any()
+            total = int(stored.sum())
+            rec = torch.full((total + 5, 10), -1, dtype=torch.int32, device=dev)
+            offs = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+            prog.batch_pack_transport(s_, B, rec.data_ptr(), total + 5, offs.data_ptr())
+            prog.stream_sync()
+            torch.cuda.synchronize()
+            first = np.concatenate([[0], np.cumsum(stored)])
+            assert np.array_equal(offs.cpu().numpy(), first)
+            assert (rec[total:] == -1).all()
+            # two runs (frames 0..2 and 3..5), the second placed first in the destination
+            cut = int(first[3])
+            corners = torch.zeros((total, 4), dtype=torch.int32, device=dev)
+            desc = torch.zeros((total, 8), dtype=torch.int32, device=dev)
+            prog.unpack_transport(rec.data_ptr(), [0, cut], [cut, total - cut], [total - cut, 0], corners.data_ptr(), desc.data_ptr())
+            prog.stream_sync()
+            torch.cuda.synchronize()
+            kc, kd = corners.cpu().numpy(), desc.cpu().numpy().view(np.uint32)
+            for i in range(B):
+                n = int(stored[i])
+                at = int(first[i]) + (total - cut if i < 3 else -cut)
+                c2, d2 = prog.batch_read(i, n)
+                got = kc[at:at + n]
+                for j, k in enumerate(("x", "y", "angle", "octave")):
+                    assert np.array_equal(got[:, j].astype(np.uint32), c2[k]), (i, k)
+                assert np.array_equal(kd[at:at + n], d2), i
+            # a destination that holds fewer records than there are: filled to its end, the offsets still tell
+            small = torch.full((max(cut, 1), 10), -1, dtype=torch.int32, device=dev)
+            prog.batch_pack_transport(s_, B, small.data_ptr(), cut, offs.data_ptr())
+            prog.stream_sync()
+            torch.cuda.synchronize()
+            assert torch.equal(small[:cut], rec[:cut]) and int(offs[B]) == total
+        with pytest.raises(tinyorb.OrbError):
+            prog.batch_pack_transport(0, B + 1, rec.data_ptr(), 1)
+    with _program(tinyorb, 64, 48, 2, max_batch=2) as p2:  # no second output set
+        with pytest.raises(tinyorb.OrbError):
+            p2.batch_pack_transport(1, 1, 1 << 20, 1)

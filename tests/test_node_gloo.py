@@ -97,3 +97,69 @@ def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def _to_transport(kp, ds, n):
+    """NumPy statement of the 40-byte transport record (include/tinyorb.h): {x | y << 16, angle | octave << 16, d[8]}."""
+    rec = np.zeros((n, 10), dtype=np.int64)
+    rec[:, 0] = kp[:n, 0] | (kp[:n, 1] << 16)
+    rec[:, 1] = kp[:n, 2] | (kp[:n, 3] << 16)
+    rec[:, 2:] = ds[:n].view(np.uint32)
+    return rec.astype(np.uint32).view(np.int32)
+
+
+def _worker_transport(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import orb_oracle
+    from tinyslam_amd import node
+    lo, hi = node.shard_range(N_FRAMES, world, rank)
+    res = [_frame_result(orb_oracle, SEED0 + i) for i in range(lo, hi)]
+    counts = torch.tensor([r[0] for r in res], dtype=torch.int32)
+    recs = [_to_transport(r[1], r[2], min(r[0], CAP)) for r in res]
+    slack = np.full((7, 10), -1, dtype=np.int32)  # rows past the rank's total must not matter
+    records = torch.from_numpy(np.concatenate(recs + [slack]))
+    out = node.collate_transport_to_root(counts, records, CAP)
+    if rank == 0:
+        c, totals, merged = out
+        np.savez(out_path, counts=c.numpy(), totals=np.array(totals), merged=merged.numpy())
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_transport_collate_world2_equals_single_process(oracle, tmp_path):
+    """collate_transport_to_root over gloo: rank r's records arrive as merged[r, :totals[r]], in frame order."""
+    out_path = str(tmp_path / "collated_t.npz")
+    mp.spawn(_worker_transport, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    got = np.load(out_path)
+    from tinyslam_amd import node
+    assert got["counts"].shape == (N_FRAMES,) and got["merged"].shape[0] == 2 and got["merged"].shape[2] == node.TRANSPORT_WORDS
+    assert got["merged"].shape[1] == max(int(got["totals"].max()), 1)
+    frame = 0
+    for r in range(2):
+        lo, hi = node.shard_range(N_FRAMES, 2, r)
+        at = 0
+        for i in range(lo, hi):
+            total, kp, ds = _frame_result(oracle, SEED0 + i)
+            assert got["counts"][frame] == total
+            n = min(total, CAP)
+            assert np.array_equal(got["merged"][r, at:at + n], _to_transport(kp, ds, n)), (r, i)
+            at += n
+            frame += 1
+        assert at == got["totals"][r]
+
+
+def test_transport_collate_world1():
+    from tinyslam_amd import node
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    try:
+        counts = torch.tensor([3, 9, 0], dtype=torch.int32)
+        records = torch.arange(20 * 10, dtype=torch.int32).reshape(20, 10)
+        c, totals, merged = node.collate_transport_to_root(counts, records, 8)  # 9 is cut to the capacity 8
+        assert totals == [11] and merged.shape == (1, 11, 10) and torch.equal(merged[0], records[:11]) and torch.equal(c, counts)
+    finally:
+        dist.destroy_process_group()

@@ -26,11 +26,11 @@ using namespace orb;
 
 namespace {
 
-enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I, KID_MATCH, KID_COMPACT, KID_BRIEF_T, KID_BRIEF_NF };
+enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I, KID_MATCH, KID_COMPACT, KID_BRIEF_T, KID_BRIEF_NF, KID_PACK_T, KID_UNPACK_T };
 const char* const kKernelNames[ORB_KERNEL_COUNT] = {"k_grayscale", "k_mip",      "k_blur_rows", "k_fast",       "k_brief",
                                                     "k_front_l0",  "k_front_ln", "k_synth",     "k_brief_rows", "k_slot_prefix",
                                                     "k_front_i",   "k_select_i", "k_brief_i",   "k_match",      "k_compact",
-                                                    "k_brief_t",   "k_brief_nf"};
+                                                    "k_brief_t",   "k_brief_nf",  "k_compact_transport", "k_unpack_transport"};
 
 thread_local std::string g_create_error;
 
@@ -1347,6 +1347,52 @@ int orb_batch_fetch(OrbProgram* p, uint32_t set, uint32_t* counts, uint64_t* off
         HIP_TRY(p, hipMemcpyAsync(corners, p->d_pack_c[set], m * sizeof(CornerData), hipMemcpyDeviceToHost, s));
         HIP_TRY(p, hipMemcpyAsync(descriptors, p->d_pack_d[set], m * sizeof(CornerDescriptor), hipMemcpyDeviceToHost, s));
     }
+    return ORB_OK;
+}
+
+int orb_batch_pack_transport(OrbProgram* p, uint32_t set, uint32_t n_frames, void* dst_dev, size_t capacity_records,
+                             uint64_t* offsets_dev, void* stream) {
+    if (!p) return ORB_EINVAL;
+    if (set > 1u || !p->out_counts[set]) return fail(p, ORB_EINVAL, "pack_transport: output set %u does not exist", set);
+    if (n_frames == 0 || n_frames > p->max_batch) return fail(p, ORB_EINVAL, "pack_transport: n_frames %u outside 1..=max_batch (%u)", n_frames, p->max_batch);
+    if (!dst_dev) return fail(p, ORB_EINVAL, "pack_transport: destination is NULL");
+    if (p->pyr.w[0] >= 65536u || p->pyr.h[0] >= 65536u) return fail(p, ORB_EINVAL, "pack_transport: coordinates do not fit 16 bits");
+    HIP_TRY(p, hipSetDevice(p->device));
+    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+    const uint32_t cap = p->cfg.max_features;
+    {
+        LaunchScope ls(p, s, KID_PACK_T);
+        hipLaunchKernelGGL(k_compact_transport, dim3(n_frames, (cap + kCompactChunk - 1u) / kCompactChunk), dim3(256), 0, s,
+                           p->out_counts[set], p->out_corners[set], p->out_desc[set], cap, n_frames,
+                           reinterpret_cast<unsigned long long*>(offsets_dev), static_cast<TransportRecord*>(dst_dev),
+                           (unsigned long long)capacity_records);
+    }
+    HIP_TRY(p, hipGetLastError());
+    return ORB_OK;
+}
+
+int orb_unpack_transport(OrbProgram* p, const void* src_dev, uint32_t n_segments, const uint64_t* src_first, const uint64_t* count,
+                         const uint64_t* dst_first, CornerData* corners_dev, CornerDescriptor* descriptors_dev, void* stream) {
+    if (!p) return ORB_EINVAL;
+    if (!src_dev || !corners_dev || !descriptors_dev || (n_segments && (!src_first || !count || !dst_first)))
+        return fail(p, ORB_EINVAL, "unpack_transport: NULL argument");
+    HIP_TRY(p, hipSetDevice(p->device));
+    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+    for (uint32_t s0 = 0; s0 < n_segments; s0 += (uint32_t)kUnpackSegments) {
+        const uint32_t m = std::min<uint32_t>(n_segments - s0, (uint32_t)kUnpackSegments);
+        UnpackGeom g{};
+        unsigned long long most = 0;
+        for (uint32_t i = 0; i < m; i++) {
+            g.src_first[i] = src_first[s0 + i], g.count[i] = count[s0 + i], g.dst_first[i] = dst_first[s0 + i];
+            most = std::max<unsigned long long>(most, g.count[i]);
+        }
+        if (most == 0) continue;
+        const unsigned long long chunks = std::min<unsigned long long>((most + 255u) / 256u, 4096u);
+        LaunchScope ls(p, s, KID_UNPACK_T);
+        hipLaunchKernelGGL(k_unpack_transport, dim3((uint32_t)chunks, m), dim3(256), 0, s,
+                           static_cast<const TransportRecord*>(src_dev), g, corners_dev, descriptors_dev);
+    }
+    HIP_TRY(p, hipGetLastError());
     return ORB_OK;
 }
 

@@ -56,8 +56,10 @@ struct OrbNode {
     std::vector<ncclComm_t> comms;
     std::vector<uint32_t*> d_sendcounts;          // [max_batch] per device, zero padded
     std::vector<uint32_t*> d_allcounts;           // [n * max_batch] per device
-    std::vector<CornerData*> d_pack_c;            // packed keypoints: [max_batch * cap], rank 0: [n * max_batch * cap]
+    std::vector<CornerData*> d_pack_c;            // rank 0 only: the collated keypoints [n * max_batch * cap] (else null)
     std::vector<CornerDescriptor*> d_pack_d;
+    std::vector<void*> d_wire;                    // 40-byte transport records (tinyorb.h): rank r >= 1 its own [max_batch * cap]
+                                                  // to send, rank 0 the received ones [(n - 1) * max_batch * cap] (null when n == 1)
     std::vector<uint8_t*> d_frames;               // per device, only for orb_node_extract_batch_host
     uint32_t* h_allcounts = nullptr;              // pinned [n * max_batch]
     std::vector<uint32_t> shard_n;                // frames of each rank in the last job
@@ -187,6 +189,7 @@ void orb_node_destroy(OrbNode* node) {
         if (r < (int)node->d_allcounts.size()) (void)hipFree(node->d_allcounts[r]);
         if (r < (int)node->d_pack_c.size()) (void)hipFree(node->d_pack_c[r]);
         if (r < (int)node->d_pack_d.size()) (void)hipFree(node->d_pack_d[r]);
+        if (r < (int)node->d_wire.size()) (void)hipFree(node->d_wire[r]);
         if (r < (int)node->d_frames.size()) (void)hipFree(node->d_frames[r]);
         if (r < (int)node->progs.size()) orb_program_destroy(node->progs[r]);
     }
@@ -233,16 +236,20 @@ int orb_node_create(const int* devices, int n_devices, const OrbConfig* config, 
         uint32_t *sc = nullptr, *ac = nullptr;
         CornerData* pc = nullptr;
         CornerDescriptor* pd = nullptr;
-        const size_t pack = (r == 0 ? (size_t)n_devices : 1u) * B * cap;
+        void* wire = nullptr;
+        const size_t pack = (size_t)n_devices * B * cap;                                // rank 0: every frame's records
+        const size_t wire_records = (r == 0 ? (size_t)(n_devices - 1) : 1u) * B * cap;  // rank 0 receives, the others send
         hipError_t e = hipSetDevice(devices[r]);
         if (e == hipSuccess) e = hipMalloc(&sc, B * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&ac, (size_t)n_devices * B * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&pc, pack * sizeof(CornerData));
-        if (e == hipSuccess) e = hipMalloc(&pd, pack * sizeof(CornerDescriptor));
+        if (e == hipSuccess && r == 0) e = hipMalloc(&pc, pack * sizeof(CornerData));
+        if (e == hipSuccess && r == 0) e = hipMalloc(&pd, pack * sizeof(CornerDescriptor));
+        if (e == hipSuccess && wire_records) e = hipMalloc(&wire, wire_records * (size_t)ORB_TRANSPORT_RECORD_BYTES);
         node->d_sendcounts.push_back(sc);
         node->d_allcounts.push_back(ac);
         node->d_pack_c.push_back(pc);
         node->d_pack_d.push_back(pd);
+        node->d_wire.push_back(wire);
         node->d_frames.push_back(nullptr);
         if (e != hipSuccess) {
             nfail(node, ORB_EHIP, "device %d: allocation failed: %s", devices[r], hipGetErrorString(e));
@@ -311,9 +318,14 @@ int orb_node_collate(OrbNode* node, uint32_t* counts, uint64_t* offsets, void** 
         NODE_ORB(node, node->progs[r], orb_batch_device_buffers(node->progs[r], &d_counts, nullptr, nullptr));
         NODE_HIP(node, hipMemcpyAsync(node->d_sendcounts[r], d_counts, node->shard_n[r] * sizeof(uint32_t),
                                       hipMemcpyDeviceToDevice, node->streams[r]));
-        NODE_ORB(node, node->progs[r],
-                 orb_batch_compact_device(node->progs[r], node->shard_n[r], nullptr, nullptr, node->d_pack_c[r],
-                                          node->d_pack_d[r], (size_t)B * cap, nullptr));
+        if (r == 0)  // rank 0's own records go straight to the head of the collated arrays
+            NODE_ORB(node, node->progs[0],
+                     orb_batch_compact_device(node->progs[0], node->shard_n[0], nullptr, nullptr, node->d_pack_c[0],
+                                              node->d_pack_d[0], (size_t)B * cap, nullptr));
+        else         // the others pack 40-byte transport records (set 0: a node never switches output sets)
+            NODE_ORB(node, node->progs[r],
+                     orb_batch_pack_transport(node->progs[r], 0, node->shard_n[r], node->d_wire[r], (size_t)B * cap, nullptr,
+                                              node->streams[r]));
     }
     // 2. counters of every frame to every rank
     NODE_NCCL(node, R.GroupStart());
@@ -333,16 +345,25 @@ int orb_node_collate(OrbNode* node, uint32_t* counts, uint64_t* offsets, void** 
         }
         rank_offset[r + 1] = rank_offset[r] + rank_records[r];
     }
-    // 4. payloads of ranks 1.. to rank 0, exact sizes, each peer on its own link
+    // 4. transport records of ranks 1.. to rank 0, exact sizes, each peer on its own link; rank 0 then expands them
+    //    behind its own records (orb_unpack_transport), in rank = frame order
+    std::vector<uint64_t> wire_first(n, 0), wire_count(n, 0), dst_first(n, 0);
     NODE_NCCL(node, R.GroupStart());
+    uint64_t at = 0;
     for (int r = 1; r < n; r++) {
+        wire_first[r - 1] = at, wire_count[r - 1] = rank_records[r], dst_first[r - 1] = rank_offset[r];
         if (rank_records[r] == 0) continue;
-        NODE_NCCL(node, R.Send(node->d_pack_c[r], rank_records[r] * sizeof(CornerData), ncclUint8, 0, node->comms[r], node->streams[r]));
-        NODE_NCCL(node, R.Send(node->d_pack_d[r], rank_records[r] * sizeof(CornerDescriptor), ncclUint8, 0, node->comms[r], node->streams[r]));
-        NODE_NCCL(node, R.Recv(node->d_pack_c[0] + rank_offset[r], rank_records[r] * sizeof(CornerData), ncclUint8, r, node->comms[0], node->streams[0]));
-        NODE_NCCL(node, R.Recv(node->d_pack_d[0] + rank_offset[r], rank_records[r] * sizeof(CornerDescriptor), ncclUint8, r, node->comms[0], node->streams[0]));
+        const size_t bytes = (size_t)rank_records[r] * ORB_TRANSPORT_RECORD_BYTES;
+        NODE_NCCL(node, R.Send(node->d_wire[r], bytes, ncclUint8, 0, node->comms[r], node->streams[r]));
+        NODE_NCCL(node, R.Recv(static_cast<uint8_t*>(node->d_wire[0]) + (size_t)at * ORB_TRANSPORT_RECORD_BYTES, bytes, ncclUint8, r,
+                               node->comms[0], node->streams[0]));
+        at += rank_records[r];
     }
     NODE_NCCL(node, R.GroupEnd());
+    if (n > 1 && at > 0)
+        NODE_ORB(node, node->progs[0],
+                 orb_unpack_transport(node->progs[0], node->d_wire[0], (uint32_t)(n - 1), wire_first.data(), wire_count.data(),
+                                      dst_first.data(), node->d_pack_c[0], node->d_pack_d[0], node->streams[0]));
     for (int r = 0; r < n; r++) {
         NODE_HIP(node, hipSetDevice(node->devices[r]));
         NODE_HIP(node, hipStreamSynchronize(node->streams[r]));

@@ -3,9 +3,10 @@
 The reference has no multi-device code (single wgpu device, orb.rs:47-51).  Frames are
 independent, so the path shards with NO data-path collective: rank g extracts the contiguous
 frame range `shard_range(F, G, g)` on its own GPU.  The only exchange is the collate of the
-results to rank 0: per-frame counts (all_gather, 4 B/frame) and the keypoint/descriptor slabs
-trimmed to the largest per-frame count (gather).  With backend "nccl" this is RCCL over xGMI;
-the CPU tests run the same code over gloo.
+results to rank 0: per-frame counts (all_gather, 4 B/frame) and the records -- as 40-byte
+transport records packed back to back (`collate_transport_to_root`, what bench.py runs), or as the
+keypoint/descriptor slabs trimmed to the largest per-frame count (`collate_to_root`).  With backend
+"nccl" this is RCCL over xGMI; the CPU tests run the same code over gloo.
 """
 from typing import Optional, Tuple
 
@@ -68,3 +69,43 @@ def collate_to_root(counts: torch.Tensor, corners: torch.Tensor, descriptors: to
     if rank != dst:
         return None
     return counts_all, merged[:, :, :4], merged[:, :, 4:]
+
+
+TRANSPORT_WORDS = 10  # ORB_TRANSPORT_RECORD_BYTES / 4: {x | y << 16, angle | octave << 16, descriptor[8]}
+
+
+def collate_transport_to_root(counts: torch.Tensor, records: torch.Tensor, cap: int, dst: int = 0,
+                              group: Optional[dist.ProcessGroup] = None):
+    """The collate on 40-byte transport records (orb_batch_pack_transport): what crosses the links is every rank's
+    stored records back to back -- no padding to the fullest frame, 10 words per keypoint instead of 12.
+
+    counts    (B,)      int32   raw per-frame counters of this rank's frames (same B on every rank)
+    records   (>= S, 10) int32   this rank's transport records, the first S = sum(min(counts, cap)) rows valid
+    Returns on dst (counts_all (G*B,), totals [S_0 .. S_{G-1}], merged (G, S_max, 10)) where rank r's records are
+    merged[r, :totals[r]], in frame order; other ranks get None.  One all_gather of the counters (they size the
+    gather), one gather of equal-size slices padded to the largest rank total (ranks hold the same number of frames,
+    their totals differ by a per cent or two)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        total = int(torch.clamp(counts, max=cap).sum().item()) if counts.numel() else 0
+        return counts, [total], records[:max(total, 1)].unsqueeze(0)
+    all_counts = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)
+    counts_all = torch.cat(all_counts)
+    totals = [int(t) for t in torch.clamp(counts_all, max=cap).view(world, -1).sum(dim=1).tolist()]
+    s_max = max(max(totals), 1)
+    if records.shape[0] >= s_max:
+        payload = records[:s_max]  # contiguous leading slice
+    else:  # a buffer sized for this rank alone: pad to the common size
+        payload = records.new_zeros((s_max, records.shape[1]))
+        payload[:records.shape[0]] = records
+    merged = None
+    bufs = None
+    if rank == dst:
+        merged = torch.empty((world, s_max, records.shape[1]), dtype=records.dtype, device=records.device)
+        bufs = list(merged.unbind(0))  # contiguous slices, one per rank
+    dist.gather(payload, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return counts_all, totals, merged

@@ -20,12 +20,13 @@ LIB_PATH = os.path.join(_PKG, "libtinyorb.so")
 
 ORB_OK, ORB_EINVAL, ORB_EHIP, ORB_ECAPACITY, ORB_ESTATE = 0, 1, 2, 3, 4
 ORB_PLANE_GRAY, ORB_PLANE_BLUR = 0, 1
-ORB_KERNEL_COUNT = 17
+ORB_KERNEL_COUNT = 19
 ORB_FLAG_STAGED = 1
 ORB_FLAG_DOUBLE_OUTPUT = 2
 ORB_FLAG_NMS = 4
 ORB_FLAG_INTENDED = 8
 ORB_FLAG_INPUT_Y8 = 16
+TRANSPORT_RECORD_WORDS = 10  # ORB_TRANSPORT_RECORD_BYTES / 4
 SYN_GRADIENT, SYN_BLOBS, SYN_WEDGES, SYN_NOISE = 1, 2, 4, 8
 SYN_ALL = 15
 
@@ -46,6 +47,7 @@ EXPORTS = [
     "orb_match_consecutive", "orb_match_read", "orb_corner_level0_xy",
     "orb_batch_read_all", "orb_batch_compact_device", "orb_host_alloc", "orb_host_free", "orb_stream_sync",
     "orb_program_stream", "orb_pipeline_note", "orb_batch_pack", "orb_batch_fetch",
+    "orb_batch_pack_transport", "orb_unpack_transport",
     "orb_node_create", "orb_node_destroy", "orb_node_last_error", "orb_node_device_count", "orb_node_program",
     "orb_node_shard", "orb_node_extract_batch", "orb_node_extract_batch_host", "orb_node_collate",
     "orb_node_read_collated",
@@ -153,6 +155,8 @@ def load_library(path=None):
     L.orb_batch_compact_device.argtypes = [vp, u32, vp, vp, vp, vp, sz, vp]
     L.orb_batch_pack.argtypes = [vp, u32, vp]
     L.orb_batch_fetch.argtypes = [vp, u32, vp, vp, vp, vp, sz, vp]
+    L.orb_batch_pack_transport.argtypes = [vp, u32, u32, vp, sz, vp, vp]
+    L.orb_unpack_transport.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp]
     L.orb_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
     L.orb_host_free.argtypes = [vp]
     L.orb_host_free.restype = None
@@ -403,6 +407,21 @@ class OrbProgram:
         self._check(self._lib.orb_batch_fetch(self._handle(), out_set, out.counts.ctypes.data, out.offsets.ctypes.data,
                                               out.corners.ctypes.data, out.descriptors.ctypes.data, out.capacity,
                                               ctypes.c_void_p(stream) if stream else None))
+
+    def batch_pack_transport(self, out_set, n_frames, dst_dev_ptr, capacity_records, offsets_dev_ptr=None, stream=None):
+        """orb_batch_pack_transport: the stored records of output set `out_set` as 40-byte transport records in device
+        memory, enqueued on `stream` (the caller orders it behind the batch)."""
+        self._check(self._lib.orb_batch_pack_transport(self._handle(), out_set, n_frames, ctypes.c_void_p(dst_dev_ptr),
+                                                       capacity_records, ctypes.c_void_p(offsets_dev_ptr) if offsets_dev_ptr else None,
+                                                       ctypes.c_void_p(stream) if stream else None))
+
+    def unpack_transport(self, src_dev_ptr, src_first, count, dst_first, corners_dev_ptr, desc_dev_ptr, stream=None):
+        """orb_unpack_transport: runs of transport records -> CornerData / CornerDescriptor arrays on this device."""
+        a = [np.ascontiguousarray(v, dtype=np.uint64) for v in (src_first, count, dst_first)]
+        assert a[0].shape == a[1].shape == a[2].shape and a[0].ndim == 1
+        self._check(self._lib.orb_unpack_transport(self._handle(), ctypes.c_void_p(src_dev_ptr), a[0].shape[0], _ptr(a[0]), _ptr(a[1]),
+                                                   _ptr(a[2]), ctypes.c_void_p(corners_dev_ptr), ctypes.c_void_p(desc_dev_ptr),
+                                                   ctypes.c_void_p(stream) if stream else None))
 
     def stream_sync(self, stream=None):
         self._check(self._lib.orb_stream_sync(self._handle(), ctypes.c_void_p(stream) if stream else None))
