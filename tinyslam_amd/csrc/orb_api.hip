@@ -673,6 +673,9 @@ int run_fused_x(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
     return ORB_OK;
 }
 
+int launch_compact(OrbProgram* p, uint32_t n, uint32_t* counts, uint64_t* offsets, CornerData* corners, CornerDescriptor* desc,
+                   size_t capacity, void* stream, hipStream_t* used);  // below, with the bulk read-back
+
 int run_pipeline(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
     if (p->fused_i) return run_fused_i(p, frames, n, s);
     if (p->fused_x) return run_fused_x(p, frames, n, s);
@@ -1094,10 +1097,26 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
     hipStream_t s = p->stream;
     if (int rc = run_pipeline(p, p->d_input, 1, s)) return rc;
     const size_t cap = p->cfg.max_features;
-    // orb.rs:537-547: counter, corners and descriptors go to host staging, then block.
-    HIP_TRY(p, hipMemcpyAsync(p->h_count, p->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(p, hipMemcpyAsync(p->h_corners, p->d_corners, cap * sizeof(CornerData), hipMemcpyDeviceToHost, s));
-    HIP_TRY(p, hipMemcpyAsync(p->h_desc, p->d_desc, cap * sizeof(CornerDescriptor), hipMemcpyDeviceToHost, s));
+    // orb.rs:537-547: counter, corners and descriptors go to host staging, then block.  The reference copies the three
+    // whole buffers; here one kernel writes the counter and the STORED records into the (pinned, device-visible) staging
+    // memory: no size has to reach the host first, and 48 bytes per keypoint cross PCIe instead of 48 * max_features.
+    // What lies behind the stored records in the staging arrays is stale, as it is in the reference's buffers.
+    void *dc = nullptr, *dk = nullptr, *dd = nullptr;
+    const bool direct = !getenv("TINYORB_SINGLE_MEMCPY") && hipHostGetDevicePointer(&dc, p->h_count, 0) == hipSuccess &&
+                        hipHostGetDevicePointer(&dk, p->h_corners, 0) == hipSuccess &&
+                        hipHostGetDevicePointer(&dd, p->h_desc, 0) == hipSuccess;
+    if (direct) {
+        p->last_batch = 1;
+        p->last_stream = s;
+        if (int rc = launch_compact(p, 1, static_cast<uint32_t*>(dc), nullptr, static_cast<CornerData*>(dk),
+                                    static_cast<CornerDescriptor*>(dd), cap, s, nullptr))
+            return rc;
+    } else {
+        (void)hipGetLastError();
+        HIP_TRY(p, hipMemcpyAsync(p->h_count, p->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(p, hipMemcpyAsync(p->h_corners, p->d_corners, cap * sizeof(CornerData), hipMemcpyDeviceToHost, s));
+        HIP_TRY(p, hipMemcpyAsync(p->h_desc, p->d_desc, cap * sizeof(CornerDescriptor), hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(p, hipStreamSynchronize(s));
     p->single_valid = true;
     p->last_batch = 1;
