@@ -108,7 +108,7 @@ struct OrbProgram {
     RowsGeom rows{};
     BriefTGeom brieft{};       // thread-per-keypoint BRIEF of the fused literal pipelines (plain and arc/NMS)
     bool use_brief_t = false;
-    uint32_t band_rows = kFrontRows;  // band height of the plain fused path (kFrontRowsWide for frames wider than 2048)
+    uint32_t band_rows_lvl[kMaxLevels] = {0};  // band height of the plain fused path per level: kFrontRows or kFrontRowsWide (chosen at create)
     uint32_t seg_classes = 1;  // lists per band slot of the plain fused path: 2 with k_brief_t (angle code 0 / the rest)
     uint32_t* d_pattern = nullptr;
     float* d_cos = nullptr;
@@ -446,7 +446,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
             dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 3u) / 4u, n);
             hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, d_gray, pyr, lvl);
         }
-        FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n, p->band_rows);
+        FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n, p->band_rows_lvl[lvl]);
         if (gw == 0) g.gh = 0;  // no FAST dispatch at this octave (orb.rs:511-515 with width 0)
         g.slot_base = p->bands.slot_base[lvl];
         g.n_slots = p->bands.n_slots;
@@ -461,7 +461,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         if (const char* e = getenv("TINYORB_LDS_PAD")) lds += (uint32_t)atoi(e);  // occupancy experiments only
         if (lds > p->max_lds) return fail(p, ORB_EINVAL, "level %u needs %u bytes of LDS", lvl, lds);
         const dim3 grid(g.n_bands * n);
-        const bool wide = p->band_rows == (uint32_t)kFrontRowsWide;
+        const bool wide = p->band_rows_lvl[lvl] == (uint32_t)kFrontRowsWide;
 #define FRONT_ARGS frames, p->frame_bytes, d_gray, d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg
         if (lvl == 0) {
             LaunchScope ls(p, s, KID_FUSED_L0);
@@ -770,23 +770,32 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         p->n_cus = cus > 0 ? (uint32_t)cus : 256u;
         p->fused = fused_eligible(p);
         if (p->fused) {
-            // 16-row bands up to 2048 texels wide (two workgroups per CU at 1280); 8-row bands up to 4096 (one per CU:
-            // 14 full-width rows); whichever fits the CU's LDS
-            auto lds_need = [&](uint32_t band_rows) {
-                uint32_t need = 0, width = W, height = H;
+            // Band height per level: 16 rows (x in 11 bits: levels up to 2048 wide) or 8 rows (up to 4096).  Two workgroups
+            // per CU matter more than the smaller halo share of the taller band (1.375 against 1.75 rows staged per row):
+            // a level takes 16 rows when two such workgroups fit the CU's LDS (up to 1280 wide), else 8 rows when two of
+            // those fit (up to about 1980 wide), else the taller band that fits at all.
+            uint32_t need = 0;
+            {
+                uint32_t width = W, height = H;
+                const char* force = getenv("TINYORB_BAND_ROWS");  // experiments: one band height for every level that can have it
                 for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
-                    FrontGeom g = front_geometry(p->pyr, lvl, ((width + 7u) / 8u) * 8u, ((height + 7u) / 8u) * 8u, 1, band_rows);
+                    const uint32_t gw = ((width + 7u) / 8u) * 8u, gh = ((height + 7u) / 8u) * 8u, w = p->pyr.w[lvl];
                     width /= 2u;
                     height /= 2u;
-                    need = std::max(need, front_lds_bytes(g));
+                    const uint32_t lds16 = front_lds_bytes(front_geometry(p->pyr, lvl, gw, gh, 1, kFrontRows));
+                    const uint32_t lds8 = front_lds_bytes(front_geometry(p->pyr, lvl, gw, gh, 1, kFrontRowsWide));
+                    const bool can16 = w <= (uint32_t)kFrontMaxWidth && lds16 <= p->max_lds;
+                    const bool can8 = w <= (uint32_t)kFrontMaxWidthWide && lds8 <= p->max_lds;
+                    uint32_t rows = 0;
+                    if (can16 && 2u * lds16 <= p->max_lds) rows = kFrontRows;
+                    else if (can8 && 2u * lds8 <= p->max_lds) rows = kFrontRowsWide;
+                    else if (can16) rows = kFrontRows;
+                    else if (can8) rows = kFrontRowsWide;
+                    if (force && atoi(force) == kFrontRowsWide && can8) rows = kFrontRowsWide;
+                    if (force && atoi(force) == kFrontRows && can16) rows = kFrontRows;
+                    p->band_rows_lvl[lvl] = rows;
+                    need = rows == 0 ? p->max_lds + 1u : std::max(need, rows == (uint32_t)kFrontRows ? lds16 : lds8);
                 }
-                return need;
-            };
-            p->band_rows = W <= (uint32_t)kFrontMaxWidth ? (uint32_t)kFrontRows : (uint32_t)kFrontRowsWide;
-            uint32_t need = lds_need(p->band_rows);
-            if (need > p->max_lds && p->band_rows == (uint32_t)kFrontRows) {
-                p->band_rows = kFrontRowsWide;
-                need = lds_need(p->band_rows);
             }
             if (need > p->max_lds) {
                 p->fused = false;
@@ -795,11 +804,13 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 uint32_t slots = 0;
                 for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
                     bg.slot_base[lvl] = slots;
-                    slots += front_bands(p->pyr, lvl, p->band_rows);
+                    slots += front_bands(p->pyr, lvl, p->band_rows_lvl[lvl]);
                 }
                 bg.slot_base[p->pyr.depth] = slots;
                 bg.n_slots = slots;
-                const uint64_t band_px = (uint64_t)p->band_rows * (((uint64_t)W + 7u) / 8u * 8u);
+                uint64_t band_px = 0;  // pixels of the largest band: no band can hold more corners
+                for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++)
+                    band_px = std::max<uint64_t>(band_px, (uint64_t)p->band_rows_lvl[lvl] * (((uint64_t)(W >> lvl) + 7u) / 8u * 8u));
                 bg.seg_cap = (uint32_t)(band_px < config->max_features ? band_px : config->max_features);
                 RowsGeom& rg = p->rows;
                 rg.n_slots = bg.n_slots;

@@ -1,10 +1,11 @@
-"""Literal mode at 4K (3840x2160): the 8-row-band fused kernels against the per-stage kernels.  usage (GPU box): python tools/wide_rate.py"""
+"""Literal mode at larger frame sizes (default 4K, 3840x2160): the fused kernels against the per-stage kernels.
+usage (GPU box): python tools/wide_rate.py [W H batch depth]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tinyslam_amd import orb
 
-W, H, B, D = 3840, 2160, 32, 3
-for name, flags in (("fused (8-row bands)", 0), ("staged", orb.ORB_FLAG_STAGED)):
+W, H, B, D = [int(a) for a in sys.argv[1:5]] if len(sys.argv) >= 5 else (3840, 2160, 32, 3)
+for name, flags in (("fused", 0), ("staged", orb.ORB_FLAG_STAGED)):
     cfg = orb.OrbConfig(orb.Extent3d(W, H), max_features=1 << 16, hierarchy_depth=D, initial_threshold=20.0 / 255.0, max_batch=B, flags=flags)
     with orb.OrbProgram(cfg) as prog:
         dev = prog.synth_frames_device(B, 1000)
@@ -19,5 +20,5 @@ for name, flags in (("fused (8-row bands)", 0), ("staged", orb.ORB_FLAG_STAGED))
         dt = (time.perf_counter() - t0) / 10
         prof = {k: round(v[0] / 10, 4) for k, v in prog.profile().items()}
         counts = prog.batch_counts(B)
-        print("%-22s %s: %.3f ms per %d frames = %.0f frames/s = %.2f Gpixel/s, %.0f keypoints/frame, ms per batch %s"
-              % (name, prog.pipeline(), dt * 1e3, B, B / dt, B * W * H / dt / 1e9, counts.mean(), prof), flush=True)
+        print("%dx%d %-8s %s: %.3f ms per %d frames = %.0f frames/s = %.2f Gpixel/s, %.0f keypoints/frame, ms per batch %s"
+              % (W, H, name, prog.pipeline(), dt * 1e3, B, B / dt, B * W * H / dt / 1e9, counts.mean(), prof), flush=True)
