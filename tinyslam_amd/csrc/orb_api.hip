@@ -772,7 +772,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         if (p->fused) {
             // Band height per level: 16 rows (x in 11 bits: levels up to 2048 wide) or 8 rows (up to 4096).  Two workgroups
             // per CU matter more than the smaller halo share of the taller band (1.375 against 1.75 rows staged per row):
-            // a level takes 16 rows when two such workgroups fit the CU's LDS (up to 1280 wide), else 8 rows when two of
+            // a level takes 16 rows when two such workgroups fit the CU's LDS (up to about 1390 wide), else 8 rows when two of
             // those fit (up to about 1980 wide), else the taller band that fits at all.
             uint32_t need = 0;
             {
