@@ -108,8 +108,8 @@ const char *orb_last_error(const OrbProgram *p);
 uint32_t orb_abi_version(void);
 /* "fused" (one kernel per pyramid level + BRIEF) or "staged" (one kernel per reference stage;
  * taken with ORB_FLAG_STAGED or for shapes the fused kernels do not cover: width not a multiple of 4, more than 2^26 pixels;
- * the reference's algorithm also: width > 4096, odd level-0 size with depth > 1; levels wider than about 1390 run on 8-row
- * bands instead of 16-row ones where that keeps two workgroups on a CU). */
+ * the reference's algorithm also: width > 4096, odd level-0 size with depth > 1; the band height of the fused kernels is
+ * chosen per level from 64 / 32 / 16 / 8 rows: tall bands for narrow levels, flat ones for wide levels). */
 const char *orb_pipeline(const OrbProgram *p);
 /* Empty unless the program runs on the staged kernels WITHOUT having asked for them: then the reason, e.g.
  * "staged pipeline (...): width 5120 exceeds 4096 (...)".  The same line goes to stderr once per process (silence it

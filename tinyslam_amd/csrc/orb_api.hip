@@ -461,27 +461,28 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         if (const char* e = getenv("TINYORB_LDS_PAD")) lds += (uint32_t)atoi(e);  // occupancy experiments only
         if (lds > p->max_lds) return fail(p, ORB_EINVAL, "level %u needs %u bytes of LDS", lvl, lds);
         const dim3 grid(g.n_bands * n);
-        const bool wide = p->band_rows_lvl[lvl] == (uint32_t)kFrontRowsWide;
 #define FRONT_ARGS frames, p->frame_bytes, d_gray, d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg
+#define FRONT_LAUNCH(L0, Y8)                                                                                       \
+    switch (p->band_rows_lvl[lvl]) {                                                                               \
+        case 64: hipLaunchKernelGGL((k_front<L0, Y8, 64>), grid, block, lds, s, FRONT_ARGS); break;                \
+        case 32: hipLaunchKernelGGL((k_front<L0, Y8, 32>), grid, block, lds, s, FRONT_ARGS); break;                \
+        case 16: hipLaunchKernelGGL((k_front<L0, Y8, 16>), grid, block, lds, s, FRONT_ARGS); break;                \
+        default: hipLaunchKernelGGL((k_front<L0, Y8, 8>), grid, block, lds, s, FRONT_ARGS); break;                 \
+    }
         if (lvl == 0) {
             LaunchScope ls(p, s, KID_FUSED_L0);
             const dim3 block(kFrontThreadsL0);
-            if (p->input_y8 && wide)
-                hipLaunchKernelGGL((k_front<true, true, kFrontRowsWide>), grid, block, lds, s, FRONT_ARGS);
-            else if (p->input_y8)
-                hipLaunchKernelGGL((k_front<true, true, kFrontRows>), grid, block, lds, s, FRONT_ARGS);
-            else if (wide)
-                hipLaunchKernelGGL((k_front<true, false, kFrontRowsWide>), grid, block, lds, s, FRONT_ARGS);
-            else
-                hipLaunchKernelGGL((k_front<true, false, kFrontRows>), grid, block, lds, s, FRONT_ARGS);
+            if (p->input_y8) {
+                FRONT_LAUNCH(true, true)
+            } else {
+                FRONT_LAUNCH(true, false)
+            }
         } else {
             LaunchScope ls(p, s, KID_FUSED_LN);
             const dim3 block(kFrontThreadsLN);
-            if (wide)
-                hipLaunchKernelGGL((k_front<false, false, kFrontRowsWide>), grid, block, lds, s, FRONT_ARGS);
-            else
-                hipLaunchKernelGGL((k_front<false, false, kFrontRows>), grid, block, lds, s, FRONT_ARGS);
+            FRONT_LAUNCH(false, false)
         }
+#undef FRONT_LAUNCH
 #undef FRONT_ARGS
     }
     // orb.rs:523-534, plus the compaction of the band segments into the final lists
@@ -770,10 +771,11 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         p->n_cus = cus > 0 ? (uint32_t)cus : 256u;
         p->fused = fused_eligible(p);
         if (p->fused) {
-            // Band height per level: 16 rows (x in 11 bits: levels up to 2048 wide) or 8 rows (up to 4096).  Two workgroups
-            // per CU matter more than the smaller halo share of the taller band (1.375 against 1.75 rows staged per row):
-            // a level takes 16 rows when two such workgroups fit the CU's LDS (up to about 1390 wide), else 8 rows when two of
-            // those fit (up to about 1980 wide), else the taller band that fits at all.
+            // Band height per level, from kFrontBandHeights (64, 32, 16, 8 rows: x of a queue entry in 9, 10, 11, 12 bits).
+            // Two workgroups per CU matter more than the smaller halo share of a taller band (0.62 against 0.45 ms at 720p
+            // with one), and a band should hold about 20 k pixels (the 1024 threads then take 2.5 pre-test items each): a
+            // level takes the tallest band of which two fit the CU's LDS -- level 0: 64 rows up to about 330 wide, 32 up to
+            // 700, 16 up to 1390, 8 up to 1980 --, else the tallest that fits at all (16 rows up to 2048, 8 rows up to 4096).
             uint32_t need = 0;
             {
                 uint32_t width = W, height = H;
@@ -782,19 +784,24 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                     const uint32_t gw = ((width + 7u) / 8u) * 8u, gh = ((height + 7u) / 8u) * 8u, w = p->pyr.w[lvl];
                     width /= 2u;
                     height /= 2u;
-                    const uint32_t lds16 = front_lds_bytes(front_geometry(p->pyr, lvl, gw, gh, 1, kFrontRows));
-                    const uint32_t lds8 = front_lds_bytes(front_geometry(p->pyr, lvl, gw, gh, 1, kFrontRowsWide));
-                    const bool can16 = w <= (uint32_t)kFrontMaxWidth && lds16 <= p->max_lds;
-                    const bool can8 = w <= (uint32_t)kFrontMaxWidthWide && lds8 <= p->max_lds;
-                    uint32_t rows = 0;
-                    if (can16 && 2u * lds16 <= p->max_lds) rows = kFrontRows;
-                    else if (can8 && 2u * lds8 <= p->max_lds) rows = kFrontRowsWide;
-                    else if (can16) rows = kFrontRows;
-                    else if (can8) rows = kFrontRowsWide;
-                    if (force && atoi(force) == kFrontRowsWide && can8) rows = kFrontRowsWide;
-                    if (force && atoi(force) == kFrontRows && can16) rows = kFrontRows;
+                    // the tallest band of which two fit a CU; else the tallest that fits at all
+                    uint32_t rows = 0, rows_lds = 0, fits = 0, fits_lds = 0, want = 0, want_lds = 0;
+                    const uint32_t forced = force ? (uint32_t)atoi(force) : 0u;
+                    for (int cand : kFrontBandHeights) {
+                        if (std::max(w, gw) > (1u << front_x_bits(cand))) continue;
+                        // levels >= 1 run on 512 threads: beyond about 16 k pixels a band only gets longer (measured at
+                        // 640 wide: 32 rows 4 % slower than 16; at 480 wide: 32 rows 16 % faster than 16)
+                        if (lvl > 0 && (uint32_t)cand * gw > 16384u && cand > kFrontRowsWide) continue;
+                        const uint32_t lds = front_lds_bytes(front_geometry(p->pyr, lvl, gw, gh, 1, (uint32_t)cand));
+                        if (lds > p->max_lds) continue;
+                        if (forced == (uint32_t)cand) want = (uint32_t)cand, want_lds = lds;
+                        if (!fits) fits = (uint32_t)cand, fits_lds = lds;
+                        if (!rows && 2u * lds <= p->max_lds) rows = (uint32_t)cand, rows_lds = lds;
+                    }
+                    if (!rows) rows = fits, rows_lds = fits_lds;
+                    if (want) rows = want, rows_lds = want_lds;
                     p->band_rows_lvl[lvl] = rows;
-                    need = rows == 0 ? p->max_lds + 1u : std::max(need, rows == (uint32_t)kFrontRows ? lds16 : lds8);
+                    need = rows == 0 ? p->max_lds + 1u : std::max(need, rows_lds);
                 }
             }
             if (need > p->max_lds) {
@@ -827,12 +834,12 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 // device's limit, so that a later, smaller program never lowers it under a live, larger one.
                 p->use_brief_t = brieft_geometry(p, rg, 2u, &p->brieft);
                 p->seg_classes = p->use_brief_t ? 2u : 1u;
-                const void* fronts[] = {reinterpret_cast<const void*>(&k_front<true, false, kFrontRows>),
-                                        reinterpret_cast<const void*>(&k_front<false, false, kFrontRows>),
-                                        reinterpret_cast<const void*>(&k_front<true, true, kFrontRows>),
-                                        reinterpret_cast<const void*>(&k_front<true, false, kFrontRowsWide>),
-                                        reinterpret_cast<const void*>(&k_front<false, false, kFrontRowsWide>),
-                                        reinterpret_cast<const void*>(&k_front<true, true, kFrontRowsWide>)};
+                const void* fronts[] = {
+#define FRONT_FN(R) reinterpret_cast<const void*>(&k_front<true, false, R>), reinterpret_cast<const void*>(&k_front<false, false, R>), \
+                    reinterpret_cast<const void*>(&k_front<true, true, R>)
+                    FRONT_FN(64), FRONT_FN(32), FRONT_FN(16), FRONT_FN(8)
+#undef FRONT_FN
+                };
                 for (const void* f : fronts)
                     CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
             }

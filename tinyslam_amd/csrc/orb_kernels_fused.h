@@ -26,17 +26,22 @@ namespace orb {
 
 constexpr int kFrontThreadsL0 = 1024;  // level 0: 16 waves per band, two bands per CU -> 8 waves/SIMD
 constexpr int kFrontThreadsLN = 512;
-constexpr int kFrontRows = 16;       // R: band height (even); frames wider than 2048 take kFrontRowsWide
-constexpr int kFrontRowsWide = 8;    // band height of the wide variant: 14 full-width rows of up to 4096 texels fit in LDS
+constexpr int kFrontRows = 16;       // R: band height at 1280 columns (the bench shape); other widths: kFrontBandHeights, chosen per level at create
+constexpr int kFrontRowsWide = 8;    // the flattest band: 14 full-width rows of up to 4096 texels fit in LDS
 constexpr int kFrontTmpRows = 2;     // rows per blur chunk (double buffered)
 constexpr int kFrontQueue = 4096;    // pre-test survivor queue, 16-bit entries
+// Band heights k_front is instantiated for, and the x bits their 16-bit queue entries leave (15 - log2(rows)): a level of
+// dispatch width <= 2^bits can run on that height.  Narrow levels take tall bands (less halo per row, and enough pixels
+// per workgroup), wide ones flat bands (two workgroups per CU).
+constexpr int kFrontBandHeights[] = {64, 32, 16, 8};
+__host__ __device__ constexpr int front_x_bits(int rows) { return rows == 64 ? 9 : rows == 32 ? 10 : rows == 16 ? 11 : 12; }
 constexpr int kFrontMaxWidth = 2048;     // widest level 0 of the 16-row bands (11-bit x in the 16-bit queue entries)
 constexpr int kFrontMaxWidthWide = 4096; // ... of the 8-row bands (12-bit x)
 constexpr int kLdsPad = 8;           // halfs of padding left of column 0
 
 struct FrontGeom {
     uint32_t lvl;       // pyramid level handled by this launch
-    uint32_t rows;      // band height: kFrontRows, or kFrontRowsWide for frames wider than kFrontMaxWidth
+    uint32_t rows;      // band height (one of kFrontBandHeights)
     uint32_t gw, gh;    // FAST dispatch domain of this octave (8-rounded, orb.rs:511-515)
     uint32_t n_bands;   // ceil(max(h, gh) / R)
     uint32_t n_frames;
@@ -202,7 +207,7 @@ __device__ __forceinline__ void segment_append(bool is_corner, uint32_t x, uint3
 }
 
 // Y8: level 0 reads a one-byte-per-pixel Y plane instead of RGBA (ORB_FLAG_INPUT_Y8), grey = f16(byte/255).
-// RB: band height (kFrontRows, or kFrontRowsWide for frames wider than kFrontMaxWidth: one workgroup per CU then).
+// RB: band height, one of kFrontBandHeights (the host picks it per level: orb_api.hip, program create).
 template <bool L0, bool Y8 = false, int RB = kFrontRows>
 __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                          uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                                                          FrontGeom geo, float thr, uint32_t* __restrict__ seg_counts,
                                                          CornerData* __restrict__ segments) {
     constexpr int NT = L0 ? kFrontThreadsL0 : kFrontThreadsLN, R = RB, TC = kFrontTmpRows;
-    constexpr int XB = RB == kFrontRows ? 11 : 12;  // 16-bit queue entries: [15] polarity, row of the band, [XB-1:0] x
+    constexpr int XB = front_x_bits(RB);  // 16-bit queue entries: [15] polarity, row of the band, [XB-1:0] x
     static_assert((RB - 1) < (1 << (15 - XB)), "band row does not fit the queue entry");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int LS = (int)geo.ls, TS = (int)geo.ts;
