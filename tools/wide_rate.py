@@ -1,12 +1,13 @@
 """Literal mode at larger frame sizes (default 4K, 3840x2160): the fused kernels against the per-stage kernels.
-usage (GPU box): python tools/wide_rate.py [W H batch depth]"""
+usage (GPU box): python tools/wide_rate.py [W H batch depth [max_features]]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tinyslam_amd import orb
 
 W, H, B, D = [int(a) for a in sys.argv[1:5]] if len(sys.argv) >= 5 else (3840, 2160, 32, 3)
+CAP = int(sys.argv[5]) if len(sys.argv) >= 6 else (8192 if W * H <= 1280 * 960 else 1 << 16)  # bench.py's capacity where it is enough
 for name, flags in (("fused", 0), ("staged", orb.ORB_FLAG_STAGED)):
-    cfg = orb.OrbConfig(orb.Extent3d(W, H), max_features=1 << 16, hierarchy_depth=D, initial_threshold=20.0 / 255.0, max_batch=B, flags=flags)
+    cfg = orb.OrbConfig(orb.Extent3d(W, H), max_features=CAP, hierarchy_depth=D, initial_threshold=20.0 / 255.0, max_batch=B, flags=flags)
     with orb.OrbProgram(cfg) as prog:
         dev = prog.synth_frames_device(B, 1000)
         for _ in range(3):
