@@ -1,9 +1,11 @@
-"""Single-frame latency through the reference-shaped API (write_input_image / extract_corners / read_*)."""
+"""Single-frame latency through the reference-shaped API (write_input_image / extract_corners / read_*).
+usage (GPU box): python tools/single_frame_latency.py [W H]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tinyslam_amd import orb
-W, H = 1280, 720
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) >= 3 else (1280, 720)
+print("%dx%d" % (W, H))
 prog = orb.OrbProgram(orb.OrbConfig(orb.Extent3d(W, H), max_batch=1)).init()
 dev = prog.synth_frames_device(1, 1000)
 frame = prog.copy_to_host(dev, W * H * 4)
