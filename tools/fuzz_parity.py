@@ -1,5 +1,6 @@
 """One-off randomized parity sweep on the GPU: random sizes, depths, thresholds, modes, arcs, capacities -- every result
-against the C oracle (tests/ hold the fixed cases).  usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+against the C oracle (tests/ hold the fixed cases).  usage: python tools/fuzz_parity.py [n_cases] [seed] [wide]
+("wide": every frame 1284..4156 columns wide -- the levels that mix 8-, 16- and 32-row bands)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,6 +9,7 @@ from oracle import orb_oracle as oo
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"
 
 
 def sort(c, d):
@@ -21,7 +23,11 @@ for case in range(n_cases):
     W = int(rng.integers(2, 180)) * 4 if rng.random() < 0.8 else int(rng.integers(9, 700))
     if rng.random() < 0.12:
         W = int(rng.integers(180, 1040)) * 4  # up to 4156 wide: 16-row bands, 8-row bands (2049..4096) and beyond
+    if WIDE:
+        W = int(rng.integers(321, 1040)) * 4
     H = int(rng.integers(8, 400)) if W <= 720 else int(rng.integers(8, 160))
+    if WIDE:
+        H = int(rng.integers(24, 260))
     depth = int(rng.integers(1, 7))
     thr = float(np.float32(rng.choice([5, 12, 20, 40, 80]) / 255.0))
     intended = bool(rng.random() < 0.3)
