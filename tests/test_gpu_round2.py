@@ -466,6 +466,19 @@ def test_transport_records_round_trip(tinyorb, oracle):
             assert torch.equal(small[:cut], rec[:cut]) and int(offs[B]) == total
         with pytest.raises(tinyorb.OrbError):
             prog.batch_pack_transport(0, B + 1, rec.data_ptr(), 1)
-    with _program(tinyorb, 64, 48, 2, max_batch=2) as p2:  # no second output set
+    with _program(tinyorb, 96, 64, 2, max_batch=2) as p2:  # no second output set: set 0 packs (the node API's case), set 1 does not exist
+        frames = np.stack([oracle.synth_frame(96, 64, 610 + i) for i in range(2)])
+        p2.extract_batch_host(frames)
+        p2.batch_sync()
+        counts = p2.batch_counts(2)
+        total = int(counts.sum())
+        rec = torch.zeros((max(total, 1), 10), dtype=torch.int32, device=dev)
+        offs = torch.zeros(3, dtype=torch.int64, device=dev)
+        p2.batch_pack_transport(0, 2, rec.data_ptr(), max(total, 1), offs.data_ptr())
+        p2.stream_sync()
+        torch.cuda.synchronize()
+        assert offs.tolist() == [0, int(counts[0]), total]
+        c0, _ = p2.batch_read(0, int(counts[0]))
+        assert np.array_equal((rec[:int(counts[0]), 0].cpu().numpy() & 0xffff).astype(np.uint32), c0["x"])
         with pytest.raises(tinyorb.OrbError):
-            p2.batch_pack_transport(1, 1, 1 << 20, 1)
+            p2.batch_pack_transport(1, 1, rec.data_ptr(), 1)
