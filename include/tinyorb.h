@@ -212,7 +212,8 @@ void *orb_program_stream(OrbProgram *p);
  * packed records of every other device by grouped ncclSend/ncclRecv of their EXACT sizes (RCCL over xGMI; librccl is
  * loaded on first use, a single-GPU program never needs it). ---- */
 typedef struct OrbNode OrbNode;
-/* options->device is ignored (devices[] decides); options->max_batch is the largest shard of one device. */
+/* options->device is ignored (devices[] decides); options->max_batch is the largest shard of one device. 
+ * TINYORB_NODE_LOOPBACK=1 in the environment (tests): devices may repeat and the exchange uses device copies, not RCCL. */
 int orb_node_create(const int *devices, int n_devices, const OrbConfig *config, const OrbOptions *options, OrbNode **out);
 void orb_node_destroy(OrbNode *node);
 const char *orb_node_last_error(const OrbNode *node);

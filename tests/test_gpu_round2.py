@@ -482,3 +482,37 @@ def test_transport_records_round_trip(tinyorb, oracle):
         assert np.array_equal((rec[:int(counts[0]), 0].cpu().numpy() & 0xffff).astype(np.uint32), c0["x"])
         with pytest.raises(tinyorb.OrbError):
             p2.batch_pack_transport(1, 1, rec.data_ptr(), 1)
+
+
+@pytest.mark.parametrize("ranks,F", [(2, 7), (3, 10), (4, 3)])
+def test_node_api_several_ranks_on_one_device(tinyorb, oracle, monkeypatch, ranks, F):
+    """The n > 1 data path of orb_node_* -- uneven shards (an empty one with 4 ranks and 3 frames), 40-byte transport
+    records from ranks >= 1, exact offsets, expansion behind rank 0's own records -- on one GPU: with
+    TINYORB_NODE_LOOPBACK=1 the exchange runs as device copies (RCCL refuses a device listed twice), everything else is
+    the code an 8-GPU node runs.  Frame order and every record against the oracle."""
+    monkeypatch.setenv("TINYORB_NODE_LOOPBACK", "1")
+    W, H, CAP = 320, 240, 300  # some frames overflow the capacity: the stored records are then cap per frame
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=CAP, hierarchy_depth=2, initial_threshold=THR, max_batch=F)
+    frames = np.stack([oracle.synth_frame(W, H, 900 + i) for i in range(F)])
+    frames[1] = 77  # an empty frame inside rank 0's shard
+    with tinyorb.OrbNode(cfg, [0] * ranks) as node:
+        assert node.device_count() == ranks
+        shards = [node.shard(F, r) for r in range(ranks)]
+        assert shards[0][0] == 0 and shards[-1][1] == F and all(a[1] == b[0] for a, b in zip(shards, shards[1:]))
+        for job in range(2):  # buffers are reused by a second job
+            node.extract_batch_host(frames if job == 0 else frames[::-1].copy())
+            counts, offsets, _, _ = node.collate(F)
+            kp, desc = node.read_collated(int(offsets[F]))
+            src = frames if job == 0 else frames[::-1]
+            for i in range(F):
+                ref = oracle.extract(src[i], depth=2, threshold=THR, max_features=1 << 16)
+                assert int(counts[i]) == ref["total"]
+                lo, hi = int(offsets[i]), int(offsets[i + 1])
+                assert hi - lo == min(ref["total"], CAP)
+                if ref["total"] <= CAP:
+                    _assert_frame_equal(oracle, ref, int(counts[i]), kp[lo:hi], desc[lo:hi])
+                else:  # which records survive the cut is not defined: each stored one must be a keypoint of the frame
+                    table = {(int(k["octave"]), int(k["y"]), int(k["x"])): (int(k["angle"]), d.tobytes())
+                             for k, d in zip(ref["corners"], ref["descriptors"])}
+                    assert all(table.get((int(k["octave"]), int(k["y"]), int(k["x"]))) == (int(k["angle"]), d.tobytes())
+                               for k, d in zip(kp[lo:hi], desc[lo:hi]))

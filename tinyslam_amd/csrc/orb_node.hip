@@ -58,6 +58,7 @@ struct OrbNode {
     std::vector<uint32_t*> d_allcounts;           // [n * max_batch] per device
     std::vector<CornerData*> d_pack_c;            // rank 0 only: the collated keypoints [n * max_batch * cap] (else null)
     std::vector<CornerDescriptor*> d_pack_d;
+    bool loopback = false;                        // TINYORB_NODE_LOOPBACK=1: the exchange runs as device copies, not RCCL (see orb_node_create)
     std::vector<void*> d_wire;                    // 40-byte transport records (tinyorb.h): rank r >= 1 its own [max_batch * cap]
                                                   // to send, rank 0 the received ones [(n - 1) * max_batch * cap] (null when n == 1)
     std::vector<uint8_t*> d_frames;               // per device, only for orb_node_extract_batch_host
@@ -133,7 +134,7 @@ int load_rccl(OrbNode* node) {
 }
 
 int ensure_comms(OrbNode* node) {
-    if (!node->comms.empty()) return ORB_OK;
+    if (node->loopback || !node->comms.empty()) return ORB_OK;
     if (int rc = load_rccl(node)) return rc;
     node->comms.assign(node->n, nullptr);
     ncclResult_t r = node->rccl.CommInitAll(node->comms.data(), node->n, node->devices.data());
@@ -203,11 +204,17 @@ int orb_node_create(const int* devices, int n_devices, const OrbConfig* config, 
     *out = nullptr;
     if (!devices || n_devices <= 0 || n_devices > 64) return nfail(nullptr, ORB_EINVAL, "need 1..64 devices");
     if (!config) return nfail(nullptr, ORB_EINVAL, "config is NULL");
-    for (int a = 0; a < n_devices; a++)
+    // TINYORB_NODE_LOOPBACK=1 (test facility): the counters and records of the ranks move by device copies instead of RCCL,
+    // and a device may be listed more than once -- the whole n > 1 data path (shards, transport records, offsets, expansion
+    // on rank 0) can then run on one GPU, which RCCL refuses.
+    const char* lb = getenv("TINYORB_NODE_LOOPBACK");
+    const bool loopback = lb && atoi(lb) != 0;
+    for (int a = 0; a < n_devices && !loopback; a++)
         for (int b = a + 1; b < n_devices; b++)
             if (devices[a] == devices[b]) return nfail(nullptr, ORB_EINVAL, "device %d listed twice", devices[a]);
     OrbNode* node = new (std::nothrow) OrbNode();
     if (!node) return nfail(nullptr, ORB_EINVAL, "out of host memory");
+    node->loopback = loopback;
     node->n = n_devices;
     node->devices.assign(devices, devices + n_devices);
     node->cfg = *config;
@@ -328,10 +335,23 @@ int orb_node_collate(OrbNode* node, uint32_t* counts, uint64_t* offsets, void** 
                                               node->streams[r]));
     }
     // 2. counters of every frame to every rank
-    NODE_NCCL(node, R.GroupStart());
-    for (int r = 0; r < n; r++)
-        NODE_NCCL(node, R.AllGather(node->d_sendcounts[r], node->d_allcounts[r], B, ncclUint32, node->comms[r], node->streams[r]));
-    NODE_NCCL(node, R.GroupEnd());
+    if (node->loopback) {
+        for (int r = 0; r < n; r++) {
+            NODE_HIP(node, hipSetDevice(node->devices[r]));
+            NODE_HIP(node, hipStreamSynchronize(node->streams[r]));  // every rank's counters and records are in place
+        }
+        for (int r = 0; r < n; r++) {
+            NODE_HIP(node, hipSetDevice(node->devices[r]));
+            for (int q = 0; q < n; q++)
+                NODE_HIP(node, hipMemcpyAsync(node->d_allcounts[r] + (size_t)q * B, node->d_sendcounts[q], B * sizeof(uint32_t),
+                                              hipMemcpyDefault, node->streams[r]));
+        }
+    } else {
+        NODE_NCCL(node, R.GroupStart());
+        for (int r = 0; r < n; r++)
+            NODE_NCCL(node, R.AllGather(node->d_sendcounts[r], node->d_allcounts[r], B, ncclUint32, node->comms[r], node->streams[r]));
+        NODE_NCCL(node, R.GroupEnd());
+    }
     // 3. one copy to the host: exact payload sizes
     NODE_HIP(node, hipSetDevice(node->devices[0]));
     NODE_HIP(node, hipMemcpyAsync(node->h_allcounts, node->d_allcounts[0], (size_t)n * B * sizeof(uint32_t),
@@ -348,18 +368,23 @@ int orb_node_collate(OrbNode* node, uint32_t* counts, uint64_t* offsets, void** 
     // 4. transport records of ranks 1.. to rank 0, exact sizes, each peer on its own link; rank 0 then expands them
     //    behind its own records (orb_unpack_transport), in rank = frame order
     std::vector<uint64_t> wire_first(n, 0), wire_count(n, 0), dst_first(n, 0);
-    NODE_NCCL(node, R.GroupStart());
+    if (!node->loopback) NODE_NCCL(node, R.GroupStart());
     uint64_t at = 0;
     for (int r = 1; r < n; r++) {
         wire_first[r - 1] = at, wire_count[r - 1] = rank_records[r], dst_first[r - 1] = rank_offset[r];
         if (rank_records[r] == 0) continue;
         const size_t bytes = (size_t)rank_records[r] * ORB_TRANSPORT_RECORD_BYTES;
-        NODE_NCCL(node, R.Send(node->d_wire[r], bytes, ncclUint8, 0, node->comms[r], node->streams[r]));
-        NODE_NCCL(node, R.Recv(static_cast<uint8_t*>(node->d_wire[0]) + (size_t)at * ORB_TRANSPORT_RECORD_BYTES, bytes, ncclUint8, r,
-                               node->comms[0], node->streams[0]));
+        uint8_t* const landing = static_cast<uint8_t*>(node->d_wire[0]) + (size_t)at * ORB_TRANSPORT_RECORD_BYTES;
+        if (node->loopback) {  // the records were complete before the counters were exchanged (stream synchronised above)
+            NODE_HIP(node, hipSetDevice(node->devices[0]));
+            NODE_HIP(node, hipMemcpyAsync(landing, node->d_wire[r], bytes, hipMemcpyDefault, node->streams[0]));
+        } else {
+            NODE_NCCL(node, R.Send(node->d_wire[r], bytes, ncclUint8, 0, node->comms[r], node->streams[r]));
+            NODE_NCCL(node, R.Recv(landing, bytes, ncclUint8, r, node->comms[0], node->streams[0]));
+        }
         at += rank_records[r];
     }
-    NODE_NCCL(node, R.GroupEnd());
+    if (!node->loopback) NODE_NCCL(node, R.GroupEnd());
     if (n > 1 && at > 0)
         NODE_ORB(node, node->progs[0],
                  orb_unpack_transport(node->progs[0], node->d_wire[0], (uint32_t)(n - 1), wire_first.data(), wire_count.data(),
