@@ -107,9 +107,10 @@ void orb_program_destroy(OrbProgram *p);
 const char *orb_last_error(const OrbProgram *p);
 uint32_t orb_abi_version(void);
 /* "fused" (one kernel per pyramid level + BRIEF) or "staged" (one kernel per reference stage;
- * taken with ORB_FLAG_STAGED or for shapes the fused kernels do not cover: width not a multiple of 4, more than 2^26 pixels;
- * the reference's algorithm also: width > 4096, odd level-0 size with depth > 1; the band height of the fused kernels is
- * chosen per level from 64 / 32 / 16 / 8 rows: tall bands for narrow levels, flat ones for wide levels). */
+ * taken with ORB_FLAG_STAGED or for shapes the fused kernels do not cover: more than 2^26 pixels; the reference's
+ * algorithm on RGBA: width > 4096 only (any other width and any halving run fused); Y8 input, the arc/NMS extensions and
+ * the intended mode also need a width that is a multiple of 4, Y8 and arc/NMS a level 0 that halves exactly.  The band
+ * height of the fused kernels is chosen per level from 64 / 32 / 16 / 8 rows). */
 const char *orb_pipeline(const OrbProgram *p);
 /* Empty unless the program runs on the staged kernels WITHOUT having asked for them: then the reason, e.g.
  * "staged pipeline (...): width 5120 exceeds 4096 (...)".  The same line goes to stderr once per process (silence it

@@ -319,9 +319,10 @@ bool fused_eligible(const OrbProgram* p) {
     // index arithmetic: v_mul_i32_i24 takes 24-bit operands (rows, widths < 2^14 here) and returns 32 bits; RGBA byte
     // offsets inside a frame are 4 * W * H < 2^32
     if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 26) || pyr.h[0] > 16384u) return false;
-    if ((pyr.w[0] & 3u) != 0u || pyr.w[0] > (uint32_t)kFrontMaxWidthWide || pyr.w[0] < 8u) return false;
-    if (pyr.depth > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) return false;
-    return true;
+    if (pyr.w[0] > (uint32_t)kFrontMaxWidthWide || pyr.w[0] < 8u) return false;
+    // RGBA rows of any width (4-byte aligned: k_front<..., UA>); a one-byte-per-pixel row has to start on a dword
+    if (p->input_y8 && ((pyr.w[0] & 3u) != 0u || (pyr.depth > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])))) return false;
+    return true;  // a level 1 that is not an exact half is built by k_mip from the stored level-0 plane (FrontGeom::store_grey)
 }
 
 uint32_t front_bands(const Pyramid& pyr, uint32_t lvl, uint32_t band_rows) {
@@ -453,6 +454,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         g.seg_cap = p->bands.seg_cap;
         g.n_classes = p->seg_classes;
         g.stamps = p->d_stamps;
+        g.store_grey = (lvl == 0 && D > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) ? 1u : 0u;
         if (g.n_bands != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: band count mismatch at level %u", lvl);
         if (sizeof(BlurCol) * (size_t)g.n_var > 8u * (size_t)g.ts)  // the column table borrows the queues' storage
@@ -474,6 +476,13 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
             const dim3 block(kFrontThreadsL0);
             if (p->input_y8) {
                 FRONT_LAUNCH(true, true)
+            } else if ((pyr.w[0] & 3u) || g.store_grey) {  // rows not 16-byte aligned, or the level-0 plane is needed: the general variant
+                switch (p->band_rows_lvl[lvl]) {
+                    case 64: hipLaunchKernelGGL((k_front<true, false, 64, true>), grid, block, lds, s, FRONT_ARGS); break;
+                    case 32: hipLaunchKernelGGL((k_front<true, false, 32, true>), grid, block, lds, s, FRONT_ARGS); break;
+                    case 16: hipLaunchKernelGGL((k_front<true, false, 16, true>), grid, block, lds, s, FRONT_ARGS); break;
+                    default: hipLaunchKernelGGL((k_front<true, false, 8, true>), grid, block, lds, s, FRONT_ARGS); break;
+                }
             } else {
                 FRONT_LAUNCH(true, false)
             }
@@ -836,7 +845,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 p->seg_classes = p->use_brief_t ? 2u : 1u;
                 const void* fronts[] = {
 #define FRONT_FN(R) reinterpret_cast<const void*>(&k_front<true, false, R>), reinterpret_cast<const void*>(&k_front<false, false, R>), \
-                    reinterpret_cast<const void*>(&k_front<true, true, R>)
+                    reinterpret_cast<const void*>(&k_front<true, true, R>), reinterpret_cast<const void*>(&k_front<true, false, R, true>)
                     FRONT_FN(64), FRONT_FN(32), FRONT_FN(16), FRONT_FN(8)
 #undef FRONT_FN
                 };
@@ -933,15 +942,17 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         // A silent fall to the per-stage kernels is a 7x performance cliff: say why, once, and keep it readable.
         const Pyramid& py = p->pyr;
         char why[256];
-        if ((py.w[0] & 3u) != 0u)
-            snprintf(why, sizeof why, "width %u is not a multiple of 4", py.w[0]);
+        const bool plain = !p->intended && !(p->opt.flags & ORB_FLAG_NMS) && p->arc == 12u;  // the reference's own algorithm
+        if ((py.w[0] & 3u) != 0u && !(plain && !p->input_y8))
+            snprintf(why, sizeof why, "width %u is not a multiple of 4 (%s)", py.w[0],
+                     p->input_y8 ? "one-byte-per-pixel rows must start on a dword" : "the tile kernels read RGBA quads");
         else if (py.w[0] < 8u)
             snprintf(why, sizeof why, "width %u is below 8", py.w[0]);
         else if (!p->intended && py.w[0] > (uint32_t)kFrontMaxWidthWide)
             snprintf(why, sizeof why, "width %u exceeds %d (a band of 14 full-width rows must fit in LDS)", py.w[0], kFrontMaxWidthWide);
         else if ((uint64_t)py.w[0] * py.h[0] > (1ull << 26) || py.h[0] > 16384u)
             snprintf(why, sizeof why, "%ux%u exceeds the fused kernels' 2^26-pixel / 16384-row index range", py.w[0], py.h[0]);
-        else if (!p->intended && py.depth > 1 && !(py.w[0] == 2u * py.w[1] && py.h[0] == 2u * py.h[1]))
+        else if (!p->intended && (!plain || p->input_y8) && py.depth > 1 && !(py.w[0] == 2u * py.w[1] && py.h[0] == 2u * py.h[1]))
             snprintf(why, sizeof why, "level 0 (%ux%u) does not halve exactly and hierarchy_depth > 1", py.w[0], py.h[0]);
         else if (p->input_y8 && ((p->opt.flags & ORB_FLAG_NMS) || p->arc != 12u))
             snprintf(why, sizeof why, "the tile kernels of the arc/NMS extensions read RGBA");

@@ -48,6 +48,7 @@ struct FrontGeom {
     uint32_t ls;        // LDS row stride of the grey rows, in halfs (multiple of 8)
     uint32_t ts;        // LDS row stride of the blur intermediate, in halfs
     uint32_t write_mip; // 1: level lvl+1 exists and is an exact 2x2 reduction
+    uint32_t store_grey; // level 0 only: 1 = level 1 is NOT an exact half, the band also stores its grey rows for k_mip
     uint32_t xcd_swizzle;
     uint32_t phase_mask;  // debug: bit0 B1, bit1 B2, bit2 C0, bit3 C (timing experiments only)
     uint32_t slot_base;   // index of this level's band 0 among the frame's band slots
@@ -208,7 +209,9 @@ __device__ __forceinline__ void segment_append(bool is_corner, uint32_t x, uint3
 
 // Y8: level 0 reads a one-byte-per-pixel Y plane instead of RGBA (ORB_FLAG_INPUT_Y8), grey = f16(byte/255).
 // RB: band height, one of kFrontBandHeights (the host picks it per level: orb_api.hip, program create).
-template <bool L0, bool Y8 = false, int RB = kFrontRows>
+// UA: the general level-0 RGBA variant -- a width that is not a multiple of 4 (rows only 4-byte aligned: texel by texel loads, a
+//     partial last quad) and/or a level 1 that is not an exact half (FrontGeom::store_grey: the band also stores its grey rows).
+template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false>
 __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                          uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                                          uint16_t* __restrict__ blur_rowc, Pyramid pyr,
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     // rows, so per item there is one address increment instead of a division; four 16-byte loads are
     // in flight per thread before the first is consumed.
     {
-        const int per_row = L0 ? (w >> 2) : ((LS - kLdsPad) >> 3);  // 16-byte items per row (RGBA quads / half8 groups)
+        const int per_row = L0 ? ((UA ? w + 3 : w) >> 2) : ((LS - kLdsPad) >> 3);  // 16-byte items per row (RGBA quads / half8 groups)
         const int rpp = NT / per_row;                                 // rows covered per pass (>= 1: W <= 2048)
         const int ty = (int)(((float)tid + 0.5f) * (1.0f / (float)per_row));
         const int tx = tid - __mul24(ty, per_row);
@@ -318,10 +321,15 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     const bool ok = in_band && (uint32_t)gy_w < (uint32_t)h;
                     dst[u] = ok ? dst_w : -1;
                     const uint32_t off = ok ? off_w : 0u;
-                    if (Y8)  // four texels = four bytes
+                    if (Y8) {  // four texels = four bytes
                         v[u].x = *reinterpret_cast<const uint32_t*>(src0 + (size_t)off);
-                    else
+                    } else if (UA) {  // rows start on a texel, not on a quad; the last quad of a row may be partial
+                        const uint32_t* q = reinterpret_cast<const uint32_t*>(src0 + (size_t)off);
+                        const int left = ok ? w - tx * 4 : 4;  // texels of this quad that exist (>= 1)
+                        v[u] = make_uint4(q[0], q[left > 1 ? 1 : 0], q[left > 2 ? 2 : 0], q[left > 3 ? 3 : 0]);
+                    } else {
                         v[u] = *reinterpret_cast<const uint4*>(src0 + (size_t)off);
+                    }
                     gy_w += rpp;
                     off_w -= off_step;
                     dst_w += dst_step;
@@ -358,6 +366,20 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                             out.y = luminance_pair_f16(v[u].z, v[u].w);
                         }
                         *reinterpret_cast<uint2*>(grey + dst[u]) = out;
+                        // Level 1 is not an exact half of level 0 (odd width or height): the generic blit (k_mip) builds
+                        // it from the level-0 plane, which the band's own rows therefore also store.
+                        const int ly = lyb + u * rpp;
+                        if (UA && geo.store_grey && ly >= 3 && ly < R + 3) {
+                            uint16_t* g = gray_f + pyr.off[lvl] + (size_t)(uint32_t)(__mul24(y0 - 3 + ly, w) + tx * 4);
+                            if (w & 3) {
+                                const uint32_t t[4] = {out.x & 0xffffu, out.x >> 16, out.y & 0xffffu, out.y >> 16};
+#pragma unroll
+                                for (int k = 0; k < 4; k++)
+                                    if (tx * 4 + k < w) g[k] = (uint16_t)t[k];
+                            } else {
+                                *reinterpret_cast<uint2*>(g) = out;
+                            }
+                        }
                     } else {
                         *reinterpret_cast<uint4*>(grey + dst[u]) = v[u];
                     }
