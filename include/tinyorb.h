@@ -108,8 +108,8 @@ const char *orb_last_error(const OrbProgram *p);
 uint32_t orb_abi_version(void);
 /* "fused" (one kernel per pyramid level + BRIEF) or "staged" (one kernel per reference stage;
  * taken with ORB_FLAG_STAGED or for shapes the fused kernels do not cover: more than 2^26 pixels; the reference's
- * algorithm on RGBA: width > 4096 only (any other width and any halving run fused); Y8 input, the arc/NMS extensions and
- * the intended mode also need a width that is a multiple of 4, Y8 and arc/NMS a level 0 that halves exactly.  The band
+ * algorithm (RGBA or Y8 input): width > 4096 only -- any other width and any halving run fused; the arc/NMS extensions
+ * and the intended mode also need a width that is a multiple of 4, arc/NMS a level 0 that halves exactly.  The band
  * height of the fused kernels is chosen per level from 64 / 32 / 16 / 8 rows). */
 const char *orb_pipeline(const OrbProgram *p);
 /* Empty unless the program runs on the staged kernels WITHOUT having asked for them: then the reason, e.g.

@@ -342,12 +342,14 @@ _Y8_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", 
 
 
 @pytest.mark.parametrize("W,H,depth,seed", [(64, 48, 2, 3), (160, 120, 3, 1), (1280, 96, 2, 4), (332, 202, 4, 9),
-                                            (2052, 40, 1, 6), (200, 97, 3, 7)])
+                                            (2052, 40, 1, 6), (200, 97, 3, 7), (1241, 376, 3, 10), (333, 77, 3, 11),
+                                            (1282, 50, 2, 12), (9, 9, 2, 13)])
 @pytest.mark.parametrize("staged", [0, 1])
 def test_y8_matches_oracle(tinyorb, oracle, W, H, depth, seed, staged):
     y8 = oracle.synth_frame_y8(W, H, seed)
     ref = oracle.extract_y8(y8, depth=depth, threshold=THR, planes=True)
     with _program(tinyorb, W, H, depth, flags=tinyorb.ORB_FLAG_INPUT_Y8 | staged) as prog:
+        assert prog.pipeline() == ("staged" if staged else "fused")  # any width, any halving (the general level-0 variant)
         total, corners, desc = prog.extract(y8)
         _assert_frame_equal(oracle, ref, total, corners, desc)
         dims, _ = oracle.level_dims(W, H, depth)

@@ -320,8 +320,7 @@ bool fused_eligible(const OrbProgram* p) {
     // offsets inside a frame are 4 * W * H < 2^32
     if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 26) || pyr.h[0] > 16384u) return false;
     if (pyr.w[0] > (uint32_t)kFrontMaxWidthWide || pyr.w[0] < 8u) return false;
-    // RGBA rows of any width (4-byte aligned: k_front<..., UA>); a one-byte-per-pixel row has to start on a dword
-    if (p->input_y8 && ((pyr.w[0] & 3u) != 0u || (pyr.depth > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])))) return false;
+    // rows of any width: k_front<..., UA> loads RGBA texel by texel (4-byte aligned) and Y8 byte by byte
     return true;  // a level 1 that is not an exact half is built by k_mip from the stored level-0 plane (FrontGeom::store_grey)
 }
 
@@ -474,18 +473,25 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         if (lvl == 0) {
             LaunchScope ls(p, s, KID_FUSED_L0);
             const dim3 block(kFrontThreadsL0);
-            if (p->input_y8) {
+#define FRONT_LAUNCH_UA(Y8)                                                                                        \
+    switch (p->band_rows_lvl[lvl]) {                                                                               \
+        case 64: hipLaunchKernelGGL((k_front<true, Y8, 64, true>), grid, block, lds, s, FRONT_ARGS); break;        \
+        case 32: hipLaunchKernelGGL((k_front<true, Y8, 32, true>), grid, block, lds, s, FRONT_ARGS); break;        \
+        case 16: hipLaunchKernelGGL((k_front<true, Y8, 16, true>), grid, block, lds, s, FRONT_ARGS); break;        \
+        default: hipLaunchKernelGGL((k_front<true, Y8, 8, true>), grid, block, lds, s, FRONT_ARGS); break;         \
+    }
+            // rows not aligned to a quad, or the level-0 plane is needed (level 1 not an exact half): the general variant
+            const bool general = (pyr.w[0] & 3u) || g.store_grey;
+            if (p->input_y8 && general) {
+                FRONT_LAUNCH_UA(true)
+            } else if (p->input_y8) {
                 FRONT_LAUNCH(true, true)
-            } else if ((pyr.w[0] & 3u) || g.store_grey) {  // rows not 16-byte aligned, or the level-0 plane is needed: the general variant
-                switch (p->band_rows_lvl[lvl]) {
-                    case 64: hipLaunchKernelGGL((k_front<true, false, 64, true>), grid, block, lds, s, FRONT_ARGS); break;
-                    case 32: hipLaunchKernelGGL((k_front<true, false, 32, true>), grid, block, lds, s, FRONT_ARGS); break;
-                    case 16: hipLaunchKernelGGL((k_front<true, false, 16, true>), grid, block, lds, s, FRONT_ARGS); break;
-                    default: hipLaunchKernelGGL((k_front<true, false, 8, true>), grid, block, lds, s, FRONT_ARGS); break;
-                }
+            } else if (general) {
+                FRONT_LAUNCH_UA(false)
             } else {
                 FRONT_LAUNCH(true, false)
             }
+#undef FRONT_LAUNCH_UA
         } else {
             LaunchScope ls(p, s, KID_FUSED_LN);
             const dim3 block(kFrontThreadsLN);
@@ -845,7 +851,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 p->seg_classes = p->use_brief_t ? 2u : 1u;
                 const void* fronts[] = {
 #define FRONT_FN(R) reinterpret_cast<const void*>(&k_front<true, false, R>), reinterpret_cast<const void*>(&k_front<false, false, R>), \
-                    reinterpret_cast<const void*>(&k_front<true, true, R>), reinterpret_cast<const void*>(&k_front<true, false, R, true>)
+                    reinterpret_cast<const void*>(&k_front<true, true, R>), reinterpret_cast<const void*>(&k_front<true, false, R, true>), \
+                    reinterpret_cast<const void*>(&k_front<true, true, R, true>)
                     FRONT_FN(64), FRONT_FN(32), FRONT_FN(16), FRONT_FN(8)
 #undef FRONT_FN
                 };
@@ -943,16 +950,15 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         const Pyramid& py = p->pyr;
         char why[256];
         const bool plain = !p->intended && !(p->opt.flags & ORB_FLAG_NMS) && p->arc == 12u;  // the reference's own algorithm
-        if ((py.w[0] & 3u) != 0u && !(plain && !p->input_y8))
-            snprintf(why, sizeof why, "width %u is not a multiple of 4 (%s)", py.w[0],
-                     p->input_y8 ? "one-byte-per-pixel rows must start on a dword" : "the tile kernels read RGBA quads");
+        if ((py.w[0] & 3u) != 0u && !plain)
+            snprintf(why, sizeof why, "width %u is not a multiple of 4 (the tile kernels read RGBA quads)", py.w[0]);
         else if (py.w[0] < 8u)
             snprintf(why, sizeof why, "width %u is below 8", py.w[0]);
         else if (!p->intended && py.w[0] > (uint32_t)kFrontMaxWidthWide)
             snprintf(why, sizeof why, "width %u exceeds %d (a band of 14 full-width rows must fit in LDS)", py.w[0], kFrontMaxWidthWide);
         else if ((uint64_t)py.w[0] * py.h[0] > (1ull << 26) || py.h[0] > 16384u)
             snprintf(why, sizeof why, "%ux%u exceeds the fused kernels' 2^26-pixel / 16384-row index range", py.w[0], py.h[0]);
-        else if (!p->intended && (!plain || p->input_y8) && py.depth > 1 && !(py.w[0] == 2u * py.w[1] && py.h[0] == 2u * py.h[1]))
+        else if (!p->intended && !plain && py.depth > 1 && !(py.w[0] == 2u * py.w[1] && py.h[0] == 2u * py.h[1]))
             snprintf(why, sizeof why, "level 0 (%ux%u) does not halve exactly and hierarchy_depth > 1", py.w[0], py.h[0]);
         else if (p->input_y8 && ((p->opt.flags & ORB_FLAG_NMS) || p->arc != 12u))
             snprintf(why, sizeof why, "the tile kernels of the arc/NMS extensions read RGBA");

@@ -209,7 +209,7 @@ __device__ __forceinline__ void segment_append(bool is_corner, uint32_t x, uint3
 
 // Y8: level 0 reads a one-byte-per-pixel Y plane instead of RGBA (ORB_FLAG_INPUT_Y8), grey = f16(byte/255).
 // RB: band height, one of kFrontBandHeights (the host picks it per level: orb_api.hip, program create).
-// UA: the general level-0 RGBA variant -- a width that is not a multiple of 4 (rows only 4-byte aligned: texel by texel loads, a
+// UA: the general level-0 variant (RGBA or Y8) -- a width that is not a multiple of 4 (rows only 4-byte aligned: texel by texel loads, a
 //     partial last quad) and/or a level 1 that is not an exact half (FrontGeom::store_grey: the band also stores its grey rows).
 template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false>
 __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
@@ -321,7 +321,12 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     const bool ok = in_band && (uint32_t)gy_w < (uint32_t)h;
                     dst[u] = ok ? dst_w : -1;
                     const uint32_t off = ok ? off_w : 0u;
-                    if (Y8) {  // four texels = four bytes
+                    if (Y8 && UA) {  // rows start on any byte; the last group of a row may be partial
+                        const uint8_t* q = src0 + (size_t)off;
+                        const int left = ok ? w - tx * 4 : 4;
+                        v[u].x = (uint32_t)q[0] | ((uint32_t)q[left > 1 ? 1 : 0] << 8) | ((uint32_t)q[left > 2 ? 2 : 0] << 16) |
+                                 ((uint32_t)q[left > 3 ? 3 : 0] << 24);
+                    } else if (Y8) {  // four texels = four bytes
                         v[u].x = *reinterpret_cast<const uint32_t*>(src0 + (size_t)off);
                     } else if (UA) {  // rows start on a texel, not on a quad; the last quad of a row may be partial
                         const uint32_t* q = reinterpret_cast<const uint32_t*>(src0 + (size_t)off);
