@@ -347,6 +347,9 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                         const uint16_t* row = srcn + (size_t)(uint32_t)__mul24(gy, w);
                         if ((w & 7) == 0 && x + 8 <= w) {
                             v[u] = *reinterpret_cast<const uint4*>(row + x);
+                        } else if ((w & 1) == 0) {  // even width: rows start on a dword, texel pairs never straddle the row end
+                            const uint32_t* row2 = reinterpret_cast<const uint32_t*>(row + x);
+                            v[u] = make_uint4(row2[0], x + 2 < w ? row2[1] : 0u, x + 4 < w ? row2[2] : 0u, x + 6 < w ? row2[3] : 0u);
                         } else {
                             uint32_t e[8];
 #pragma unroll
