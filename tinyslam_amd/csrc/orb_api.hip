@@ -241,8 +241,8 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
     }
     for (uint32_t m = 1; m < D; m++) {  // orb.rs:413-429
         LaunchScope ls(p, s, KID_MIP);
-        dim3 grid((pyr.w[m] + 63u) / 64u, (pyr.h[m] + 3u) / 4u, n);
-        hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, p->d_gray, pyr, m);
+        dim3 grid((pyr.w[m] + 63u) / 64u, (pyr.h[m] + 4u * kMipRows - 1u) / (4u * kMipRows), n);
+        hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, p->d_gray, pyr, m, (float)pyr.w[m - 1] / (float)pyr.w[m], (float)pyr.h[m - 1] / (float)pyr.h[m]);
     }
     for (uint32_t m = 0; m < D; m++) {  // orb.rs:432-466 (both passes)
         LaunchScope ls(p, s, KID_BLUR);
@@ -443,8 +443,8 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         height /= 2u;
         if (lvl > 0 && !(pyr.w[lvl - 1] == 2u * pyr.w[lvl] && pyr.h[lvl - 1] == 2u * pyr.h[lvl])) {
             LaunchScope ls(p, s, KID_MIP);  // inexact reduction (odd source size): generic bilinear blit
-            dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 3u) / 4u, n);
-            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, d_gray, pyr, lvl);
+            dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 4u * kMipRows - 1u) / (4u * kMipRows), n);
+            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, d_gray, pyr, lvl, (float)pyr.w[lvl - 1] / (float)pyr.w[lvl], (float)pyr.h[lvl - 1] / (float)pyr.h[lvl]);
         }
         FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n, p->band_rows_lvl[lvl]);
         if (gw == 0) g.gh = 0;  // no FAST dispatch at this octave (orb.rs:511-515 with width 0)
@@ -537,8 +537,8 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
     for (uint32_t lvl = 0; lvl < D; lvl++) {
         if (lvl > 0 && !(pyr.w[lvl - 1] == 2u * pyr.w[lvl] && pyr.h[lvl - 1] == 2u * pyr.h[lvl])) {
             LaunchScope ls(p, s, KID_MIP);
-            dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 3u) / 4u, n);
-            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, p->d_gray, pyr, lvl);
+            dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 4u * kMipRows - 1u) / (4u * kMipRows), n);
+            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, p->d_gray, pyr, lvl, (float)pyr.w[lvl - 1] / (float)pyr.w[lvl], (float)pyr.h[lvl - 1] / (float)pyr.h[lvl]);
         }
         IGeom g{};
         g.lvl = lvl;
@@ -626,8 +626,8 @@ int run_fused_x(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
     for (uint32_t lvl = 0; lvl < D; lvl++) {
         if (lvl > 0 && !(pyr.w[lvl - 1] == 2u * pyr.w[lvl] && pyr.h[lvl - 1] == 2u * pyr.h[lvl])) {
             LaunchScope ls(p, s, KID_MIP);
-            dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 3u) / 4u, n);
-            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, p->d_gray, pyr, lvl);
+            dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 4u * kMipRows - 1u) / (4u * kMipRows), n);
+            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, p->d_gray, pyr, lvl, (float)pyr.w[lvl - 1] / (float)pyr.w[lvl], (float)pyr.h[lvl - 1] / (float)pyr.h[lvl]);
         }
         uint32_t gw, gh;
         reference_grid(pyr, lvl, &gw, &gh);

@@ -57,41 +57,65 @@ __global__ __launch_bounds__(256) void k_grayscale_y8(const uint8_t* __restrict_
 
 // ---------------------------------------------------------------------------------------------
 // K2  blit.wgsl:17-36 -- mip m from mip m-1 (CRD-4).  One thread per target texel.
-// grid: (ceil(wd/64), ceil(hd/4), frames), block (64,4)
+// grid: (ceil(wd/64), ceil(hd/(4*kMipRows)), frames), block (64,4)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mip(uint16_t* __restrict__ gray, Pyramid pyr, uint32_t m) {
+constexpr int kMipRows = 4;  // target rows per thread
+// rx, ry: source/target size ratios of the generic case, (float)ws / (float)wd and (float)hs / (float)hd, divided once on the
+// host (IEEE binary32 division on both sides: the same value the kernel used to compute per thread).
+__global__ __launch_bounds__(256) void k_mip(uint16_t* __restrict__ gray, Pyramid pyr, uint32_t m, float rx, float ry) {
     const uint32_t wd = pyr.w[m], hd = pyr.h[m], ws = pyr.w[m - 1], hs = pyr.h[m - 1];
-    const uint32_t x = blockIdx.x * 64u + threadIdx.x, y = blockIdx.y * 4u + threadIdx.y;
-    if (x >= wd || y >= hd) return;
+    const uint32_t x = blockIdx.x * 64u + threadIdx.x;
+    if (x >= wd) return;
     const uint16_t* src = gray + (size_t)blockIdx.z * pyr.stride + pyr.off[m - 1];
     uint16_t* dst = gray + (size_t)blockIdx.z * pyr.stride + pyr.off[m];
-    float v;
+    // a thread takes kMipRows target rows (y, y + 4, ...): their loads are issued together
+    const uint32_t yb = blockIdx.y * (4u * (uint32_t)kMipRows) + threadIdx.y;
     if (ws == 2u * wd && hs == 2u * hd) {
-        const uint32_t two = *reinterpret_cast<const uint32_t*>(src + (size_t)(2u * y) * ws + 2u * x);
-        const uint32_t two2 = *reinterpret_cast<const uint32_t*>(src + (size_t)(2u * y + 1u) * ws + 2u * x);
-        float a = from_half(bits_half((uint16_t)(two & 0xffffu))), b = from_half(bits_half((uint16_t)(two >> 16)));
-        float c = from_half(bits_half((uint16_t)(two2 & 0xffffu))), d = from_half(bits_half((uint16_t)(two2 >> 16)));
-        float top = a + b;
-        float bot = c + d;
-        v = (top + bot) * 0.25f;
-    } else {
-        float rx = (float)ws / (float)wd, ry = (float)hs / (float)hd;
-        float sx = ((float)x + 0.5f) * rx - 0.5f, sy = ((float)y + 0.5f) * ry - 0.5f;
-        float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
-        float fx = sx - fx0, fy = sy - fy0;
-        int ix = (int)fx0, iy = (int)fy0;
-        int x0 = min(max(ix, 0), (int)ws - 1), x1 = min(max(ix + 1, 0), (int)ws - 1);
-        int y0 = min(max(iy, 0), (int)hs - 1), y1 = min(max(iy + 1, 0), (int)hs - 1);
-        float a = from_half(bits_half(src[(size_t)y0 * ws + x0])), b = from_half(bits_half(src[(size_t)y0 * ws + x1]));
-        float c = from_half(bits_half(src[(size_t)y1 * ws + x0])), d = from_half(bits_half(src[(size_t)y1 * ws + x1]));
-        float dab = b - a;
-        float top = a + fx * dab;
-        float dcd = d - c;
-        float bot = c + fx * dcd;
-        float dtb = bot - top;
-        v = top + fy * dtb;
+#pragma unroll
+        for (int r = 0; r < kMipRows; r++) {
+            const uint32_t y = yb + 4u * (uint32_t)r;
+            if (y >= hd) break;
+            const uint32_t two = *reinterpret_cast<const uint32_t*>(src + (size_t)(2u * y) * ws + 2u * x);
+            const uint32_t two2 = *reinterpret_cast<const uint32_t*>(src + (size_t)(2u * y + 1u) * ws + 2u * x);
+            float a = from_half(bits_half((uint16_t)(two & 0xffffu))), b = from_half(bits_half((uint16_t)(two >> 16)));
+            float c = from_half(bits_half((uint16_t)(two2 & 0xffffu))), d = from_half(bits_half((uint16_t)(two2 >> 16)));
+            float top = a + b;
+            float bot = c + d;
+            dst[(size_t)y * wd + x] = half_bits(to_half((top + bot) * 0.25f));
+        }
+        return;
     }
-    dst[(size_t)y * wd + x] = half_bits(to_half(v));
+    const float sx = ((float)x + 0.5f) * rx - 0.5f;
+    const float fx0 = __builtin_floorf(sx);
+    const float fx = sx - fx0;
+    const int ix = (int)fx0;
+    const int x0 = min(max(ix, 0), (int)ws - 1), x1 = min(max(ix + 1, 0), (int)ws - 1);
+    uint32_t ta[kMipRows], tb[kMipRows], tc[kMipRows], td[kMipRows];
+    float fy[kMipRows];
+#pragma unroll
+    for (int r = 0; r < kMipRows; r++) {
+        const uint32_t y = min(yb + 4u * (uint32_t)r, hd - 1u);  // rows past the level repeat the last one (not stored)
+        const float sy = ((float)y + 0.5f) * ry - 0.5f;
+        const float fy0 = __builtin_floorf(sy);
+        fy[r] = sy - fy0;
+        const int iy = (int)fy0;
+        const int y0 = min(max(iy, 0), (int)hs - 1), y1 = min(max(iy + 1, 0), (int)hs - 1);
+        ta[r] = src[(size_t)y0 * ws + x0], tb[r] = src[(size_t)y0 * ws + x1];
+        tc[r] = src[(size_t)y1 * ws + x0], td[r] = src[(size_t)y1 * ws + x1];
+    }
+#pragma unroll
+    for (int r = 0; r < kMipRows; r++) {
+        const uint32_t y = yb + 4u * (uint32_t)r;
+        if (y >= hd) break;
+        const float a = from_half(bits_half((uint16_t)ta[r])), b = from_half(bits_half((uint16_t)tb[r]));
+        const float c = from_half(bits_half((uint16_t)tc[r])), d = from_half(bits_half((uint16_t)td[r]));
+        const float dab = b - a;
+        const float top = a + fx * dab;
+        const float dcd = d - c;
+        const float bot = c + fx * dcd;
+        const float dtb = bot - top;
+        dst[(size_t)y * wd + x] = half_bits(to_half(top + fy[r] * dtb));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
