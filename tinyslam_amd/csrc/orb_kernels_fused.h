@@ -292,6 +292,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
         const int tx = tid - __mul24(ty, per_row);
         const bool lane_ok = ty < rpp;
         const uint8_t* src0 = frames + (size_t)frame * frame_bytes;
+        const __amdgpu_buffer_rsrc_t frame_rsrc =  // gfx9 raw buffer: stride 0, num_records = bytes of the frame (< 2^32, checked at create)
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src0), 0, (int)frame_bytes, 0x00020000);
         const uint16_t* srcn = gray_f + pyr.off[lvl];
         constexpr int U = L0 ? 8 : 4;  // 16-byte loads in flight per thread (VGPR budget: 64 at 8 waves/SIMD): level 0 issues all of a thread's rows at once
         // Level 0 walks with increments: the mirrored source offset, the LDS offset and the row of the thread's first
@@ -316,24 +318,26 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 if (L0) {
                     // rows outside the image are never read by a pixel that passes the guard (fast.wgsl:77);
                     // the input row is the vertically mirrored one (grayscale.wgsl:16-25).  Byte offsets inside a frame
-                    // are < 2^32 (checked at create).  The load itself is unconditional (offset 0 where the item does
-                    // not exist) so that all of a thread's loads are issued back to back.
+                    // are < 2^28 (checked at create).  The load itself is unconditional so that all of a thread's loads
+                    // are issued back to back.
                     const bool ok = in_band && (uint32_t)gy_w < (uint32_t)h;
                     dst[u] = ok ? dst_w : -1;
-                    const uint32_t off = ok ? off_w : 0u;
+                    // BUFFER loads with the frame as the buffer (stride 0, num_records = its bytes): a 32-bit offset per lane
+                    // instead of a 64-bit address, and no select for the items that do not exist -- a row above or below
+                    // the image has an offset past the frame ((h-1-gy)*w*4 >= h*w*4, or negative = huge) and reads zeros,
+                    // any other lane without an item reads something valid that is never stored.  Buffer loads also only
+                    // ask for dword alignment, which is what the general variant's rows have.
+                    const int off = (int)off_w;
                     if (Y8 && UA) {  // rows start on any byte; the last group of a row may be partial
-                        const uint8_t* q = src0 + (size_t)off;
+                        const uint8_t* q = src0 + (size_t)(ok ? off_w : 0u);
                         const int left = ok ? w - tx * 4 : 4;
                         v[u].x = (uint32_t)q[0] | ((uint32_t)q[left > 1 ? 1 : 0] << 8) | ((uint32_t)q[left > 2 ? 2 : 0] << 16) |
                                  ((uint32_t)q[left > 3 ? 3 : 0] << 24);
                     } else if (Y8) {  // four texels = four bytes
-                        v[u].x = *reinterpret_cast<const uint32_t*>(src0 + (size_t)off);
-                    } else if (UA) {  // rows start on a texel, not on a quad; the last quad of a row may be partial
-                        const uint32_t* q = reinterpret_cast<const uint32_t*>(src0 + (size_t)off);
-                        const int left = ok ? w - tx * 4 : 4;  // texels of this quad that exist (>= 1)
-                        v[u] = make_uint4(q[0], q[left > 1 ? 1 : 0], q[left > 2 ? 2 : 0], q[left > 3 ? 3 : 0]);
-                    } else {
-                        v[u] = *reinterpret_cast<const uint4*>(src0 + (size_t)off);
+                        v[u].x = __builtin_amdgcn_raw_buffer_load_b32(frame_rsrc, off, 0, 0);
+                    } else {  // RGBA quad; in the general variant (UA) the last quad of a row may run into the next row: those
+                              // texels land in columns >= w, which nothing ever uses
+                        v[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(frame_rsrc, off, 0, 0));
                     }
                     gy_w += rpp;
                     off_w -= off_step;
