@@ -309,6 +309,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
         for (int lyb = ty; lyb < R + 6; lyb += rpp * U) {
             uint4 v[U];
             int dst[U];
+            bool live[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int ly = lyb + u * rpp;
@@ -320,8 +321,12 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     // the input row is the vertically mirrored one (grayscale.wgsl:16-25).  Byte offsets inside a frame
                     // are < 2^28 (checked at create).  The load itself is unconditional so that all of a thread's loads
                     // are issued back to back.
-                    const bool ok = in_band && (uint32_t)gy_w < (uint32_t)h;
-                    dst[u] = ok ? dst_w : -1;
+                    // A row above or below the image needs no test of its own in the aligned variants: its buffer load
+                    // returns zeros, which are staged like any other row and never read.  The general variant stores
+                    // rows to HBM and reads Y8 bytes through a pointer: it keeps the test.
+                    const bool ok = in_band && (!UA || (uint32_t)gy_w < (uint32_t)h);
+                    live[u] = ok;  // a lane mask in scalar registers: no select here and no compare at the store
+                    dst[u] = dst_w;
                     // BUFFER loads with the frame as the buffer (stride 0, num_records = its bytes): a 32-bit offset per lane
                     // instead of a 64-bit address, and no select for the items that do not exist -- a row above or below
                     // the image has an offset past the frame ((h-1-gy)*w*4 >= h*w*4, or negative = huge) and reads zeros,
@@ -346,7 +351,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     // f16 mip from HBM; texels outside the level are stored as 0 (CRD-6): at octaves >= 1 the
                     // reference's guard and dispatch size let pixels near/over the level edge through (Q8).
                     const int x = tx * 8;
-                    dst[u] = in_band ? __mul24(ly, LS) + kLdsPad + x : -1;
+                    live[u] = in_band;
+                    dst[u] = __mul24(ly, LS) + kLdsPad + x;
                     if (in_band && gy >= 0 && gy < h && x < w) {
                         const uint16_t* row = srcn + (size_t)(uint32_t)__mul24(gy, w);
                         if ((w & 7) == 0 && x + 8 <= w) {
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if (dst[u] >= 0) {
+                if (live[u]) {
                     if (L0) {
                         uint2 out;
                         if (Y8) {
