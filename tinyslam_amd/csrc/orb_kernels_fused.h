@@ -370,6 +370,10 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     }
                 }
             }
+            // The first item is the first to be consumed: pin its load here, in front of the conversions.  Left alone, hipcc
+            // sinks that one load into the conditional block that consumes it -- behind the other seven --, and the loads
+            // returning in order, the first conversion then waits for all eight instead of one.
+            if (L0) asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[0].z), "+v"(v[0].w));
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (live[u]) {
