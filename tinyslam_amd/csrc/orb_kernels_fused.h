@@ -546,20 +546,31 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 if (cand) {  // one LDS atomic for all survivors of this item
                     const uint32_t cand_over = gather_signs(e_ovr);
                     // every lane reserves its own slots with the LDS's returning add (lds_add_rtn, orb_device.h)
-                    uint32_t qs = lds_add_rtn(qa_count, (uint32_t)__builtin_popcount(cand));
-                    while (cand) {
-                        const int p = __builtin_ctz(cand);
-                        cand &= cand - 1u;
-                        const int k = (p >> 3) | ((p & 4) ^ 4);
-                        const bool over = (cand_over >> p) & 1u;
-                        if (qs < (uint32_t)kFrontQueue) {
-                            queue_a[qs] = (uint16_t)((over ? 0x8000u : 0u) | ((uint32_t)lyc << XB) | (uint32_t)(x + k));
-                        } else {  // queue full (pathological frame): finish in place
-                            uint32_t angle;
-                            const bool hit = fast_full_test(rowc + k, LS, thr, &angle);
-                            segment_append(hit, (uint32_t)(x + k), gy, angle, lvl, c_count, seg, geo.seg_cap, two_lists);
+                    const uint32_t n_cand = (uint32_t)__builtin_popcount(cand);
+                    uint32_t qs = lds_add_rtn(qa_count, n_cand);
+                    if (qs + n_cand <= (uint32_t)kFrontQueue) {  // all survivors of the item fit: no test per entry
+                        const uint32_t base = ((uint32_t)lyc << XB) | (uint32_t)x;  // x is a multiple of 8: + k stays inside the x field
+                        while (cand) {
+                            const int p = __builtin_ctz(cand);
+                            cand &= cand - 1u;
+                            const uint32_t k = (uint32_t)((p >> 3) | ((p & 4) ^ 4));
+                            queue_a[qs++] = (uint16_t)((((cand_over >> p) & 1u) << 15) | (base + k));
                         }
-                        qs++;
+                    } else {
+                        while (cand) {
+                            const int p = __builtin_ctz(cand);
+                            cand &= cand - 1u;
+                            const int k = (p >> 3) | ((p & 4) ^ 4);
+                            const bool over = (cand_over >> p) & 1u;
+                            if (qs < (uint32_t)kFrontQueue) {
+                                queue_a[qs] = (uint16_t)((over ? 0x8000u : 0u) | ((uint32_t)lyc << XB) | (uint32_t)(x + k));
+                            } else {  // queue full (pathological frame): finish in place
+                                uint32_t angle;
+                                const bool hit = fast_full_test(rowc + k, LS, thr, &angle);
+                                segment_append(hit, (uint32_t)(x + k), gy, angle, lvl, c_count, seg, geo.seg_cap, two_lists);
+                            }
+                            qs++;
+                        }
                     }
                 }
             }
