@@ -693,17 +693,23 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     const int r = i / (Q - Qa), x = Qa + i % (Q - Qa);
                     blur_lvl[(size_t)(uint32_t)(__mul24(y0 + r, w) + x)] = half_bits(to_half(blur_k2[r].w));
                 }
-                // per-pixel stretch [Q, w): a thread takes one column and kBlurRowsPerItem rows of the band; the
-                // column's tap positions come from the band's table, so no blur_tap() (a division and a floor) runs here
+                // per-pixel stretch [Q, w): a thread takes two neighbouring columns (level 0) and RPI rows of the band; the columns' tap
+                // positions come from the band's table, so no blur_tap() (a division and a floor) runs here.  Pass 2 at
+                // column x lerps pass 1 at columns j, j + 1 and at x + 1 at j + 1, j + 2: the middle one is evaluated once
+                // (when the table says it is the same sample -- it is, save for clamping at the row's end).
                 const int nvar = w - Q;
                 if (nvar > 0) {
                     constexpr int RPI = 4;
-                    const float inv_nvar = 1.0f / (float)nvar;
-                    const int n_items = ((rows + RPI - 1) / RPI) * nvar;
+                    constexpr int CPI = L0 ? 2 : 1;  // columns per item: pairs at level 0 (-1.8 %); the narrower levels have too few items (+3 % there)
+                    const int npair = (nvar + CPI - 1) / CPI;
+                    const float inv_npair = 1.0f / (float)npair;
+                    const int n_items = ((rows + RPI - 1) / RPI) * npair;
                     for (int i = tid; i < n_items; i += NT) {
-                        const int rg = (int)(((float)i + 0.5f) * inv_nvar);
-                        const int c = i - __mul24(rg, nvar);
-                        const BlurCol e = blur_cols[c];
+                        const int rg = (int)(((float)i + 0.5f) * inv_npair);
+                        const int c = (i - __mul24(rg, npair)) * CPI;
+                        const bool second = CPI == 2 && c + 1 < nvar;
+                        const BlurCol e = blur_cols[c], e2 = blur_cols[second ? c + 1 : c];
+                        const bool shared = e2.a0 == e.b0 && e2.a1 == e.b1 && e2.fa == e.fb;
 #pragma unroll
                         for (int k = 0; k < RPI; k++) {
                             const int r = rg * RPI + k;
@@ -722,16 +728,25 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                                 acc = acc + k1.z;
                                 return from_half(to_half(acc));
                             };
+                            auto pass2 = [&](float u0, float u1, float f2) {
+                                const float d = u1 - u0;
+                                const float fd = f2 * d;
+                                const float lerp = u0 + fd;
+                                const float ws = lerp * kBlurWgt[1];
+                                float acc = k2.x + ws;
+                                acc = acc + k2.y;
+                                acc = acc + k2.z;
+                                return half_bits(to_half(acc));
+                            };
                             const float u0 = pass1(e.a0, e.a1, e.fa);
                             const float u1 = pass1(e.b0, e.b1, e.fb);
-                            const float d = u1 - u0;
-                            const float fd = e.f2 * d;
-                            const float lerp = u0 + fd;
-                            const float ws = lerp * kBlurWgt[1];
-                            float acc = k2.x + ws;
-                            acc = acc + k2.y;
-                            acc = acc + k2.z;
-                            blur_lvl[(size_t)(uint32_t)(__mul24(y0 + r, w) + Q + c)] = half_bits(to_half(acc));
+                            uint16_t* out = blur_lvl + (size_t)(uint32_t)(__mul24(y0 + r, w) + Q + c);
+                            out[0] = pass2(u0, u1, e.f2);
+                            if (second) {
+                                const float v0 = shared ? u1 : pass1(e2.a0, e2.a1, e2.fa);
+                                const float v1 = pass1(e2.b0, e2.b1, e2.fb);
+                                out[1] = pass2(v0, v1, e2.f2);
+                            }
                         }
                     }
                 }
