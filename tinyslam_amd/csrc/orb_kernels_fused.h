@@ -35,6 +35,7 @@ constexpr int kFrontQueue = 4096;    // pre-test survivor queue, 16-bit entries
 // per workgroup), wide ones flat bands (two workgroups per CU).
 constexpr int kFrontBandHeights[] = {64, 32, 16, 8};
 __host__ __device__ constexpr int front_x_bits(int rows) { return rows == 64 ? 9 : rows == 32 ? 10 : rows == 16 ? 11 : 12; }
+constexpr int kFrontSignPos0 = 7;  // bit of pixel 0 in the gathered sign word of a pre-test item (pixel k: 8 * (k & 3) + (k < 4 ? 7 : 3))
 constexpr int kFrontMaxWidth = 2048;     // widest level 0 of the 16-row bands (11-bit x in the 16-bit queue entries)
 constexpr int kFrontMaxWidthWide = 4096; // ... of the 8-row bands (12-bit x)
 constexpr int kLdsPad = 8;           // halfs of padding left of column 0
@@ -479,6 +480,12 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
             const int n_items = R * g8;
             // fast.wgsl:77 -- level-0 dimensions for every octave, u32 arithmetic (Q8)
             const uint32_t lim_x = pyr.w[0] - 16u, lim_y = pyr.h[0] - 16u;
+            // the item that holds column lim_x (the first one past the guard) and the sign bits of its pixels below lim_x
+            const int x_cut = (int)(lim_x & ~7u);
+            uint32_t keep_cut = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k < (int)(lim_x & 7u)) keep_cut |= 1u << (8 * (k & 3) + (k < 4 ? 7 : 3));
             // thr_lo: one f16 ulp below RD16(thr) (see below); -min_subnormal when that would pass zero
             uint32_t tb = half_bits(to_half(thr));
             if (from_half(bits_half((uint16_t)tb)) > thr) tb--;
@@ -533,16 +540,11 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     return (p01 & 0x80808080u) | ((p23 & 0x80808080u) >> 4);
                 };
                 uint32_t cand = gather_signs(e_any);
-                {  // fast.wgsl:77 guard on x: keep pixels k with 16 < x+k < lim_x (only the two items at the ends of a row cut)
-                    const int first = 17 - x, past = (int)lim_x - x;
-                    if (first > 0 || past < 8) {
-                        uint32_t keep = 0;
-    #pragma unroll
-                        for (int k = 0; k < 8; k++)
-                            if (k >= first && k < past) keep |= 1u << (8 * (k & 3) + (k < 4 ? 7 : 3));
-                        cand &= keep;
-                    }
-                }
+                // fast.wgsl:77 guard on x: keep pixels k with 16 < x+k < lim_x.  Only two items of a row are cut -- the one
+                // at x = 16 loses pixel 0, the one that holds column lim_x loses its tail --, and both masks are the same for
+                // every row: two compares and selects here instead of eight each.
+                cand &= x == 16 ? ~(1u << kFrontSignPos0) : ~0u;
+                cand &= x == x_cut ? keep_cut : ~0u;
                 if (cand) {  // one LDS atomic for all survivors of this item
                     const uint32_t cand_over = gather_signs(e_ovr);
                     // every lane reserves its own slots with the LDS's returning add (lds_add_rtn, orb_device.h)
