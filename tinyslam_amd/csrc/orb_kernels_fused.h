@@ -223,6 +223,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     static_assert((RB - 1) < (1 << (15 - XB)), "band row does not fit the queue entry");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int LS = (int)geo.ls, TS = (int)geo.ts;
+    const int row3 = 3 * LS + kLdsPad;  // band row 0, column 0 inside the staged rows (three halo rows above, the left pad)
     half_t* const grey = reinterpret_cast<half_t*>(lds_raw);             // (R+6) rows x LS
     half_t* const tmp = grey + (R + 6) * LS;                              // 2 x TC rows x TS
     // Queues of the FAST phase, 16-bit entries [15] run polarity (1 = brighter), [14:11] band row, [10:0] x.
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 const uint32_t gy = (uint32_t)(y0 + lyc);
                 if (!(gy < geo.gh && gy > 16u && gy < lim_y)) continue;
                 if ((uint32_t)x + 7u <= 16u || (uint32_t)x >= lim_x) continue;
-                const half_t* rowc = grey + __mul24(lyc + 3, LS) + kLdsPad + x;
+                const half_t* rowc = grey + row3 + (int)__umul24((uint32_t)lyc, (uint32_t)LS) + x;  // row lyc + 3 of the staged rows
                 const uint2 qa = *reinterpret_cast<const uint2*>(rowc - 4);
                 const uint4 qb = *reinterpret_cast<const uint4*>(rowc);
                 const uint2 qc = *reinterpret_cast<const uint2*>(rowc + 8);
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 const int lyc = (int)((e >> XB) & (uint32_t)(RB - 1));
                 *x = e & ((1u << XB) - 1u);
                 *gy = (uint32_t)(y0 + lyc);
-                return grey + __mul24(lyc + 3, LS) + kLdsPad + (int)*x;
+                return grey + row3 + (int)__umul24((uint32_t)lyc, (uint32_t)LS) + (int)*x;
             };
             // stage 1: diagonal 3-of-4 filter (a necessary condition of a 12-run), A -> B
             const uint32_t n_a = min(*qa_count, (uint32_t)kFrontQueue);
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 const int xd = (i - __mul24(r, g4)) * 4;
                 const int yd = (y0 >> 1) + r;
                 if (yd >= hd) continue;
-                const half_t* top = grey + __mul24(2 * r + 3, LS) + kLdsPad + 2 * xd;
+                const half_t* top = grey + row3 + (int)__umul24((uint32_t)r, (uint32_t)(2 * LS)) + 2 * xd;
                 const uint4 qt = *reinterpret_cast<const uint4*>(top);
                 const uint4 qb = *reinterpret_cast<const uint4*>(top + LS);
                 const uint32_t tw[4] = {qt.x, qt.y, qt.z, qt.w}, bw[4] = {qb.x, qb.y, qb.z, qb.w};
