@@ -21,6 +21,10 @@ HIPCC_FLAGS = [
     # wave-aggregate LDS/global atomic adds of lane-varying amounts with a DPP scan; the default
     # ("Iterative") serialises over the active lanes with a scalar loop of ~8 instructions per lane
     "-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP",
+    # no SLP vectorisation: it pairs scalar binary32 products and sums of k_brief_t's literal pattern into v_pk_mul/add_f32
+    # (half rate on gfx950) behind hundreds of v_mov that assemble their operands; the kernels that want packed
+    # arithmetic ask for it themselves (float2 / half2 types)
+    "-fno-slp-vectorize",
 ]
 
 
