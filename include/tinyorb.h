@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TINYORB_ABI_VERSION 2
+#define TINYORB_ABI_VERSION 3
 
 /* status codes (the reference panics instead: orb.rs:553 unwrap, label look-ups) */
 #define ORB_OK 0
@@ -139,6 +139,12 @@ int orb_extract_batch_device(OrbProgram *p, const uint8_t *frames_dev, uint32_t 
 /* Same with host frames: they are pinned in place for the call and uploaded in chunks on a copy stream while the
  * kernels of the chunks already on the device run.  Blocks until the uploads are done; results as above. */
 int orb_extract_batch_host(OrbProgram *p, const uint8_t *frames_host, uint32_t n_frames);
+/* The same for frames that already lie in PINNED host memory (orb_host_alloc, or registered with the HIP runtime by the
+ * caller), without pinning and without blocking: returns once the chunked uploads and the kernels are enqueued.
+ * orb_upload_sync() waits until the last upload has left the host array (which may then be reused); the kernels may
+ * still be running (orb_batch_sync). */
+int orb_extract_batch_pinned(OrbProgram *p, const uint8_t *frames_pinned, uint32_t n_frames);
+int orb_upload_sync(OrbProgram *p);
 /* Wait for the last batched call to finish. */
 int orb_batch_sync(OrbProgram *p);
 /* Raw per-frame counters of the last batch (synchronises). */
@@ -209,11 +215,18 @@ void *orb_program_stream(OrbProgram *p);
 /* ---- one node, several GPUs (BASELINE.json configs[4]).  NOT in the reference, which drives one wgpu
  * device (orb.rs:47-51): an OrbNode owns one OrbProgram per listed device of this process and shards a batch of
  * independent frames over them in contiguous ranges (rank r gets frames [F*r/n, F*(r+1)/n) -- no data-path
- * collective).  The only exchange is the collate to the first device: per-frame counters by ncclAllGather, then the
- * packed records of every other device by grouped ncclSend/ncclRecv of their EXACT sizes (RCCL over xGMI; librccl is
- * loaded on first use, a single-GPU program never needs it). ---- */
+ * collective).  The only exchange is the collate to the first device: every other device sends its packed records by
+ * grouped ncclSend/ncclRecv of their EXACT sizes (RCCL over xGMI, one link per peer; librccl is loaded on first use, a
+ * single-GPU program never needs it); the per-frame counters reach the host through pinned memory, no all-gather.
+ *
+ * A job runs through three stages -- extract, collate_begin, collate_end -- and up to two jobs may be outstanding, so
+ * that a host which streams batches overlaps the collate of batch k with the kernels of batch k+1:
+ *     orb_node_extract_batch(k);  orb_node_collate_begin() [job k-1];  orb_node_collate_end() [job k-1];  ...
+ * One blocking call per job stays available: orb_node_extract_batch + orb_node_collate (the reference's call shape,
+ * orb.rs:469-557, is one blocking call per frame). ---- */
 typedef struct OrbNode OrbNode;
-/* options->device is ignored (devices[] decides); options->max_batch is the largest shard of one device. 
+/* options->device is ignored (devices[] decides); options->max_batch is the largest shard of one device;
+ * ORB_FLAG_DOUBLE_OUTPUT is implied.  ORB_FLAG_INPUT_Y8 nodes take one byte per pixel, as their programs do.
  * TINYORB_NODE_LOOPBACK=1 in the environment (tests): devices may repeat and the exchange uses device copies, not RCCL. */
 int orb_node_create(const int *devices, int n_devices, const OrbConfig *config, const OrbOptions *options, OrbNode **out);
 void orb_node_destroy(OrbNode *node);
@@ -223,17 +236,27 @@ int orb_node_device_count(const OrbNode *node);
 OrbProgram *orb_node_program(OrbNode *node, int rank);
 /* Frame range [*lo, *hi) of rank `rank` for a job of n_frames frames. */
 int orb_node_shard(const OrbNode *node, uint32_t n_frames, int rank, uint32_t *lo, uint32_t *hi);
-/* frames_dev[r]: rank r's shard, resident on ITS device (frames lo_r.. of the job, contiguous RGBA8).  Asynchronous:
- * every device runs its shard on its own stream. */
+/* Stage 1.  frames_dev[r]: rank r's shard, resident on ITS device (frames lo_r.. of the job, contiguous).  Asynchronous:
+ * every device runs its shard on its own stream and packs the results behind it on a second one.  ORB_ESTATE when two
+ * jobs are already outstanding. */
 int orb_node_extract_batch(OrbNode *node, const uint8_t *const *frames_dev, uint32_t n_frames);
-/* The same from one host array of n_frames frames (each shard is uploaded to its device first). */
+/* The same from one host array of n_frames frames: every shard is uploaded in chunks while its first chunks already
+ * compute (orb_extract_batch_pinned; the array is pinned in place for the call).  Returns when the uploads are done. */
 int orb_node_extract_batch_host(OrbNode *node, const uint8_t *frames_host, uint32_t n_frames);
-/* Collates the last job on the first device and blocks until it is there.  counts[n_frames] and offsets[n_frames + 1]
- * are HOST arrays (as in orb_batch_read_all; either may be NULL); *corners_dev / *descriptors_dev receive the
- * addresses of the packed records on the first device (frame order, valid until the next collate).  Between devices
- * the records travel as transport records of their exact number (see orb_batch_pack_transport). */
+/* Stage 2, for the oldest job that has not begun it: waits on the host for that job's per-frame counters (its kernels
+ * and pack; later jobs keep the devices busy meanwhile) and enqueues the exchange -- exact-size transport records to
+ * the first device, expanded there behind its own records.  Does not wait for the exchange. */
+int orb_node_collate_begin(OrbNode *node);
+/* Stage 3, for the oldest job (begins its exchange if nobody has): blocks until the collated result is on the first
+ * device.  counts[n_frames] and offsets[n_frames + 1] are HOST arrays (as in orb_batch_read_all; either may be NULL);
+ * *corners_dev / *descriptors_dev receive the addresses of the packed records (frame order), which stay valid while
+ * the next TWO jobs are extracted (three result buffers). */
+int orb_node_collate_end(OrbNode *node, uint32_t *counts, uint64_t *offsets, void **corners_dev, void **descriptors_dev);
+/* orb_node_collate_begin + orb_node_collate_end for the oldest job: the blocking form. */
 int orb_node_collate(OrbNode *node, uint32_t *counts, uint64_t *offsets, void **corners_dev, void **descriptors_dev);
-/* Copies the collated records to the host (after orb_node_collate); capacity in records. */
+/* Jobs extracted and not yet ended (0..2). */
+int orb_node_pending(const OrbNode *node);
+/* Copies the records of the job ended last to the host; capacity in records. */
 int orb_node_read_collated(OrbNode *node, CornerData *corners, CornerDescriptor *descriptors, size_t capacity);
 
 /* ---- descriptor matching (the SLAM stage that consumes this path's output; NOT in the

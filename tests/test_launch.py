@@ -63,6 +63,38 @@ def test_launcher_relays_a_failing_rank(tmp_path):
     assert r.returncode == 7
 
 
+def test_launcher_kills_a_rank_that_ignores_sigterm(tmp_path):
+    """Rank 1 fails; rank 0 ignores SIGTERM and would sleep for ten minutes (a rank blocked in a collective): the
+    launcher must escalate to SIGKILL after its grace period and return rank 1's status."""
+    stub = tmp_path / "stubborn.py"
+    stub.write_text(
+        "import os, signal, sys, time\n"
+        "if os.environ['RANK'] == '1':\n"
+        "    time.sleep(0.3); sys.exit(5)\n"
+        "signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+        "open(os.path.join(os.environ['STUB_DIR'], 'rank0.pid'), 'w').write(str(os.getpid()))\n"
+        "time.sleep(600)\n")
+    driver = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from tinyslam_amd import launch\n"
+        "sys.exit(launch.launch_ranks(2, [%r], grace=1.0))\n" % (ROOT, str(stub)))
+    env = dict(os.environ, STUB_DIR=str(tmp_path))
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, "-c", driver], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 5, (r.returncode, r.stderr)
+    assert time.monotonic() - t0 < 30
+    pid = int(open(tmp_path / "rank0.pid").read())
+    try:
+        os.kill(pid, 0)
+        alive = True
+    except OSError:
+        alive = False
+    assert not alive, "the stubborn rank survived the launcher"
+
+
 def test_bench_hands_over_to_the_launcher_before_importing_torch(tmp_path):
     """bench.py --gpus 3 without WORLD_SIZE: main() must reach launch_ranks with torch not imported.  The launcher is
     replaced by a recorder so nothing is spawned."""

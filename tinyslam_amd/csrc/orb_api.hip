@@ -48,6 +48,8 @@ struct OrbProgram {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // chunked uploads of orb_extract_batch_host
     hipEvent_t order_event = nullptr;   // orders work on a caller's stream behind the last batch
+    std::vector<hipEvent_t> upload_events;  // one per chunk of a chunked upload (reused)
+    hipEvent_t upload_done = nullptr;       // behind the last host-to-device copy of the last host batch
     // orb_batch_pack / orb_batch_fetch: packed records of an output set on the device, its counters and offsets in pinned
     // host memory (written by the packing kernel), and the event that says the pack is done
     CornerData* d_pack_c[2] = {nullptr, nullptr};
@@ -1096,6 +1098,8 @@ void orb_program_destroy(OrbProgram* p) {
     if (p->stream) (void)hipStreamDestroy(p->stream);
     if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     if (p->order_event) (void)hipEventDestroy(p->order_event);
+    for (hipEvent_t ev : p->upload_events) (void)hipEventDestroy(ev);
+    if (p->upload_done) (void)hipEventDestroy(p->upload_done);
     for (int set = 0; set < 2; set++) {
         (void)hipFree(p->d_pack_c[set]);
         (void)hipFree(p->d_pack_d[set]);
@@ -1193,6 +1197,62 @@ int orb_extract_batch_device(OrbProgram* p, const uint8_t* frames_dev, uint32_t 
     return ORB_OK;
 }
 
+// Chunked upload of pinned host frames on the copy stream, the kernels of chunk c running while chunk c+1 is still
+// crossing PCIe (only the fused path can work on a sub-range of the batch).  Asynchronous.
+static int upload_chunked_and_run(OrbProgram* p, const uint8_t* frames_pinned, uint32_t n_frames, hipStream_t s) {
+    const uint32_t chunk = 16;
+    const size_t total = p->frame_bytes * n_frames;
+    if (!p->upload_done) HIP_TRY(p, hipEventCreateWithFlags(&p->upload_done, hipEventDisableTiming));
+    if (!p->fused || n_frames <= chunk) {
+        HIP_TRY(p, hipMemcpyAsync(p->d_input, frames_pinned, total, hipMemcpyHostToDevice, s));
+        HIP_TRY(p, hipEventRecord(p->upload_done, s));
+        return run_pipeline(p, p->d_input, n_frames, s);
+    }
+    if (!p->copy_stream) HIP_TRY(p, hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    const size_t n_chunks = (n_frames + chunk - 1) / chunk;
+    while (p->upload_events.size() < n_chunks) {
+        hipEvent_t ev = nullptr;
+        HIP_TRY(p, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        p->upload_events.push_back(ev);
+    }
+    // the input slab is reused: the first upload must not overtake the kernels of the previous batch that still read it
+    if (!p->order_event) HIP_TRY(p, hipEventCreateWithFlags(&p->order_event, hipEventDisableTiming));
+    HIP_TRY(p, hipEventRecord(p->order_event, s));
+    HIP_TRY(p, hipStreamWaitEvent(p->copy_stream, p->order_event, 0));
+    for (uint32_t c = 0, f0 = 0; f0 < n_frames; c++, f0 += chunk) {
+        const uint32_t m = n_frames - f0 < chunk ? n_frames - f0 : chunk;
+        HIP_TRY(p, hipMemcpyAsync(p->d_input + (size_t)f0 * p->frame_bytes, frames_pinned + (size_t)f0 * p->frame_bytes,
+                                  (size_t)m * p->frame_bytes, hipMemcpyHostToDevice, p->copy_stream));
+        HIP_TRY(p, hipEventRecord(p->upload_events[c], p->copy_stream));
+        HIP_TRY(p, hipStreamWaitEvent(s, p->upload_events[c], 0));
+        if (int rc = run_fused_range(p, p->d_input, f0, m, s)) return rc;
+    }
+    HIP_TRY(p, hipEventRecord(p->upload_done, p->copy_stream));
+    p->planes_valid = true;
+    return ORB_OK;
+}
+
+int orb_extract_batch_pinned(OrbProgram* p, const uint8_t* frames_pinned, uint32_t n_frames) {
+    if (!p) return ORB_EINVAL;
+    if (!frames_pinned) return fail(p, ORB_EINVAL, "frames_pinned is NULL");
+    if (n_frames == 0 || n_frames > p->max_batch)
+        return fail(p, ORB_EINVAL, "n_frames %u outside 1..=max_batch (%u)", n_frames, p->max_batch);
+    HIP_TRY(p, hipSetDevice(p->device));
+    if (int rc = ensure_input(p)) return rc;
+    if (int rc = upload_chunked_and_run(p, frames_pinned, n_frames, p->stream)) return rc;
+    p->last_batch = n_frames;
+    p->last_stream = p->stream;
+    p->single_valid = false;
+    return ORB_OK;
+}
+
+int orb_upload_sync(OrbProgram* p) {
+    if (!p) return ORB_EINVAL;
+    HIP_TRY(p, hipSetDevice(p->device));
+    if (p->upload_done) HIP_TRY(p, hipEventSynchronize(p->upload_done));  // recorded behind the last upload
+    return ORB_OK;
+}
+
 int orb_extract_batch_host(OrbProgram* p, const uint8_t* frames_host, uint32_t n_frames) {
     if (!p) return ORB_EINVAL;
     if (!frames_host) return fail(p, ORB_EINVAL, "frames_host is NULL");
@@ -1203,43 +1263,20 @@ int orb_extract_batch_host(OrbProgram* p, const uint8_t* frames_host, uint32_t n
     hipStream_t s = p->stream;
     // Ingest (README.md:42 of the reference): the caller's frames are pinned in place for the
     // duration of the call and uploaded in chunks on a copy stream; the kernels of chunk c run while chunk c+1 is
-    // still crossing PCIe.  Only the fused path can work on a sub-range of the batch.
-    const uint32_t chunk = 16;
+    // still crossing PCIe.
     const size_t total = p->frame_bytes * n_frames;
     const bool pinned = hipHostRegister(const_cast<uint8_t*>(frames_host), total, hipHostRegisterDefault) == hipSuccess;
     if (!pinned) (void)hipGetLastError();
     int rc = ORB_OK;
-    if (!p->fused || !pinned || n_frames <= chunk) {
+    if (!pinned) {  // pageable source: the copy is staged by the runtime
         hipError_t e = hipMemcpyAsync(p->d_input, frames_host, total, hipMemcpyHostToDevice, s);
         if (e != hipSuccess) rc = fail(p, ORB_EHIP, "upload failed: %s", hipGetErrorString(e));
         if (!rc) rc = run_pipeline(p, p->d_input, n_frames, s);
     } else {
-        if (!p->copy_stream) {
-            hipError_t e = hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking);
-            if (e != hipSuccess) rc = fail(p, ORB_EHIP, "copy stream: %s", hipGetErrorString(e));
-        }
-        std::vector<hipEvent_t> up((n_frames + chunk - 1) / chunk, nullptr);
-        for (uint32_t c = 0, f0 = 0; !rc && f0 < n_frames; c++, f0 += chunk) {
-            const uint32_t m = n_frames - f0 < chunk ? n_frames - f0 : chunk;
-            hipError_t e = hipMemcpyAsync(p->d_input + (size_t)f0 * p->frame_bytes, frames_host + (size_t)f0 * p->frame_bytes,
-                                          (size_t)m * p->frame_bytes, hipMemcpyHostToDevice, p->copy_stream);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&up[c], hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventRecord(up[c], p->copy_stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(s, up[c], 0);
-            if (e != hipSuccess) {
-                rc = fail(p, ORB_EHIP, "chunked upload failed: %s", hipGetErrorString(e));
-                break;
-            }
-            rc = run_fused_range(p, p->d_input, f0, m, s);
-        }
-        if (hipStreamSynchronize(p->copy_stream) != hipSuccess && !rc) rc = fail(p, ORB_EHIP, "copy stream sync failed");
-        for (hipEvent_t ev : up)
-            if (ev) (void)hipEventDestroy(ev);
-        if (!rc) p->planes_valid = true;
-    }
-    if (pinned) {
+        rc = upload_chunked_and_run(p, frames_host, n_frames, s);
         // the host pages must stay pinned until the last upload has finished
-        if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(p, ORB_EHIP, "stream sync failed");
+        if (p->upload_done && hipEventSynchronize(p->upload_done) != hipSuccess && !rc) rc = fail(p, ORB_EHIP, "upload sync failed");
+        if (rc) (void)hipStreamSynchronize(s), (void)(p->copy_stream && hipStreamSynchronize(p->copy_stream));
         (void)hipHostUnregister(const_cast<uint8_t*>(frames_host));
     }
     if (rc) return rc;

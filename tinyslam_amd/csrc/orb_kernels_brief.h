@@ -292,6 +292,10 @@ __global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ b
                 }
                 if (where[rr] >= 0) *reinterpret_cast<uint4*>(&patch[where[rr]]) = v;
             }
+            // the patch is filled with 16-byte stores and sampled as halfs by OTHER lanes of this wave: order the two
+            // (LDS is in order within a wave; the fence keeps the compiler from moving the differently typed accesses)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             const int xo = (int)r.x - c0;  // 18..25
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -299,6 +303,8 @@ __global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ b
                 const uint32_t vb = patch[(dyb[e] + kBriefHalo) * kNfPatchCols + xo + dxb[e]];
                 bal[e] = __ballot(va > vb);  // non-negative f16: bit patterns order like the values (brief.wgsl:62)
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next keypoint's fill overwrites what was just sampled
+            __builtin_amdgcn_wave_barrier();
         } else {
             // ---- odd width: rows of the plane are only 2-byte aligned; gather sample by sample
             const int gy = (int)r.y - kBriefHalo + (int)lane;  // lanes 0..36 are the patch rows

@@ -450,8 +450,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     }
 
     // ---- blur column table (the last threads of the workgroup, so that wave 0 is not doing both) ----
-    if ((geo.phase_mask & 8u) && tid >= NT - (int)geo.n_var) {
-        const int c = NT - 1 - tid;
+    if (geo.phase_mask & 8u)
+    for (int c = NT - 1 - tid; c < (int)geo.n_var; c += NT) {  // one entry per thread while n_var <= NT (it is about 0.12 w)
         const int x = (int)geo.blur_q + c, P = (int)geo.blur_p;
         const BlurTap t2 = blur_tap((uint32_t)x, (uint32_t)w, kBlurOff[1]);
         BlurCol e;

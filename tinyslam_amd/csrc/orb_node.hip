@@ -3,13 +3,20 @@
 //
 // The reference has no counterpart (one wgpu device per OrbProgram, orb.rs:47-51).  Built only on the public C ABI of
 // libtinyorb + HIP + RCCL.  Frames are independent, so there is NO data-path collective: rank r extracts the contiguous
-// range [F*r/n, F*(r+1)/n) on its own device and stream, all devices at once.  The collate is the only exchange:
-//   1. every rank packs its stored records back to back (k_compact) -- rank 0 straight into the collate buffer;
-//   2. ncclAllGather of the per-frame counters (4 B per frame);
-//   3. the counters go to the host once, which gives every rank's exact payload size;
-//   4. one group of ncclSend/ncclRecv: rank r -> rank 0, exactly S_r * 16 B of keypoints and S_r * 32 B of descriptors,
-//      received at rank r's offset of the frame-ordered collate buffer.  xGMI is point to point: every peer uses its own
-//      link to rank 0, nothing is relayed, nothing is padded.
+// range [F*r/n, F*(r+1)/n) on its own device and stream, all devices at once.  The collate is the only exchange, and it
+// is a PIPELINE of three stages per job, so that batch k+1 computes while batch k is collated:
+//   extract  kernels of the shard on the device's compute stream (output set k % 2); behind them, on the device's PACK
+//            stream, the stored records are packed back to back -- rank 0 with k_compact straight into the collated
+//            arrays, the others as 40-byte transport records into a wire buffer -- and the per-frame counters and
+//            offsets land in pinned host memory (written by the packing kernel / one small copy): no host
+//            synchronisation, and no all-gather -- one process sees every rank's counters;
+//   begin    the host waits for the pack events only (the next job's kernels are already queued), reads the exact
+//            payload sizes and enqueues, on every device's EXCHANGE stream, one group of ncclSend/ncclRecv: rank r ->
+//            rank 0, exactly S_r * 40 bytes.  xGMI is point to point: every peer uses its own link to rank 0, nothing
+//            is relayed, nothing is padded.  Rank 0 then expands the records behind its own (k_unpack_transport);
+//   end      waits for that exchange and hands out the frame-ordered result.
+// Buffers: two output sets and two wire buffers per device (slot k % 2), three collated result buffers on rank 0
+// (k % 3: a result stays valid while the next two jobs are extracted), all ordered by events.
 // librccl is opened with dlopen on first use, so a single-GPU user of libtinyorb never loads it.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -20,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <string>
 #include <vector>
@@ -32,7 +40,6 @@ struct Rccl {
     void* handle = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -42,31 +49,46 @@ struct Rccl {
 
 thread_local std::string g_node_create_error;
 
+constexpr int kSlots = 2;      // output sets / wire buffers / pinned counter sets
+constexpr int kCollSlots = 3;  // collated result buffers on rank 0
+
+struct NodeJob {
+    uint32_t n_frames = 0;
+    int slot = 0, coll = 0;
+    bool exchanging = false;
+    std::vector<uint32_t> shard_n;
+};
+
 }  // namespace
 
 struct OrbNode {
     int n = 0;
     std::vector<int> devices;
     std::vector<OrbProgram*> progs;
-    std::vector<hipStream_t> streams;
+    std::vector<hipStream_t> streams;       // compute: the program's own stream
+    std::vector<hipStream_t> pack_streams;  // packing of a finished shard
+    std::vector<hipStream_t> xchg_streams;  // Send/Recv (or loopback copies) and the expansion on rank 0
     OrbConfig cfg{};
     uint32_t max_batch = 1;
     size_t frame_bytes = 0;
     Rccl rccl;
     std::vector<ncclComm_t> comms;
-    std::vector<uint32_t*> d_sendcounts;          // [max_batch] per device, zero padded
-    std::vector<uint32_t*> d_allcounts;           // [n * max_batch] per device
-    std::vector<CornerData*> d_pack_c;            // rank 0 only: the collated keypoints [n * max_batch * cap] (else null)
-    std::vector<CornerDescriptor*> d_pack_d;
-    bool loopback = false;                        // TINYORB_NODE_LOOPBACK=1: the exchange runs as device copies, not RCCL (see orb_node_create)
-    std::vector<void*> d_wire;                    // 40-byte transport records (tinyorb.h): rank r >= 1 its own [max_batch * cap]
-                                                  // to send, rank 0 the received ones [(n - 1) * max_batch * cap] (null when n == 1)
-    std::vector<uint8_t*> d_frames;               // per device, only for orb_node_extract_batch_host
-    uint32_t* h_allcounts = nullptr;              // pinned [n * max_batch]
-    std::vector<uint32_t> shard_n;                // frames of each rank in the last job
-    uint32_t last_frames = 0;
-    bool extracted = false, collated = false;
+    bool loopback = false;  // TINYORB_NODE_LOOPBACK=1: the exchange runs as device copies, not RCCL (see orb_node_create)
+    // per slot (job k uses slot k % kSlots) and rank
+    std::vector<void*> d_wire[kSlots];         // 40-byte transport records (tinyorb.h): rank r >= 1 its own [max_batch * cap]
+                                               // to send, rank 0 the received ones [(n - 1) * max_batch * cap] (null when n == 1)
+    std::vector<uint32_t*> h_counts[kSlots];   // pinned [max_batch]: raw per-frame counters of the rank's shard
+    std::vector<uint64_t*> h_offsets[kSlots];  // pinned [max_batch + 1]: exclusive prefix of the stored counts
+    std::vector<hipEvent_t> ev_kernels[kSlots], ev_pack[kSlots], ev_xchg[kSlots];
+    std::vector<char> pack_set[kSlots], xchg_set[kSlots];  // has the event been recorded (is there anything to wait for)?
+    CornerData* d_coll_c[kCollSlots] = {nullptr, nullptr, nullptr};  // rank 0: collated keypoints [n * max_batch * cap]
+    CornerDescriptor* d_coll_d[kCollSlots] = {nullptr, nullptr, nullptr};
+    std::vector<uint8_t*> d_frames;            // per device, only for orb_node_extract_batch_host
+    std::deque<NodeJob> jobs;                  // outstanding jobs, oldest first (at most kSlots)
+    uint64_t job_seq = 0;
+    bool collated = false;                     // a job has been ended: read_collated has something to read
     uint64_t total_records = 0;
+    int last_coll = 0;
     std::string err;
 };
 
@@ -90,13 +112,6 @@ int nfail(OrbNode* node, int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                               \
         if (e_ != hipSuccess) return nfail((node), ORB_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
-#define NODE_NCCL(node, expr)                                                                                  \
-    do {                                                                                                       \
-        ncclResult_t r_ = (expr);                                                                              \
-        if (r_ != ncclSuccess)                                                                                 \
-            return nfail((node), ORB_EHIP, "%s failed: %s", #expr,                                            \
-                         (node)->rccl.GetErrorString ? (node)->rccl.GetErrorString(r_) : "rccl error");      \
-    } while (0)
 #define NODE_ORB(node, prog, expr)                                                             \
     do {                                                                                       \
         int rc_ = (expr);                                                                      \
@@ -119,13 +134,12 @@ int load_rccl(OrbNode* node) {
     auto sym = [&](const char* name) { return dlsym(R.handle, name); };
     R.CommInitAll = reinterpret_cast<decltype(R.CommInitAll)>(sym("ncclCommInitAll"));
     R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
-    R.AllGather = reinterpret_cast<decltype(R.AllGather)>(sym("ncclAllGather"));
     R.Send = reinterpret_cast<decltype(R.Send)>(sym("ncclSend"));
     R.Recv = reinterpret_cast<decltype(R.Recv)>(sym("ncclRecv"));
     R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(sym("ncclGroupStart"));
     R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(sym("ncclGroupEnd"));
     R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
-    if (!R.CommInitAll || !R.CommDestroy || !R.AllGather || !R.Send || !R.Recv || !R.GroupStart || !R.GroupEnd) {
+    if (!R.CommInitAll || !R.CommDestroy || !R.Send || !R.Recv || !R.GroupStart || !R.GroupEnd) {
         dlclose(R.handle);
         R = Rccl{};
         return nfail(node, ORB_EHIP, "librccl lacks a required entry point");
@@ -134,7 +148,7 @@ int load_rccl(OrbNode* node) {
 }
 
 int ensure_comms(OrbNode* node) {
-    if (node->loopback || !node->comms.empty()) return ORB_OK;
+    if (node->loopback || node->n == 1 || !node->comms.empty()) return ORB_OK;
     if (int rc = load_rccl(node)) return rc;
     node->comms.assign(node->n, nullptr);
     ncclResult_t r = node->rccl.CommInitAll(node->comms.data(), node->n, node->devices.data());
@@ -153,6 +167,8 @@ void shard_range(uint32_t n_frames, int n, int rank, uint32_t* lo, uint32_t* hi)
 
 int check_job(OrbNode* node, uint32_t n_frames) {
     if (n_frames == 0) return nfail(node, ORB_EINVAL, "n_frames is 0");
+    if ((int)node->jobs.size() >= kSlots)
+        return nfail(node, ORB_ESTATE, "%d jobs are outstanding: orb_node_collate_end the oldest one first", kSlots);
     for (int r = 0; r < node->n; r++) {
         uint32_t lo, hi;
         shard_range(n_frames, node->n, r, &lo, &hi);
@@ -162,6 +178,107 @@ int check_job(OrbNode* node, uint32_t n_frames) {
     return ORB_OK;
 }
 
+// Device-visible address of pinned host memory on the current device.
+template <typename T>
+T* dev_ptr(T* host) {
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) return nullptr;
+    return static_cast<T*>(d);
+}
+
+// The exchange of one job: exact-size transfers rank r -> rank 0, then the expansion behind rank 0's own records.
+// An RCCL error inside the group still closes the group (a communicator left in an open group hangs the next call).
+int enqueue_exchange(OrbNode* node, NodeJob& job) {
+    const int n = node->n, slot = job.slot;
+    const uint32_t B = node->max_batch;
+    const size_t cap = node->cfg.max_features;
+    const Rccl& R = node->rccl;
+    std::vector<uint64_t> rank_records(n, 0), rank_offset(n + 1, 0);
+    for (int r = 0; r < n; r++) {
+        rank_records[r] = job.shard_n[r] ? node->h_offsets[slot][r][job.shard_n[r]] : 0u;
+        if (rank_records[r] > (uint64_t)B * cap) return nfail(node, ORB_EHIP, "internal: rank %d reports %llu records", r, (unsigned long long)rank_records[r]);
+        rank_offset[r + 1] = rank_offset[r] + rank_records[r];
+    }
+    std::vector<uint64_t> wire_first(n, 0), wire_count(n, 0), dst_first(n, 0);
+    uint64_t at = 0;
+    for (int r = 1; r < n; r++) {
+        wire_first[r - 1] = at, wire_count[r - 1] = rank_records[r], dst_first[r - 1] = rank_offset[r];
+        at += rank_records[r];
+    }
+    if (n > 1 && at > 0) {
+        // every sender's exchange stream waits for its pack; rank 0's wire buffer is reused in stream order
+        for (int r = 1; r < n; r++) {
+            if (rank_records[r] == 0) continue;
+            NODE_HIP(node, hipSetDevice(node->devices[r]));
+            NODE_HIP(node, hipStreamWaitEvent(node->xchg_streams[r], node->ev_pack[slot][r], 0));
+        }
+        if (node->loopback) {
+            for (int r = 1; r < n; r++) {
+                if (rank_records[r] == 0) continue;
+                const size_t bytes = (size_t)rank_records[r] * ORB_TRANSPORT_RECORD_BYTES;
+                uint8_t* const landing = static_cast<uint8_t*>(node->d_wire[slot][0]) + (size_t)wire_first[r - 1] * ORB_TRANSPORT_RECORD_BYTES;
+                NODE_HIP(node, hipSetDevice(node->devices[r]));
+                NODE_HIP(node, hipMemcpyAsync(landing, node->d_wire[slot][r], bytes, hipMemcpyDefault, node->xchg_streams[r]));
+                NODE_HIP(node, hipEventRecord(node->ev_xchg[slot][r], node->xchg_streams[r]));
+                node->xchg_set[slot][r] = 1;
+                NODE_HIP(node, hipSetDevice(node->devices[0]));
+                NODE_HIP(node, hipStreamWaitEvent(node->xchg_streams[0], node->ev_xchg[slot][r], 0));
+            }
+        } else {
+            ncclResult_t bad = ncclSuccess;
+            const char* what = "";
+            ncclResult_t g = R.GroupStart();
+            if (g != ncclSuccess) return nfail(node, ORB_EHIP, "ncclGroupStart failed: %s", R.GetErrorString ? R.GetErrorString(g) : "rccl error");
+            for (int r = 1; r < n && bad == ncclSuccess; r++) {
+                if (rank_records[r] == 0) continue;
+                const size_t bytes = (size_t)rank_records[r] * ORB_TRANSPORT_RECORD_BYTES;
+                uint8_t* const landing = static_cast<uint8_t*>(node->d_wire[slot][0]) + (size_t)wire_first[r - 1] * ORB_TRANSPORT_RECORD_BYTES;
+                bad = R.Send(node->d_wire[slot][r], bytes, ncclUint8, 0, node->comms[r], node->xchg_streams[r]);
+                what = "ncclSend";
+                if (bad != ncclSuccess) break;
+                bad = R.Recv(landing, bytes, ncclUint8, r, node->comms[0], node->xchg_streams[0]);
+                what = "ncclRecv";
+            }
+            g = R.GroupEnd();  // always: the group must not stay open
+            if (bad != ncclSuccess) return nfail(node, ORB_EHIP, "%s failed: %s", what, R.GetErrorString ? R.GetErrorString(bad) : "rccl error");
+            if (g != ncclSuccess) return nfail(node, ORB_EHIP, "ncclGroupEnd failed: %s", R.GetErrorString ? R.GetErrorString(g) : "rccl error");
+            for (int r = 1; r < n; r++) {
+                if (rank_records[r] == 0) continue;
+                NODE_HIP(node, hipSetDevice(node->devices[r]));
+                NODE_HIP(node, hipEventRecord(node->ev_xchg[slot][r], node->xchg_streams[r]));  // the wire buffer is free again
+                node->xchg_set[slot][r] = 1;
+            }
+        }
+        NODE_HIP(node, hipSetDevice(node->devices[0]));
+        NODE_ORB(node, node->progs[0],
+                 orb_unpack_transport(node->progs[0], node->d_wire[slot][0], (uint32_t)(n - 1), wire_first.data(), wire_count.data(),
+                                      dst_first.data(), node->d_coll_c[job.coll], node->d_coll_d[job.coll], node->xchg_streams[0]));
+    }
+    NODE_HIP(node, hipSetDevice(node->devices[0]));
+    NODE_HIP(node, hipEventRecord(node->ev_xchg[slot][0], node->xchg_streams[0]));
+    node->xchg_set[slot][0] = 1;
+    job.exchanging = true;
+    return ORB_OK;
+}
+
+int begin_oldest(OrbNode* node) {
+    NodeJob* job = nullptr;
+    for (NodeJob& j : node->jobs)
+        if (!j.exchanging) {
+            job = &j;
+            break;
+        }
+    if (!job) return nfail(node, ORB_ESTATE, "collate_begin: no extracted job is waiting for its exchange");
+    if (int rc = ensure_comms(node)) return rc;
+    // the only host wait of the pipeline: the counters of THIS job (its kernels + pack; the next job is already queued)
+    for (int r = 0; r < node->n; r++) {
+        if (job->shard_n[r] == 0) continue;
+        NODE_HIP(node, hipSetDevice(node->devices[r]));
+        NODE_HIP(node, hipEventSynchronize(node->ev_pack[job->slot][r]));
+    }
+    return enqueue_exchange(node, *job);
+}
+
 }  // namespace
 
 extern "C" {
@@ -169,6 +286,8 @@ extern "C" {
 const char* orb_node_last_error(const OrbNode* node) { return node ? node->err.c_str() : g_node_create_error.c_str(); }
 
 int orb_node_device_count(const OrbNode* node) { return node ? node->n : 0; }
+
+int orb_node_pending(const OrbNode* node) { return node ? (int)node->jobs.size() : 0; }
 
 OrbProgram* orb_node_program(OrbNode* node, int rank) {
     return (node && rank >= 0 && rank < node->n) ? node->progs[rank] : nullptr;
@@ -185,16 +304,30 @@ void orb_node_destroy(OrbNode* node) {
     for (int r = 0; r < node->n; r++) {
         if (r < (int)node->devices.size()) (void)hipSetDevice(node->devices[r]);
         if (r < (int)node->streams.size() && node->streams[r]) (void)hipStreamSynchronize(node->streams[r]);
+        if (r < (int)node->pack_streams.size() && node->pack_streams[r]) (void)hipStreamSynchronize(node->pack_streams[r]);
+        if (r < (int)node->xchg_streams.size() && node->xchg_streams[r]) (void)hipStreamSynchronize(node->xchg_streams[r]);
+    }
+    for (int r = 0; r < node->n; r++) {
+        if (r < (int)node->devices.size()) (void)hipSetDevice(node->devices[r]);
         if (r < (int)node->comms.size() && node->comms[r]) (void)node->rccl.CommDestroy(node->comms[r]);
-        if (r < (int)node->d_sendcounts.size()) (void)hipFree(node->d_sendcounts[r]);
-        if (r < (int)node->d_allcounts.size()) (void)hipFree(node->d_allcounts[r]);
-        if (r < (int)node->d_pack_c.size()) (void)hipFree(node->d_pack_c[r]);
-        if (r < (int)node->d_pack_d.size()) (void)hipFree(node->d_pack_d[r]);
-        if (r < (int)node->d_wire.size()) (void)hipFree(node->d_wire[r]);
+        for (int s = 0; s < kSlots; s++) {
+            if (r < (int)node->d_wire[s].size()) (void)hipFree(node->d_wire[s][r]);
+            if (r < (int)node->h_counts[s].size() && node->h_counts[s][r]) (void)hipHostFree(node->h_counts[s][r]);
+            if (r < (int)node->h_offsets[s].size() && node->h_offsets[s][r]) (void)hipHostFree(node->h_offsets[s][r]);
+            if (r < (int)node->ev_kernels[s].size() && node->ev_kernels[s][r]) (void)hipEventDestroy(node->ev_kernels[s][r]);
+            if (r < (int)node->ev_pack[s].size() && node->ev_pack[s][r]) (void)hipEventDestroy(node->ev_pack[s][r]);
+            if (r < (int)node->ev_xchg[s].size() && node->ev_xchg[s][r]) (void)hipEventDestroy(node->ev_xchg[s][r]);
+        }
         if (r < (int)node->d_frames.size()) (void)hipFree(node->d_frames[r]);
+        if (r < (int)node->pack_streams.size() && node->pack_streams[r]) (void)hipStreamDestroy(node->pack_streams[r]);
+        if (r < (int)node->xchg_streams.size() && node->xchg_streams[r]) (void)hipStreamDestroy(node->xchg_streams[r]);
         if (r < (int)node->progs.size()) orb_program_destroy(node->progs[r]);
     }
-    if (node->h_allcounts) (void)hipHostFree(node->h_allcounts);
+    if (!node->devices.empty()) (void)hipSetDevice(node->devices[0]);
+    for (int c = 0; c < kCollSlots; c++) {
+        (void)hipFree(node->d_coll_c[c]);
+        (void)hipFree(node->d_coll_d[c]);
+    }
     // the RCCL handle stays open: unloading a library with live background threads is not safe
     delete node;
 }
@@ -204,9 +337,9 @@ int orb_node_create(const int* devices, int n_devices, const OrbConfig* config, 
     *out = nullptr;
     if (!devices || n_devices <= 0 || n_devices > 64) return nfail(nullptr, ORB_EINVAL, "need 1..64 devices");
     if (!config) return nfail(nullptr, ORB_EINVAL, "config is NULL");
-    // TINYORB_NODE_LOOPBACK=1 (test facility): the counters and records of the ranks move by device copies instead of RCCL,
-    // and a device may be listed more than once -- the whole n > 1 data path (shards, transport records, offsets, expansion
-    // on rank 0) can then run on one GPU, which RCCL refuses.
+    // TINYORB_NODE_LOOPBACK=1 (test facility): the records of the ranks move by device copies instead of RCCL, and a
+    // device may be listed more than once -- the whole n > 1 data path (shards, transport records, offsets, expansion
+    // on rank 0, the pipeline's events) can then run on one GPU, which RCCL refuses.
     const char* lb = getenv("TINYORB_NODE_LOOPBACK");
     const bool loopback = lb && atoi(lb) != 0;
     for (int a = 0; a < n_devices && !loopback; a++)
@@ -220,9 +353,10 @@ int orb_node_create(const int* devices, int n_devices, const OrbConfig* config, 
     node->cfg = *config;
     OrbOptions opt{};
     if (options) opt = *options;
+    opt.flags |= ORB_FLAG_DOUBLE_OUTPUT;  // batch k+1 computes while batch k is packed
     node->max_batch = opt.max_batch ? opt.max_batch : 1u;
-    node->frame_bytes = (size_t)config->image_size.width * config->image_size.height * 4u;
-    node->shard_n.assign(n_devices, 0u);
+    // ORB_FLAG_INPUT_Y8 programs take one byte per pixel: the shard offsets into a host array follow the flag
+    node->frame_bytes = (size_t)config->image_size.width * config->image_size.height * ((opt.flags & ORB_FLAG_INPUT_Y8) ? 1u : 4u);
     auto bail = [&](int code) {
         g_node_create_error = node->err;
         orb_node_destroy(node);
@@ -240,175 +374,165 @@ int orb_node_create(const int* devices, int n_devices, const OrbConfig* config, 
         }
         node->progs.push_back(p);
         node->streams.push_back((hipStream_t)orb_program_stream(p));
-        uint32_t *sc = nullptr, *ac = nullptr;
-        CornerData* pc = nullptr;
-        CornerDescriptor* pd = nullptr;
-        void* wire = nullptr;
-        const size_t pack = (size_t)n_devices * B * cap;                                // rank 0: every frame's records
-        const size_t wire_records = (r == 0 ? (size_t)(n_devices - 1) : 1u) * B * cap;  // rank 0 receives, the others send
-        hipError_t e = hipSetDevice(devices[r]);
-        if (e == hipSuccess) e = hipMalloc(&sc, B * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&ac, (size_t)n_devices * B * sizeof(uint32_t));
-        if (e == hipSuccess && r == 0) e = hipMalloc(&pc, pack * sizeof(CornerData));
-        if (e == hipSuccess && r == 0) e = hipMalloc(&pd, pack * sizeof(CornerDescriptor));
-        if (e == hipSuccess && wire_records) e = hipMalloc(&wire, wire_records * (size_t)ORB_TRANSPORT_RECORD_BYTES);
-        node->d_sendcounts.push_back(sc);
-        node->d_allcounts.push_back(ac);
-        node->d_pack_c.push_back(pc);
-        node->d_pack_d.push_back(pd);
-        node->d_wire.push_back(wire);
         node->d_frames.push_back(nullptr);
+        hipStream_t ps = nullptr, xs = nullptr;
+        hipError_t e = hipSetDevice(devices[r]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ps, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&xs, hipStreamNonBlocking);
+        node->pack_streams.push_back(ps);
+        node->xchg_streams.push_back(xs);
+        const size_t wire_records = (r == 0 ? (size_t)(n_devices - 1) : 1u) * B * cap;  // rank 0 receives, the others send
+        for (int s = 0; s < kSlots; s++) {
+            void* wire = nullptr;
+            uint32_t* hc = nullptr;
+            uint64_t* ho = nullptr;
+            hipEvent_t ek = nullptr, ep = nullptr, ex = nullptr;
+            if (e == hipSuccess && wire_records) e = hipMalloc(&wire, wire_records * (size_t)ORB_TRANSPORT_RECORD_BYTES);
+            if (e == hipSuccess) e = hipHostMalloc(&hc, B * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocPortable);
+            if (e == hipSuccess) e = hipHostMalloc(&ho, (B + 1u) * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocPortable);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ek, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ep, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ex, hipEventDisableTiming);
+            if (hc) memset(hc, 0, B * sizeof(uint32_t));
+            if (ho) memset(ho, 0, (B + 1u) * sizeof(uint64_t));
+            node->d_wire[s].push_back(wire);
+            node->h_counts[s].push_back(hc);
+            node->h_offsets[s].push_back(ho);
+            node->ev_kernels[s].push_back(ek);
+            node->ev_pack[s].push_back(ep);
+            node->ev_xchg[s].push_back(ex);
+            node->pack_set[s].push_back(0);
+            node->xchg_set[s].push_back(0);
+        }
+        if (r == 0) {
+            const size_t pack = (size_t)n_devices * B * cap;  // every frame's records
+            for (int c = 0; c < kCollSlots && e == hipSuccess; c++) {
+                e = hipMalloc(&node->d_coll_c[c], pack * sizeof(CornerData));
+                if (e == hipSuccess) e = hipMalloc(&node->d_coll_d[c], pack * sizeof(CornerDescriptor));
+            }
+        }
         if (e != hipSuccess) {
             nfail(node, ORB_EHIP, "device %d: allocation failed: %s", devices[r], hipGetErrorString(e));
             return bail(ORB_EHIP);
         }
     }
-    if (hipHostMalloc(&node->h_allcounts, (size_t)n_devices * B * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
-        nfail(node, ORB_EHIP, "pinned host allocation failed");
-        return bail(ORB_EHIP);
-    }
     *out = node;
+    return ORB_OK;
+}
+
+// Stage 1 of a job: the kernels of every shard, and behind them the packing of its results (see the head of this file).
+static int submit_job(OrbNode* node, const uint8_t* const* frames_dev, const uint8_t* frames_pinned, uint32_t n_frames) {
+    if (int rc = check_job(node, n_frames)) return rc;
+    NodeJob job;
+    job.n_frames = n_frames;
+    job.slot = (int)(node->job_seq % (uint64_t)kSlots);
+    job.coll = (int)(node->job_seq % (uint64_t)kCollSlots);
+    job.shard_n.assign(node->n, 0u);
+    const int slot = job.slot;
+    const size_t cap = node->cfg.max_features, B = node->max_batch;
+    for (int r = 0; r < node->n; r++) {  // asynchronous per device: all shards run at once
+        uint32_t lo, hi;
+        shard_range(n_frames, node->n, r, &lo, &hi);
+        const uint32_t m = hi - lo;
+        job.shard_n[r] = m;
+        if (m == 0) continue;
+        if (frames_dev && !frames_dev[r]) return nfail(node, ORB_EINVAL, "frames_dev[%d] is NULL", r);
+        OrbProgram* const prog = node->progs[r];
+        NODE_HIP(node, hipSetDevice(node->devices[r]));
+        NODE_ORB(node, prog, orb_batch_select_output(prog, (uint32_t)slot));
+        // output set `slot` was last read by the pack of the job two back
+        if (node->pack_set[slot][r]) NODE_HIP(node, hipStreamWaitEvent(node->streams[r], node->ev_pack[slot][r], 0));
+        if (frames_dev)
+            NODE_ORB(node, prog, orb_extract_batch_device(prog, frames_dev[r], m, nullptr));
+        else
+            NODE_ORB(node, prog, orb_extract_batch_pinned(prog, frames_pinned + (size_t)lo * node->frame_bytes, m));
+        NODE_HIP(node, hipEventRecord(node->ev_kernels[slot][r], node->streams[r]));
+        hipStream_t ps = node->pack_streams[r];
+        NODE_HIP(node, hipStreamWaitEvent(ps, node->ev_kernels[slot][r], 0));
+        uint32_t* const dc = dev_ptr(node->h_counts[slot][r]);
+        uint64_t* const dof = dev_ptr(node->h_offsets[slot][r]);
+        if (!dc || !dof) return nfail(node, ORB_EHIP, "pinned counters are not visible to device %d", node->devices[r]);
+        if (r == 0) {  // rank 0's own records go straight to the head of the collated arrays
+            NODE_ORB(node, prog, orb_batch_compact_device(prog, m, dc, dof, node->d_coll_c[job.coll], node->d_coll_d[job.coll],
+                                                          B * cap, ps));
+        } else {       // the others pack 40-byte transport records; the wire buffer was last read by the sends two jobs back
+            if (node->xchg_set[slot][r]) NODE_HIP(node, hipStreamWaitEvent(ps, node->ev_xchg[slot][r], 0));
+            void* d_counts = nullptr;
+            NODE_ORB(node, prog, orb_batch_device_buffers(prog, &d_counts, nullptr, nullptr));
+            NODE_ORB(node, prog, orb_batch_pack_transport(prog, (uint32_t)slot, m, node->d_wire[slot][r], B * cap, dof, ps));
+            NODE_HIP(node, hipMemcpyAsync(node->h_counts[slot][r], d_counts, m * sizeof(uint32_t), hipMemcpyDeviceToHost, ps));
+        }
+        NODE_HIP(node, hipEventRecord(node->ev_pack[slot][r], ps));
+        node->pack_set[slot][r] = 1;
+    }
+    node->jobs.push_back(std::move(job));
+    node->job_seq++;
     return ORB_OK;
 }
 
 int orb_node_extract_batch(OrbNode* node, const uint8_t* const* frames_dev, uint32_t n_frames) {
     if (!node) return ORB_EINVAL;
     if (!frames_dev) return nfail(node, ORB_EINVAL, "frames_dev is NULL");
-    if (int rc = check_job(node, n_frames)) return rc;
-    node->extracted = node->collated = false;
-    for (int r = 0; r < node->n; r++) {  // asynchronous per device: all shards run at once
-        uint32_t lo, hi;
-        shard_range(n_frames, node->n, r, &lo, &hi);
-        node->shard_n[r] = hi - lo;
-        if (hi == lo) continue;
-        if (!frames_dev[r]) return nfail(node, ORB_EINVAL, "frames_dev[%d] is NULL", r);
-        NODE_ORB(node, node->progs[r], orb_extract_batch_device(node->progs[r], frames_dev[r], hi - lo, nullptr));
-    }
-    node->last_frames = n_frames;
-    node->extracted = true;
-    return ORB_OK;
+    return submit_job(node, frames_dev, nullptr, n_frames);
 }
 
 int orb_node_extract_batch_host(OrbNode* node, const uint8_t* frames_host, uint32_t n_frames) {
     if (!node) return ORB_EINVAL;
     if (!frames_host) return nfail(node, ORB_EINVAL, "frames_host is NULL");
     if (int rc = check_job(node, n_frames)) return rc;
-    std::vector<const uint8_t*> ptrs(node->n, nullptr);
+    // Every shard goes up in 16-frame chunks from the caller's array, pinned in place for the duration of the uploads,
+    // on its device's copy stream while the kernels of the chunks already there run (orb_extract_batch_pinned): all
+    // links at once.  Returns when the uploads are done (the array may be reused); the kernels may still be running.
+    const size_t total = node->frame_bytes * n_frames;
+    const bool pinned = hipHostRegister(const_cast<uint8_t*>(frames_host), total, hipHostRegisterPortable) == hipSuccess;
+    if (!pinned) (void)hipGetLastError();  // already pinned by the caller (orb_host_alloc), or not pinnable: the runtime stages the copies
+    int rc = submit_job(node, nullptr, frames_host, n_frames);
     for (int r = 0; r < node->n; r++) {
-        uint32_t lo, hi;
-        shard_range(n_frames, node->n, r, &lo, &hi);
-        if (hi == lo) continue;
-        NODE_HIP(node, hipSetDevice(node->devices[r]));
-        if (!node->d_frames[r]) NODE_HIP(node, hipMalloc(&node->d_frames[r], node->frame_bytes * node->max_batch));
-        // pageable source: the copy is staged by the runtime and the source may be reused on return
-        NODE_HIP(node, hipMemcpyAsync(node->d_frames[r], frames_host + (size_t)lo * node->frame_bytes,
-                                      (size_t)(hi - lo) * node->frame_bytes, hipMemcpyHostToDevice, node->streams[r]));
-        ptrs[r] = node->d_frames[r];
+        const int rs = orb_upload_sync(node->progs[r]);
+        if (rs != ORB_OK && rc == ORB_OK) rc = nfail(node, rs, "upload to device %d: %s", node->devices[r], orb_last_error(node->progs[r]));
     }
-    return orb_node_extract_batch(node, ptrs.data(), n_frames);
+    if (pinned) (void)hipHostUnregister(const_cast<uint8_t*>(frames_host));
+    return rc;
 }
 
-int orb_node_collate(OrbNode* node, uint32_t* counts, uint64_t* offsets, void** corners_dev, void** descriptors_dev) {
+int orb_node_collate_begin(OrbNode* node) {
     if (!node) return ORB_EINVAL;
-    if (!node->extracted) return nfail(node, ORB_ESTATE, "collate before extract_batch");
-    if (int rc = ensure_comms(node)) return rc;
-    const int n = node->n;
-    const uint32_t B = node->max_batch;
+    return begin_oldest(node);
+}
+
+int orb_node_collate_end(OrbNode* node, uint32_t* counts, uint64_t* offsets, void** corners_dev, void** descriptors_dev) {
+    if (!node) return ORB_EINVAL;
+    if (node->jobs.empty()) return nfail(node, ORB_ESTATE, "collate before extract_batch");
+    if (!node->jobs.front().exchanging)
+        if (int rc = begin_oldest(node)) return rc;
+    NodeJob& job = node->jobs.front();
+    const int slot = job.slot;
     const size_t cap = node->cfg.max_features;
-    const Rccl& R = node->rccl;
-    // 1. pack every shard on its own device (rank 0 directly at the head of the collate buffer) and stage the counters
-    for (int r = 0; r < n; r++) {
-        NODE_HIP(node, hipSetDevice(node->devices[r]));
-        NODE_HIP(node, hipMemsetAsync(node->d_sendcounts[r], 0, B * sizeof(uint32_t), node->streams[r]));
-        if (node->shard_n[r] == 0) continue;
-        void* d_counts = nullptr;
-        NODE_ORB(node, node->progs[r], orb_batch_device_buffers(node->progs[r], &d_counts, nullptr, nullptr));
-        NODE_HIP(node, hipMemcpyAsync(node->d_sendcounts[r], d_counts, node->shard_n[r] * sizeof(uint32_t),
-                                      hipMemcpyDeviceToDevice, node->streams[r]));
-        if (r == 0)  // rank 0's own records go straight to the head of the collated arrays
-            NODE_ORB(node, node->progs[0],
-                     orb_batch_compact_device(node->progs[0], node->shard_n[0], nullptr, nullptr, node->d_pack_c[0],
-                                              node->d_pack_d[0], (size_t)B * cap, nullptr));
-        else         // the others pack 40-byte transport records (set 0: a node never switches output sets)
-            NODE_ORB(node, node->progs[r],
-                     orb_batch_pack_transport(node->progs[r], 0, node->shard_n[r], node->d_wire[r], (size_t)B * cap, nullptr,
-                                              node->streams[r]));
-    }
-    // 2. counters of every frame to every rank
-    if (node->loopback) {
-        for (int r = 0; r < n; r++) {
-            NODE_HIP(node, hipSetDevice(node->devices[r]));
-            NODE_HIP(node, hipStreamSynchronize(node->streams[r]));  // every rank's counters and records are in place
-        }
-        for (int r = 0; r < n; r++) {
-            NODE_HIP(node, hipSetDevice(node->devices[r]));
-            for (int q = 0; q < n; q++)
-                NODE_HIP(node, hipMemcpyAsync(node->d_allcounts[r] + (size_t)q * B, node->d_sendcounts[q], B * sizeof(uint32_t),
-                                              hipMemcpyDefault, node->streams[r]));
-        }
-    } else {
-        NODE_NCCL(node, R.GroupStart());
-        for (int r = 0; r < n; r++)
-            NODE_NCCL(node, R.AllGather(node->d_sendcounts[r], node->d_allcounts[r], B, ncclUint32, node->comms[r], node->streams[r]));
-        NODE_NCCL(node, R.GroupEnd());
-    }
-    // 3. one copy to the host: exact payload sizes
     NODE_HIP(node, hipSetDevice(node->devices[0]));
-    NODE_HIP(node, hipMemcpyAsync(node->h_allcounts, node->d_allcounts[0], (size_t)n * B * sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, node->streams[0]));
-    NODE_HIP(node, hipStreamSynchronize(node->streams[0]));
-    std::vector<uint64_t> rank_records(n, 0), rank_offset(n + 1, 0);
-    for (int r = 0; r < n; r++) {
-        for (uint32_t f = 0; f < node->shard_n[r]; f++) {
-            const uint32_t raw = node->h_allcounts[(size_t)r * B + f];
-            rank_records[r] += raw < cap ? raw : cap;
-        }
-        rank_offset[r + 1] = rank_offset[r] + rank_records[r];
-    }
-    // 4. transport records of ranks 1.. to rank 0, exact sizes, each peer on its own link; rank 0 then expands them
-    //    behind its own records (orb_unpack_transport), in rank = frame order
-    std::vector<uint64_t> wire_first(n, 0), wire_count(n, 0), dst_first(n, 0);
-    if (!node->loopback) NODE_NCCL(node, R.GroupStart());
-    uint64_t at = 0;
-    for (int r = 1; r < n; r++) {
-        wire_first[r - 1] = at, wire_count[r - 1] = rank_records[r], dst_first[r - 1] = rank_offset[r];
-        if (rank_records[r] == 0) continue;
-        const size_t bytes = (size_t)rank_records[r] * ORB_TRANSPORT_RECORD_BYTES;
-        uint8_t* const landing = static_cast<uint8_t*>(node->d_wire[0]) + (size_t)at * ORB_TRANSPORT_RECORD_BYTES;
-        if (node->loopback) {  // the records were complete before the counters were exchanged (stream synchronised above)
-            NODE_HIP(node, hipSetDevice(node->devices[0]));
-            NODE_HIP(node, hipMemcpyAsync(landing, node->d_wire[r], bytes, hipMemcpyDefault, node->streams[0]));
-        } else {
-            NODE_NCCL(node, R.Send(node->d_wire[r], bytes, ncclUint8, 0, node->comms[r], node->streams[r]));
-            NODE_NCCL(node, R.Recv(landing, bytes, ncclUint8, r, node->comms[0], node->streams[0]));
-        }
-        at += rank_records[r];
-    }
-    if (!node->loopback) NODE_NCCL(node, R.GroupEnd());
-    if (n > 1 && at > 0)
-        NODE_ORB(node, node->progs[0],
-                 orb_unpack_transport(node->progs[0], node->d_wire[0], (uint32_t)(n - 1), wire_first.data(), wire_count.data(),
-                                      dst_first.data(), node->d_pack_c[0], node->d_pack_d[0], node->streams[0]));
-    for (int r = 0; r < n; r++) {
-        NODE_HIP(node, hipSetDevice(node->devices[r]));
-        NODE_HIP(node, hipStreamSynchronize(node->streams[r]));
-    }
+    if (job.shard_n[0]) NODE_HIP(node, hipEventSynchronize(node->ev_pack[slot][0]));  // rank 0's own records are in place
+    NODE_HIP(node, hipEventSynchronize(node->ev_xchg[slot][0]));                       // and everybody else's
     // frame-ordered counters and offsets for the caller
     uint64_t off = 0;
     uint32_t f_out = 0;
-    for (int r = 0; r < n; r++)
-        for (uint32_t f = 0; f < node->shard_n[r]; f++, f_out++) {
-            const uint32_t raw = node->h_allcounts[(size_t)r * B + f];
+    for (int r = 0; r < node->n; r++)
+        for (uint32_t f = 0; f < job.shard_n[r]; f++, f_out++) {
+            const uint32_t raw = node->h_counts[slot][r][f];
             if (counts) counts[f_out] = raw;
             if (offsets) offsets[f_out] = off;
             off += raw < cap ? raw : cap;
         }
     if (offsets) offsets[f_out] = off;
     node->total_records = off;
+    node->last_coll = job.coll;
     node->collated = true;
-    if (corners_dev) *corners_dev = node->d_pack_c[0];
-    if (descriptors_dev) *descriptors_dev = node->d_pack_d[0];
+    if (corners_dev) *corners_dev = node->d_coll_c[job.coll];
+    if (descriptors_dev) *descriptors_dev = node->d_coll_d[job.coll];
+    node->jobs.pop_front();
     return ORB_OK;
+}
+
+int orb_node_collate(OrbNode* node, uint32_t* counts, uint64_t* offsets, void** corners_dev, void** descriptors_dev) {
+    return orb_node_collate_end(node, counts, offsets, corners_dev, descriptors_dev);  // begins the exchange if nobody has
 }
 
 int orb_node_read_collated(OrbNode* node, CornerData* corners, CornerDescriptor* descriptors, size_t capacity) {
@@ -416,9 +540,9 @@ int orb_node_read_collated(OrbNode* node, CornerData* corners, CornerDescriptor*
     if (!node->collated) return nfail(node, ORB_ESTATE, "read_collated before collate");
     const size_t m = node->total_records < capacity ? (size_t)node->total_records : capacity;
     NODE_HIP(node, hipSetDevice(node->devices[0]));
-    if (corners && m) NODE_HIP(node, hipMemcpy(corners, node->d_pack_c[0], m * sizeof(CornerData), hipMemcpyDeviceToHost));
+    if (corners && m) NODE_HIP(node, hipMemcpy(corners, node->d_coll_c[node->last_coll], m * sizeof(CornerData), hipMemcpyDeviceToHost));
     if (descriptors && m)
-        NODE_HIP(node, hipMemcpy(descriptors, node->d_pack_d[0], m * sizeof(CornerDescriptor), hipMemcpyDeviceToHost));
+        NODE_HIP(node, hipMemcpy(descriptors, node->d_coll_d[node->last_coll], m * sizeof(CornerDescriptor), hipMemcpyDeviceToHost));
     return ORB_OK;
 }
 

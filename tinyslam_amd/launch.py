@@ -51,15 +51,35 @@ def _gpu_libraries_mapped():
     return sorted(found)
 
 
-def launch_ranks(world, argv, worker=None, timeout=None):
+def _kill_all(procs):
+    for p in procs:
+        if p.poll() is None:
+            try:
+                p.kill()
+            except OSError:
+                pass
+    for p in procs:
+        try:
+            p.wait(timeout=5)
+        except Exception:
+            pass
+
+
+def launch_ranks(world, argv, worker=None, timeout=None, grace=10.0):
     """Spawns `world` rank processes running `worker + argv` (default worker: this interpreter on bench.py's path in
-    argv[0]) and waits for them.  Returns the worst exit status.  If a rank fails the others are terminated by PID."""
+    argv[0]) and waits for them.  Returns the worst exit status.  If a rank fails (or `timeout` passes) the others get
+    SIGTERM by PID and, `grace` seconds later, SIGKILL: a rank blocked in a driver call or a collective does not die on
+    SIGTERM, and the launcher must not hang on it.  Nothing is ever restarted."""
     if worker is None:
         worker = [sys.executable]
     port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
     procs = []
-    for r in range(world):
-        procs.append(subprocess.Popen(list(worker) + list(argv), env=rank_env(r, world, port)))
+    try:
+        for r in range(world):
+            procs.append(subprocess.Popen(list(worker) + list(argv), env=rank_env(r, world, port)))
+    except BaseException:
+        _kill_all(procs)  # rank k could not be started: ranks 0..k-1 must not stay behind
+        raise
     report = os.environ.get("TINYORB_LAUNCH_REPORT")
     if report:  # test hook: what the launcher did, and proof that it stayed off the GPU
         with open(report, "w") as f:
@@ -68,24 +88,33 @@ def launch_ranks(world, argv, worker=None, timeout=None):
     t0 = time.monotonic()
     status = 0
     live = list(procs)
-    while live:
-        for p in list(live):
-            rc = p.poll()
-            if rc is None:
-                continue
-            live.remove(p)
-            if rc != 0:
-                status = status or (rc if rc > 0 else 128 - rc)
-                for q in live:  # one rank failed: the others would wait for it in a collective forever
+    kill_at = None  # set when the survivors were sent SIGTERM
+    try:
+        while live:
+            for p in list(live):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0 and kill_at is None:
+                    status = status or (rc if rc > 0 else 128 - rc)
+                    for q in live:  # one rank failed: the others would wait for it in a collective forever
+                        q.terminate()
+                    kill_at = time.monotonic() + grace
+                elif rc != 0:
+                    status = status or (rc if rc > 0 else 128 - rc)
+            now = time.monotonic()
+            if timeout is not None and kill_at is None and now - t0 > timeout and live:
+                status = status or 124
+                for q in live:
                     q.terminate()
-        if timeout is not None and time.monotonic() - t0 > timeout and live:
-            status = status or 124
-            for q in live:
-                q.terminate()
-            timeout = None
-        if live:
-            time.sleep(0.05)
-    for p in procs:  # make sure nothing survives us
-        if p.poll() is None:
-            p.send_signal(signal.SIGKILL)
+                kill_at = now + grace
+            if kill_at is not None and now > kill_at and live:
+                for q in live:
+                    q.kill()
+                kill_at = float("inf")
+            if live:
+                time.sleep(0.05)
+    finally:
+        _kill_all(procs)  # make sure nothing survives us
     return status

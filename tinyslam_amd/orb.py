@@ -50,7 +50,8 @@ EXPORTS = [
     "orb_batch_pack_transport", "orb_unpack_transport",
     "orb_node_create", "orb_node_destroy", "orb_node_last_error", "orb_node_device_count", "orb_node_program",
     "orb_node_shard", "orb_node_extract_batch", "orb_node_extract_batch_host", "orb_node_collate",
-    "orb_node_read_collated",
+    "orb_node_read_collated", "orb_node_collate_begin", "orb_node_collate_end", "orb_node_pending",
+    "orb_extract_batch_pinned", "orb_upload_sync",
 ]
 
 
@@ -177,7 +178,12 @@ def load_library(path=None):
     L.orb_node_extract_batch_host.argtypes = [vp, vp, u32]
     L.orb_node_collate.argtypes = [vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.orb_node_read_collated.argtypes = [vp, vp, vp, sz]
-    if L.orb_abi_version() != 2:
+    L.orb_node_collate_begin.argtypes = [vp]
+    L.orb_node_collate_end.argtypes = [vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.orb_node_pending.argtypes = [vp]
+    L.orb_extract_batch_pinned.argtypes = [vp, vp, u32]
+    L.orb_upload_sync.argtypes = [vp]
+    if L.orb_abi_version() != 3:
         raise OrbError(ORB_EINVAL, "libtinyorb ABI version mismatch")
     if path == LIB_PATH:
         _lib = L
@@ -365,6 +371,16 @@ class OrbProgram:
     def extract_batch_host(self, frames):
         a = np.ascontiguousarray(frames, dtype=np.uint8)
         self._check(self._lib.orb_extract_batch_host(self._handle(), _ptr(a), a.shape[0]))
+
+    def extract_batch_pinned(self, frames, n_frames=None):
+        """orb_extract_batch_pinned: `frames` is a numpy view of PINNED memory (PinnedArray.array); asynchronous."""
+        a = np.asarray(frames)
+        assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+        self._check(self._lib.orb_extract_batch_pinned(self._handle(), ctypes.c_void_p(a.ctypes.data),
+                                                       a.shape[0] if n_frames is None else n_frames))
+
+    def upload_sync(self):
+        self._check(self._lib.orb_upload_sync(self._handle()))
 
     def batch_sync(self):
         self._check(self._lib.orb_batch_sync(self._handle()))
@@ -580,6 +596,21 @@ class OrbNode:
         c, d = ctypes.c_void_p(), ctypes.c_void_p()
         self._check(self._lib.orb_node_collate(self._h, _ptr(counts), _ptr(offsets), ctypes.byref(c), ctypes.byref(d)))
         return counts, offsets, c.value, d.value
+
+    def collate_begin(self):
+        """Stage 2 of the oldest job that has not begun it: enqueue its exchange (waits only for its counters)."""
+        self._check(self._lib.orb_node_collate_begin(self._h))
+
+    def collate_end(self, n_frames):
+        """Stage 3 of the oldest job: blocks until its collated result is on the first device; returns like collate()."""
+        counts = np.zeros(n_frames, dtype=np.uint32)
+        offsets = np.zeros(n_frames + 1, dtype=np.uint64)
+        c, d = ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self._lib.orb_node_collate_end(self._h, _ptr(counts), _ptr(offsets), ctypes.byref(c), ctypes.byref(d)))
+        return counts, offsets, c.value, d.value
+
+    def pending(self):
+        return self._lib.orb_node_pending(self._h)
 
     def read_collated(self, total):
         corners = np.zeros(total, dtype=CORNER_DTYPE)
