@@ -59,6 +59,14 @@ def parse_args(argv=None):
     ap.add_argument("--mode", choices=("literal", "intended"), default="literal",
                     help="literal = the reference's algorithm (the headline, BASELINE.json); intended = the opt-in "
                          "repaired algorithm with FAST-9 + NMS (DESIGN.md section 8; not in the reference)")
+    ap.add_argument("--host", choices=("ranks", "node"), default="ranks",
+                    help="ranks = one process per GPU over torch.distributed (the driver's contract); node = ONE process "
+                         "driving all GPUs through the orb_node_* C ABI (what a Rust host binds), pipelined collate, no "
+                         "torch.distributed")
+    ap.add_argument("--no-single-frame", action="store_true", help="skip the single-frame latency figure (profiling runs)")
+    ap.add_argument("--preheat-ms", type=float, default=300.0,
+                    help="untimed steps run for this long before the W warm-up steps, so that the clocks are up (the "
+                         "first of five repeats used to read 10 %% slow)")
     return ap.parse_args(argv)
 
 
@@ -92,6 +100,150 @@ def cpu_baseline(n_sample, gpu_counts, intended=False, y8=False):
             "counts_equal_gpu": bool(np.array_equal(np.asarray(totals[:m], dtype=np.int64),
                                                     np.asarray(gpu_counts[:m], dtype=np.int64))),
             "counts_compared": int(m)}
+
+
+def roofline_of(args, prof, launches_frames, bytes_per_frame, profiled_s):
+    """`roofline` of the dominant kernel from the profiled pass (HIP events around every launch)."""
+    prof_k = {k_: v for k_, v in prof.items() if k_ not in ("k_compact", "k_compact_transport", "k_unpack_transport")}
+    dom = max(prof_k.items(), key=lambda kv: kv[1][0]) if prof_k else (None, (0.0, 0))
+    if not dom[0]:
+        return None
+    avg_ms = dom[1][0] / dom[1][1]
+    frames_per_launch = launches_frames / dom[1][1]
+    achieved = bytes_per_frame * frames_per_launch / (avg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                "algorithmic_bytes_per_launch": bytes_per_frame * frames_per_launch,
+                "frames_per_launch": frames_per_launch,
+                "measured": "HIP events around every launch on the launch stream, in a pass of the same %d steps "
+                            "right after the timed repeats (%.4f ms per step with the events in)"
+                            % (args.steps, profiled_s / args.steps * 1e3),
+                "all_kernels_ms_per_step": {k_: v[0] / args.steps for k_, v in prof.items()}}
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.mode, args.input))
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # the headline: literal mode, RGBA input
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if (tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == frames_per_launch
+                and tj.get("input", "rgba") == args.input and tj.get("mode", "literal") == args.mode):
+            roofline["traffic"] = tj.get("hbm_bytes_per_launch")
+            roofline["traffic_source"] = tj.get("source")
+    return roofline
+
+
+def workload_text(args, world, B, strong):
+    return (("BASELINE.json configs[4]: one job of %d independent 1280x720 RGBA frames sharded over "
+             "%d GPU(s), %d-frame batches" % (args.total_frames, world, B)) if strong else
+            ("BASELINE.json configs[3]: batch of %d independent 1280x720 RGBA frames per GPU" % B)
+            + ", device-resident, full ORB (%s)"
+            % ("FAST-12 + orientation + blur + BRIEF-256" if args.mode == "literal" else
+               "opt-in intended mode, NOT the reference's algorithm: FAST-9 + NMS + full-circle "
+               "orientation + separable Gaussian + BRIEF-256"))
+
+
+def single_frame_latency(orb, cfg_kwargs, n=200):
+    """The reference's only call shape (orb.rs:469-557): one blocking extract_corners per frame.  Mean microseconds of
+    orb_extract_corners alone on a resident frame, 1280x720."""
+    cfg = orb.OrbConfig(orb.Extent3d(W, H), max_batch=1, **cfg_kwargs)
+    with orb.OrbProgram(cfg).init() as p1:
+        p1.synth_frames_device(1, SEED0)
+        for _ in range(20):
+            p1.extract_corners()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            p1.extract_corners()
+        return (time.perf_counter() - t0) / n * 1e6
+
+
+def run_node(args):
+    """--host node: one process, the GPUs of the node through the orb_node_* C ABI (include/tinyorb.h) -- the path a
+    Rust host binds.  A step = one job of B frames per GPU (weak) sharded over the devices; the collate of job k (pack,
+    exact-size Send/Recv to the first device, expansion) overlaps the kernels of job k+1: extract(k), then
+    collate_begin + collate_end of job k-1.  Every job is collated inside the timed region."""
+    import numpy as np
+    from tinyslam_amd import orb
+    world, B = args.gpus, args.frames
+    if args.total_frames:
+        raise SystemExit("--host node runs the weak-scaling workload (one B-frame shard per GPU per step)")
+    loop = os.environ.get("TINYORB_NODE_LOOPBACK", "0") not in ("", "0")
+    devices = [0] * world if loop else list(range(world))
+    cfg_kwargs = dict(max_features=MAX_FEATURES, hierarchy_depth=DEPTH, initial_threshold=THRESHOLD,
+                      flags=(orb.ORB_FLAG_STAGED if args.staged else 0)
+                      | ((orb.ORB_FLAG_INTENDED | orb.ORB_FLAG_NMS) if args.mode == "intended" else 0)
+                      | (orb.ORB_FLAG_INPUT_Y8 if args.input == "y8" else 0),
+                      fast_arc=9 if args.mode == "intended" else 0)
+    cfg = orb.OrbConfig(orb.Extent3d(W, H), max_batch=B, **cfg_kwargs)
+    frame_bytes = W * H * (1 if args.input == "y8" else 4)
+    F = B * world
+    with orb.OrbNode(cfg, devices) as node:
+        progs = [node.program(r) for r in range(world)]
+        ptrs = [progs[r].synth_frames_device(B, SEED0 + r * B) for r in range(world)]
+        last = {}
+
+        def steps(n):
+            for _ in range(n):
+                node.extract_batch(ptrs, F)
+                if node.pending() == 2:
+                    node.collate_begin()
+                    last["r"] = node.collate_end(F)
+
+        def drain():
+            while node.pending():
+                last["r"] = node.collate_end(F)
+            for pr in progs:
+                pr.batch_sync()
+
+        def timed(n):
+            drain()
+            t0 = time.perf_counter()
+            steps(n)
+            drain()
+            return time.perf_counter() - t0
+
+        t_end = time.perf_counter() + args.preheat_ms * 1e-3
+        while time.perf_counter() < t_end:
+            steps(2)
+        steps(args.warmup)
+        repeats = [timed(args.steps) for _ in range(max(1, args.repeats))]
+        progs[0].profile_enable(True)
+        progs[0].profile_reset()
+        profiled = timed(args.steps)
+        prof = progs[0].profile()
+        progs[0].profile_enable(False)
+        elapsed = sorted(repeats)[len(repeats) // 2]
+        counts, offsets, _, _ = last["r"]
+        kp_per_step = float(offsets[F])
+        n_mean = kp_per_step / F
+        bytes_per_frame = frame_bytes + 48 * n_mean + 4
+        fps = F * args.steps / elapsed
+        out = {
+            "metric": "ORB extract throughput, 1280x720 (frames/sec; Mkeypoints/sec alongside)",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (gradient+blobs+wedges+noise, seeds %d.., generated on device)" % SEED0,
+            "config": {"workload": workload_text(args, world, B, False),
+                       "frames_per_gpu_per_batch": B, "frames_per_step": F, "width": W, "height": H,
+                       "hierarchy_depth": DEPTH, "max_features": MAX_FEATURES, "threshold": THRESHOLD, "mode": args.mode,
+                       "input": args.input, "pipeline": "staged" if args.staged else "default",
+                       "host": "node: one process, orb_node_* C ABI, no torch.distributed"
+                               + (" (TINYORB_NODE_LOOPBACK: %d ranks on device 0, device copies instead of RCCL)" % world if loop else ""),
+                       "collate": "every job packed and collated on the first device (exact-size transport records), "
+                                  "overlapped with the next job's kernels"},
+            "repeats_ms_per_step": [r / args.steps * 1e3 for r in repeats],
+            "min_ms_per_step": min(repeats) / args.steps * 1e3, "max_ms_per_step": max(repeats) / args.steps * 1e3,
+            "mkeypoints_per_s": kp_per_step * args.steps / elapsed / 1e6,
+            "keypoints_per_frame": n_mean,
+            "hbm_algorithmic_gbs": bytes_per_frame * fps / 1e9,
+            "roofline": roofline_of(args, prof, B * args.steps, bytes_per_frame, profiled),
+        }
+        if world == 1:
+            n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 128
+            if n_cpu > 0:
+                out["cpu_baseline"] = cpu_baseline(n_cpu, counts[:B], intended=args.mode == "intended", y8=args.input == "y8")
+    if args.mode == "literal" and not args.staged and not args.no_single_frame:
+        out["single_frame_us"] = single_frame_latency(orb, cfg_kwargs)
+    print(json.dumps(out), flush=True)
 
 
 def run_rank(args):
@@ -241,6 +393,11 @@ def run_rank(args):
             raise SystemExit("--total-frames %d does not split into the same number of %d-frame batches on every rank"
                              % (args.total_frames, B))
 
+    if world == 1:  # clocks up before the W warm-up steps (N > 1: every rank would have to agree on the count)
+        t_end = time.perf_counter() + args.preheat_ms * 1e-3
+        while time.perf_counter() < t_end:
+            step()
+            prog.batch_sync()
     for _ in range(args.warmup):
         step()
     repeats = [timed(args.steps) for _ in range(max(1, args.repeats))]
@@ -364,46 +521,17 @@ def run_rank(args):
         total_frames = job_frames * args.steps
         fps = total_frames / elapsed
         launches_frames = n_local * args.steps  # frames this rank pushed through each kernel in the profiled pass
-        prof_k = {k_: v for k_, v in prof.items() if k_ != "k_compact"}
-        dom = max(prof_k.items(), key=lambda kv: kv[1][0]) if prof_k else (None, (0.0, 0))
         n_mean = kp_per_step / job_frames
         # the frame read once (RGBA: 4 B per pixel, Y8: 1) + records + counter
         bytes_per_frame = frame_bytes + 48 * n_mean + 4
-        roofline = None
-        if dom[0]:
-            avg_ms = dom[1][0] / dom[1][1]
-            frames_per_launch = launches_frames / dom[1][1]
-            achieved = bytes_per_frame * frames_per_launch / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
-                        "algorithmic_bytes_per_launch": bytes_per_frame * frames_per_launch,
-                        "frames_per_launch": frames_per_launch,
-                        "measured": "HIP events around every launch on the launch stream, in a pass of the same %d steps "
-                                    "right after the timed repeats (%.4f ms per step with the events in)"
-                                    % (args.steps, profiled / args.steps * 1e3),
-                        "all_kernels_ms_per_step": {k_: v[0] / args.steps for k_, v in prof.items()}}
-            tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.mode, args.input))
-            if not os.path.exists(tpath):
-                tpath = os.path.join(ROOT, "profiles", "traffic.json")  # the headline: literal mode, RGBA input
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                if (tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == frames_per_launch
-                        and tj.get("input", "rgba") == args.input and tj.get("mode", "literal") == args.mode):
-                    roofline["traffic"] = tj.get("hbm_bytes_per_launch")
-                    roofline["traffic_source"] = tj.get("source")
+        roofline = roofline_of(args, prof, launches_frames, bytes_per_frame, profiled)
         out = {
             "metric": "ORB extract throughput, 1280x720 (frames/sec; Mkeypoints/sec alongside)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (gradient+blobs+wedges+noise, seeds %d.., generated on device)" % SEED0,
-            "config": {"workload": ("BASELINE.json configs[4]: one job of %d independent 1280x720 RGBA frames sharded over "
-                                    "%d GPU(s), %d-frame batches" % (args.total_frames, world, B)) if strong else
-                                   ("BASELINE.json configs[3]: batch of %d independent 1280x720 RGBA frames per GPU"
-                                    % B) + ", device-resident, full ORB (%s)"
-                                   % ("FAST-12 + orientation + blur + BRIEF-256" if args.mode == "literal" else
-                                      "opt-in intended mode, NOT the reference's algorithm: FAST-9 + NMS + full-circle "
-                                      "orientation + separable Gaussian + BRIEF-256"),
+            "config": {"workload": workload_text(args, world, B, strong),
                        "frames_per_gpu_per_batch": B, "frames_per_step": job_frames, "width": W, "height": H,
                        "hierarchy_depth": DEPTH, "max_features": MAX_FEATURES, "threshold": THRESHOLD, "mode": args.mode,
                        "input": args.input,
@@ -425,6 +553,10 @@ def run_rank(args):
             n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 128
             if n_cpu > 0:
                 out["cpu_baseline"] = cpu_baseline(n_cpu, counts_first, intended=args.mode == "intended", y8=args.input == "y8")
+            if args.mode == "literal" and args.input == "rgba" and not args.staged and not args.no_single_frame:
+                # the reference's only call shape (orb.rs:469-557): one blocking extract per frame, microseconds per call
+                out["single_frame_us"] = single_frame_latency(orb, dict(max_features=MAX_FEATURES, hierarchy_depth=DEPTH,
+                                                                        initial_threshold=THRESHOLD, device=dev_index))
         print(json.dumps(out), flush=True)
     prog.close()
     if world > 1:
@@ -434,6 +566,8 @@ def run_rank(args):
 
 def main():
     args = parse_args()
+    if args.host == "node":
+        return run_node(args)  # one process for all GPUs: nothing to launch
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not started by torch.distributed.run: spawn the ranks ourselves -- before torch, libtinyorb or anything else
         # that could initialise the GPU is imported into this process (a process that holds a HIP context must not fork

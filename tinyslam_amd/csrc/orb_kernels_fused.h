@@ -35,7 +35,10 @@ constexpr int kFrontQueue = 4096;    // pre-test survivor queue, 16-bit entries
 // per workgroup), wide ones flat bands (two workgroups per CU).
 constexpr int kFrontBandHeights[] = {64, 32, 16, 8};
 __host__ __device__ constexpr int front_x_bits(int rows) { return rows == 64 ? 9 : rows == 32 ? 10 : rows == 16 ? 11 : 12; }
-constexpr int kFrontSignPos0 = 7;  // bit of pixel 0 in the gathered sign word of a pre-test item (pixel k: 8 * (k & 3) + (k < 4 ? 7 : 3))
+// Survivor mask of a pre-test item (8 pixels, two polarities): bit p = 8 * (k & 1) + 4 * under + (k >> 1) for pixel k.  A
+// 16-bit queue entry is [15:4] the item (band row, x / 8) and [3:0] that bit number: the push loop of B1 is then ffbl /
+// clear / or / store, and the dense stages decode (front_entry_*).
+__host__ __device__ constexpr uint32_t front_mask_bit(int k, bool under) { return 1u << (8 * (k & 1) + (under ? 4 : 0) + (k >> 1)); }
 constexpr int kFrontMaxWidth = 2048;     // widest level 0 of the 16-row bands (11-bit x in the 16-bit queue entries)
 constexpr int kFrontMaxWidthWide = 4096; // ... of the 8-row bands (12-bit x)
 constexpr int kLdsPad = 8;           // halfs of padding left of column 0
@@ -80,6 +83,17 @@ __host__ __device__ inline uint32_t front_lds_bytes(const FrontGeom& g) {
     // + queue A + 5 counters + blur row constants (2 x rows float4)
     return ((g.rows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + kFrontQueue * 2u + 32u + 32u * g.rows;
 }
+
+// Typed buffer loads (the texture path converts): with DATA_FORMAT 8_8_8_8 / NUM_FORMAT UNORM a lane receives byte/255 of
+// four consecutive bytes as binary32 -- bit-identical to fl32(byte / 255.0f) (CRD-1) for all 256 bytes and all 2^24
+// colours (tools/ubench/fmt_rate.hip checks it on the device).  hipcc has no builtin for them; the LLVM intrinsics are
+// reached by name, so the compiler still schedules the loads and tracks their completion (an asm load would not be).
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float3_t __attribute__((ext_vector_type(3)));
+__device__ float4_t buffer_load_format_xyzw(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.format.v4f32");
+__device__ float3_t buffer_load_format_xyz(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.format.v3f32");
+constexpr int kBufferWord3Raw = 0x00020000;        // raw dword buffer
+constexpr int kBufferWord3Unorm8x4 = 0x00050FAC;   // DST_SEL xyzw, NUM_FORMAT UNORM, DATA_FORMAT 8_8_8_8
 
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
@@ -219,14 +233,14 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                                                          FrontGeom geo, float thr, uint32_t* __restrict__ seg_counts,
                                                          CornerData* __restrict__ segments) {
     constexpr int NT = L0 ? kFrontThreadsL0 : kFrontThreadsLN, R = RB, TC = kFrontTmpRows;
-    constexpr int XB = front_x_bits(RB);  // 16-bit queue entries: [15] polarity, row of the band, [XB-1:0] x
+    constexpr int XB = front_x_bits(RB);  // 16-bit queue entries: [15:XB+1] row of the band, [XB:4] x / 8, [3:0] pixel and polarity (front_mask_bit)
     static_assert((RB - 1) < (1 << (15 - XB)), "band row does not fit the queue entry");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int LS = (int)geo.ls, TS = (int)geo.ts;
     const int row3 = 3 * LS + kLdsPad;  // band row 0, column 0 inside the staged rows (three halo rows above, the left pad)
     half_t* const grey = reinterpret_cast<half_t*>(lds_raw);             // (R+6) rows x LS
     half_t* const tmp = grey + (R + 6) * LS;                              // 2 x TC rows x TS
-    // Queues of the FAST phase, 16-bit entries [15] run polarity (1 = brighter), [14:11] band row, [10:0] x.
+    // Queues of the FAST phase, 16-bit entries (see XB above).
     //   A: pre-test survivors (own storage); B: survivors of the diagonal filter; C: corners.  B and C
     //   live in the blur intermediate's storage (phase C starts after a barrier).  Whenever a queue is
     //   full the item is finished in place, so capacities only affect speed.
@@ -295,7 +309,11 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
         const bool lane_ok = ty < rpp;
         const uint8_t* src0 = frames + (size_t)frame * frame_bytes;
         const __amdgpu_buffer_rsrc_t frame_rsrc =  // gfx9 raw buffer: stride 0, num_records = bytes of the frame (< 2^32, checked at create)
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src0), 0, (int)frame_bytes, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src0), 0, (int)frame_bytes, kBufferWord3Raw);
+        // Y8: the same frame as a typed buffer -- four texels come back as byte/255 in binary32, converted by the texture
+        // path instead of 4 v_cvt_f32_ubyte + 8 multiply/fma on the vector unit, which is what bounds this kernel
+        const __amdgpu_buffer_rsrc_t frame_unorm =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src0), 0, (int)frame_bytes, kBufferWord3Unorm8x4);
         const uint16_t* srcn = gray_f + pyr.off[lvl];
         constexpr int U = L0 ? 8 : 4;  // 16-byte loads in flight per thread (VGPR budget: 64 at 8 waves/SIMD): level 0 issues all of a thread's rows at once
         // Level 0 walks with increments: the mirrored source offset, the LDS offset and the row of the thread's first
@@ -340,8 +358,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                         const int left = ok ? w - tx * 4 : 4;
                         v[u].x = (uint32_t)q[0] | ((uint32_t)q[left > 1 ? 1 : 0] << 8) | ((uint32_t)q[left > 2 ? 2 : 0] << 16) |
                                  ((uint32_t)q[left > 3 ? 3 : 0] << 24);
-                    } else if (Y8) {  // four texels = four bytes
-                        v[u].x = __builtin_amdgcn_raw_buffer_load_b32(frame_rsrc, off, 0, 0);
+                    } else if (Y8) {  // four texels = four bytes, converted on the way in (rows are 4-byte aligned here)
+                        v[u] = __builtin_bit_cast(uint4, buffer_load_format_xyzw(frame_unorm, off, 0, 0));
                     } else {  // RGBA quad; in the general variant (UA) the last quad of a row may run into the next row: those
                               // texels land in columns >= w, which nothing ever uses
                         v[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(frame_rsrc, off, 0, 0));
@@ -381,10 +399,13 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 if (live[u]) {
                     if (L0) {
                         uint2 out;
-                        if (Y8) {
+                        if (Y8 && UA) {
                             const uint32_t b = v[u].x;
                             out.x = pack_half2(unorm8_exact((float)(b & 255u)), unorm8_exact((float)((b >> 8) & 255u)));
                             out.y = pack_half2(unorm8_exact((float)((b >> 16) & 255u)), unorm8_exact((float)(b >> 24)));
+                        } else if (Y8) {  // v holds byte/255 of the four texels: two packed conversions (CRD-3)
+                            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(out.x) : "v"(__builtin_bit_cast(float, v[u].x)), "v"(__builtin_bit_cast(float, v[u].y)));
+                            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(out.y) : "v"(__builtin_bit_cast(float, v[u].z)), "v"(__builtin_bit_cast(float, v[u].w)));
                         } else {
                             out.x = luminance_pair_f16(v[u].x, v[u].y);
                             out.y = luminance_pair_f16(v[u].z, v[u].w);
@@ -486,7 +507,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
             uint32_t keep_cut = 0;
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                if (k < (int)(lim_x & 7u)) keep_cut |= 1u << (8 * (k & 3) + (k < 4 ? 7 : 3));
+                if (k < (int)(lim_x & 7u)) keep_cut |= front_mask_bit(k, false) | front_mask_bit(k, true);
             // thr_lo: one f16 ulp below RD16(thr) (see below); -min_subnormal when that would pass zero
             uint32_t tb = half_bits(to_half(thr));
             if (from_half(bits_half((uint16_t)tb)) > thr) tb--;
@@ -516,7 +537,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 //    sign of the exact difference).
                 const uint32_t dw[8] = {qa.x, qa.y, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};  // dw[j] = grey(x-4+2j, x-3+2j)
                 const uint32_t upw[4] = {qu.x, qu.y, qu.z, qu.w}, dnw[4] = {qd.x, qd.y, qd.z, qd.w};
-                uint32_t e_any[4], e_ovr[4];  // sign bit of each half = the answer for that pixel
+                uint32_t e_ovr[4], e_und[4];  // sign bit of each half = the answer for that pixel
     #pragma unroll
                 for (int j = 0; j < 4; j++) {  // pixel pair (x+2j, x+2j+1)
                     const ushort2_t left = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 1], dw[j], 16));       // x+2j-3, x+2j-2
@@ -531,43 +552,45 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     const half2_t e_over = thr_lo2 - (second_lo - c2);   // negative  <=>  second_lo - c > thr_lo
                     const half2_t e_under = (second_hi - c2) + thr_lo2;  // negative  <=>  second_hi - c < -thr_lo
                     e_ovr[j] = __builtin_bit_cast(uint32_t, e_over);
-                    e_any[j] = e_ovr[j] | __builtin_bit_cast(uint32_t, e_under);
+                    e_und[j] = __builtin_bit_cast(uint32_t, e_under);
                 }
-                // Gather the eight sign bits (bit 7 of bytes 1 and 3 of each word) into one word with two byte
-                // permutes: pixel k of the item sits at bit kFrontSignPos(k) = 8*(k & 3) + (k < 4 ? 7 : 3).
-                auto gather_signs = [](const uint32_t (&e)[4]) {
-                    const uint32_t p01 = __builtin_amdgcn_perm(e[1], e[0], 0x07050301u);  // pixels 0..3 -> bytes 0..3
-                    const uint32_t p23 = __builtin_amdgcn_perm(e[3], e[2], 0x07050301u);  // pixels 4..7
-                    return (p01 & 0x80808080u) | ((p23 & 0x80808080u) >> 4);
-                };
-                uint32_t cand = gather_signs(e_any);
+                // The sixteen sign bits (8 pixels x 2 polarities, which exclude each other) as one 16-bit mask, bit
+                // front_mask_bit(k, under): every word's two sign bits become 0/1 in its halves (one packed shift), a
+                // shift-or per word places them -- even pixels in the low half, odd ones in the high half --, one byte
+                // permute folds the halves.
+                uint32_t acc = 0;
+    #pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t so = __builtin_bit_cast(uint32_t, as_u16x2(e_ovr[j]) >> (unsigned short)15);
+                    const uint32_t su = __builtin_bit_cast(uint32_t, as_u16x2(e_und[j]) >> (unsigned short)15);
+                    acc = j == 0 ? so : ((so << j) | acc);
+                    acc = (su << (4 + j)) | acc;
+                }
+                uint32_t cand = __builtin_amdgcn_perm(0u, acc, 0x0c0c0200u);  // byte 0 | byte 2 << 8
                 // fast.wgsl:77 guard on x: keep pixels k with 16 < x+k < lim_x.  Only two items of a row are cut -- the one
                 // at x = 16 loses pixel 0, the one that holds column lim_x loses its tail --, and both masks are the same for
                 // every row: two compares and selects here instead of eight each.
-                cand &= x == 16 ? ~(1u << kFrontSignPos0) : ~0u;
+                cand &= x == 16 ? ~(front_mask_bit(0, false) | front_mask_bit(0, true)) : ~0u;
                 cand &= x == x_cut ? keep_cut : ~0u;
                 if (cand) {  // one LDS atomic for all survivors of this item
-                    const uint32_t cand_over = gather_signs(e_ovr);
                     // every lane reserves its own slots with the LDS's returning add (lds_add_rtn, orb_device.h)
                     const uint32_t n_cand = (uint32_t)__builtin_popcount(cand);
                     uint32_t qs = lds_add_rtn(qa_count, n_cand);
+                    const uint32_t base = ((uint32_t)lyc << (XB + 1)) | ((uint32_t)x << 1);  // x is a multiple of 8: the low four bits are free
                     if (qs + n_cand <= (uint32_t)kFrontQueue) {  // all survivors of the item fit: no test per entry
-                        const uint32_t base = ((uint32_t)lyc << XB) | (uint32_t)x;  // x is a multiple of 8: + k stays inside the x field
                         while (cand) {
-                            const int p = __builtin_ctz(cand);
+                            const uint32_t p = (uint32_t)__builtin_ctz(cand);
                             cand &= cand - 1u;
-                            const uint32_t k = (uint32_t)((p >> 3) | ((p & 4) ^ 4));
-                            queue_a[qs++] = (uint16_t)((((cand_over >> p) & 1u) << 15) | (base + k));
+                            queue_a[qs++] = (uint16_t)(base | p);
                         }
                     } else {
                         while (cand) {
-                            const int p = __builtin_ctz(cand);
+                            const uint32_t p = (uint32_t)__builtin_ctz(cand);
                             cand &= cand - 1u;
-                            const int k = (p >> 3) | ((p & 4) ^ 4);
-                            const bool over = (cand_over >> p) & 1u;
                             if (qs < (uint32_t)kFrontQueue) {
-                                queue_a[qs] = (uint16_t)((over ? 0x8000u : 0u) | ((uint32_t)lyc << XB) | (uint32_t)(x + k));
+                                queue_a[qs] = (uint16_t)(base | p);
                             } else {  // queue full (pathological frame): finish in place
+                                const int k = (int)(((p & 3u) << 1) | (p >> 3));
                                 uint32_t angle;
                                 const bool hit = fast_full_test(rowc + k, LS, thr, &angle);
                                 segment_append(hit, (uint32_t)(x + k), gy, angle, lvl, c_count, seg, geo.seg_cap, two_lists);
@@ -585,18 +608,20 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
         // =========================== B2: thin, test, orient -- each stage on densely packed lanes ===========
         if (geo.phase_mask & 2u) {
             auto locate = [&](uint32_t e, uint32_t* x, uint32_t* gy) -> const half_t* {
-                const int lyc = (int)((e >> XB) & (uint32_t)(RB - 1));
-                *x = e & ((1u << XB) - 1u);
-                *gy = (uint32_t)(y0 + lyc);
-                return grey + row3 + (int)__umul24((uint32_t)lyc, (uint32_t)LS) + (int)*x;
+                const uint32_t lyc = e >> (XB + 1);                                       // e is a 16-bit entry
+                const uint32_t k = ((e & 3u) << 1) | ((e >> 3) & 1u);                     // pixel of the item (front_mask_bit)
+                *x = ((e >> 1) & (((1u << XB) - 1u) & ~7u)) | k;
+                *gy = (uint32_t)y0 + lyc;
+                return grey + row3 + (int)__umul24(lyc, (uint32_t)LS) + (int)*x;
             };
+            auto is_over = [](uint32_t e) { return (e & 4u) == 0u; };  // polarity of the pre-test that passed
             // stage 1: diagonal 3-of-4 filter (a necessary condition of a 12-run), A -> B
             const uint32_t n_a = min(*qa_count, (uint32_t)kFrontQueue);
             for (uint32_t i = (uint32_t)tid; i < n_a; i += NT) {
                 const uint32_t e = queue_a[i];
                 uint32_t x, gy;
                 const half_t* ctr = locate(e, &x, &gy);
-                if (diagonal_filter(ctr, LS, thr, (e & 0x8000u) != 0u)) {
+                if (diagonal_filter(ctr, LS, thr, is_over(e))) {
                     const uint32_t qs = atomicAdd(qb_count, 1u);
                     if (qs < cap_b) {
                         queue_b[qs] = (uint16_t)e;
@@ -616,7 +641,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 const uint32_t e = queue_b[i];
                 uint32_t x, gy;
                 const half_t* ctr = locate(e, &x, &gy);
-                if (ring_is_corner_polar(ctr, LS, thr, (e & 0x8000u) != 0u)) {
+                if (ring_is_corner_polar(ctr, LS, thr, is_over(e))) {
                     const uint32_t qs = atomicAdd(qc_count, 1u);
                     if (qs < cap_c)
                         queue_c[qs] = (uint16_t)e;

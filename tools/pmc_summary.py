@@ -8,7 +8,7 @@ import sys
 import pandas as pd
 
 src = sys.argv[1]
-KERNELS = ("k_front<true>", "k_front<false>", "k_brief_rows", "k_slot_prefix", "k_front_y", "k_compact", "k_brief_t", "k_brief_nf")
+KERNELS = ("k_front<true>", "k_front<false>", "k_brief_rows", "k_slot_prefix", "k_front_y", "k_compact", "k_brief_t", "k_brief_nfb", "k_brief_nf")
 
 
 def short(name):
@@ -30,6 +30,7 @@ for sub in sorted(os.listdir(src)):
     d = pd.read_csv(fs[-1])
     d["kernel"] = d["Kernel_Name"].map(short)
     d = d.dropna(subset=["kernel"])
+    d = d[d["Grid_Size"] == d.groupby("kernel")["Grid_Size"].transform("max")]  # the batch launches, not single-frame ones
     g = d.groupby(["kernel", "Counter_Name"])["Counter_Value"].agg(["mean", "count"]).reset_index()
     g["pass"] = sub
     rows.append(g)
