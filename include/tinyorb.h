@@ -295,7 +295,7 @@ int orb_debug_f32_to_f16(OrbProgram *p, const float *src, uint16_t *dst, size_t 
 int orb_debug_angle_code(OrbProgram *p, const float *cy, const float *cx, uint32_t *dst, size_t n);
 
 /* ---- measurement ---- */
-#define ORB_KERNEL_COUNT 19
+#define ORB_KERNEL_COUNT 20
 /* When enabled every kernel launch is bracketed by hipEvents on its stream. */
 int orb_profile_enable(OrbProgram *p, int enable);
 int orb_profile_reset(OrbProgram *p);

@@ -26,11 +26,12 @@ using namespace orb;
 
 namespace {
 
-enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I, KID_MATCH, KID_COMPACT, KID_BRIEF_T, KID_BRIEF_NF, KID_PACK_T, KID_UNPACK_T };
+enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I, KID_MATCH, KID_COMPACT, KID_BRIEF_T, KID_BRIEF_NF, KID_PACK_T, KID_UNPACK_T, KID_BRIEF_ONE };
 const char* const kKernelNames[ORB_KERNEL_COUNT] = {"k_grayscale", "k_mip",      "k_blur_rows", "k_fast",       "k_brief",
                                                     "k_front_l0",  "k_front_ln", "k_synth",     "k_brief_rows", "k_slot_prefix",
                                                     "k_front_i",   "k_select_i", "k_brief_i",   "k_match",      "k_compact",
-                                                    "k_brief_t",   "k_brief_nf",  "k_compact_transport", "k_unpack_transport"};
+                                                    "k_brief_t",   "k_brief_nf",  "k_compact_transport", "k_unpack_transport",
+                                                    "k_brief_one"};
 
 thread_local std::string g_create_error;
 
@@ -421,8 +422,9 @@ int launch_brief(OrbProgram* p, hipStream_t s, uint32_t n, const RowsGeom& rows_
     return ORB_OK;
 }
 
-// The fused pipeline for frames [f0, f0 + n) of the batch on stream s: one k_front launch per level + BRIEF.
-int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint32_t n, hipStream_t s) {
+// The fused pipeline for frames [f0, f0 + n) of the batch on stream s: one k_front launch per level + BRIEF
+// (with_brief = false: the caller launches its own BRIEF kernel -- the single-frame path's k_brief_one).
+int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint32_t n, hipStream_t s, bool with_brief = true) {
     const Pyramid& pyr = p->pyr;
     const uint32_t D = pyr.depth, cap = p->cfg.max_features;
     const uint8_t* frames = frames_all + (size_t)f0 * p->frame_bytes;
@@ -503,7 +505,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
 #undef FRONT_ARGS
     }
     // orb.rs:523-534, plus the compaction of the band segments into the final lists
-    launch_brief(p, s, n, p->rows, d_blur, d_blur_rowc, d_seg_counts, d_seg_before, d_seg, d_counts, d_corners, d_desc);
+    if (with_brief) launch_brief(p, s, n, p->rows, d_blur, d_blur_rowc, d_seg_counts, d_seg_before, d_seg, d_counts, d_corners, d_desc);
     HIP_TRY(p, hipGetLastError());
     return ORB_OK;
 }
@@ -1134,16 +1136,38 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
     HIP_TRY(p, hipSetDevice(p->device));
     if (int rc = ensure_input(p)) return rc;
     hipStream_t s = p->stream;
-    if (int rc = run_pipeline(p, p->d_input, 1, s)) return rc;
     const size_t cap = p->cfg.max_features;
     // orb.rs:537-547: counter, corners and descriptors go to host staging, then block.  The reference copies the three
-    // whole buffers; here one kernel writes the counter and the STORED records into the (pinned, device-visible) staging
+    // whole buffers; here a kernel writes the counter and the STORED records into the (pinned, device-visible) staging
     // memory: no size has to reach the host first, and 48 bytes per keypoint cross PCIe instead of 48 * max_features.
     // What lies behind the stored records in the staging arrays is stale, as it is in the reference's buffers.
     void *dc = nullptr, *dk = nullptr, *dd = nullptr;
     const bool direct = !getenv("TINYORB_SINGLE_MEMCPY") && hipHostGetDevicePointer(&dc, p->h_count, 0) == hipSuccess &&
                         hipHostGetDevicePointer(&dk, p->h_corners, 0) == hipSuccess &&
                         hipHostGetDevicePointer(&dd, p->h_desc, 0) == hipSuccess;
+    if (direct && p->fused && p->use_brief_t && !getenv("TINYORB_SINGLE_SPLIT")) {
+        // Three launches per frame: one k_front per level, then k_brief_one -- slot prefix, both BRIEF kernels and the
+        // write to host staging in one (a dependent launch costs 6-10 us whatever it does, and this call is the
+        // reference's only shape).
+        if (int rc = run_fused_range(p, p->d_input, 0, 1, s, false)) return rc;
+        {
+            LaunchScope ls(p, s, KID_BRIEF_ONE);
+            hipLaunchKernelGGL(k_brief_one, dim3((unsigned)((cap + kBriefOneChunk - 1u) / kBriefOneChunk)), dim3(256), brieft_lds_bytes(p->brieft), s, p->d_blur,
+                               p->d_blur_rowc, p->pyr, p->brieft, p->d_seg_counts, p->d_seg_before, p->d_seg, p->d_counts, p->d_corners,
+                               (uint32_t)cap, p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin}, static_cast<uint32_t*>(dc),
+                               static_cast<CornerData*>(dk), static_cast<CornerDescriptor*>(dd));
+        }
+        HIP_TRY(p, hipGetLastError());
+        p->planes_valid = true;
+        HIP_TRY(p, hipStreamSynchronize(s));
+        p->single_valid = true;
+        p->last_batch = 1;
+        p->last_stream = s;
+        *corner_count = *p->h_count;  // raw counter, orb.rs:550-556
+        if (*corner_count > cap) return fail(p, ORB_ECAPACITY, "%u corners detected, max_features is %zu", *corner_count, cap);
+        return ORB_OK;
+    }
+    if (int rc = run_pipeline(p, p->d_input, 1, s)) return rc;
     if (direct) {
         p->last_batch = 1;
         p->last_stream = s;

@@ -48,47 +48,59 @@ __device__ __forceinline__ uint32_t push_gt(uint32_t word, uint32_t a, uint32_t 
     return __builtin_amdgcn_alignbit(word, b - a, 31);  // bit 31 of (b - a) is set iff a > b
 }
 
-template <int kWavesPerSimd>
-__global__ __launch_bounds__(kBriefTThreads, kWavesPerSimd) void k_brief_t(const uint16_t* __restrict__ blur_rowc, Pyramid pyr, BriefTGeom bg,
-                                                                const uint32_t* __restrict__ seg_counts,
-                                                                const uint32_t* __restrict__ seg_before,
-                                                                const CornerData* __restrict__ segments,
-                                                                CornerData* __restrict__ corners, uint32_t cap,
-                                                                CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+// Body of k_brief_t for the workgroup that takes keypoints [chunk * 256, chunk * 256 + 256) of `frame` (the batch kernel:
+// blockIdx; the single-frame kernel k_brief_one: its own chunk).  lds_raw: brieft_lds_bytes() of dynamic LDS.
+// The frame's blur row constants into LDS, 18 zero rows in front of every level and 26 behind it (BriefTGeom::row_base).
+__device__ __forceinline__ void brief_t_stage_rows(uint16_t* rows, const uint16_t* __restrict__ src, const Pyramid& pyr,
+                                                   const BriefTGeom& bg, uint32_t tid) {
+    uint32_t m = 0;
+    for (uint32_t i = tid; i < bg.rows_padded; i += kBriefTThreads) {
+        while (m + 1u < pyr.depth && i + (uint32_t)kBriefHalo >= bg.row_base[m + 1u]) m++;  // level whose padded range holds i
+        const uint32_t y = i - bg.row_base[m];  // wraps for the zero rows in front of the level
+        rows[i] = y < pyr.h[m] ? src[pyr.row_off[m] + y] : (uint16_t)0;
+    }
+}
+
+// CHUNK: keypoints per workgroup (the first CHUNK threads take one each; all 256 stage).  STAGED: the caller has already
+// put the list prefix and the row constants into lds_raw (k_brief_one does, next to its own prefix scan).
+template <int CHUNK = kBriefTThreads, bool STAGED = false>
+__device__ __forceinline__ void brief_t_body(uint8_t* lds_raw, uint32_t frame, uint32_t chunk, const uint16_t* __restrict__ blur_rowc,
+                                             const Pyramid& pyr, const BriefTGeom& bg, const uint32_t* __restrict__ seg_counts,
+                                             const uint32_t* __restrict__ seg_before, const CornerData* __restrict__ segments,
+                                             CornerData* __restrict__ corners, uint32_t cap,
+                                             CornerDescriptor* __restrict__ descriptors, const BriefTables& tab) {
     const uint32_t n_ent = bg.n_slots * bg.n_classes;  // lists of a frame, in final order: class-major, slot-minor
     uint32_t* const before = reinterpret_cast<uint32_t*>(lds_raw);                    // [n_ent + 1]
     uint16_t* const rows = reinterpret_cast<uint16_t*>(before + n_ent + 1u);          // [rows_padded]
     __shared__ uint32_t lv[kMaxLevels][2];  // flat_end, row_base (a run-time index into kernel arguments is a global load)
 
-    // The frame is the FAST grid index: chunks past a frame's keypoint count exit at once, and with the chunk as the fast
-    // index their regular pattern (15 busy, 17 idle, ...) lands every busy workgroup on the same half of the CUs.
-    const uint32_t frame = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     const size_t sbase = (size_t)frame * n_ent;
     // the last list (last class, last slot): seg_before is [class][slot], seg_counts is [slot][class]
-    const uint32_t stored_total = seg_before[sbase + n_ent - 1u] + min(seg_counts[sbase + n_ent - 1u], bg.seg_cap);
+    uint32_t stored_total;
+    if (STAGED) {
+        if (tid < pyr.depth) lv[tid][0] = bg.flat_end[tid], lv[tid][1] = bg.row_base[tid];
+        __syncthreads();
+        stored_total = before[n_ent];
+    } else {
+        stored_total = seg_before[sbase + n_ent - 1u] + min(seg_counts[sbase + n_ent - 1u], bg.seg_cap);
+    }
     const uint32_t n_frame = min(stored_total, cap);
-    const uint32_t k0 = blockIdx.y * (uint32_t)kBriefTThreads;
+    const uint32_t k0 = chunk * (uint32_t)CHUNK;
     if (k0 >= n_frame) return;  // uniform for the workgroup
 
-    // ---- stage the frame's list prefix and row constants (zeros around every level)
-    for (uint32_t s = tid; s < n_ent; s += kBriefTThreads) before[s] = seg_before[sbase + s];
-    if (tid == 0) before[n_ent] = stored_total;
-    if (tid < pyr.depth) lv[tid][0] = bg.flat_end[tid], lv[tid][1] = bg.row_base[tid];
-    {
-        const uint16_t* src = blur_rowc + (size_t)frame * pyr.row_stride;
-        uint32_t m = 0;
-        for (uint32_t i = tid; i < bg.rows_padded; i += kBriefTThreads) {
-            while (m + 1u < pyr.depth && i + (uint32_t)kBriefHalo >= bg.row_base[m + 1u]) m++;  // level whose padded range holds i
-            const uint32_t y = i - bg.row_base[m];  // wraps for the zero rows in front of the level
-            rows[i] = y < pyr.h[m] ? src[pyr.row_off[m] + y] : (uint16_t)0;
-        }
+    if (!STAGED) {
+        // ---- stage the frame's list prefix and row constants (zeros around every level)
+        for (uint32_t s = tid; s < n_ent; s += kBriefTThreads) before[s] = seg_before[sbase + s];
+        if (tid == 0) before[n_ent] = stored_total;
+        if (tid < pyr.depth) lv[tid][0] = bg.flat_end[tid], lv[tid][1] = bg.row_base[tid];
+        brief_t_stage_rows(rows, blur_rowc + (size_t)frame * pyr.row_stride, pyr, bg, tid);
+        __syncthreads();
     }
-    __syncthreads();
 
     // ---- this thread's keypoint: slot by binary search in the prefix, record from the band segment
     const uint32_t k = k0 + tid;
-    if (k >= n_frame) return;
+    if (tid >= (uint32_t)CHUNK || k >= n_frame) return;
     uint32_t lo = 0, hi = n_ent;  // largest e with before[e] <= k (empty lists repeat the value: take the last)
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -151,6 +163,19 @@ __global__ __launch_bounds__(kBriefTThreads, kWavesPerSimd) void k_brief_t(const
     o[1] = make_uint4(d[4], d[5], d[6], d[7]);
 }
 
+template <int kWavesPerSimd>
+__global__ __launch_bounds__(kBriefTThreads, kWavesPerSimd) void k_brief_t(const uint16_t* __restrict__ blur_rowc, Pyramid pyr, BriefTGeom bg,
+                                                                const uint32_t* __restrict__ seg_counts,
+                                                                const uint32_t* __restrict__ seg_before,
+                                                                const CornerData* __restrict__ segments,
+                                                                CornerData* __restrict__ corners, uint32_t cap,
+                                                                CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    // The frame is the FAST grid index: chunks past a frame's keypoint count exit at once, and with the chunk as the fast
+    // index their regular pattern (15 busy, 17 idle, ...) lands every busy workgroup on the same half of the CUs.
+    brief_t_body(lds_raw, blockIdx.x, blockIdx.y, blur_rowc, pyr, bg, seg_counts, seg_before, segments, corners, cap, descriptors, tab);
+}
+
 // The keypoints k_brief_t leaves (not flat, 12 %: a sample may come from the stored tail of the blur plane, or lie left
 // of the level).  A workgroup scans 256 consecutive keypoints of a frame's final list, compacts the ones that are not
 // flat (ballots, no atomics) and deals them to its four waves, one wave per keypoint: lane l evaluates tests l, 64+l,
@@ -164,11 +189,15 @@ __global__ __launch_bounds__(kBriefTThreads, kWavesPerSimd) void k_brief_t(const
 constexpr int kNfPatchCols = 48, kNfPatchRows = 2 * kBriefHalo + 1;                       // halfs, rows
 constexpr int kNfPatchHalfs = kNfPatchRows * kNfPatchCols;
 
-__global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ blur, const uint16_t* __restrict__ blur_rowc,
-                                                  Pyramid pyr, BriefTGeom bg, const uint32_t* __restrict__ seg_counts,
-                                                  const uint32_t* __restrict__ seg_before,
-                                                  const CornerData* __restrict__ corners, uint32_t cap,
-                                                  CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
+// CHUNK: keypoints per workgroup (k_brief_one takes 64 so that a frame's ~450 such keypoints spread over 60 workgroups
+// instead of 15 -- a wave works through its share one memory round trip after the other).  n_known: the frame's stored
+// count when the caller has it (else ~0u: read from the prefix).
+template <int CHUNK = 256>
+__device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, uint32_t n_known, const uint16_t* __restrict__ blur,
+                                              const uint16_t* __restrict__ blur_rowc, const Pyramid& pyr, const BriefTGeom& bg,
+                                              const uint32_t* __restrict__ seg_counts, const uint32_t* __restrict__ seg_before,
+                                              const CornerData* __restrict__ corners, uint32_t cap,
+                                              CornerDescriptor* __restrict__ descriptors, const BriefTables& tab) {
     __shared__ __attribute__((aligned(16))) uint16_t patches[4][kNfPatchHalfs];
     __shared__ uint4 recs[256];
     __shared__ float2 rot[256];  // (cos, sin) of the keypoint's angle code (CRD-10 table), fetched during the scan
@@ -177,22 +206,23 @@ __global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ b
     // per-level geometry: indexing the by-value kernel arguments with a run-time level is a global load from the
     // kernarg segment (a memory round trip in front of every keypoint); from LDS it is 64 cycles
     __shared__ uint32_t lv[kMaxLevels][6];  // w, h, qa, row_off, off, flat_end
-    const uint32_t frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;  // frame = fast index, as above
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid < pyr.depth) {
         lv[tid][0] = pyr.w[tid], lv[tid][1] = pyr.h[tid], lv[tid][2] = bg.qa[tid], lv[tid][3] = pyr.row_off[tid];
         lv[tid][4] = pyr.off[tid], lv[tid][5] = bg.flat_end[tid];
     }
     const uint32_t n_ent = bg.n_slots * bg.n_classes;
     const size_t sbase = (size_t)frame * n_ent;
-    const uint32_t n_frame = min(seg_before[sbase + n_ent - 1u] + min(seg_counts[sbase + n_ent - 1u], bg.seg_cap), cap);
-    const uint32_t k0 = blockIdx.y * 256u;
+    const uint32_t n_frame = n_known != ~0u ? min(n_known, cap)
+                                            : min(seg_before[sbase + n_ent - 1u] + min(seg_counts[sbase + n_ent - 1u], bg.seg_cap), cap);
+    const uint32_t k0 = chunk * (uint32_t)CHUNK;
     if (k0 >= n_frame) return;  // uniform for the workgroup
     __syncthreads();
     // ---- scan: which of this chunk's keypoints are not flat (k_brief_t has written the final list)
     const uint32_t kk = k0 + tid;
     uint4 rec = make_uint4(0u, 0u, 0u, 0u);
     bool mine = false;
-    if (kk < n_frame) {
+    if (tid < (uint32_t)CHUNK && kk < n_frame) {
         rec = *reinterpret_cast<const uint4*>(&corners[(size_t)frame * cap + kk]);
         const uint32_t l = min(rec.w, pyr.depth - 1u);
         mine = !(rec.x >= (uint32_t)kBriefHalo && rec.x < lv[l][5]);
@@ -332,6 +362,86 @@ __global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ b
             const uint64_t src = lane < 2u ? bal[0] : (lane < 4u ? bal[1] : (lane < 6u ? bal[2] : bal[3]));
             out_desc[(size_t)idx * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ blur, const uint16_t* __restrict__ blur_rowc,
+                                                  Pyramid pyr, BriefTGeom bg, const uint32_t* __restrict__ seg_counts,
+                                                  const uint32_t* __restrict__ seg_before,
+                                                  const CornerData* __restrict__ corners, uint32_t cap,
+                                                  CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
+    brief_nf_body(blockIdx.x, blockIdx.y, ~0u, blur, blur_rowc, pyr, bg, seg_counts, seg_before, corners, cap, descriptors, tab);  // frame = fast index, as above
+}
+
+// ---------------------------------------------------------------------------------------------
+// The reference's only call shape is ONE frame per blocking call (orb.rs:469-557).  Launched one after the other, the
+// slot prefix, the two BRIEF kernels and the packing of the results into host staging are four dependent launches of
+// 6-19 us each for a few microseconds of work.  k_brief_one is the four in one launch for a single frame: every
+// workgroup (kBriefOneChunk keypoints of the final list each; 256 threads) derives the prefix of the frame's lists
+// itself, straight into the LDS layout of k_brief_t -- 2 x 68 lists at 720p: every count is loaded once, together with
+// the row constants, wave 0 scans --, then runs k_brief_t's and k_brief_nf's bodies on its chunk, and finally copies its
+// records and descriptors into the (pinned, device-visible) host staging arrays; workgroup 0 also writes the raw
+// counter there (orb.rs:550-556).  Latency, not throughput, is what it is built for: small chunks, so that the
+// keypoints that are not flat (one memory round trip each, per wave) spread over many workgroups.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBriefOneChunk = 64;
+__global__ __launch_bounds__(256) void k_brief_one(const uint16_t* __restrict__ blur, const uint16_t* __restrict__ blur_rowc, Pyramid pyr,
+                                                   BriefTGeom bg, const uint32_t* __restrict__ seg_counts,
+                                                   uint32_t* __restrict__ seg_before, const CornerData* __restrict__ segments,
+                                                   uint32_t* __restrict__ counts, CornerData* __restrict__ corners, uint32_t cap,
+                                                   CornerDescriptor* __restrict__ descriptors, BriefTables tab,
+                                                   uint32_t* __restrict__ host_count, CornerData* __restrict__ host_corners,
+                                                   CornerDescriptor* __restrict__ host_descriptors) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const uint32_t tid = threadIdx.x, chunk = blockIdx.x;
+    const uint32_t n_ent = bg.n_slots * bg.n_classes;
+    uint32_t* const before = reinterpret_cast<uint32_t*>(lds_raw);             // k_brief_t's layout: [n_ent + 1] ...
+    uint16_t* const rows = reinterpret_cast<uint16_t*>(before + n_ent + 1u);   // ... then [rows_padded]
+    // raw counts in final order (class-major) into before[], all loads of the workgroup in flight together
+    for (uint32_t e = tid; e < n_ent; e += 256u) {
+        const uint32_t cls = e / bg.n_slots, sl = e - cls * bg.n_slots;
+        before[e] = seg_counts[sl * bg.n_classes + cls];
+    }
+    brief_t_stage_rows(rows, blur_rowc, pyr, bg, tid);
+    __syncthreads();
+    if (tid < 64u) {  // k_slot_prefix, by wave 0 of every workgroup: exclusive prefix of the stored counts, in place
+        uint32_t carry = 0, total = 0;
+        for (uint32_t e0 = 0; e0 < n_ent; e0 += 64u) {
+            const uint32_t e = e0 + tid;
+            const uint32_t raw = e < n_ent ? before[e] : 0u;
+            const uint32_t stored = min(raw, bg.seg_cap);
+            uint32_t incl = stored;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d);
+                if ((int)tid >= d) incl += t;
+            }
+            if (e < n_ent) before[e] = carry + incl - stored;
+            carry += __shfl(incl, 63);
+            uint32_t r = raw;
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) r += __shfl_xor(r, sh);
+            total += r;
+        }
+        if (tid == 0u) {
+            before[n_ent] = carry;  // stored keypoints of the frame
+            if (chunk == 0u) counts[0] = total, *host_count = total;
+        }
+    }
+    // (brief_t_body's first barrier publishes the prefix)
+    brief_t_body<kBriefOneChunk, true>(lds_raw, 0u, chunk, blur_rowc, pyr, bg, seg_counts, seg_before, segments, corners, cap,
+                                       descriptors, tab);
+    __syncthreads();  // the chunk's records are in the final list: brief_nf_body reads them
+    const uint32_t n_stored = before[n_ent];
+    brief_nf_body<kBriefOneChunk>(0u, chunk, n_stored, blur, blur_rowc, pyr, bg, seg_counts, seg_before, corners, cap, descriptors, tab);
+    __syncthreads();
+    // ---- this chunk's part of the frame's result, into host staging (orb.rs:537-547)
+    const uint32_t n_frame = min(n_stored, cap), k = chunk * (uint32_t)kBriefOneChunk + tid;
+    if (tid < (uint32_t)kBriefOneChunk && k < n_frame) {
+        *reinterpret_cast<uint4*>(&host_corners[k]) = *reinterpret_cast<const uint4*>(&corners[k]);
+        const uint4* sd = reinterpret_cast<const uint4*>(&descriptors[k]);
+        uint4* dd = reinterpret_cast<uint4*>(&host_descriptors[k]);
+        dd[0] = sd[0], dd[1] = sd[1];
     }
 }
 

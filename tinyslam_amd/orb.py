@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_PKG, "libtinyorb.so")
 
 ORB_OK, ORB_EINVAL, ORB_EHIP, ORB_ECAPACITY, ORB_ESTATE = 0, 1, 2, 3, 4
 ORB_PLANE_GRAY, ORB_PLANE_BLUR = 0, 1
-ORB_KERNEL_COUNT = 19
+ORB_KERNEL_COUNT = 20
 ORB_FLAG_STAGED = 1
 ORB_FLAG_DOUBLE_OUTPUT = 2
 ORB_FLAG_NMS = 4
