@@ -161,17 +161,39 @@ __device__ __forceinline__ bool ring_is_corner(const half_t* ctr, int ls, float 
     return (detect_streak_16(m_over) | detect_streak_16(m_under)) != 0u;  // fast.wgsl:117-121
 }
 // The same for a pixel whose compass pre-test passed with the given polarity: a 12-run holds three of the four
-// compass points, so a run of the other polarity is impossible and one mask is enough (+-(v - c) is exact).
+// compass points, so a run of the other polarity is impossible and one mask is enough.
+// Exact, on packed 16-bit integers: v - c is exact in binary32 for grey values (f16, <= 1), so `fl32(v - c) > thr` is the
+// real comparison v > c + thr, i.e. v >= T with T the smallest f16 above c + thr -- and grey values are non-negative f16,
+// whose bit patterns order like the values.  T is found once per pixel (round c + thr to f16, test that candidate with
+// the reference's own expression, step one pattern if it fails); "darker" is the mirror image (v <= T', T' the largest
+// f16 below c - thr, none if that is not positive), folded into the same subtraction by complementing both sides.
+// Ring points i and i + 8 share a register: 8 packed subtractions whose sign bits are the mask, gathered in ring order
+// by a packed shift and a shift-or per register and one byte permute.
 __device__ __forceinline__ bool ring_is_corner_polar(const half_t* ctr, int ls, float thr, bool over) {
     const float c = from_half(ctr[0]);
-    const float sgn = over ? 1.0f : -1.0f, cneg = over ? -c : c;
-    uint32_t m = 0;
+    const float sgn = over ? 1.0f : -1.0f;
+    const float s = __builtin_fmaf(sgn, thr, c);           // c + thr / c - thr (rounded: only a first guess)
+    const uint32_t h0 = half_bits(to_half(s));
+    const float d = from_half(bits_half((uint16_t)h0)) - c;  // exact
+    const bool pass = d * sgn > thr;                       // the candidate itself, by the reference's expression (CRD-7; +-d is exact)
+    const int isgn = over ? 1 : -1;
+    int t = (int)h0 + (pass ? 0 : isgn);                   // over: smallest v that passes; under: largest v that passes
+    if (!over && !(s > 0.0f)) t = -1;                      // nothing is darker than a non-positive bound
+    // pass  <=>  over: v >= t  |  under: v <= t  <=>  (v ^ m) >= (t ^ m) as signed 16-bit, m = under ? 0xffff : 0
+    //       <=>  ((t ^ m) - 1) - (v ^ m) < 0
+    const uint32_t m = over ? 0u : 0xffffu;
+    const uint32_t tm1 = (uint32_t)(((t ^ (int)m) - 1) & 0xffff), tt = tm1 | (tm1 << 16), mm = m | (m << 16);
+    uint32_t acc = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const float diff = fma_mix_h(half_bits(ctr[kRingDy[i] * ls + kRingDx[i]]), sgn, cneg);  // +-(v - c), exact
-        m |= (diff > thr) ? (1u << i) : 0u;
+    for (int j = 0; j < 8; j++) {
+        const ushort2_t v = {half_bits(ctr[kRingDy[j] * ls + kRingDx[j]]), half_bits(ctr[kRingDy[j + 8] * ls + kRingDx[j + 8]])};
+        typedef short short2_t __attribute__((ext_vector_type(2)));
+        const short2_t df = __builtin_bit_cast(short2_t, tt) - __builtin_bit_cast(short2_t, __builtin_bit_cast(uint32_t, v) ^ mm);
+        const uint32_t sb = __builtin_bit_cast(uint32_t, __builtin_bit_cast(ushort2_t, df) >> (unsigned short)15);  // 1 = passes
+        acc = j == 0 ? sb : ((sb << j) | acc);
     }
-    return detect_streak_16(m) != 0u;
+    const uint32_t mask = __builtin_amdgcn_perm(0u, acc, 0x0c0c0200u);  // bits 0..7: ring 0..7, bits 8..15: ring 8..15
+    return detect_streak_16(mask) != 0u;
 }
 // ring centroid -> milliradian code (fast.wgsl:106,115,153; CRD-8: ring order, unfused)
 __device__ __forceinline__ uint32_t ring_angle(const half_t* ctr, int ls) {
