@@ -310,30 +310,66 @@ def run_rank(args):
     transport = world > 1 and args.collate == "transport"
     tbuf = [torch.empty((B * MAX_FEATURES, node.TRANSPORT_WORDS), dtype=torch.int32, device=dev) for _ in range(2)] if transport else None
 
+    # N > 1, transport form: the lagged collator (no host stall per batch) and, on rank 0, the two record arrays of a
+    # whole job per output set, allocated once
+    collator = node.TransportCollator(B, MAX_FEATURES, dev) if transport else None
+    all_records = world * B * MAX_FEATURES
+    corners_all = [torch.empty((all_records, 4), dtype=torch.int32, device=dev) for _ in range(2)] if transport and rank == 0 else None
+    desc_all = [torch.empty((all_records, 8), dtype=torch.int32, device=dev) for _ in range(2)] if transport and rank == 0 else None
+    state["ticket"] = None
+    state["host_s"] = 0.0
+    state["regathers"] = 0
+
+    def expand(info, merged, stride):
+        """Rank 0: transport records of every rank -> the reference's two record arrays, frames of the job in order."""
+        totals = info["totals"]
+        first = np.concatenate([[0], np.cumsum(totals)])
+        sl = info["slot"]
+        prog.unpack_transport(merged.data_ptr(), [r * stride for r in range(world)], totals, first[:-1],
+                              corners_all[sl].data_ptr(), desc_all[sl].data_ptr(), stream=comm_stream.cuda_stream)
+        state["last"] = (sl, torch.from_numpy(info["counts_all"]), first, corners_all[sl], desc_all[sl])
+
+    def finish_ticket():
+        """Batch k-1, one batch later: its counters are on the host; expand it on rank 0.  Should the lagged size of its
+        gather have been too small (the frames changed a lot from one batch to the next), gather it again, exactly."""
+        if state["ticket"] is None:
+            return
+        info = collator.finish(state["ticket"])
+        state["ticket"] = None
+        if info["complete"]:
+            if rank == 0:
+                expand(info, info["merged"], collator.s_cap)
+            return
+        state["regathers"] += 1
+        sl = info["slot"]
+        out = node.collate_transport_to_root(views[sl][0], tbuf[sl], MAX_FEATURES)
+        if out is not None:
+            _, totals, merged = out
+            info["totals"] = totals
+            expand(info, merged, merged.shape[1])
+            state["gathered_bytes"] += merged.numel() * 4
+
     def collate(pending):
         slot, done, nb = pending
         counts_t, corners_t, desc_t = views[slot]
+        t_host = time.perf_counter()
         with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(done)  # the kernels that wrote this output set
             if transport:
+                finish_ticket()  # the batch before: sizes this batch's gather
+                comm_stream.wait_event(done)  # the kernels that wrote this output set
                 cs = comm_stream.cuda_stream
                 prog.batch_pack_transport(slot, B, tbuf[slot].data_ptr(), B * MAX_FEATURES, stream=cs)
-                out = node.collate_transport_to_root(counts_t, tbuf[slot], MAX_FEATURES)
-                if out is not None:  # rank 0: back to the reference's two record arrays, all frames of the job in order
-                    counts_all, totals, merged = out
-                    s_max, first = merged.shape[1], np.concatenate([[0], np.cumsum(totals)])
-                    corners_all = torch.empty((max(int(first[-1]), 1), 4), dtype=torch.int32, device=dev)
-                    desc_all = torch.empty((max(int(first[-1]), 1), 8), dtype=torch.int32, device=dev)
-                    prog.unpack_transport(merged.data_ptr(), [r * s_max for r in range(world)], totals, first[:-1],
-                                          corners_all.data_ptr(), desc_all.data_ptr(), stream=cs)
-                    state["gathered_bytes"] += merged.numel() * 4
-                    state["last"] = (slot, counts_all, first, corners_all, desc_all)
+                before = collator.bytes_gathered
+                state["ticket"] = collator.submit(slot, counts_t, tbuf[slot])
+                state["gathered_bytes"] += collator.bytes_gathered - before
             else:
+                comm_stream.wait_event(done)
                 out = node.collate_to_root(counts_t, corners_t, desc_t, MAX_FEATURES)
                 if out is not None:
                     state["gathered_bytes"] += out[1].numel() * 4 + out[2].numel() * 4
             free[slot] = torch.cuda.Event()
             free[slot].record(comm_stream)  # the gather has read this output set
+        state["host_s"] += time.perf_counter() - t_host
 
     def step():
         """One pass over this rank's frames.  N = 1: extract, batch by batch.  N > 1: batch k goes into output set k%2 on
@@ -365,6 +401,9 @@ def run_rank(args):
         if world > 1 and state["pending"] is not None:
             collate(state["pending"])
             state["pending"] = None
+        if transport:
+            with torch.cuda.stream(comm_stream):
+                finish_ticket()
 
     def fence():
         flush()
@@ -400,7 +439,9 @@ def run_rank(args):
             prog.batch_sync()
     for _ in range(args.warmup):
         step()
+    state["host_s"] = 0.0
     repeats = [timed(args.steps) for _ in range(max(1, args.repeats))]
+    collate_host_ms = state["host_s"] / max(1, len(repeats) * args.steps * max(1, len(batches))) * 1e3
     state["gathered_bytes"] = 0
     prog.profile_enable(True)
     prog.profile_reset()
@@ -440,6 +481,9 @@ def run_rank(args):
         t0 = time.perf_counter()
         for _ in range(n_rep):
             collate((0, done, batches[0][1]))
+        if transport:
+            with torch.cuda.stream(comm_stream):
+                finish_ticket()
         torch.cuda.synchronize()
         dist.barrier()
         dt = time.perf_counter() - t0
@@ -460,7 +504,10 @@ def run_rank(args):
                         "bytes_gathered_per_batch": per, "bytes_from_peers_per_batch": from_peers,
                         "ms_alone_per_batch": dt / n_rep * 1e3, "gbs_into_root": from_peers / (dt / n_rep) / 1e9,
                         "gbs_per_link": from_peers / (dt / n_rep) / 1e9 / (world - 1),
-                        "bytes_gathered_per_step_timed": gathered_per_step, "backend": backend}
+                        "bytes_gathered_per_step_timed": gathered_per_step, "backend": backend,
+                        "host_ms_per_batch": collate_host_ms, "regathers": state["regathers"],
+                        "how": ("lagged: the gather of batch k is sized by batch k-1's totals (+25 %), the counters are read on the "
+                                "host one batch late; buffers allocated once" if transport else "padded slabs")}
 
     # device-resident in -> host-resident out (N = 1): every batch is packed on the device (orb_batch_pack) and fetched
     # into pinned host memory by two exact-size DMA copies on a second stream (orb_batch_fetch) while the next batch

@@ -163,3 +163,67 @@ def test_transport_collate_world1():
         assert totals == [11] and merged.shape == (1, 11, 10) and torch.equal(merged[0], records[:11]) and torch.equal(c, counts)
     finally:
         dist.destroy_process_group()
+
+
+def _worker_collator(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tinyslam_amd import node
+    B, cap = 3, 8
+    col = node.TransportCollator(B, cap, "cpu", headroom=1.0, slack=0)
+    rng = np.random.RandomState(7)
+    # four batches; the third holds far more than the second did: its lagged size is too small and says so
+    all_counts = [rng.randint(0, 4, size=(world, B)), rng.randint(0, 3, size=(world, B)),
+                  np.full((world, B), 9), rng.randint(0, 5, size=(world, B))]
+    log, pending = [], None
+    for k, cnt in enumerate(all_counts):
+        mine = torch.tensor(cnt[rank], dtype=torch.int32)
+        total = int(np.minimum(cnt[rank], cap).sum())
+        records = torch.full((B * cap, 10), -1, dtype=torch.int32)
+        records[:total] = (torch.arange(total, dtype=torch.int32) + 1000 * k + 100 * rank).unsqueeze(1)
+        if pending is not None:  # batch k-1: its counters went to the host a whole batch ago
+            log.append((k - 1, col.finish(pending)))
+        pending = col.submit(k & 1, mine, records)
+    log.append((len(all_counts) - 1, col.finish(pending)))
+    if rank == 0:
+        out = {}
+        for k, info in log:
+            out["counts%d" % k] = info["counts_all"]
+            out["totals%d" % k] = np.array(info["totals"])
+            out["complete%d" % k] = np.array(info["complete"])
+            out["s_used%d" % k] = np.array(info["s_used"])
+        # the landing area of the last two batches is still intact (two slots)
+        for k, info in log[-2:]:
+            out["merged%d" % k] = info["merged"].numpy().copy()
+        np.savez(out_path, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lagged_transport_collator_world2(tmp_path):
+    """TransportCollator over gloo: the gather of batch k is sized by batch k-1's totals, the counters are read one batch
+    late, an undersized gather is reported (never silently truncated), buffers are reused across batches."""
+    out_path = str(tmp_path / "collator.npz")
+    mp.spawn(_worker_collator, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    got = np.load(out_path)
+    rng = np.random.RandomState(7)
+    B, cap, world = 3, 8, 2
+    all_counts = [rng.randint(0, 4, size=(world, B)), rng.randint(0, 3, size=(world, B)),
+                  np.full((world, B), 9), rng.randint(0, 5, size=(world, B))]
+    s_fix = B * cap
+    for k, cnt in enumerate(all_counts):
+        assert np.array_equal(got["counts%d" % k], cnt.reshape(-1))
+        totals = np.minimum(cnt, cap).sum(axis=1)
+        assert np.array_equal(got["totals%d" % k], totals)
+        assert int(got["s_used%d" % k]) == s_fix
+        assert bool(got["complete%d" % k]) == (totals.max() <= s_fix)
+        s_fix = min(B * cap, max(int(totals.max()), 1))
+    assert bool(got["complete0"]) and bool(got["complete1"]) and not bool(got["complete2"])
+    for k in (2, 3):
+        totals = np.minimum(all_counts[k], cap).sum(axis=1)
+        for r in range(world):
+            n = min(int(totals[r]), int(got["s_used%d" % k]))
+            want = np.arange(n, dtype=np.int32) + 1000 * k + 100 * r
+            assert np.array_equal(got["merged%d" % k][r, :n, 0], want)

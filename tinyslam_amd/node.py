@@ -109,3 +109,73 @@ def collate_transport_to_root(counts: torch.Tensor, records: torch.Tensor, cap: 
     if rank != dst:
         return None
     return counts_all, totals, merged
+
+
+class TransportCollator:
+    """The transport collate without a host stall per batch (bench.py, N > 1).
+
+    `collate_transport_to_root` needs the counters on the host before it can size the gather: one `.tolist()` per batch,
+    which at half a millisecond per batch makes the Python thread, not the links, the limiter.  Here the size of batch
+    k's gather comes from what batch k-1 held: every rank sends its first `s_fix` records (`s_fix` = the largest rank
+    total seen last time plus a quarter, at most the capacity), the all-gathered counters travel to pinned host memory
+    by an asynchronous copy, and they are looked at one batch later -- when they have long arrived -- by `finish()`,
+    which returns what the root needs to expand batch k-1 and says whether `s_fix` was too small for it (then the
+    caller gathers that batch again, exactly: `collate_transport_to_root`; every rank sees the same counters, so every
+    rank takes the same decision).  Buffers are allocated once.
+
+        if ticket is not None:
+            info = col.finish(ticket)              # batch k-1: its counters are on the host by now; sizes batch k's gather
+        ticket = col.submit(slot, counts, records)  # batch k: enqueue only
+    """
+
+    def __init__(self, n_frames: int, cap: int, device, dst: int = 0, group: Optional[dist.ProcessGroup] = None,
+                 headroom: float = 1.25, slack: int = 1024, slots: int = 2):
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.B, self.cap, self.dst, self.group, self.headroom, self.slack = n_frames, cap, dst, group, headroom, slack
+        self.s_cap = n_frames * cap          # records a rank can hold
+        self.s_fix = self.s_cap              # records per rank in the next gather (no history yet: everything)
+        self.device = torch.device(device)
+        pin = self.device.type == "cuda"
+        self.counts_all = [torch.empty(self.world * n_frames, dtype=torch.int32, device=self.device) for _ in range(slots)]
+        self.h_counts = [torch.empty(self.world * n_frames, dtype=torch.int32, pin_memory=pin) for _ in range(slots)]
+        self.copied = [None] * slots         # event behind the counters' copy to the host
+        self.merged = [None] * slots         # root: (world, s_cap, 10) landing area per slot, allocated on first use
+        self.bytes_gathered = 0
+
+    def submit(self, slot: int, counts: torch.Tensor, records: torch.Tensor):
+        """Enqueues batch `slot`'s exchange on the current stream: all_gather of the counters, their copy to pinned host
+        memory, one gather of the first s_fix records of every rank.  Returns the ticket (slot, s_fix used)."""
+        s_use = self.s_fix
+        chunks = list(self.counts_all[slot].chunk(self.world))
+        dist.all_gather(chunks, counts, group=self.group)
+        self.h_counts[slot].copy_(self.counts_all[slot], non_blocking=True)
+        if self.device.type == "cuda":
+            self.copied[slot] = torch.cuda.Event()
+            self.copied[slot].record()
+        payload = records[:s_use]
+        if payload.shape[0] < s_use:  # a buffer sized for this rank alone
+            pad = records.new_zeros((s_use, records.shape[1]))
+            pad[:payload.shape[0]] = payload
+            payload = pad
+        bufs = None
+        if self.rank == self.dst:
+            if self.merged[slot] is None:
+                self.merged[slot] = torch.empty((self.world, self.s_cap, records.shape[1]), dtype=records.dtype, device=records.device)
+            bufs = [self.merged[slot][r, :s_use] for r in range(self.world)]  # contiguous leading slices
+            self.bytes_gathered += self.world * s_use * records.shape[1] * records.element_size()
+        dist.gather(payload, bufs, dst=self.dst, group=self.group)
+        return (slot, s_use)
+
+    def finish(self, ticket):
+        """Host side of a submitted batch, one batch later: the counters (on the host by now), every rank's total, and
+        whether the gather carried all of them.  Also sets the size of the next gather."""
+        slot, s_used = ticket
+        if self.copied[slot] is not None:
+            self.copied[slot].synchronize()
+        counts_all = self.h_counts[slot].numpy().copy()
+        totals = [int(t) for t in counts_all.clip(max=self.cap).reshape(self.world, -1).sum(axis=1)]
+        complete = max(totals) <= s_used
+        self.s_fix = min(self.s_cap, max(int(max(totals) * self.headroom) + self.slack, 1))
+        return {"slot": slot, "counts_all": counts_all, "totals": totals, "complete": complete, "s_used": s_used,
+                "merged": self.merged[slot] if self.rank == self.dst else None}
