@@ -247,18 +247,17 @@ def test_corner_level0_xy_matches_python_mirror(tinyorb):
     assert (x0.value, y0.value) == (29.5, 37.5)
 
 
-@pytest.mark.parametrize("W,H,depth", [(3840, 96, 2), (2560, 64, 3), (4096, 40, 2), (2052, 100, 2), (4100, 24, 1), (2050, 48, 2)])
+@pytest.mark.parametrize("W,H,depth", [(3840, 96, 2), (2560, 64, 3), (4096, 40, 2), (2052, 100, 2), (4100, 24, 1), (2050, 48, 2),
+                                       (1920, 120, 3), (5120, 40, 2), (8200, 24, 2), (1442, 70, 2)])
 def test_wide_literal_frames(tinyorb, oracle, W, H, depth):
-    """Literal mode on frames wider than the 16-row bands take (W > 2048: 8-row bands up to 4096, one workgroup per CU),
-    on a width that is not a multiple of 4 (the general level-0 variant) and on a shape that only the per-stage kernels
-    take (W > 4096) -- that one must say so.  Whichever pipeline runs, the results are the oracle's."""
+    """Literal mode on levels too wide for two full-width bands per CU: they run on column tiles (k_front<..., TILED>) --
+    tile 0 doing the band's blur with three grey columns fetched from beyond its own --, also on widths that are not a
+    multiple of 4 (the general level-0 variant), past 4096 (round 2 sent those to the per-stage kernels) and where the
+    next level runs on full-width bands again.  The fused pipeline takes all of them, and the results are the oracle's."""
     rgba = oracle.synth_frame(W, H, 21)
     ref = oracle.extract(rgba, depth=depth, threshold=THR, planes=True)
     with _program(tinyorb, W, H, depth) as prog:
-        if W <= 4096:
-            assert prog.pipeline() == "fused" and prog.pipeline_note() == ""
-        else:  # the fall to the per-stage kernels is announced, with its reason
-            assert prog.pipeline() == "staged" and ("width %d" % W) in prog.pipeline_note()
+        assert prog.pipeline() == "fused" and prog.pipeline_note() == ""
         total, corners, desc = prog.extract(rgba)
         _assert_frame_equal(oracle, ref, total, corners, desc)
         dims, _ = oracle.level_dims(W, H, depth)

@@ -112,6 +112,7 @@ struct OrbProgram {
     BriefTGeom brieft{};       // thread-per-keypoint BRIEF of the fused literal pipelines (plain and arc/NMS)
     bool use_brief_t = false;
     uint32_t band_rows_lvl[kMaxLevels] = {0};  // band height of the plain fused path per level: kFrontRows or kFrontRowsWide (chosen at create)
+    uint32_t tile_w_lvl[kMaxLevels] = {0};     // 0: full-width bands; else the level runs on column tiles of this width (k_front<..., TILED>)
     uint32_t seg_classes = 1;  // lists per band slot of the plain fused path: 2 with k_brief_t (angle code 0 / the rest)
     uint32_t* d_pattern = nullptr;
     float* d_cos = nullptr;
@@ -322,7 +323,7 @@ bool fused_eligible(const OrbProgram* p) {
     // index arithmetic: v_mul_i32_i24 takes 24-bit operands (rows, widths < 2^14 here) and returns 32 bits; RGBA byte
     // offsets inside a frame are 4 * W * H < 2^32
     if ((uint64_t)pyr.w[0] * pyr.h[0] > (1ull << 26) || pyr.h[0] > 16384u) return false;
-    if (pyr.w[0] > (uint32_t)kFrontMaxWidthWide || pyr.w[0] < 8u) return false;
+    if (pyr.w[0] > (uint32_t)kFrontMaxWidthTiled || pyr.w[0] < 8u) return false;
     // rows of any width: k_front<..., UA> loads RGBA texel by texel (4-byte aligned) and Y8 byte by byte
     return true;  // a level 1 that is not an exact half is built by k_mip from the stored level-0 plane (FrontGeom::store_grey)
 }
@@ -333,8 +334,9 @@ uint32_t front_bands(const Pyramid& pyr, uint32_t lvl, uint32_t band_rows) {
     return (rows + band_rows - 1) / band_rows;
 }
 
+// tile_w = 0: full-width bands; else column tiles of that width (rounded up to 8; FrontGeom::tiled)
 FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t gh, uint32_t n_frames,
-                         uint32_t band_rows = kFrontRows) {
+                         uint32_t band_rows = kFrontRows, uint32_t tile_w = 0) {
     FrontGeom g{};
     g.lvl = lvl;
     g.rows = band_rows;
@@ -358,11 +360,39 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
         g.blur_q = Q;
         g.n_var = w - Q;
     }
+    if (tile_w) {
+        const uint32_t dom = ((w > gw ? w : gw) + 7u) & ~7u;  // columns of the level / of its dispatch domain
+        g.tiled = 1u;
+        g.tw = std::min((tile_w + 7u) & ~7u, dom);
+        g.n_ct = (dom + g.tw - 1u) / g.tw;
+        g.xb = 3u;
+        while ((1u << g.xb) < g.tw) g.xb++;
+        g.ls = kLdsPad + ((g.tw + 4u + 7u) & ~7u);
+        g.ts = std::min(g.tw, (w + 7u) & ~7u);
+        const BlurTap t = blur_tap(w - 1u, w, kBlurOffHost);
+        g.far_i0 = (uint32_t)t.i0;
+        g.far_i1 = (uint32_t)t.i1;
+        // queues B (3 ts entries) and C (ts), or the blur column table (24 bytes per column that varies), whichever is larger
+        g.tmp_halfs = std::max<uint32_t>(2u * kFrontTmpRows * g.ts, (uint32_t)(sizeof(BlurCol) / 2u) * g.n_var);
+        g.tmp_halfs = (g.tmp_halfs + 7u) & ~7u;
+    }
     g.n_classes = 1u;
     g.phase_mask = 15u;
     if (const char* e = getenv("TINYORB_PHASE_MASK")) g.phase_mask = (uint32_t)atoi(e);
     if (const char* e = getenv("TINYORB_NO_SWIZZLE")) g.xcd_swizzle = atoi(e) ? 0u : g.xcd_swizzle;
     return g;
+}
+
+// Can tile 0 of a tiled level do the band's blur from its own columns?  The column table's grey texels lie in [0, ~0.12 w].
+bool front_tile0_holds_blur(const FrontGeom& g, uint32_t w) {
+    if (!g.tiled || g.n_ct == 1u) return true;
+    uint32_t hi = 0;
+    for (uint32_t x = g.blur_q; x < w; x++) {
+        const BlurTap t2 = blur_tap(x, w, kBlurOffHost);
+        for (int j : {t2.i0, t2.i1})
+            if ((uint32_t)j >= g.blur_p) hi = std::max<uint32_t>(hi, (uint32_t)blur_tap((uint32_t)j, w, kBlurOffHost).i1);
+    }
+    return hi + 1u <= g.tw;
 }
 
 // Geometry of k_brief_t over the band (or tile) slots described by `rg`; false when the frame is too large for its LDS
@@ -450,7 +480,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
             dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 4u * kMipRows - 1u) / (4u * kMipRows), n);
             hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, d_gray, pyr, lvl, (float)pyr.w[lvl - 1] / (float)pyr.w[lvl], (float)pyr.h[lvl - 1] / (float)pyr.h[lvl]);
         }
-        FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n, p->band_rows_lvl[lvl]);
+        FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n, p->band_rows_lvl[lvl], p->tile_w_lvl[lvl]);
         if (gw == 0) g.gh = 0;  // no FAST dispatch at this octave (orb.rs:511-515 with width 0)
         g.slot_base = p->bands.slot_base[lvl];
         g.n_slots = p->bands.n_slots;
@@ -458,15 +488,18 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         g.n_classes = p->seg_classes;
         g.stamps = p->d_stamps;
         g.store_grey = (lvl == 0 && D > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) ? 1u : 0u;
-        if (g.n_bands != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
+        if (g.n_bands * (g.tiled ? g.n_ct : 1u) != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: band count mismatch at level %u", lvl);
-        if (sizeof(BlurCol) * (size_t)g.n_var > 8u * (size_t)g.ts)  // the column table borrows the queues' storage
+        if (!g.tiled && sizeof(BlurCol) * (size_t)g.n_var > 8u * (size_t)g.ts)  // the column table borrows the queues' storage
             return fail(p, ORB_EINVAL, "internal: blur column table of level %u does not fit", lvl);
         uint32_t lds = front_lds_bytes(g);
         if (const char* e = getenv("TINYORB_LDS_PAD")) lds += (uint32_t)atoi(e);  // occupancy experiments only
         if (lds > p->max_lds) return fail(p, ORB_EINVAL, "level %u needs %u bytes of LDS", lvl, lds);
-        const dim3 grid(g.n_bands * n);
+        const dim3 grid(g.n_bands * (g.tiled ? g.n_ct : 1u) * n);
 #define FRONT_ARGS frames, p->frame_bytes, d_gray, d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg
+#define FRONT_LAUNCH_TILED(L0, Y8, UA)                                                                             \
+    if (p->band_rows_lvl[lvl] == 16u) hipLaunchKernelGGL((k_front<L0, Y8, 16, UA, true>), grid, block, lds, s, FRONT_ARGS); \
+    else hipLaunchKernelGGL((k_front<L0, Y8, 8, UA, true>), grid, block, lds, s, FRONT_ARGS);
 #define FRONT_LAUNCH(L0, Y8)                                                                                       \
     switch (p->band_rows_lvl[lvl]) {                                                                               \
         case 64: hipLaunchKernelGGL((k_front<L0, Y8, 64>), grid, block, lds, s, FRONT_ARGS); break;                \
@@ -486,7 +519,12 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
     }
             // rows not aligned to a quad, or the level-0 plane is needed (level 1 not an exact half): the general variant
             const bool general = (pyr.w[0] & 3u) || g.store_grey;
-            if (p->input_y8 && general) {
+            if (g.tiled) {
+                if (p->input_y8 && general) { FRONT_LAUNCH_TILED(true, true, true) }
+                else if (p->input_y8) { FRONT_LAUNCH_TILED(true, true, false) }
+                else if (general) { FRONT_LAUNCH_TILED(true, false, true) }
+                else { FRONT_LAUNCH_TILED(true, false, false) }
+            } else if (p->input_y8 && general) {
                 FRONT_LAUNCH_UA(true)
             } else if (p->input_y8) {
                 FRONT_LAUNCH(true, true)
@@ -499,9 +537,11 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         } else {
             LaunchScope ls(p, s, KID_FUSED_LN);
             const dim3 block(kFrontThreadsLN);
-            FRONT_LAUNCH(false, false)
+            if (g.tiled) { FRONT_LAUNCH_TILED(false, false, false) }
+            else { FRONT_LAUNCH(false, false) }
         }
 #undef FRONT_LAUNCH
+#undef FRONT_LAUNCH_TILED
 #undef FRONT_ARGS
     }
     // orb.rs:523-534, plus the compaction of the band segments into the final lists
@@ -807,7 +847,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                     uint32_t rows = 0, rows_lds = 0, fits = 0, fits_lds = 0, want = 0, want_lds = 0;
                     const uint32_t forced = force ? (uint32_t)atoi(force) : 0u;
                     for (int cand : kFrontBandHeights) {
-                        if (std::max(w, gw) > (1u << front_x_bits(cand))) continue;
+                        if (std::max(w, gw) > (1u << front_x_bits(cand)) || std::max(w, gw) > (uint32_t)kFrontMaxWidthWide) continue;
                         // levels >= 1 run on 512 threads: beyond about 16 k pixels a band only gets longer (measured at
                         // 640 wide: 32 rows 4 % slower than 16; at 480 wide: 32 rows 16 % faster than 16)
                         if (lvl > 0 && (uint32_t)cand * gw > 16384u && cand > kFrontRowsWide) continue;
@@ -817,8 +857,38 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                         if (!fits) fits = (uint32_t)cand, fits_lds = lds;
                         if (!rows && 2u * lds <= p->max_lds) rows = (uint32_t)cand, rows_lds = lds;
                     }
+                    const bool two_per_cu = rows != 0u;
                     if (!rows) rows = fits, rows_lds = fits_lds;
                     if (want) rows = want, rows_lds = want_lds;
+                    // Too wide for two full-width bands per CU (one workgroup per CU costs a third of the rate: 0.62 against
+                    // 0.45 ms at 720p), or for any: column tiles of about kFrontTileW columns -- 16 rows x 1280 columns is the
+                    // shape the kernel is tuned on --, equal ones, wide enough for tile 0 to hold the columns the band's blur
+                    // reads (front_tile0_holds_blur); 8 rows where 16-row tiles of that width do not fit a CU twice.
+                    const char* force_w = getenv("TINYORB_TILE_W");
+                    if ((!two_per_cu && !want) || force_w) {
+                        const uint32_t dom = (std::max(w, gw) + 7u) & ~7u;
+                        uint32_t want_w = force_w ? std::max(64u, (uint32_t)atoi(force_w)) : (uint32_t)kFrontTileW, tw = dom, t_rows = 0, t_lds = 0;
+                        for (; tw >= dom || t_rows == 0u; want_w += 64u) {
+                            const uint32_t n_ct = std::max(1u, (dom + want_w - 1u) / want_w);
+                            tw = std::min(dom, (((dom + n_ct - 1u) / n_ct) + 7u) & ~7u);
+                            t_rows = 0;
+                            for (uint32_t cand : {16u, 8u}) {
+                                const FrontGeom tg = front_geometry(p->pyr, lvl, gw, gh, 1, cand, tw);
+                                const uint32_t lds = front_lds_bytes(tg);
+                                const uint32_t items = lvl == 0 ? (tg.tw + 12u) / 4u : (tg.tw + 20u) / 8u;  // staged items of a row <= threads
+                                if (!front_tile0_holds_blur(tg, w) || cand > (1u << (15u - tg.xb)) || lds > p->max_lds ||
+                                    items > (lvl == 0 ? (uint32_t)kFrontThreadsL0 : (uint32_t)kFrontThreadsLN))
+                                    continue;
+                                if (!t_rows || (2u * lds <= p->max_lds && 2u * t_lds > p->max_lds)) t_rows = cand, t_lds = lds;
+                                if (2u * t_lds <= p->max_lds) break;
+                            }
+                            if (t_rows || want_w >= dom) break;
+                        }
+                        if (t_rows) {
+                            rows = t_rows, rows_lds = t_lds;
+                            p->tile_w_lvl[lvl] = tw;
+                        }
+                    }
                     p->band_rows_lvl[lvl] = rows;
                     need = rows == 0 ? p->max_lds + 1u : std::max(need, rows_lds);
                 }
@@ -828,15 +898,17 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
             } else {
                 BandGeom& bg = p->bands;
                 uint32_t slots = 0;
+                uint64_t band_px = 0;  // pixels of the largest band (tile): no band can hold more corners
                 for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
                     bg.slot_base[lvl] = slots;
-                    slots += front_bands(p->pyr, lvl, p->band_rows_lvl[lvl]);
+                    const uint64_t lvl_cols = ((uint64_t)(W >> lvl) + 7u) / 8u * 8u;
+                    uint32_t n_ct = 1;
+                    if (p->tile_w_lvl[lvl]) n_ct = (uint32_t)((lvl_cols + p->tile_w_lvl[lvl] - 1u) / p->tile_w_lvl[lvl]);
+                    slots += front_bands(p->pyr, lvl, p->band_rows_lvl[lvl]) * n_ct;
+                    band_px = std::max<uint64_t>(band_px, (uint64_t)p->band_rows_lvl[lvl] * (p->tile_w_lvl[lvl] ? p->tile_w_lvl[lvl] : lvl_cols));
                 }
                 bg.slot_base[p->pyr.depth] = slots;
                 bg.n_slots = slots;
-                uint64_t band_px = 0;  // pixels of the largest band: no band can hold more corners
-                for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++)
-                    band_px = std::max<uint64_t>(band_px, (uint64_t)p->band_rows_lvl[lvl] * (((uint64_t)(W >> lvl) + 7u) / 8u * 8u));
                 bg.seg_cap = (uint32_t)(band_px < config->max_features ? band_px : config->max_features);
                 RowsGeom& rg = p->rows;
                 rg.n_slots = bg.n_slots;
@@ -857,8 +929,12 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
 #define FRONT_FN(R) reinterpret_cast<const void*>(&k_front<true, false, R>), reinterpret_cast<const void*>(&k_front<false, false, R>), \
                     reinterpret_cast<const void*>(&k_front<true, true, R>), reinterpret_cast<const void*>(&k_front<true, false, R, true>), \
                     reinterpret_cast<const void*>(&k_front<true, true, R, true>)
-                    FRONT_FN(64), FRONT_FN(32), FRONT_FN(16), FRONT_FN(8)
+#define FRONT_FN_TILED(R) reinterpret_cast<const void*>(&k_front<true, false, R, false, true>), reinterpret_cast<const void*>(&k_front<false, false, R, false, true>), \
+                    reinterpret_cast<const void*>(&k_front<true, true, R, false, true>), reinterpret_cast<const void*>(&k_front<true, false, R, true, true>), \
+                    reinterpret_cast<const void*>(&k_front<true, true, R, true, true>)
+                    FRONT_FN(64), FRONT_FN(32), FRONT_FN(16), FRONT_FN(8), FRONT_FN_TILED(16), FRONT_FN_TILED(8)
 #undef FRONT_FN
+#undef FRONT_FN_TILED
                 };
                 for (const void* f : fronts)
                     CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
@@ -958,8 +1034,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
             snprintf(why, sizeof why, "width %u is not a multiple of 4 (the tile kernels read RGBA quads)", py.w[0]);
         else if (py.w[0] < 8u)
             snprintf(why, sizeof why, "width %u is below 8", py.w[0]);
-        else if (!p->intended && py.w[0] > (uint32_t)kFrontMaxWidthWide)
-            snprintf(why, sizeof why, "width %u exceeds %d (a band of 14 full-width rows must fit in LDS)", py.w[0], kFrontMaxWidthWide);
+        else if (!p->intended && py.w[0] > (uint32_t)kFrontMaxWidthTiled)
+            snprintf(why, sizeof why, "width %u exceeds %d", py.w[0], kFrontMaxWidthTiled);
         else if ((uint64_t)py.w[0] * py.h[0] > (1ull << 26) || py.h[0] > 16384u)
             snprintf(why, sizeof why, "%ux%u exceeds the fused kernels' 2^26-pixel / 16384-row index range", py.w[0], py.h[0]);
         else if (!p->intended && !plain && py.depth > 1 && !(py.w[0] == 2u * py.w[1] && py.h[0] == 2u * py.h[1]))

@@ -41,11 +41,24 @@ __host__ __device__ constexpr int front_x_bits(int rows) { return rows == 64 ? 9
 __host__ __device__ constexpr uint32_t front_mask_bit(int k, bool under) { return 1u << (8 * (k & 1) + (under ? 4 : 0) + (k >> 1)); }
 constexpr int kFrontMaxWidth = 2048;     // widest level 0 of the 16-row bands (11-bit x in the 16-bit queue entries)
 constexpr int kFrontMaxWidthWide = 4096; // ... of the 8-row bands (12-bit x)
+constexpr int kFrontMaxWidthTiled = 16384;  // widest level 0 of the fused literal pipeline: levels too wide for two full-width bands
+                                            // per CU are cut into column tiles (k_front<..., TILED>)
+constexpr int kFrontTileW = 1280;           // preferred tile width there: the shape the kernel is tuned on (16 rows x 1280 columns)
 constexpr int kLdsPad = 8;           // halfs of padding left of column 0
 
 struct FrontGeom {
     uint32_t lvl;       // pyramid level handled by this launch
     uint32_t rows;      // band height (one of kFrontBandHeights)
+    // Column tiles (k_front<..., TILED = true>; tiled == 0: a workgroup owns full-width rows and the next six fields are unused).
+    // A level too wide for two full-width bands per CU is cut into n_ct tiles of tw columns; a workgroup then owns rows x tw
+    // texels, stages 4 columns of halo on either side, and tile 0 also does the band's whole blur (phase C), for which it
+    // fetches the three grey texels per row that lie beyond its own columns.
+    uint32_t tiled;
+    uint32_t tw;        // tile width (multiple of 8); the level's last tile may be narrower
+    uint32_t n_ct;      // ceil(max(w, gw) / tw)
+    uint32_t xb;        // bits of a tile-local x in a queue entry (tw <= 2^xb, rows <= 2^(15 - xb))
+    uint32_t far_i0, far_i1;  // the two grey columns pass 1 lerps at the level's last column (blur_tap(w - 1)); the third far one is w - 1
+    uint32_t tmp_halfs; // halfs of the storage shared by the blur column table (phase C) and queues B and C (phase B)
     uint32_t gw, gh;    // FAST dispatch domain of this octave (8-rounded, orb.rs:511-515)
     uint32_t n_bands;   // ceil(max(h, gh) / R)
     uint32_t n_frames;
@@ -81,6 +94,8 @@ static_assert(sizeof(BlurCol) == 24, "BlurCol layout");
 __host__ __device__ inline uint32_t front_lds_bytes(const FrontGeom& g) {
     // grey rows + queues B/C (the blur column table lives there first: 24 B x n_var <= 8 B x ts, checked on the host)
     // + queue A + 5 counters + blur row constants (2 x rows float4)
+    if (g.tiled)  // the same, the shared storage sized for whichever of its two uses is larger, + the far grey columns of tile 0
+        return ((g.rows + 6) * g.ls + g.tmp_halfs) * 2u + kFrontQueue * 2u + 32u + 32u * g.rows + 8u * g.rows;
     return ((g.rows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + kFrontQueue * 2u + 32u + 32u * g.rows;
 }
 
@@ -248,25 +263,27 @@ __device__ __forceinline__ void segment_append(bool is_corner, uint32_t x, uint3
 // RB: band height, one of kFrontBandHeights (the host picks it per level: orb_api.hip, program create).
 // UA: the general level-0 variant (RGBA or Y8) -- a width that is not a multiple of 4 (rows only 4-byte aligned: texel by texel loads, a
 //     partial last quad) and/or a level 1 that is not an exact half (FrontGeom::store_grey: the band also stores its grey rows).
-template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false>
+// TILED: column tiles (FrontGeom::tiled).  With TILED = false every tile expression below folds to the full-width form.
+template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false, bool TILED = false>
 __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                          uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                                          uint16_t* __restrict__ blur_rowc, Pyramid pyr,
                                                          FrontGeom geo, float thr, uint32_t* __restrict__ seg_counts,
                                                          CornerData* __restrict__ segments) {
     constexpr int NT = L0 ? kFrontThreadsL0 : kFrontThreadsLN, R = RB, TC = kFrontTmpRows;
-    constexpr int XB = front_x_bits(RB);  // 16-bit queue entries: [15:XB+1] row of the band, [XB:4] x / 8, [3:0] pixel and polarity (front_mask_bit)
-    static_assert((RB - 1) < (1 << (15 - XB)), "band row does not fit the queue entry");
+    // 16-bit queue entries: [15:XB+1] row of the band, [XB:4] (x - x0) / 8, [3:0] pixel and polarity (front_mask_bit)
+    const int XB = TILED ? (int)geo.xb : front_x_bits(RB);
+    static_assert((RB - 1) < (1 << (15 - front_x_bits(RB))), "band row does not fit the queue entry");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int LS = (int)geo.ls, TS = (int)geo.ts;
     const int row3 = 3 * LS + kLdsPad;  // band row 0, column 0 inside the staged rows (three halo rows above, the left pad)
     half_t* const grey = reinterpret_cast<half_t*>(lds_raw);             // (R+6) rows x LS
-    half_t* const tmp = grey + (R + 6) * LS;                              // 2 x TC rows x TS
+    half_t* const tmp = grey + (R + 6) * LS;                              // 2 x TC rows x TS (TILED: geo.tmp_halfs)
     // Queues of the FAST phase, 16-bit entries (see XB above).
     //   A: pre-test survivors (own storage); B: survivors of the diagonal filter; C: corners.  B and C
     //   live in the blur intermediate's storage (phase C starts after a barrier).  Whenever a queue is
     //   full the item is finished in place, so capacities only affect speed.
-    uint16_t* const queue_a = reinterpret_cast<uint16_t*>(tmp + 2 * TC * TS);
+    uint16_t* const queue_a = reinterpret_cast<uint16_t*>(tmp + (TILED ? (int)geo.tmp_halfs : 2 * TC * TS));
     uint16_t* const queue_b = reinterpret_cast<uint16_t*>(tmp);
     const uint32_t cap_b = 3u * (uint32_t)TS, cap_c = (uint32_t)TS;
     uint16_t* const queue_c = queue_b + cap_b;
@@ -276,31 +293,39 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     uint32_t* const c_count = qa_count + 3;  // corners found by this band: [0] first list, [1] second list
     float4* const blur_k1 = reinterpret_cast<float4*>(qa_count + 8);  // per band row: taps 0, 2, 3 of blur pass 1
     float4* const blur_k2 = blur_k1 + R;                              // per band row: the same for pass 2, and c2
+    half_t* const far = reinterpret_cast<half_t*>(blur_k2 + R);       // TILED, tile 0: per band row grey(w - 1), grey(far_i0), grey(far_i1)
     // per column >= blur_q: tap positions.  Used by phase C only, which runs before the detector: it borrows the storage of
     // queues B and C, which are first written in stage S1 -- behind the barrier that ends the pre-test, which every wave
     // reaches after its share of phase C.
     BlurCol* const blur_cols = reinterpret_cast<BlurCol*>(tmp);
 
-    // ---- which band of which frame: keep all bands of a frame on one XCD so halo rows hit its L2
-    uint32_t frame, band;
+    // ---- which band (tile) of which frame: keep all bands of a frame on one XCD so halo rows hit its L2
+    uint32_t frame, band, tile = 0;
     {
-        const uint32_t L = blockIdx.x;
+        const uint32_t L = blockIdx.x, n_wg = TILED ? geo.n_bands * geo.n_ct : geo.n_bands;  // TILED: band-major, a band's tiles side by side
+        uint32_t wg;
         if (geo.xcd_swizzle) {
             const uint32_t xcd = L & 7u, slot = L >> 3;
-            frame = (slot / geo.n_bands) * 8u + xcd;
-            band = slot % geo.n_bands;
+            frame = (slot / n_wg) * 8u + xcd;
+            wg = slot % n_wg;
         } else {
-            frame = L / geo.n_bands;
-            band = L % geo.n_bands;
+            frame = L / n_wg;
+            wg = L % n_wg;
         }
+        band = wg;
+        if (TILED) band = wg / geo.n_ct, tile = wg - band * geo.n_ct;
     }
     const uint32_t lvl = geo.lvl;
     const int w = (int)pyr.w[lvl], h = (int)pyr.h[lvl];
     const int y0 = (int)band * R;
+    const int x0 = TILED ? (int)(tile * geo.tw) : 0;                                          // first column of the tile
+    const int xe = TILED ? min(x0 + (int)geo.tw, max(w, (int)geo.gw)) : max(w, (int)geo.gw);  // one past its last (level or dispatch domain)
+    const bool blur_tile = !TILED || tile == 0u;                                              // tile 0 does the band's blur (phase C)
+    const bool far_cols = TILED && geo.n_ct > 1u;                                             // ... with three grey columns from beyond its own
     const int tid = (int)threadIdx.x;
     uint16_t* const gray_f = gray + (size_t)frame * pyr.stride;
     uint16_t* const blur_lvl = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
-    const size_t slot = (size_t)frame * geo.n_slots + geo.slot_base + band;
+    const size_t slot = (size_t)frame * geo.n_slots + geo.slot_base + (TILED ? band * geo.n_ct + tile : band);
     const bool two_lists = geo.n_classes == 2u;
     CornerData* const seg = segments + slot * geo.seg_cap * geo.n_classes;
 
@@ -324,8 +349,12 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     // rows, so per item there is one address increment instead of a division; four 16-byte loads are
     // in flight per thread before the first is consumed.
     {
-        const int per_row = L0 ? ((UA ? w + 3 : w) >> 2) : ((LS - kLdsPad) >> 3);  // 16-byte items per row (RGBA quads / half8 groups)
-        const int rpp = NT / per_row;                                 // rows covered per pass (>= 1: W <= 2048)
+        // 16-byte items of a staged row (RGBA quads / half8 groups).  TILED: the tile's own columns, one item of halo to its
+        // left when it has a neighbour there, and what covers 4 columns to its right (as far as the row goes)
+        const int it0 = !TILED ? 0 : (L0 ? (x0 >> 2) - (x0 > 0 ? 1 : 0) : (x0 >> 3) - (x0 > 0 ? 1 : 0));  // first item, counted from the row's start
+        const int it1 = L0 ? min(xe + 4 + 3, UA ? w + 3 : w) >> 2 : (xe + 4 + 7) >> 3;                     // TILED: one past the last
+        const int per_row = TILED ? it1 - it0 : (L0 ? ((UA ? w + 3 : w) >> 2) : ((LS - kLdsPad) >> 3));
+        const int rpp = NT / per_row;                                 // rows covered per pass (>= 1: checked on the host)
         const int ty = (int)(((float)tid + 0.5f) * (1.0f / (float)per_row));
         const int tx = tid - __mul24(ty, per_row);
         const bool lane_ok = ty < rpp;
@@ -344,20 +373,28 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
         const int bpp = Y8 ? 1 : 4;
         const int txc = lane_ok ? tx : 0;
         int gy_w = y0 - 3 + ty;                                                        // row of the walking item
-        uint32_t off_w = (uint32_t)(__mul24(h - 1 - gy_w, w) + txc * 4) * (uint32_t)bpp;   // its (mirrored) byte offset
-        int dst_w = __mul24(ty, LS) + kLdsPad + tx * 4;                                // its LDS offset (halfs)
+        uint32_t off_w = (uint32_t)(__mul24(h - 1 - gy_w, w) + (it0 + txc) * 4) * (uint32_t)bpp;   // its (mirrored) byte offset
+        int dst_w = __mul24(ty, LS) + kLdsPad + (it0 + tx) * 4 - x0;                   // its LDS offset (halfs): LDS column kLdsPad <-> image column x0
         const uint32_t off_step = (uint32_t)(rpp * w * bpp);
         const int dst_step = rpp * LS;
-        for (int lyb = ty; lyb < R + 6; lyb += rpp * U) {
+        for (int lyb = ty, ly_base = 0; lyb < R + 6; lyb += rpp * U, ly_base += rpp * U) {
             uint4 v[U];
             int dst[U];
             bool live[U];
+            // TILED: passes of this round that still reach rows of the tile (uniform: a narrow tile stages many rows per
+            // pass, and a load for a row past the tile would be real traffic for nothing)
+            const int n_u = TILED ? min(U, (R + 6 - ly_base + rpp - 1) / rpp) : U;
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int ly = lyb + u * rpp;
                 const int gy = y0 - 3 + ly;
                 const bool in_band = lane_ok && ly < R + 6;
                 v[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (TILED) {
+                    live[u] = false;
+                    dst[u] = 0;
+                    if (u >= n_u) continue;
+                }
                 if (L0) {
                     // rows outside the image are never read by a pixel that passes the guard (fast.wgsl:77);
                     // the input row is the vertically mirrored one (grayscale.wgsl:16-25).  Byte offsets inside a frame
@@ -377,7 +414,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     const int off = (int)off_w;
                     if (Y8 && UA) {  // rows start on any byte; the last group of a row may be partial
                         const uint8_t* q = src0 + (size_t)(ok ? off_w : 0u);
-                        const int left = ok ? w - tx * 4 : 4;
+                        const int left = ok ? w - (it0 + tx) * 4 : 4;
                         v[u].x = (uint32_t)q[0] | ((uint32_t)q[left > 1 ? 1 : 0] << 8) | ((uint32_t)q[left > 2 ? 2 : 0] << 16) |
                                  ((uint32_t)q[left > 3 ? 3 : 0] << 24);
                     } else if (Y8) {  // four texels = four bytes, converted on the way in (rows are 4-byte aligned here)
@@ -392,9 +429,9 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 } else {
                     // f16 mip from HBM; texels outside the level are stored as 0 (CRD-6): at octaves >= 1 the
                     // reference's guard and dispatch size let pixels near/over the level edge through (Q8).
-                    const int x = tx * 8;
+                    const int x = (it0 + tx) * 8;
                     live[u] = in_band;
-                    dst[u] = __mul24(ly, LS) + kLdsPad + x;
+                    dst[u] = __mul24(ly, LS) + kLdsPad + x - x0;
                     if (in_band && gy >= 0 && gy < h && x < w) {
                         const uint16_t* row = srcn + (size_t)(uint32_t)__mul24(gy, w);
                         if ((w & 7) == 0 && x + 8 <= w) {
@@ -436,13 +473,14 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                         // Level 1 is not an exact half of level 0 (odd width or height): the generic blit (k_mip) builds
                         // it from the level-0 plane, which the band's own rows therefore also store.
                         const int ly = lyb + u * rpp;
-                        if (UA && geo.store_grey && ly >= 3 && ly < R + 3) {
-                            uint16_t* g = gray_f + pyr.off[lvl] + (size_t)(uint32_t)(__mul24(y0 - 3 + ly, w) + tx * 4);
+                        const int qx = (it0 + tx) * 4;  // first column of this quad
+                        if (UA && geo.store_grey && ly >= 3 && ly < R + 3 && (!TILED || (qx >= x0 && qx < xe))) {  // TILED: the tile's own columns
+                            uint16_t* g = gray_f + pyr.off[lvl] + (size_t)(uint32_t)(__mul24(y0 - 3 + ly, w) + qx);
                             if (w & 3) {
                                 const uint32_t t[4] = {out.x & 0xffffu, out.x >> 16, out.y & 0xffffu, out.y >> 16};
 #pragma unroll
                                 for (int k = 0; k < 4; k++)
-                                    if (tx * 4 + k < w) g[k] = (uint16_t)t[k];
+                                    if (qx + k < w) g[k] = (uint16_t)t[k];
                             } else {
                                 *reinterpret_cast<uint2*>(g) = out;
                             }
@@ -452,6 +490,30 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     }
                 }
             }
+        }
+    }
+    // TILED: tile 0 of several does the band's blur, whose row constants read three grey texels per row that lie beyond its
+    // own columns: the row's last one and the two that pass 1 lerps at the last column.  Same conversion
+    // as the staged rows (CRD-1..3); rows outside the level are never used.
+    if (TILED && blur_tile && far_cols && (geo.phase_mask & 8u)) {
+        for (int i = tid; i < 3 * R; i += NT) {
+            const int r = i / 3, k = i - 3 * r, gy = y0 + r;
+            const int col = k == 0 ? w - 1 : (k == 1 ? (int)geo.far_i0 : (int)geo.far_i1);
+            uint16_t g = 0;
+            if (gy < h) {
+                if (L0) {
+                    const uint8_t* px = frames + (size_t)frame * frame_bytes + (size_t)(uint32_t)(__mul24(h - 1 - gy, w) + col) * (Y8 ? 1u : 4u);
+                    if (Y8) {
+                        g = half_bits(to_half(unorm8_exact((float)px[0])));
+                    } else {
+                        const uint32_t t = *reinterpret_cast<const uint32_t*>(px);
+                        g = (uint16_t)(luminance_pair_f16(t, t) & 0xffffu);
+                    }
+                } else {
+                    g = gray_f[pyr.off[lvl] + (size_t)(uint32_t)(__mul24(gy, w) + col)];
+                }
+            }
+            far[4 * r + k] = bits_half(g);
         }
     }
     stamp(0);  // A: staging
@@ -466,9 +528,9 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     // row (c2) for every x < blur_q -- 88 % of the columns.
     //   blur_k1[r] = pass 1: {0 + t0*w0, tl*w2, tl*w3, c1}          (t0, tl: grey row r at columns 0, w-1)
     //   blur_k2[r] = pass 2: {0 + c1*w0, p1l*w2, p1l*w3, c2}        (p1l: pass 1 at column w-1)
-    if (tid < R) {
+    if (blur_tile && tid < R) {
         const half_t* row = grey + (tid + 3) * LS + kLdsPad;
-        const float t0 = from_half(row[0]), tl = from_half(row[w - 1]);
+        const float t0 = from_half(row[0]), tl = from_half(far_cols ? far[4 * tid] : row[w - 1]);
         const float a0 = t0 * kBlurWgt[0], a2 = tl * kBlurWgt[2], a3 = tl * kBlurWgt[3];
         const float base = 0.0f + a0;
         auto finish = [&](float bs, float lerp, float k2, float k3) {
@@ -481,8 +543,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
         const float c1 = finish(base, t0, a2, a3);
         float p1l = c1;  // pass 1 at the last column
         if ((int)geo.blur_p < w) {
-            const BlurTap t = blur_tap((uint32_t)(w - 1), (uint32_t)w, kBlurOff[1]);
-            const float v0 = from_half(row[t.i0]), v1 = from_half(row[t.i1]);
+            const BlurTap t = blur_tap((uint32_t)(w - 1), (uint32_t)w, kBlurOff[1]);  // (t.i0, t.i1) = (geo.far_i0, geo.far_i1)
+            const float v0 = from_half(far_cols ? far[4 * tid + 1] : row[t.i0]), v1 = from_half(far_cols ? far[4 * tid + 2] : row[t.i1]);
             const float d = v1 - v0;
             p1l = finish(base, v0 + t.f * d, a2, a3);
         }
@@ -493,7 +555,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     }
 
     // ---- blur column table (the last threads of the workgroup, so that wave 0 is not doing both) ----
-    if (geo.phase_mask & 8u)
+    if ((geo.phase_mask & 8u) && blur_tile)
     for (int c = NT - 1 - tid; c < (int)geo.n_var; c += NT) {  // one entry per thread while n_var <= NT (it is about 0.12 w)
         const int x = (int)geo.blur_q + c, P = (int)geo.blur_p;
         const BlurTap t2 = blur_tap((uint32_t)x, (uint32_t)w, kBlurOff[1]);
@@ -519,8 +581,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
     auto phase_B = [&]() {
         // =========================== B1: 4-point pre-test, 8 px per item ===========================
         if (geo.phase_mask & 1u) {
-            const int g8 = (int)geo.gw >> 3;
-            const float inv_g8 = 1.0f / (float)g8;
+            const int g8 = TILED ? (min(x0 + (int)geo.tw, (int)geo.gw) - x0) >> 3 : (int)geo.gw >> 3;  // items of a row (of this tile)
+            const float inv_g8 = 1.0f / (float)max(g8, 1);
             const int n_items = R * g8;
             // fast.wgsl:77 -- level-0 dimensions for every octave, u32 arithmetic (Q8)
             const uint32_t lim_x = pyr.w[0] - 16u, lim_y = pyr.h[0] - 16u;
@@ -537,11 +599,11 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
             const half2_t thr_lo2 = __builtin_bit_cast(half2_t, tb | (tb << 16));
             for (int i = tid; i < n_items; i += NT) {
                 const int lyc = (int)(((float)i + 0.5f) * inv_g8);
-                const int x = (i - __mul24(lyc, g8)) * 8;
+                const int xl = (i - __mul24(lyc, g8)) * 8, x = x0 + xl;  // tile-local and image column of the item's first pixel
                 const uint32_t gy = (uint32_t)(y0 + lyc);
                 if (!(gy < geo.gh && gy > 16u && gy < lim_y)) continue;
                 if ((uint32_t)x + 7u <= 16u || (uint32_t)x >= lim_x) continue;
-                const half_t* rowc = grey + row3 + (int)__umul24((uint32_t)lyc, (uint32_t)LS) + x;  // row lyc + 3 of the staged rows
+                const half_t* rowc = grey + row3 + (int)__umul24((uint32_t)lyc, (uint32_t)LS) + xl;  // row lyc + 3 of the staged rows
                 const uint2 qa = *reinterpret_cast<const uint2*>(rowc - 4);
                 const uint4 qb = *reinterpret_cast<const uint4*>(rowc);
                 const uint2 qc = *reinterpret_cast<const uint2*>(rowc + 8);
@@ -598,7 +660,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                     // every lane reserves its own slots with the LDS's returning add (lds_add_rtn, orb_device.h)
                     const uint32_t n_cand = (uint32_t)__builtin_popcount(cand);
                     uint32_t qs = lds_add_rtn(qa_count, n_cand);
-                    const uint32_t base = ((uint32_t)lyc << (XB + 1)) | ((uint32_t)x << 1);  // x is a multiple of 8: the low four bits are free
+                    const uint32_t base = ((uint32_t)lyc << (XB + 1)) | ((uint32_t)xl << 1);  // xl is a multiple of 8: the low four bits are free
                     if (qs + n_cand <= (uint32_t)kFrontQueue) {  // all survivors of the item fit: no test per entry
                         while (cand) {
                             const uint32_t p = (uint32_t)__builtin_ctz(cand);
@@ -632,9 +694,10 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
             auto locate = [&](uint32_t e, uint32_t* x, uint32_t* gy) -> const half_t* {
                 const uint32_t lyc = e >> (XB + 1);                                       // e is a 16-bit entry
                 const uint32_t k = ((e & 3u) << 1) | ((e >> 3) & 1u);                     // pixel of the item (front_mask_bit)
-                *x = ((e >> 1) & (((1u << XB) - 1u) & ~7u)) | k;
+                const uint32_t xl = ((e >> 1) & (((1u << XB) - 1u) & ~7u)) | k;  // tile-local column
+                *x = (uint32_t)x0 + xl;
                 *gy = (uint32_t)y0 + lyc;
-                return grey + row3 + (int)__umul24(lyc, (uint32_t)LS) + (int)*x;
+                return grey + row3 + (int)__umul24(lyc, (uint32_t)LS) + (int)xl;
             };
             auto is_over = [](uint32_t e) { return (e & 4u) == 0u; };  // polarity of the pre-test that passed
             // stage 1: diagonal 3-of-4 filter (a necessary condition of a 12-run), A -> B
@@ -691,16 +754,17 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
         if (geo.write_mip && (geo.phase_mask & 4u)) {
             const int wd = (int)pyr.w[lvl + 1], hd = (int)pyr.h[lvl + 1];
             uint16_t* dst = gray_f + pyr.off[lvl + 1];
-            const int g4 = (wd + 3) >> 2;
-            const float inv_g4 = 1.0f / (float)g4;
+            const int xd0 = x0 >> 1, xd1 = TILED ? min(min(x0 + (int)geo.tw, w) >> 1, wd) : wd;  // the tile's columns of the next level
+            const int g4 = max(xd1 - xd0 + 3, 0) >> 2;
+            const float inv_g4 = 1.0f / (float)max(g4, 1);
             const int n_items = (R / 2) * g4;
             const bool vec_ok = (wd & 3) == 0;
             for (int i = tid; i < n_items; i += NT) {
                 const int r = (int)(((float)i + 0.5f) * inv_g4);
-                const int xd = (i - __mul24(r, g4)) * 4;
+                const int xdl = (i - __mul24(r, g4)) * 4, xd = xd0 + xdl;
                 const int yd = (y0 >> 1) + r;
                 if (yd >= hd) continue;
-                const half_t* top = grey + row3 + (int)__umul24((uint32_t)r, (uint32_t)(2 * LS)) + 2 * xd;
+                const half_t* top = grey + row3 + (int)__umul24((uint32_t)r, (uint32_t)(2 * LS)) + 2 * xdl;
                 const uint4 qt = *reinterpret_cast<const uint4*>(top);
                 const uint4 qb = *reinterpret_cast<const uint4*>(top + LS);
                 const uint32_t tw[4] = {qt.x, qt.y, qt.z, qt.w}, bw[4] = {qb.x, qb.y, qb.z, qb.w};
@@ -717,7 +781,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 } else {
     #pragma unroll
                     for (int k = 0; k < 4; k++)
-                        if (xd + k < wd) out[k] = o[k];
+                        if (xd + k < xd1) out[k] = o[k];
                 }
             }
         }
@@ -728,7 +792,7 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
         // pass 1 at two neighbouring columns j0, j1 (>= blur_p - 1), each of which needs two grey texels: the
         // thread evaluates those two pass-1 values itself (f16-rounded like the R16Float intermediate,
         // orb.rs:291-304) -- no intermediate plane, no barrier.  Pass 1 at any other column is never read.
-        if (geo.phase_mask & 8u) {
+        if ((geo.phase_mask & 8u) && blur_tile) {
             const int rows = min(R, h - y0);  // band rows that exist in this level (uniform per block)
             const int Q = (int)geo.blur_q;
             if (rows > 0) {
