@@ -49,9 +49,10 @@ def parse_args(argv=None):
     ap.add_argument("--repeats", type=int, default=5, help="how often the K-step timed region is repeated (median reported)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-host-out", action="store_true", help="skip the device-in -> host-out measurement (N = 1)")
-    ap.add_argument("--collate", choices=("transport", "padded"), default="transport",
+    ap.add_argument("--collate", choices=("transport", "padded", "none"), default="transport",
                     help="N > 1: what the gather to rank 0 carries -- 40-byte transport records packed back to back, or "
-                         "the 48-byte record slabs padded to the fullest frame (round 1's form)")
+                         "the 48-byte record slabs padded to the fullest frame (round 1's form); none = the results stay "
+                         "sharded on their GPUs (a consumer that runs where the frames were extracted): kernels only")
     ap.add_argument("--staged", action="store_true", help="force the one-kernel-per-stage pipeline")
     ap.add_argument("--input", choices=("rgba", "y8"), default="rgba",
                     help="rgba = the reference's input (the headline); y8 = the opt-in one-byte-per-pixel variant "
@@ -362,11 +363,13 @@ def run_rank(args):
                 before = collator.bytes_gathered
                 state["ticket"] = collator.submit(slot, counts_t, tbuf[slot])
                 state["gathered_bytes"] += collator.bytes_gathered - before
-            else:
+            elif args.collate == "padded":
                 comm_stream.wait_event(done)
                 out = node.collate_to_root(counts_t, corners_t, desc_t, MAX_FEATURES)
                 if out is not None:
                     state["gathered_bytes"] += out[1].numel() * 4 + out[2].numel() * 4
+            else:  # none: nothing leaves the GPU
+                comm_stream.wait_event(done)
             free[slot] = torch.cuda.Event()
             free[slot].record(comm_stream)  # the gather has read this output set
         state["host_s"] += time.perf_counter() - t_host
@@ -583,7 +586,8 @@ def run_rank(args):
                        "hierarchy_depth": DEPTH, "max_features": MAX_FEATURES, "threshold": THRESHOLD, "mode": args.mode,
                        "input": args.input,
                        "pipeline": "staged" if args.staged else "default",
-                       "collate": "RCCL gather of every batch to rank 0, overlapped with the next batch's kernels" if world > 1 else "none (1 GPU)"},
+                       "collate": ("none: results stay sharded on their GPUs" if args.collate == "none" else
+                                   "RCCL gather of every batch to rank 0, overlapped with the next batch's kernels") if world > 1 else "none (1 GPU)"},
             "repeats_ms_per_step": [r / args.steps * 1e3 for r in repeats],
             "min_ms_per_step": min(repeats) / args.steps * 1e3, "max_ms_per_step": max(repeats) / args.steps * 1e3,
             "mkeypoints_per_s": kp_per_step * args.steps / elapsed / 1e6,

@@ -5,7 +5,9 @@
  * frames.rgba holds n_frames tightly packed RGBA8 frames.  The job is sharded over the first n_devices GPUs (default:
  * 1), collated on the first one (RCCL) and dumped: n_frames (u32), counts[n], offsets[n+1] (u64), total corners, total
  * descriptors.  The same job then goes through the single-device bulk read-back (orb_extract_batch_host +
- * orb_batch_read_all into pinned memory) and both results must be identical byte for byte. */
+ * orb_batch_read_all into pinned memory) and both results must be identical byte for byte.  Last, the job is streamed
+ * through the node three times in its pipelined form (orb_node_extract_batch_host / orb_node_collate_begin /
+ * orb_node_collate_end, two jobs outstanding): every pass must return the counters of the first. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -89,6 +91,28 @@ int main(int argc, char **argv) {
     }
     printf("%u frames on %d device(s): %zu records, node collate %s single-device read-back\n", F,
            orb_node_device_count(node), total, same ? "==" : "!=");
+
+    /* ---- the pipelined form: job k is extracted while job k-1 is exchanged and collated ---- */
+    uint32_t *counts2 = calloc(F, sizeof *counts2);
+    uint64_t *offsets2 = calloc((size_t)F + 1, sizeof *offsets2);
+    int ended = 0;
+    for (int k = 0; k < 3 && same; k++) {
+        CHECK(orb_node_extract_batch_host(node, frames, F), orb_node_last_error(node));
+        if (orb_node_pending(node) == 2) {
+            CHECK(orb_node_collate_begin(node), orb_node_last_error(node));
+            CHECK(orb_node_collate_end(node, counts2, offsets2, NULL, NULL), orb_node_last_error(node));
+            same = memcmp(counts2, counts, sizeof(uint32_t) * F) == 0 && offsets2[F] == offsets[F];
+            ended++;
+        }
+    }
+    while (same && orb_node_pending(node) > 0) {
+        CHECK(orb_node_collate_end(node, counts2, offsets2, NULL, NULL), orb_node_last_error(node));
+        same = memcmp(counts2, counts, sizeof(uint32_t) * F) == 0 && offsets2[F] == offsets[F];
+        ended++;
+    }
+    printf("pipelined: %d jobs collated, counters %s\n", ended, same ? "equal" : "DIFFER");
+    free(counts2);
+    free(offsets2);
 
     f = fopen(argv[5], "wb");
     if (!f || fwrite(&F, 4, 1, f) != 1 || fwrite(counts, 4, F, f) != F || fwrite(offsets, 8, (size_t)F + 1, f) != (size_t)F + 1 ||

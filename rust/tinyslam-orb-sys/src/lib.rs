@@ -161,6 +161,10 @@ pub mod orb {
         fn orb_node_extract_batch(node: *mut c_void, frames_dev: *const *const u8, n_frames: u32) -> c_int;
         fn orb_node_collate(node: *mut c_void, counts: *mut u32, offsets: *mut u64, corners_dev: *mut *mut c_void,
                             descriptors_dev: *mut *mut c_void) -> c_int;
+        fn orb_node_collate_begin(node: *mut c_void) -> c_int;
+        fn orb_node_collate_end(node: *mut c_void, counts: *mut u32, offsets: *mut u64, corners_dev: *mut *mut c_void,
+                                descriptors_dev: *mut *mut c_void) -> c_int;
+        fn orb_node_pending(node: *const c_void) -> c_int;
         fn orb_node_read_collated(node: *mut c_void, corners: *mut CornerData, descriptors: *mut CornerDescriptor,
                                   capacity: usize) -> c_int;
     }
@@ -181,7 +185,8 @@ pub mod orb {
 
     impl OrbNode {
         /// `max_batch` = the largest shard one device may get (frames per job / devices, rounded up).
-        pub fn new(devices: &[i32], config: &OrbConfig, max_batch: u32) -> Self {
+        /// `flags`: ORB_FLAG_* of include/tinyorb.h; with ORB_FLAG_INPUT_Y8 (16) frames are one byte per pixel.
+        pub fn new(devices: &[i32], config: &OrbConfig, max_batch: u32, flags: u32) -> Self {
             let c = OrbConfigC {
                 image_size: Extent3dC {
                     width: config.image_size.width,
@@ -192,14 +197,16 @@ pub mod orb {
                 hierarchy_depth: config.hierarchy_depth,
                 initial_threshold: config.initial_threshold,
             };
-            let opt = OrbOptionsC { max_batch, ..Default::default() };
+            let opt = OrbOptionsC { max_batch, flags, ..Default::default() };
             let mut handle = std::ptr::null_mut();
             let rc = unsafe { orb_node_create(devices.as_ptr(), devices.len() as c_int, &c, &opt, &mut handle) };
             if rc != ORB_OK {
                 let msg = unsafe { std::ffi::CStr::from_ptr(orb_node_last_error(std::ptr::null())) };
                 panic!("tinyorb: {}", msg.to_string_lossy());
             }
-            let frame_bytes = config.image_size.width as usize * config.image_size.height as usize * 4;
+            const ORB_FLAG_INPUT_Y8: u32 = 16;
+            let bytes_per_pixel = if flags & ORB_FLAG_INPUT_Y8 != 0 { 1 } else { 4 };  // the node slices the host array the same way
+            let frame_bytes = config.image_size.width as usize * config.image_size.height as usize * bytes_per_pixel;
             Self { handle, frame_bytes }
         }
 
@@ -229,12 +236,36 @@ pub mod orb {
             self.collate(n_frames)
         }
 
+        /// Stage 1 of a streamed job (up to two may be outstanding): the kernels of every shard, asynchronously.
+        pub fn submit(&self, frames: &[u8]) -> u32 {
+            let n = (frames.len() / self.frame_bytes) as u32;
+            assert_eq!(frames.len(), n as usize * self.frame_bytes);
+            self.check(unsafe { orb_node_extract_batch_host(self.handle, frames.as_ptr(), n) });
+            n
+        }
+
+        /// Stage 2 of the oldest job that has not begun it: enqueue its exchange (overlaps the kernels of the job
+        /// submitted after it).
+        pub fn collate_begin(&self) {
+            self.check(unsafe { orb_node_collate_begin(self.handle) });
+        }
+
+        /// Stage 3 of the oldest job (`n` = its frames): blocks until it is collated, copies the records to the host.
+        ///     let n0 = node.submit(a);  let n1 = node.submit(b);  node.collate_begin();  let ra = node.finish(n0); ...
+        pub fn finish(&self, n: u32) -> BatchResult {
+            self.collate(n)
+        }
+
+        pub fn pending(&self) -> usize {
+            unsafe { orb_node_pending(self.handle) as usize }
+        }
+
         fn collate(&self, n: u32) -> BatchResult {
             let mut counts = vec![0u32; n as usize];
             let mut offsets = vec![0u64; n as usize + 1];
             self.check(unsafe {
-                orb_node_collate(self.handle, counts.as_mut_ptr(), offsets.as_mut_ptr(), std::ptr::null_mut(),
-                                 std::ptr::null_mut())
+                orb_node_collate_end(self.handle, counts.as_mut_ptr(), offsets.as_mut_ptr(), std::ptr::null_mut(),
+                                     std::ptr::null_mut())
             });
             let total = offsets[n as usize] as usize;
             let mut corners = vec![CornerData::default(); total];

@@ -4,7 +4,7 @@
 set -e
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 TAG=${1:-r01}; OUT=gpurun_out/$TAG; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-single-frame --preheat-ms 0 --no-host-out > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-single-frame --no-host-out > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 PMC_ARGS="python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-single-frame --preheat-ms 0 --no-host-out --repeats 1"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $PMC_ARGS > $OUT/fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $PMC_ARGS > $OUT/write.json 2> $OUT/write.err

@@ -1,6 +1,7 @@
 """One-off randomized parity sweep on the GPU: random sizes, depths, thresholds, modes, arcs, capacities -- every result
 against the C oracle (tests/ hold the fixed cases).  usage: python tools/fuzz_parity.py [n_cases] [seed] [wide]
-("wide": every frame 1284..4156 columns wide -- the levels that mix 8-, 16- and 32-row bands)"""
+("wide": every frame 1284..4156 columns wide -- the levels that mix 8-, 16- and 32-row bands and column tiles;
+ "xwide": 1284..9196 columns, low frames: column tiles at several levels, widths past 4096)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +10,8 @@ from oracle import orb_oracle as oo
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"
+WIDE = len(sys.argv) > 3 and sys.argv[3] in ("wide", "xwide")
+XWIDE = len(sys.argv) > 3 and sys.argv[3] == "xwide"
 
 
 def sort(c, d):
@@ -28,6 +30,9 @@ for case in range(n_cases):
     H = int(rng.integers(8, 400)) if W <= 720 else int(rng.integers(8, 160))
     if WIDE:
         H = int(rng.integers(24, 260))
+    if XWIDE:
+        W = int(rng.integers(321, 2300)) * 4 + (int(rng.integers(0, 4)) if rng.random() < 0.2 else 0)
+        H = int(rng.integers(20, 90))
     depth = int(rng.integers(1, 7))
     thr = float(np.float32(rng.choice([5, 12, 20, 40, 80]) / 255.0))
     intended = bool(rng.random() < 0.3)
