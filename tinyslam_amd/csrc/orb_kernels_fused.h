@@ -35,9 +35,9 @@ constexpr int kFrontQueue = 4096;    // pre-test survivor queue, 16-bit entries
 // per workgroup), wide ones flat bands (two workgroups per CU).
 constexpr int kFrontBandHeights[] = {64, 32, 16, 8};
 __host__ __device__ constexpr int front_x_bits(int rows) { return rows == 64 ? 9 : rows == 32 ? 10 : rows == 16 ? 11 : 12; }
-// Survivor mask of a pre-test item (8 pixels, two polarities): bit p = 8 * (k & 1) + 4 * under + (k >> 1) for pixel k.  A
-// 16-bit queue entry is [15:4] the item (band row, x / 8) and [3:0] that bit number: the push loop of B1 is then ffbl /
-// clear / or / store, and the dense stages decode (front_entry_*).
+// Survivor mask of half a pre-test item (8 pixels, two polarities): bit p = 8 * (k & 1) + 4 * under + (k >> 1) for pixel k;
+// an item is two halves (bits 0..15 and 16..31).  A 16-bit queue entry is [15:5] the item (band row, x / 16) and [4:0] that
+// bit number: the push loop of B1 is then ffbl / clear / or / store, and the dense stages decode (locate()).
 __host__ __device__ constexpr uint32_t front_mask_bit(int k, bool under) { return 1u << (8 * (k & 1) + (under ? 4 : 0) + (k >> 1)); }
 constexpr int kFrontMaxWidth = 2048;     // widest level 0 of the 16-row bands (11-bit x in the 16-bit queue entries)
 constexpr int kFrontMaxWidthWide = 4096; // ... of the 8-row bands (12-bit x)
@@ -579,36 +579,40 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
 
     // Phases B (FAST) and C (mip + blur) only share the read-only grey rows.
     auto phase_B = [&]() {
-        // =========================== B1: 4-point pre-test, 8 px per item ===========================
+        // =========================== B1: 4-point pre-test, 16 px per item (8 above level 0) ===========================
         if (geo.phase_mask & 1u) {
-            const int g8 = TILED ? (min(x0 + (int)geo.tw, (int)geo.gw) - x0) >> 3 : (int)geo.gw >> 3;  // items of a row (of this tile)
-            const float inv_g8 = 1.0f / (float)max(g8, 1);
-            const int n_items = R * g8;
+            // Level 0: an item is sixteen pixels of a row, tested as two halves of eight (two packed pixels per operation,
+            // four pixel pairs per half); what is done once per item -- index arithmetic, the fast.wgsl:77 guard, the slot
+            // reservation for its survivors -- then weighs half as much per pixel as with items of eight (k_front<true>
+            // 0.354 -> 0.346 ms).  The levels above keep items of eight: their bands hold 1.25 sixteen-pixel items per
+            // thread, and the two waves with a second item set the pace (0.072 -> 0.076 ms).
+            constexpr int IH = L0 ? 2 : 1, IW = 8 * IH;  // halves and pixels per item
+            const int cols_t = TILED ? min(x0 + (int)geo.tw, (int)geo.gw) - x0 : (int)geo.gw;  // dispatch columns (of this tile): a multiple of 8
+            const int g16 = (cols_t + IW - 1) / IW;                                           // items of a row
+            const float inv_g16 = 1.0f / (float)max(g16, 1);
+            const int n_items = R * g16;
             // fast.wgsl:77 -- level-0 dimensions for every octave, u32 arithmetic (Q8)
             const uint32_t lim_x = pyr.w[0] - 16u, lim_y = pyr.h[0] - 16u;
-            // the item that holds column lim_x (the first one past the guard) and the sign bits of its pixels below lim_x
-            const int x_cut = (int)(lim_x & ~7u);
+            // the item that holds column lim_x (the first one past the guard) and the mask bits of its pixels below lim_x;
+            // the item whose second half lies outside the dispatch domain (a row of 8 (mod 16) columns)
+            const int x_cut = x0 + (((int)lim_x - x0) & ~(IW - 1));
+            const int x_half = (IH == 2 && (cols_t & 8)) ? x0 + (cols_t & ~15) : -1;
             uint32_t keep_cut = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (k < (int)(lim_x & 7u)) keep_cut |= front_mask_bit(k, false) | front_mask_bit(k, true);
+            for (int k = 0; k < IW; k++)
+                if (k < (int)lim_x - x_cut) keep_cut |= (front_mask_bit(k & 7, false) | front_mask_bit(k & 7, true)) << (16 * (k >> 3));
             // thr_lo: one f16 ulp below RD16(thr) (see below); -min_subnormal when that would pass zero
             uint32_t tb = half_bits(to_half(thr));
             if (from_half(bits_half((uint16_t)tb)) > thr) tb--;
             tb = tb ? tb - 1u : 0x8001u;
             const half2_t thr_lo2 = __builtin_bit_cast(half2_t, tb | (tb << 16));
             for (int i = tid; i < n_items; i += NT) {
-                const int lyc = (int)(((float)i + 0.5f) * inv_g8);
-                const int xl = (i - __mul24(lyc, g8)) * 8, x = x0 + xl;  // tile-local and image column of the item's first pixel
+                const int lyc = (int)(((float)i + 0.5f) * inv_g16);
+                const int xl = (i - __mul24(lyc, g16)) * IW, x = x0 + xl;  // tile-local and image column of the item's first pixel
                 const uint32_t gy = (uint32_t)(y0 + lyc);
                 if (!(gy < geo.gh && gy > 16u && gy < lim_y)) continue;
-                if ((uint32_t)x + 7u <= 16u || (uint32_t)x >= lim_x) continue;
-                const half_t* rowc = grey + row3 + (int)__umul24((uint32_t)lyc, (uint32_t)LS) + xl;  // row lyc + 3 of the staged rows
-                const uint2 qa = *reinterpret_cast<const uint2*>(rowc - 4);
-                const uint4 qb = *reinterpret_cast<const uint4*>(rowc);
-                const uint2 qc = *reinterpret_cast<const uint2*>(rowc + 8);
-                const uint4 qu = *reinterpret_cast<const uint4*>(rowc - 3 * LS);
-                const uint4 qd = *reinterpret_cast<const uint4*>(rowc + 3 * LS);
+                if ((uint32_t)x + (uint32_t)(IW - 1) <= 16u || (uint32_t)x >= lim_x) continue;
+                const half_t* row16 = grey + row3 + (int)__umul24((uint32_t)lyc, (uint32_t)LS) + xl;  // row lyc + 3 of the staged rows
                 // Pre-test (fast.wgsl:85-95), as a CONSERVATIVE filter: every pixel the reference's pre-test
                 // passes is kept, a few extra may be; the decision itself is made by the 16-point test, whose
                 // 12-run already implies the 3-of-4 compass condition, so results do not change.
@@ -619,48 +623,59 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                 //    RD16(thr): x > thr  =>  RN16(x) >= RD16(thr) > thr_lo, so nothing is missed;
                 //  * compares are subtractions whose sign bits are the answer (a float subtraction has the
                 //    sign of the exact difference).
-                const uint32_t dw[8] = {qa.x, qa.y, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};  // dw[j] = grey(x-4+2j, x-3+2j)
-                const uint32_t upw[4] = {qu.x, qu.y, qu.z, qu.w}, dnw[4] = {qd.x, qd.y, qd.z, qd.w};
-                uint32_t e_ovr[4], e_und[4];  // sign bit of each half = the answer for that pixel
+                uint32_t cand = 0;  // bit 16 h + front_mask_bit(k, under): pixel 8 h + k survives
     #pragma unroll
-                for (int j = 0; j < 4; j++) {  // pixel pair (x+2j, x+2j+1)
-                    const ushort2_t left = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 1], dw[j], 16));       // x+2j-3, x+2j-2
-                    const ushort2_t right = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 4], dw[j + 3], 16));  // x+2j+3, x+2j+4
-                    const ushort2_t upp = as_u16x2(upw[j]), dwn = as_u16x2(dnw[j]);
-                    const ushort2_t lo1 = __builtin_elementwise_min(left, right), hi1 = __builtin_elementwise_max(left, right);
-                    const ushort2_t lo2 = __builtin_elementwise_min(upp, dwn), hi2 = __builtin_elementwise_max(upp, dwn);
-                    const ushort2_t m1 = __builtin_elementwise_max(lo1, lo2), m2 = __builtin_elementwise_min(hi1, hi2);
-                    const half2_t second_lo = __builtin_bit_cast(half2_t, __builtin_elementwise_min(m1, m2));
-                    const half2_t second_hi = __builtin_bit_cast(half2_t, __builtin_elementwise_max(m1, m2));
-                    const half2_t c2 = __builtin_bit_cast(half2_t, dw[j + 2]);
-                    const half2_t e_over = thr_lo2 - (second_lo - c2);   // negative  <=>  second_lo - c > thr_lo
-                    const half2_t e_under = (second_hi - c2) + thr_lo2;  // negative  <=>  second_hi - c < -thr_lo
-                    e_ovr[j] = __builtin_bit_cast(uint32_t, e_over);
-                    e_und[j] = __builtin_bit_cast(uint32_t, e_under);
-                }
-                // The sixteen sign bits (8 pixels x 2 polarities, which exclude each other) as one 16-bit mask, bit
-                // front_mask_bit(k, under): every word's two sign bits become 0/1 in its halves (one packed shift), a
-                // shift-or per word places them -- even pixels in the low half, odd ones in the high half --, one byte
-                // permute folds the halves.
-                uint32_t acc = 0;
+                for (int hh = 0; hh < IH; hh++) {
+                    const half_t* rowc = row16 + 8 * hh;
+                    const uint2 qa = *reinterpret_cast<const uint2*>(rowc - 4);
+                    const uint4 qb = *reinterpret_cast<const uint4*>(rowc);
+                    const uint2 qc = *reinterpret_cast<const uint2*>(rowc + 8);
+                    const uint4 qu = *reinterpret_cast<const uint4*>(rowc - 3 * LS);
+                    const uint4 qd = *reinterpret_cast<const uint4*>(rowc + 3 * LS);
+                    const uint32_t dw[8] = {qa.x, qa.y, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};  // dw[j] = grey(x-4+2j, x-3+2j) of this half
+                    const uint32_t upw[4] = {qu.x, qu.y, qu.z, qu.w}, dnw[4] = {qd.x, qd.y, qd.z, qd.w};
+                    uint32_t e_ovr[4], e_und[4];  // sign bit of each half word = the answer for that pixel
     #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t so = __builtin_bit_cast(uint32_t, as_u16x2(e_ovr[j]) >> (unsigned short)15);
-                    const uint32_t su = __builtin_bit_cast(uint32_t, as_u16x2(e_und[j]) >> (unsigned short)15);
-                    acc = j == 0 ? so : ((so << j) | acc);
-                    acc = (su << (4 + j)) | acc;
+                    for (int j = 0; j < 4; j++) {  // pixel pair (x+2j, x+2j+1)
+                        const ushort2_t left = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 1], dw[j], 16));       // x+2j-3, x+2j-2
+                        const ushort2_t right = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 4], dw[j + 3], 16));  // x+2j+3, x+2j+4
+                        const ushort2_t upp = as_u16x2(upw[j]), dwn = as_u16x2(dnw[j]);
+                        const ushort2_t lo1 = __builtin_elementwise_min(left, right), hi1 = __builtin_elementwise_max(left, right);
+                        const ushort2_t lo2 = __builtin_elementwise_min(upp, dwn), hi2 = __builtin_elementwise_max(upp, dwn);
+                        const ushort2_t m1 = __builtin_elementwise_max(lo1, lo2), m2 = __builtin_elementwise_min(hi1, hi2);
+                        const half2_t second_lo = __builtin_bit_cast(half2_t, __builtin_elementwise_min(m1, m2));
+                        const half2_t second_hi = __builtin_bit_cast(half2_t, __builtin_elementwise_max(m1, m2));
+                        const half2_t c2 = __builtin_bit_cast(half2_t, dw[j + 2]);
+                        const half2_t e_over = thr_lo2 - (second_lo - c2);   // negative  <=>  second_lo - c > thr_lo
+                        const half2_t e_under = (second_hi - c2) + thr_lo2;  // negative  <=>  second_hi - c < -thr_lo
+                        e_ovr[j] = __builtin_bit_cast(uint32_t, e_over);
+                        e_und[j] = __builtin_bit_cast(uint32_t, e_under);
+                    }
+                    // The sixteen sign bits (8 pixels x 2 polarities, which exclude each other) as one 16-bit mask, bit
+                    // front_mask_bit(k, under): every word's two sign bits become 0/1 in its halves (one packed shift), a
+                    // shift-or per word places them -- even pixels in the low half, odd ones in the high half --, one byte
+                    // permute folds the halves (into the upper 16 bits for the item's second half).
+                    uint32_t acc = 0;
+    #pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t so = __builtin_bit_cast(uint32_t, as_u16x2(e_ovr[j]) >> (unsigned short)15);
+                        const uint32_t su = __builtin_bit_cast(uint32_t, as_u16x2(e_und[j]) >> (unsigned short)15);
+                        acc = j == 0 ? so : ((so << j) | acc);
+                        acc = (su << (4 + j)) | acc;
+                    }
+                    cand |= __builtin_amdgcn_perm(0u, acc, hh == 0 ? 0x0c0c0200u : 0x02000c0cu);  // byte 0 | byte 2 << 8 (<< 16)
                 }
-                uint32_t cand = __builtin_amdgcn_perm(0u, acc, 0x0c0c0200u);  // byte 0 | byte 2 << 8
                 // fast.wgsl:77 guard on x: keep pixels k with 16 < x+k < lim_x.  Only two items of a row are cut -- the one
                 // at x = 16 loses pixel 0, the one that holds column lim_x loses its tail --, and both masks are the same for
-                // every row: two compares and selects here instead of eight each.
+                // every row: two compares and selects here instead of sixteen each.  A third item may have no second half.
                 cand &= x == 16 ? ~(front_mask_bit(0, false) | front_mask_bit(0, true)) : ~0u;
                 cand &= x == x_cut ? keep_cut : ~0u;
+                if (IH == 2) cand &= x == x_half ? 0xffffu : ~0u;
                 if (cand) {  // one LDS atomic for all survivors of this item
                     // every lane reserves its own slots with the LDS's returning add (lds_add_rtn, orb_device.h)
                     const uint32_t n_cand = (uint32_t)__builtin_popcount(cand);
                     uint32_t qs = lds_add_rtn(qa_count, n_cand);
-                    const uint32_t base = ((uint32_t)lyc << (XB + 1)) | ((uint32_t)xl << 1);  // xl is a multiple of 8: the low four bits are free
+                    const uint32_t base = ((uint32_t)lyc << (XB + 1)) | ((uint32_t)xl << 1);  // xl is a multiple of 16 (8): the low five (four) bits are free
                     if (qs + n_cand <= (uint32_t)kFrontQueue) {  // all survivors of the item fit: no test per entry
                         while (cand) {
                             const uint32_t p = (uint32_t)__builtin_ctz(cand);
@@ -674,9 +689,9 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
                             if (qs < (uint32_t)kFrontQueue) {
                                 queue_a[qs] = (uint16_t)(base | p);
                             } else {  // queue full (pathological frame): finish in place
-                                const int k = (int)(((p & 3u) << 1) | (p >> 3));
+                                const int k = (int)(((p & 3u) << 1) | ((p >> 3) & 1u) | ((p >> 4) << 3));
                                 uint32_t angle;
-                                const bool hit = fast_full_test(rowc + k, LS, thr, &angle);
+                                const bool hit = fast_full_test(row16 + k, LS, thr, &angle);
                                 segment_append(hit, (uint32_t)(x + k), gy, angle, lvl, c_count, seg, geo.seg_cap, two_lists);
                             }
                             qs++;
@@ -693,8 +708,8 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
         if (geo.phase_mask & 2u) {
             auto locate = [&](uint32_t e, uint32_t* x, uint32_t* gy) -> const half_t* {
                 const uint32_t lyc = e >> (XB + 1);                                       // e is a 16-bit entry
-                const uint32_t k = ((e & 3u) << 1) | ((e >> 3) & 1u);                     // pixel of the item (front_mask_bit)
-                const uint32_t xl = ((e >> 1) & (((1u << XB) - 1u) & ~7u)) | k;  // tile-local column
+                const uint32_t k = ((e & 3u) << 1) | ((e >> 3) & 1u) | ((e >> 1) & 8u);   // pixel of the item: front_mask_bit in [3:0], the half in [4]
+                const uint32_t xl = ((e >> 1) & (((1u << XB) - 1u) & ~15u)) | k;  // tile-local column
                 *x = (uint32_t)x0 + xl;
                 *gy = (uint32_t)y0 + lyc;
                 return grey + row3 + (int)__umul24(lyc, (uint32_t)LS) + (int)xl;
