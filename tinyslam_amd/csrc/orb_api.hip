@@ -454,7 +454,9 @@ int launch_brief(OrbProgram* p, hipStream_t s, uint32_t n, const RowsGeom& rows_
 
 // The fused pipeline for frames [f0, f0 + n) of the batch on stream s: one k_front launch per level + BRIEF
 // (with_brief = false: the caller launches its own BRIEF kernel -- the single-frame path's k_brief_one).
-int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint32_t n, hipStream_t s, bool with_brief = true) {
+// first_level > 0 (single-frame call): the levels below it have been launched already (k_front_pair).
+int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint32_t n, hipStream_t s, bool with_brief = true,
+                    uint32_t first_level = 0) {
     const Pyramid& pyr = p->pyr;
     const uint32_t D = pyr.depth, cap = p->cfg.max_features;
     const uint8_t* frames = frames_all + (size_t)f0 * p->frame_bytes;
@@ -475,12 +477,15 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         const uint32_t gw = ((width + 7u) / 8u) * 8u, gh = ((height + 7u) / 8u) * 8u;
         width /= 2u;
         height /= 2u;
+        if (lvl < first_level) continue;  // launched by the caller
         if (lvl > 0 && !(pyr.w[lvl - 1] == 2u * pyr.w[lvl] && pyr.h[lvl - 1] == 2u * pyr.h[lvl])) {
-            LaunchScope ls(p, s, KID_MIP);  // inexact reduction (odd source size): generic bilinear blit
+            hipStream_t sm = s;
+            LaunchScope ls(p, sm, KID_MIP);  // inexact reduction (odd source size): generic bilinear blit
             dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 4u * kMipRows - 1u) / (4u * kMipRows), n);
-            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, d_gray, pyr, lvl, (float)pyr.w[lvl - 1] / (float)pyr.w[lvl], (float)pyr.h[lvl - 1] / (float)pyr.h[lvl]);
+            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, sm, d_gray, pyr, lvl, (float)pyr.w[lvl - 1] / (float)pyr.w[lvl], (float)pyr.h[lvl - 1] / (float)pyr.h[lvl]);
         }
         FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n, p->band_rows_lvl[lvl], p->tile_w_lvl[lvl]);
+        hipStream_t s_lvl = s;
         if (gw == 0) g.gh = 0;  // no FAST dispatch at this octave (orb.rs:511-515 with width 0)
         g.slot_base = p->bands.slot_base[lvl];
         g.n_slots = p->bands.n_slots;
@@ -498,24 +503,24 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         const dim3 grid(g.n_bands * (g.tiled ? g.n_ct : 1u) * n);
 #define FRONT_ARGS frames, p->frame_bytes, d_gray, d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg
 #define FRONT_LAUNCH_TILED(L0, Y8, UA)                                                                             \
-    if (p->band_rows_lvl[lvl] == 16u) hipLaunchKernelGGL((k_front<L0, Y8, 16, UA, true>), grid, block, lds, s, FRONT_ARGS); \
-    else hipLaunchKernelGGL((k_front<L0, Y8, 8, UA, true>), grid, block, lds, s, FRONT_ARGS);
+    if (p->band_rows_lvl[lvl] == 16u) hipLaunchKernelGGL((k_front<L0, Y8, 16, UA, true>), grid, block, lds, s_lvl, FRONT_ARGS); \
+    else hipLaunchKernelGGL((k_front<L0, Y8, 8, UA, true>), grid, block, lds, s_lvl, FRONT_ARGS);
 #define FRONT_LAUNCH(L0, Y8)                                                                                       \
     switch (p->band_rows_lvl[lvl]) {                                                                               \
-        case 64: hipLaunchKernelGGL((k_front<L0, Y8, 64>), grid, block, lds, s, FRONT_ARGS); break;                \
-        case 32: hipLaunchKernelGGL((k_front<L0, Y8, 32>), grid, block, lds, s, FRONT_ARGS); break;                \
-        case 16: hipLaunchKernelGGL((k_front<L0, Y8, 16>), grid, block, lds, s, FRONT_ARGS); break;                \
-        default: hipLaunchKernelGGL((k_front<L0, Y8, 8>), grid, block, lds, s, FRONT_ARGS); break;                 \
+        case 64: hipLaunchKernelGGL((k_front<L0, Y8, 64>), grid, block, lds, s_lvl, FRONT_ARGS); break;                \
+        case 32: hipLaunchKernelGGL((k_front<L0, Y8, 32>), grid, block, lds, s_lvl, FRONT_ARGS); break;                \
+        case 16: hipLaunchKernelGGL((k_front<L0, Y8, 16>), grid, block, lds, s_lvl, FRONT_ARGS); break;                \
+        default: hipLaunchKernelGGL((k_front<L0, Y8, 8>), grid, block, lds, s_lvl, FRONT_ARGS); break;                 \
     }
         if (lvl == 0) {
-            LaunchScope ls(p, s, KID_FUSED_L0);
+            LaunchScope ls(p, s_lvl, KID_FUSED_L0);
             const dim3 block(kFrontThreadsL0);
 #define FRONT_LAUNCH_UA(Y8)                                                                                        \
     switch (p->band_rows_lvl[lvl]) {                                                                               \
-        case 64: hipLaunchKernelGGL((k_front<true, Y8, 64, true>), grid, block, lds, s, FRONT_ARGS); break;        \
-        case 32: hipLaunchKernelGGL((k_front<true, Y8, 32, true>), grid, block, lds, s, FRONT_ARGS); break;        \
-        case 16: hipLaunchKernelGGL((k_front<true, Y8, 16, true>), grid, block, lds, s, FRONT_ARGS); break;        \
-        default: hipLaunchKernelGGL((k_front<true, Y8, 8, true>), grid, block, lds, s, FRONT_ARGS); break;         \
+        case 64: hipLaunchKernelGGL((k_front<true, Y8, 64, true>), grid, block, lds, s_lvl, FRONT_ARGS); break;        \
+        case 32: hipLaunchKernelGGL((k_front<true, Y8, 32, true>), grid, block, lds, s_lvl, FRONT_ARGS); break;        \
+        case 16: hipLaunchKernelGGL((k_front<true, Y8, 16, true>), grid, block, lds, s_lvl, FRONT_ARGS); break;        \
+        default: hipLaunchKernelGGL((k_front<true, Y8, 8, true>), grid, block, lds, s_lvl, FRONT_ARGS); break;         \
     }
             // rows not aligned to a quad, or the level-0 plane is needed (level 1 not an exact half): the general variant
             const bool general = (pyr.w[0] & 3u) || g.store_grey;
@@ -535,7 +540,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
             }
 #undef FRONT_LAUNCH_UA
         } else {
-            LaunchScope ls(p, s, KID_FUSED_LN);
+            LaunchScope ls(p, s_lvl, KID_FUSED_LN);
             const dim3 block(kFrontThreadsLN);
             if (g.tiled) { FRONT_LAUNCH_TILED(false, false, false) }
             else { FRONT_LAUNCH(false, false) }
@@ -859,6 +864,14 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                     }
                     const bool two_per_cu = rows != 0u;
                     if (!rows) rows = fits, rows_lds = fits_lds;
+                    // A program for one frame at a time (the reference's call shape) is after latency, not throughput: its 45 + 23
+                    // bands cannot fill 256 CUs anyway, so it takes the flattest bands -- twice the workgroups, each with half
+                    // the work on its critical path (k_front<true> 16.3 -> 13.6 us at 720p).
+                    if (p->max_batch == 1u && two_per_cu && !want && !getenv("TINYORB_NO_LATENCY_BANDS")) {
+                        const uint32_t flat = (uint32_t)kFrontRowsWide;
+                        const uint32_t lds = front_lds_bytes(front_geometry(p->pyr, lvl, gw, gh, 1, flat));
+                        if (std::max(w, gw) <= (1u << front_x_bits((int)flat)) && lds <= p->max_lds) rows = flat, rows_lds = lds;
+                    }
                     if (want) rows = want, rows_lds = want_lds;
                     // Too wide for two full-width bands per CU (one workgroup per CU costs a third of the rate: 0.62 against
                     // 0.45 ms at 720p), or for any: column tiles of about kFrontTileW columns -- 16 rows x 1280 columns is the
@@ -938,6 +951,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 };
                 for (const void* f : fronts)
                     CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
+                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_pair<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
             }
         }
     }
@@ -1225,7 +1239,39 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
         // Three launches per frame: one k_front per level, then k_brief_one -- slot prefix, both BRIEF kernels and the
         // write to host staging in one (a dependent launch costs 6-10 us whatever it does, and this call is the
         // reference's only shape).
-        if (int rc = run_fused_range(p, p->d_input, 0, 1, s, false)) return rc;
+        // Levels 0 and 1 in ONE launch when level 1 can build its rows from the frame (k_front_pair): RGBA input, level 1 an
+        // exact half of a level 0 whose width is a multiple of 8, both on full-width bands of 8 rows (the latency shape).
+        const Pyramid& py = p->pyr;
+        const bool pair_ok = py.depth >= 2u && !p->input_y8 && py.w[0] == 2u * py.w[1] && py.h[0] == 2u * py.h[1] && (py.w[0] & 7u) == 0u &&
+                             p->tile_w_lvl[0] == 0u && p->tile_w_lvl[1] == 0u && p->band_rows_lvl[0] == 8u && p->band_rows_lvl[1] == 8u &&
+                             !p->d_stamps && !getenv("TINYORB_SINGLE_SERIAL");
+        if (pair_ok) {
+            FrontGeom g[2];
+            uint32_t width = py.w[0], height = py.h[0], lds = 0;
+            for (uint32_t lvl = 0; lvl < 2u; lvl++) {
+                const uint32_t gw = ((width + 7u) / 8u) * 8u, gh = ((height + 7u) / 8u) * 8u;
+                width /= 2u;
+                height /= 2u;
+                g[lvl] = front_geometry(py, lvl, gw ? gw : 8u, gh, 1, 8u, 0u);
+                if (gw == 0) g[lvl].gh = 0;
+                g[lvl].slot_base = p->bands.slot_base[lvl];
+                g[lvl].n_slots = p->bands.n_slots;
+                g[lvl].seg_cap = p->bands.seg_cap;
+                g[lvl].n_classes = p->seg_classes;
+                g[lvl].xcd_swizzle = 0u;
+                lds = std::max(lds, front_lds_bytes(g[lvl]));
+            }
+            if (lds > p->max_lds) return fail(p, ORB_EINVAL, "internal: k_front_pair needs %u bytes of LDS", lds);
+            {
+                LaunchScope ls(p, s, KID_FUSED_L0);
+                hipLaunchKernelGGL((k_front_pair<8, 8>), dim3(g[0].n_bands + g[1].n_bands), dim3(kFrontThreadsL0), lds, s, p->d_input,
+                                   p->frame_bytes, p->d_gray, p->d_blur, p->d_blur_rowc, py, g[0], g[1], p->threshold, p->d_seg_counts, p->d_seg);
+            }
+            if (py.depth > 2u)
+                if (int rc = run_fused_range(p, p->d_input, 0, 1, s, false, 2u)) return rc;
+        } else if (int rc = run_fused_range(p, p->d_input, 0, 1, s, false)) {
+            return rc;
+        }
         {
             LaunchScope ls(p, s, KID_BRIEF_ONE);
             hipLaunchKernelGGL(k_brief_one, dim3((unsigned)((cap + kBriefOneChunk - 1u) / kBriefOneChunk)), dim3(256), brieft_lds_bytes(p->brieft), s, p->d_blur,

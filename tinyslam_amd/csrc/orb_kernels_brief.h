@@ -68,7 +68,10 @@ __device__ __forceinline__ void brief_t_body(uint8_t* lds_raw, uint32_t frame, u
                                              const Pyramid& pyr, const BriefTGeom& bg, const uint32_t* __restrict__ seg_counts,
                                              const uint32_t* __restrict__ seg_before, const CornerData* __restrict__ segments,
                                              CornerData* __restrict__ corners, uint32_t cap,
-                                             CornerDescriptor* __restrict__ descriptors, const BriefTables& tab) {
+                                             CornerDescriptor* __restrict__ descriptors, const BriefTables& tab,
+                                             CornerData* __restrict__ host_corners = nullptr,
+                                             CornerDescriptor* __restrict__ host_descriptors = nullptr) {
+    // host_corners / host_descriptors (k_brief_one): every record and descriptor is also written to these (pinned host) arrays
     const uint32_t n_ent = bg.n_slots * bg.n_classes;  // lists of a frame, in final order: class-major, slot-minor
     uint32_t* const before = reinterpret_cast<uint32_t*>(lds_raw);                    // [n_ent + 1]
     uint16_t* const rows = reinterpret_cast<uint16_t*>(before + n_ent + 1u);          // [rows_padded]
@@ -113,6 +116,7 @@ __device__ __forceinline__ void brief_t_body(uint8_t* lds_raw, uint32_t frame, u
     const uint4 rec = *reinterpret_cast<const uint4*>(
         &segments[(((size_t)frame * bg.n_slots + slot) * bg.n_classes + cls) * bg.seg_cap + (k - before[lo])]);
     *reinterpret_cast<uint4*>(&corners[(size_t)frame * cap + k]) = rec;  // final list = the lists back to back
+    if (host_corners) *reinterpret_cast<uint4*>(&host_corners[k]) = rec;
     const uint32_t lvl = min(rec.w, pyr.depth - 1u);
     if (!(rec.x >= (uint32_t)kBriefHalo && rec.x < lv[lvl][0])) return;  // not flat: k_brief_nf takes it
 
@@ -135,6 +139,11 @@ __device__ __forceinline__ void brief_t_body(uint8_t* lds_raw, uint32_t frame, u
         }
         o[0] = make_uint4(d[0], d[1], d[2], d[3]);
         o[1] = make_uint4(d[4], d[5], d[6], d[7]);
+        if (host_descriptors) {
+            uint4* const ho = reinterpret_cast<uint4*>(host_descriptors + k);
+            ho[0] = make_uint4(d[0], d[1], d[2], d[3]);
+            ho[1] = make_uint4(d[4], d[5], d[6], d[7]);
+        }
         return;
     }
     const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
@@ -161,6 +170,11 @@ __device__ __forceinline__ void brief_t_body(uint8_t* lds_raw, uint32_t frame, u
     }
     o[0] = make_uint4(d[0], d[1], d[2], d[3]);
     o[1] = make_uint4(d[4], d[5], d[6], d[7]);
+    if (host_descriptors) {
+        uint4* const ho = reinterpret_cast<uint4*>(host_descriptors + k);
+        ho[0] = make_uint4(d[0], d[1], d[2], d[3]);
+        ho[1] = make_uint4(d[4], d[5], d[6], d[7]);
+    }
 }
 
 template <int kWavesPerSimd>
@@ -197,7 +211,8 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
                                               const uint16_t* __restrict__ blur_rowc, const Pyramid& pyr, const BriefTGeom& bg,
                                               const uint32_t* __restrict__ seg_counts, const uint32_t* __restrict__ seg_before,
                                               const CornerData* __restrict__ corners, uint32_t cap,
-                                              CornerDescriptor* __restrict__ descriptors, const BriefTables& tab) {
+                                              CornerDescriptor* __restrict__ descriptors, const BriefTables& tab,
+                                              CornerDescriptor* __restrict__ host_descriptors = nullptr) {
     __shared__ __attribute__((aligned(16))) uint16_t patches[4][kNfPatchHalfs];
     __shared__ uint4 recs[256];
     __shared__ float2 rot[256];  // (cos, sin) of the keypoint's angle code (CRD-10 table), fetched during the scan
@@ -361,6 +376,7 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
         if (lane < 8u) {
             const uint64_t src = lane < 2u ? bal[0] : (lane < 4u ? bal[1] : (lane < 6u ? bal[2] : bal[3]));
             out_desc[(size_t)idx * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
+            if (host_descriptors) reinterpret_cast<uint32_t*>(host_descriptors + k0)[(size_t)idx * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
         }
     }
 }
@@ -379,8 +395,8 @@ __global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ b
 // 6-19 us each for a few microseconds of work.  k_brief_one is the four in one launch for a single frame: every
 // workgroup (kBriefOneChunk keypoints of the final list each; 256 threads) derives the prefix of the frame's lists
 // itself, straight into the LDS layout of k_brief_t -- 2 x 68 lists at 720p: every count is loaded once, together with
-// the row constants, wave 0 scans --, then runs k_brief_t's and k_brief_nf's bodies on its chunk, and finally copies its
-// records and descriptors into the (pinned, device-visible) host staging arrays; workgroup 0 also writes the raw
+// the row constants, wave 0 scans --, then runs k_brief_t's and k_brief_nf's bodies on its chunk, which write their
+// records and descriptors into the (pinned, device-visible) host staging arrays as well; workgroup 0 also writes the raw
 // counter there (orb.rs:550-556).  Latency, not throughput, is what it is built for: small chunks, so that the
 // keypoints that are not flat (one memory round trip each, per wave) spread over many workgroups.
 // ---------------------------------------------------------------------------------------------
@@ -429,20 +445,13 @@ __global__ __launch_bounds__(256) void k_brief_one(const uint16_t* __restrict__ 
         }
     }
     // (brief_t_body's first barrier publishes the prefix)
+    // both bodies write their records and descriptors to the device lists AND to host staging (orb.rs:537-547): no copy pass
     brief_t_body<kBriefOneChunk, true>(lds_raw, 0u, chunk, blur_rowc, pyr, bg, seg_counts, seg_before, segments, corners, cap,
-                                       descriptors, tab);
+                                       descriptors, tab, host_corners, host_descriptors);
     __syncthreads();  // the chunk's records are in the final list: brief_nf_body reads them
     const uint32_t n_stored = before[n_ent];
-    brief_nf_body<kBriefOneChunk>(0u, chunk, n_stored, blur, blur_rowc, pyr, bg, seg_counts, seg_before, corners, cap, descriptors, tab);
-    __syncthreads();
-    // ---- this chunk's part of the frame's result, into host staging (orb.rs:537-547)
-    const uint32_t n_frame = min(n_stored, cap), k = chunk * (uint32_t)kBriefOneChunk + tid;
-    if (tid < (uint32_t)kBriefOneChunk && k < n_frame) {
-        *reinterpret_cast<uint4*>(&host_corners[k]) = *reinterpret_cast<const uint4*>(&corners[k]);
-        const uint4* sd = reinterpret_cast<const uint4*>(&descriptors[k]);
-        uint4* dd = reinterpret_cast<uint4*>(&host_descriptors[k]);
-        dd[0] = sd[0], dd[1] = sd[1];
-    }
+    brief_nf_body<kBriefOneChunk>(0u, chunk, n_stored, blur, blur_rowc, pyr, bg, seg_counts, seg_before, corners, cap, descriptors, tab,
+                                  host_descriptors);
 }
 
 }  // namespace orb

@@ -16,7 +16,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libtinyorb.so")
+LIB_PATH = os.environ.get("TINYORB_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtinyorb.so")  # TINYORB_LIB: A/B of two builds on one box
 
 ORB_OK, ORB_EINVAL, ORB_EHIP, ORB_ECAPACITY, ORB_ESTATE = 0, 1, 2, 3, 4
 ORB_PLANE_GRAY, ORB_PLANE_BLUR = 0, 1
