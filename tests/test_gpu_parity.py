@@ -346,6 +346,16 @@ def test_bad_arc_is_rejected(tinyorb):
 # "intended" mode (ORB_FLAG_INTENDED; definitions IM-1..IM-8 in oracle/orb_oracle.h).
 # Not in the reference -- GPU vs the build's C oracle, bit for bit, planes included.
 # ---------------------------------------------------------------------------------------------
+def _gray_plane(tinyorb, prog, m):
+    """Grey plane of level m, or None where the fused intended pipeline keeps it in LDS only (level 0, when every level is an
+    exact half: k_front_i blurs its own tile, nothing reads the plane).  Any other refusal is an error."""
+    try:
+        return prog.read_plane(tinyorb.ORB_PLANE_GRAY, m)
+    except tinyorb.OrbError:
+        assert m == 0 and prog.pipeline() == "fused"
+        return None
+
+
 def _intended_program(tinyorb, W, H, depth, cap, arc, nms, max_batch=1, staged=False):
     flags = tinyorb.ORB_FLAG_INTENDED | (tinyorb.ORB_FLAG_NMS if nms else 0) | (tinyorb.ORB_FLAG_STAGED if staged else 0)
     cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=cap, hierarchy_depth=depth, initial_threshold=THR,
@@ -369,7 +379,8 @@ def test_intended_mode_matches_oracle(tinyorb, oracle, W, H, depth, arc, nms, ca
         total, corners, desc = prog.extract(rgba)
         dims, _ = oracle.level_dims(W, H, depth)
         for m, (w, h, off) in enumerate(dims):
-            assert np.array_equal(prog.read_plane(tinyorb.ORB_PLANE_GRAY, m).ravel(), ref["gray"][off:off + w * h])
+            g = _gray_plane(tinyorb, prog, m)
+            assert g is None or np.array_equal(g.ravel(), ref["gray"][off:off + w * h])
             assert np.array_equal(prog.read_plane(tinyorb.ORB_PLANE_BLUR, m).ravel(), ref["blur"][off:off + w * h])
         assert total == ref["total"]
         n = min(total, cap)
@@ -378,6 +389,24 @@ def test_intended_mode_matches_oracle(tinyorb, oracle, W, H, depth, arc, nms, ca
         for k in ("octave", "y", "x", "angle"):
             assert np.array_equal(c[k], rc[k]), k
         assert np.array_equal(d, rd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,depth,nms", [(320, 240, 3, True), (1284, 250, 4, False), (36, 40, 2, False)])
+def test_intended_blur_kernel_of_its_own(tinyorb, oracle, monkeypatch, W, H, depth, nms):
+    """TINYORB_I_GAUSS_KERNEL=1: the fused intended pipeline with k_gauss over a stored grey plane instead of k_front_i's
+    phase G (the round-2 form, kept for A/B measurements): same planes, same keypoints."""
+    monkeypatch.setenv("TINYORB_I_GAUSS_KERNEL", "1")
+    rgba = oracle.synth_frame(W, H, 77)
+    ref = oracle.extract_intended(rgba, depth=depth, threshold=THR, max_features=8192, arc=9, nms=nms, planes=True)
+    with _intended_program(tinyorb, W, H, depth, 8192, 9, nms) as prog:
+        assert prog.pipeline() == "fused"
+        total, corners, desc = prog.extract(rgba)
+        dims, _ = oracle.level_dims(W, H, depth)
+        for m, (w, h, off) in enumerate(dims):
+            assert np.array_equal(prog.read_plane(tinyorb.ORB_PLANE_GRAY, m).ravel(), ref["gray"][off:off + w * h])
+            assert np.array_equal(prog.read_plane(tinyorb.ORB_PLANE_BLUR, m).ravel(), ref["blur"][off:off + w * h])
+        _assert_frame_equal(oracle, ref, total, corners, desc)
 
 
 _INTENDED = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "intended", "*.npz")))
@@ -398,7 +427,8 @@ def test_intended_golden_fixture_on_gpu(tinyorb, path, staged):
         assert np.array_equal(np.stack([c[k] for k in ("x", "y", "angle", "octave")], 1), g["corners"])
         assert np.array_equal(d, g["descriptors"])
         for m in range(depth):
-            assert hashlib.sha256(prog.read_plane(tinyorb.ORB_PLANE_GRAY, m).tobytes()).hexdigest() == str(g["gray_sha256"][m])
+            gp = _gray_plane(tinyorb, prog, m)
+            assert gp is None or hashlib.sha256(gp.tobytes()).hexdigest() == str(g["gray_sha256"][m])
             assert hashlib.sha256(prog.read_plane(tinyorb.ORB_PLANE_BLUR, m).tobytes()).hexdigest() == str(g["blur_sha256"][m])
 
 

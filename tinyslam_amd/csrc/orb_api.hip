@@ -5,6 +5,7 @@
 // extract_corners (orb.rs:469-557) becomes a short sequence of kernel launches on one HIP stream
 // instead of 3*D render passes + D+1 compute dispatches + 3 staging copies.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <cstdarg>
 #include <cstdio>
@@ -77,6 +78,8 @@ struct OrbProgram {
     bool input_y8 = false;  // ORB_FLAG_INPUT_Y8: frames are one byte per pixel
     // fused "intended" pipeline (orb_kernels_intended.h): tile slots, their segments (record + score), the cut
     bool fused_i = false;
+    bool igauss_fused = false;  // fused_i: k_front_i blurs its own tile (phase G); false: k_gauss over the stored grey plane (TINYORB_I_GAUSS_KERNEL=1)
+    bool igrey_stored = false;  // fused_i: k_front_i<true> stores the level-0 grey plane (k_gauss or k_mip reads it)
     bool fused_x = false;  // the reference's algorithm with the opt-in arc / NMS on the tile kernels
     uint32_t* d_xband_counts = nullptr;  // band-slot counters written by the blur-only k_front launches (unused)
     RowsGeom xrows{};
@@ -120,7 +123,9 @@ struct OrbProgram {
     unsigned long long* d_stamps = nullptr;  // TINYORB_STAMPS=1: phase cycle sums of k_front (2 x 16 slots)
 
     // host staging of the single-frame API (orb.rs:216-218 staging buffers)
-    uint32_t* h_count = nullptr;
+    uint32_t* h_count = nullptr;      // pinned: [0] the raw counter of the last single-frame extract, [16] its completion sequence number (own cache line)
+    uint32_t* d_single_done = nullptr;  // workgroups of k_brief_one that have finished (the last one publishes the sequence number and clears it)
+    uint32_t single_seq = 0;
     CornerData* h_corners = nullptr;
     CornerDescriptor* h_desc = nullptr;
     bool single_valid = false;
@@ -609,18 +614,21 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
         g.dh = pyr.h[lvl];
         g.gx1 = (uint32_t)((int)pyr.w[lvl] - 16);
         g.gy1 = (uint32_t)((int)pyr.h[lvl] - 16);
+        g.blur = p->igauss_fused ? 1u : 0u;
+        g.store_grey = p->igrey_stored ? 1u : 0u;
         if (g.n_bands * g.n_ct != bg.slot_base[lvl + 1] - bg.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: tile count mismatch at level %u", lvl);
+        if (g.blur && !ifront_gauss_fits(g.tw)) return fail(p, ORB_EINVAL, "internal: tile width %u too wide for the fused Gaussian", g.tw);
         const dim3 grid(g.n_bands * g.n_ct * n);
         LaunchScope ls(p, s, KID_FRONT_I);
         if (lvl == 0)
             hipLaunchKernelGGL(k_front_i<true>, grid, dim3(kIThreads), ifront_lds_bytes(g), s, frames, p->frame_bytes,
-                               p->d_gray, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
+                               p->d_gray, p->d_blur, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
         else
             hipLaunchKernelGGL(k_front_i<false>, grid, dim3(kIThreads), ifront_lds_bytes(g), s, frames, p->frame_bytes,
-                               p->d_gray, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
+                               p->d_gray, p->d_blur, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
     }
-    for (uint32_t m = 0; m < D; m++) {
+    for (uint32_t m = 0; m < D && !p->igauss_fused; m++) {
         LaunchScope ls(p, s, KID_BLUR);
         hipLaunchKernelGGL(k_gauss, dim3((pyr.w[m] + kGaussTW - 1u) / kGaussTW, (pyr.h[m] + kGaussTH - 1u) / kGaussTH, n), dim3(256), 0, s, p->d_gray,
                            p->d_blur, pyr, m);
@@ -695,6 +703,8 @@ int run_fused_x(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
         g.nms = (p->opt.flags & ORB_FLAG_NMS) ? 1u : 0u;
         g.phase_mask = 31u;
         g.literal = 1u;
+        g.store_grey = 1u;  // the literal blur below reads the grey plane
+        g.blur = 0u;
         g.dw = std::max(pyr.w[lvl], gw);
         g.dh = std::max(pyr.h[lvl], gh);
         g.gx1 = std::min<uint32_t>(gw, pyr.w[0] > 16u ? pyr.w[0] - 16u : 0u);  // fast.wgsl:77 with level-0 dimensions (Q8)
@@ -706,10 +716,10 @@ int run_fused_x(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
             const dim3 grid(g.n_bands * g.n_ct * n);
             if (lvl == 0)
                 hipLaunchKernelGGL(k_front_i<true>, grid, dim3(kIThreads), ifront_lds_bytes(g), s, frames, p->frame_bytes,
-                                   p->d_gray, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
+                                   p->d_gray, p->d_blur, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
             else
                 hipLaunchKernelGGL(k_front_i<false>, grid, dim3(kIThreads), ifront_lds_bytes(g), s, frames, p->frame_bytes,
-                                   p->d_gray, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
+                                   p->d_gray, p->d_blur, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
         }
         // else: no FAST dispatch at this octave (orb.rs:511-515 with width 0).  Its tile slots were zeroed at create and
         // no kernel of this program ever writes them, so there is nothing to clear (clearing the whole counter array
@@ -976,6 +986,11 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
             if (rows > max_rows) max_rows = rows;
         }
         bg.group_base[p->pyr.depth] = groups;
+        // The Gaussian (IM-3) inside k_front_i, straight from the tile; the level-0 grey plane is then only stored when a level
+        // that is not an exact half needs it (k_mip reads planes).
+        p->igauss_fused = !getenv("TINYORB_I_GAUSS_KERNEL");
+        for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) p->igauss_fused = p->igauss_fused && ifront_gauss_fits(bg.tw[lvl]);
+        p->igrey_stored = !p->igauss_fused || (p->pyr.depth > 1 && !(p->pyr.w[0] == 2u * p->pyr.w[1] && p->pyr.h[0] == 2u * p->pyr.h[1]));
         // a tile's segment holds every keypoint the tile can have (one per pixel), whatever max_features is: the
         // top-K cut (IM-8) must see all candidates, not the ones that happened to be appended first
         bg.seg_cap = (uint32_t)kFrontRows * bg.tw[0];
@@ -1137,7 +1152,10 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         CREATE_TRY(hipMalloc(&p->d_stamps, 32 * sizeof(unsigned long long)));
         CREATE_TRY(hipMemset(p->d_stamps, 0, 32 * sizeof(unsigned long long)));
     }
-    CREATE_TRY(hipHostMalloc(&p->h_count, sizeof(uint32_t), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(&p->h_count, 32 * sizeof(uint32_t), hipHostMallocDefault));
+    memset(p->h_count, 0, 32 * sizeof(uint32_t));
+    CREATE_TRY(hipMalloc(&p->d_single_done, sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(p->d_single_done, 0, sizeof(uint32_t)));
     CREATE_TRY(hipHostMalloc(&p->h_corners, cap * sizeof(CornerData), hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc(&p->h_desc, cap * sizeof(CornerDescriptor), hipHostMallocDefault));
 #undef CREATE_TRY
@@ -1185,6 +1203,7 @@ void orb_program_destroy(OrbProgram* p) {
     (void)hipFree(p->d_sin);
     (void)hipFree(p->d_stamps);
     if (p->h_count) (void)hipHostFree(p->h_count);
+    if (p->d_single_done) (void)hipFree(p->d_single_done);
     if (p->h_corners) (void)hipHostFree(p->h_corners);
     if (p->h_desc) (void)hipHostFree(p->h_desc);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -1272,16 +1291,35 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
         } else if (int rc = run_fused_range(p, p->d_input, 0, 1, s, false)) {
             return rc;
         }
+        const uint32_t seq = ++p->single_seq ? p->single_seq : ++p->single_seq;  // never 0
         {
             LaunchScope ls(p, s, KID_BRIEF_ONE);
             hipLaunchKernelGGL(k_brief_one, dim3((unsigned)((cap + kBriefOneChunk - 1u) / kBriefOneChunk)), dim3(256), brieft_lds_bytes(p->brieft), s, p->d_blur,
                                p->d_blur_rowc, p->pyr, p->brieft, p->d_seg_counts, p->d_seg_before, p->d_seg, p->d_counts, p->d_corners,
                                (uint32_t)cap, p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin}, static_cast<uint32_t*>(dc),
-                               static_cast<CornerData*>(dk), static_cast<CornerDescriptor*>(dd));
+                               static_cast<CornerData*>(dk), static_cast<CornerDescriptor*>(dd), p->d_single_done, seq);
         }
         HIP_TRY(p, hipGetLastError());
         p->planes_valid = true;
-        HIP_TRY(p, hipStreamSynchronize(s));
+        // Block (orb.rs:549): the last workgroup of k_brief_one to finish publishes the call's sequence number in pinned memory
+        // behind everything the launch wrote there, and the host polls that word -- hipStreamSynchronize costs 5 us more
+        // than the poll (tools/ubench/launch_floor.hip: 11.6 against 6.5 us for an empty launch).  The poll gives up after
+        // 20 ms (a faulted kernel never publishes) and a stream synchronisation reports what happened.
+        bool seen = false;
+        if (!p->profiling && !getenv("TINYORB_SINGLE_SYNC")) {
+            const volatile uint32_t* const done = p->h_count + 16;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint32_t spins = 0; !(seen = __atomic_load_n(done, __ATOMIC_ACQUIRE) == seq); spins++)
+                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+        if (!seen) HIP_TRY(p, hipStreamSynchronize(s));
+#ifdef TINYORB_STAMPS
+        if (getenv("TINYORB_PRINT_STAMPS")) {  // k_brief_one's joints, workgroups 0 and 24, in units of 10 ns
+            fprintf(stderr, "k_brief_one stamps (load+stage, scan, flat body, other body, fence) x 10 ns:");
+            for (int i = 1; i <= 10; i++) fprintf(stderr, " %u%s", p->h_count[i], i == 5 ? " |" : "");
+            fprintf(stderr, "\n");
+        }
+#endif
         p->single_valid = true;
         p->last_batch = 1;
         p->last_stream = s;
@@ -1725,7 +1763,7 @@ int orb_debug_read_plane(OrbProgram* p, uint32_t frame, int kind, uint32_t level
     if (!p) return ORB_EINVAL;
     if (!dst || level >= p->pyr.depth || frame >= p->last_batch || (kind != ORB_PLANE_GRAY && kind != ORB_PLANE_BLUR))
         return fail(p, ORB_EINVAL, "debug_read_plane: bad arguments");
-    if (!p->planes_valid || (p->fused && kind == ORB_PLANE_GRAY && level == 0))
+    if (!p->planes_valid || ((p->fused || (p->fused_i && !p->igrey_stored)) && kind == ORB_PLANE_GRAY && level == 0))
         return fail(p, ORB_ESTATE, "plane not materialised by the last call");
     const size_t texels = (size_t)p->pyr.w[level] * p->pyr.h[level];
     if (n_texels != texels) return fail(p, ORB_EINVAL, "debug_read_plane: expected %zu texels", texels);

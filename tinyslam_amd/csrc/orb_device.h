@@ -143,6 +143,17 @@ __device__ constexpr float kBlurWgt[4] = {0.13748623236806098f, 0.50377565537684
 
 // "intended" mode IM-3: the same four bilinear taps read in texel units = a symmetric 7-tap kernel (centre first)
 __device__ constexpr float kGauss[4] = {0.282523781f, 0.221251875f, 0.106235079f, 0.0312511548f};
+// one output of a pass: centre tap, then the three symmetric pairs outwards, every product and sum rounded (IM-3)
+__device__ __forceinline__ float gauss7(const float (&t)[7]) {
+    float acc = kGauss[0] * t[3];
+#pragma unroll
+    for (int k = 1; k <= 3; k++) {
+        const float pair = t[3 - k] + t[3 + k];
+        const float term = kGauss[k] * pair;
+        acc = acc + term;
+    }
+    return acc;
+}
 
 // One literal blur tap position (CRD-5): indices of the two texels and the lerp fraction.
 struct BlurTap {

@@ -43,6 +43,19 @@ __device__ __forceinline__ constexpr int pat_ay(int j) { return ORB_BRIEF_PATTER
 __device__ __forceinline__ constexpr int pat_bx(int j) { return ORB_BRIEF_PATTERN[4 * j + 2]; }
 __device__ __forceinline__ constexpr int pat_by(int j) { return ORB_BRIEF_PATTERN[4 * j + 3]; }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (row shifts inside the rows of 16, then the two row
+// broadcasts): six adds in registers where a __shfl_up chain is six LDS round trips.  All lanes must be active.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)v;
+}
+
 // word = (word << 1) | (a > b), a and b non-negative f16 bit patterns (they order like the values, brief.wgsl:62)
 __device__ __forceinline__ uint32_t push_gt(uint32_t word, uint32_t a, uint32_t b) {
     return __builtin_amdgcn_alignbit(word, b - a, 31);  // bit 31 of (b - a) is set iff a > b
@@ -407,10 +420,19 @@ __global__ __launch_bounds__(256) void k_brief_one(const uint16_t* __restrict__ 
                                                    uint32_t* __restrict__ counts, CornerData* __restrict__ corners, uint32_t cap,
                                                    CornerDescriptor* __restrict__ descriptors, BriefTables tab,
                                                    uint32_t* __restrict__ host_count, CornerData* __restrict__ host_corners,
-                                                   CornerDescriptor* __restrict__ host_descriptors) {
+                                                   CornerDescriptor* __restrict__ host_descriptors, uint32_t* __restrict__ done_count,
+                                                   uint32_t seq) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t tid = threadIdx.x, chunk = blockIdx.x;
     const uint32_t n_ent = bg.n_slots * bg.n_classes;
+#ifdef TINYORB_STAMPS  // diagnostic build: 100 MHz wall clock of thread 0 of workgroups 0 and 24 at the kernel's joints, read with orb_single_stamps()
+    uint64_t st[6];
+    int n_st = 0;
+#define BRIEF_ONE_STAMP() do { if (n_st < 6) st[n_st++] = wall_clock64(); } while (0)
+#else
+#define BRIEF_ONE_STAMP() do { } while (0)
+#endif
+    BRIEF_ONE_STAMP();
     uint32_t* const before = reinterpret_cast<uint32_t*>(lds_raw);             // k_brief_t's layout: [n_ent + 1] ...
     uint16_t* const rows = reinterpret_cast<uint16_t*>(before + n_ent + 1u);   // ... then [rows_padded]
     // raw counts in final order (class-major) into before[], all loads of the workgroup in flight together
@@ -420,38 +442,51 @@ __global__ __launch_bounds__(256) void k_brief_one(const uint16_t* __restrict__ 
     }
     brief_t_stage_rows(rows, blur_rowc, pyr, bg, tid);
     __syncthreads();
+    BRIEF_ONE_STAMP();
     if (tid < 64u) {  // k_slot_prefix, by wave 0 of every workgroup: exclusive prefix of the stored counts, in place
         uint32_t carry = 0, total = 0;
         for (uint32_t e0 = 0; e0 < n_ent; e0 += 64u) {
             const uint32_t e = e0 + tid;
             const uint32_t raw = e < n_ent ? before[e] : 0u;
             const uint32_t stored = min(raw, bg.seg_cap);
-            uint32_t incl = stored;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t t = __shfl_up(incl, d);
-                if ((int)tid >= d) incl += t;
-            }
+            const uint32_t incl = wave_inclusive_sum(stored);  // DPP: no LDS round trip per step
             if (e < n_ent) before[e] = carry + incl - stored;
-            carry += __shfl(incl, 63);
-            uint32_t r = raw;
-#pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) r += __shfl_xor(r, sh);
-            total += r;
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            total += (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(raw), 63);
         }
         if (tid == 0u) {
             before[n_ent] = carry;  // stored keypoints of the frame
             if (chunk == 0u) counts[0] = total, *host_count = total;
         }
     }
+    BRIEF_ONE_STAMP();
     // (brief_t_body's first barrier publishes the prefix)
     // both bodies write their records and descriptors to the device lists AND to host staging (orb.rs:537-547): no copy pass
     brief_t_body<kBriefOneChunk, true>(lds_raw, 0u, chunk, blur_rowc, pyr, bg, seg_counts, seg_before, segments, corners, cap,
                                        descriptors, tab, host_corners, host_descriptors);
     __syncthreads();  // the chunk's records are in the final list: brief_nf_body reads them
+    BRIEF_ONE_STAMP();
     const uint32_t n_stored = before[n_ent];
     brief_nf_body<kBriefOneChunk>(0u, chunk, n_stored, blur, blur_rowc, pyr, bg, seg_counts, seg_before, corners, cap, descriptors, tab,
                                   host_descriptors);
+    // ---- completion, for a host that polls instead of synchronising the stream: every wave's stores to host memory are
+    // performed (system-scope fence) before its workgroup counts itself done; the last workgroup publishes the sequence number
+    // behind the counter, in a cache line of its own, and clears the count for the next call.
+    BRIEF_ONE_STAMP();
+    __threadfence_system();
+    __syncthreads();
+    BRIEF_ONE_STAMP();
+#ifdef TINYORB_STAMPS
+    if (tid == 0u && (chunk == 0u || chunk == 24u))
+        for (int i = 0; i < 5; i++) host_count[(chunk ? 6 : 1) + i] = (uint32_t)(st[i + 1] - st[i]);
+#endif
+    if (tid == 0u) {
+        const uint32_t prev = __hip_atomic_fetch_add(done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1u == gridDim.x) {
+            __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(host_count + 16, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 }  // namespace orb

@@ -1,11 +1,13 @@
 // orb_kernels_intended.h -- fused pipeline of the opt-in "intended" mode (ORB_FLAG_INTENDED; definitions IM-1..IM-8
 // in DESIGN.md section 8; NOT in the reference, whose literal algorithm is orb_kernels_fused.h).
 //
-//   k_front_i<L0>   per level: grey tile in LDS (level 0: RGBA -> BT.601 luminance, no mirror, grey plane also
-//                   stored for k_gauss; level >= 1: the f16 mip) -> segment test with arc 9..16 on the octave's
-//                   own guard -> score + full-circle angle -> 3x3 NMS inside the tile -> survivors appended to
-//                   the tile's segment (record + score) -> next mip level.
-//   k_gauss         (orb_kernels_staged.h) separable 7-tap blur per level.
+//   k_front_i<L0>   per level: grey tile in LDS (level 0: RGBA -> BT.601 luminance, no mirror; level >= 1: the f16
+//                   mip) -> next mip level -> separable 7-tap Gaussian of the tile's own pixels straight from the
+//                   tile (IM-3: the grey plane of level 0 never goes to HBM and comes back) -> segment test with
+//                   arc 9..16 on the octave's own guard -> score + full-circle angle -> 3x3 NMS inside the tile ->
+//                   survivors appended to the tile's segment (record + score).
+//   k_gauss         (orb_kernels_staged.h) the same blur as a kernel of its own over a stored grey plane: the
+//                   staged cross-check, and TINYORB_I_GAUSS_KERNEL=1.
 //   k_select_i      per frame: raw counter, the top-K cut (IM-8) as a 64-bit key threshold, and where each tile's
 //                   kept keypoints start in the final lists.
 //   k_brief_i       per tile: blur window in LDS, rotated BRIEF-256 (+theta) of the kept keypoints.
@@ -47,7 +49,13 @@ struct IGeom {
     uint32_t literal;
     uint32_t dw, dh;        // domain: columns / rows covered by tiles
     uint32_t gx1, gy1;      // guard: 16 < x < gx1, 16 < y < gy1
+    uint32_t store_grey;    // level 0: the tile's own grey pixels also go to the grey plane (k_mip / k_gauss / the literal blur read it)
+    uint32_t blur;          // phase G: the separable Gaussian of the tile's own pixels, written to the blur plane (intended mode)
 };
+
+constexpr int kIGaussRows = kFrontRows + 6;  // rows of the X pass a tile's Y pass reads
+// the X pass's output of one column half of a tile lives in the queues' storage (phase G runs before the detector)
+__host__ __device__ inline bool ifront_gauss_fits(uint32_t tw) { return (uint32_t)kIGaussRows * (tw / 2u) <= (uint32_t)(kIQueueA + kIQueueB + kIQueueC); }
 
 __host__ __device__ inline uint32_t ifront_lds_bytes(const IGeom& g) {
     return kIRows * g.ls * 2u + (kIQueueA + kIQueueB + kIQueueC) * 2u + 32u;
@@ -145,7 +153,7 @@ __device__ __forceinline__ void ring_score_angle(const half_t* ctr, int ls, floa
 
 template <bool L0>
 __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restrict__ frames, size_t frame_bytes,
-                                                          uint16_t* __restrict__ gray, Pyramid pyr, IGeom geo, float thr,
+                                                          uint16_t* __restrict__ gray, uint16_t* __restrict__ blur, Pyramid pyr, IGeom geo, float thr,
                                                           uint32_t* __restrict__ seg_counts,
                                                           CornerData* __restrict__ segments,
                                                           float* __restrict__ seg_scores) {
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
                 const int gyc = min(max(gy, 0), h - 1);
                 const int off = __mul24(gyc, w) + q * 4;                      // grey plane: row gy
                 const int src = __mul24(lit ? h - 1 - gyc : gyc, w) + q * 4;  // input: mirrored row in the literal mode
-                pix[u] = own ? off : -1;
+                pix[u] = own && geo.store_grey ? off : -1;
                 v[u] = *reinterpret_cast<const uint4*>(src0 + (size_t)((uint32_t)src * 4u));
             }
 #pragma unroll
@@ -309,6 +317,85 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
                 for (int k = 0; k < 4; k++)
                     if (xd + k < wd) out[k] = o[k];
             }
+        }
+    }
+
+    // =========================== G: separable 7-tap Gaussian of the tile's own pixels (IM-3) ===========================
+    // X pass then Y pass, f16 after each (gauss7, the arithmetic of k_gauss), clamp-to-edge.  The tile holds what both
+    // passes need: rows y0-3 .. y0+R+2 and columns cx0-3 .. cx0+tw+2 lie inside its apron.  Rows outside the level are
+    // read from the level's first / last row, which this band stages whenever it needs them; columns outside the
+    // level are filled in place first (the detector's guard keeps it 16 texels away from them).  The X pass's output
+    // (22 rows) of one column HALF of the tile at a time borrows the queues' storage: 7 KB at tw = 320.
+    if (geo.blur) {
+        uint16_t* const mid = queue_a;
+        const bool left_edge = cx0 == 0, right_edge = cx0 + TW + 3 > w;  // uniform; the right apron of a tile may cross the edge without the tile reaching it
+        if (left_edge || right_edge) {
+            const int we = w - cx0;  // columns of the level in this tile
+            for (int i = tid; i < kIRows * 3; i += NT) {
+                const int ly = i / 3, k = i - ly * 3;
+                half_t* const row = grey + __mul24(ly, LS) + kIPad;
+                if (left_edge) row[-1 - k] = row[0];
+                if (right_edge) row[we + k] = row[we - 1];
+            }
+            __syncthreads();
+        }
+        const int HW = TW >> 1, Q = HW >> 2, P2 = HW >> 1;  // half width (multiple of 4), its quads, its column pairs
+        const float inv_q = 1.0f / (float)Q, inv_p2 = 1.0f / (float)P2;
+        uint16_t* const plane = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
+        for (int c0 = 0; c0 < tw; c0 += HW) {  // uniform
+            // X pass: item = 4 consecutive columns of one row; inputs x-3 .. x+6 from three 8-byte reads
+            for (int i = tid; i < kIGaussRows * Q; i += NT) {
+                const int r = (int)(((float)i + 0.5f) * inv_q), x = (i - __mul24(r, Q)) * 4;
+                const int lyc = min(max(y0 - 3 + r, 0), h - 1) - y0 + kIApron;
+                const half_t* p = grey + __mul24(lyc, LS) + kIPad + c0 + x - 4;
+                const uint2 q0 = *reinterpret_cast<const uint2*>(p), q1 = *reinterpret_cast<const uint2*>(p + 4),
+                            q2 = *reinterpret_cast<const uint2*>(p + 8);
+                const uint32_t wds[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
+                float f[12];
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    f[2 * k] = from_half(bits_half((uint16_t)(wds[k] & 0xffffu)));
+                    f[2 * k + 1] = from_half(bits_half((uint16_t)(wds[k] >> 16)));
+                }
+                uint16_t o[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {  // output column x + c: taps f[c + 1 .. c + 7]
+                    const float t[7] = {f[c + 1], f[c + 2], f[c + 3], f[c + 4], f[c + 5], f[c + 6], f[c + 7]};
+                    o[c] = half_bits(to_half(gauss7(t)));
+                }
+                *reinterpret_cast<uint2*>(&mid[__mul24(r, HW) + x]) = make_uint2(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16));
+            }
+            __syncthreads();
+            // Y pass: item = 2 columns x 8 rows from 14 rows of the X pass
+            for (int i = tid; i < 2 * P2; i += NT) {
+                const int rg = (int)(((float)i + 0.5f) * inv_p2), x = (i - __mul24(rg, P2)) * 2, r0 = rg * 8;
+                const int gx = cx0 + c0 + x;
+                if (gx >= w) continue;
+                float lo[14], hi[14];
+#pragma unroll
+                for (int k = 0; k < 14; k++) {
+                    const uint32_t v = *reinterpret_cast<const uint32_t*>(&mid[__mul24(r0 + k, HW) + x]);
+                    lo[k] = from_half(bits_half((uint16_t)(v & 0xffffu)));
+                    hi[k] = from_half(bits_half((uint16_t)(v >> 16)));
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int gy = y0 + r0 + k;
+                    const float ta[7] = {lo[k], lo[k + 1], lo[k + 2], lo[k + 3], lo[k + 4], lo[k + 5], lo[k + 6]};
+                    const float tb[7] = {hi[k], hi[k + 1], hi[k + 2], hi[k + 3], hi[k + 4], hi[k + 5], hi[k + 6]};
+                    const uint32_t oa = half_bits(to_half(gauss7(ta))), ob = half_bits(to_half(gauss7(tb)));
+                    if (gy < h) {
+                        uint16_t* out = plane + (size_t)(uint32_t)(__mul24(gy, w) + gx);
+                        if (gx + 1 < w && (w & 1) == 0)
+                            *reinterpret_cast<uint32_t*>(out) = oa | (ob << 16);
+                        else {
+                            out[0] = (uint16_t)oa;
+                            if (gx + 1 < w) out[1] = (uint16_t)ob;
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // the next half's X pass, then the detector's queues, overwrite mid
         }
     }
 

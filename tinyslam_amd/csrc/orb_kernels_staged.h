@@ -165,17 +165,6 @@ __global__ __launch_bounds__(256) void k_blur_rows(const uint16_t* __restrict__ 
 constexpr int kGaussTW = 256, kGaussTH = 16, kGaussPad = 8;
 constexpr int kGaussPitch = kGaussTW + 2 * kGaussPad;  // grey tile: LDS column kGaussPad <-> image column bx
 
-__device__ __forceinline__ float gauss7(const float (&t)[7]) {
-    float acc = kGauss[0] * t[3];
-#pragma unroll
-    for (int k = 1; k <= 3; k++) {
-        const float pair = t[3 - k] + t[3 + k];
-        const float term = kGauss[k] * pair;
-        acc = acc + term;
-    }
-    return acc;
-}
-
 __global__ __launch_bounds__(256) void k_gauss(const uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                                Pyramid pyr, uint32_t m) {
     constexpr int TW = kGaussTW, TH = kGaussTH, R = 3, ROWS = TH + 2 * R;
