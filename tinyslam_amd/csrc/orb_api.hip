@@ -607,7 +607,7 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
         g.seg_cap = bg.seg_cap;
         g.arc = p->arc;
         g.nms = (p->opt.flags & ORB_FLAG_NMS) ? 1u : 0u;
-        g.phase_mask = 31u;
+        g.phase_mask = 63u;
         if (const char* e = getenv("TINYORB_PHASE_MASK")) g.phase_mask = (uint32_t)atoi(e);
         g.literal = 0u;
         g.dw = pyr.w[lvl];
@@ -701,7 +701,7 @@ int run_fused_x(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
         g.seg_cap = bg.seg_cap;
         g.arc = p->arc;
         g.nms = (p->opt.flags & ORB_FLAG_NMS) ? 1u : 0u;
-        g.phase_mask = 31u;
+        g.phase_mask = 63u;
         g.literal = 1u;
         g.store_grey = 1u;  // the literal blur below reads the grey plane
         g.blur = 0u;
@@ -1294,7 +1294,7 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
         const uint32_t seq = ++p->single_seq ? p->single_seq : ++p->single_seq;  // never 0
         {
             LaunchScope ls(p, s, KID_BRIEF_ONE);
-            hipLaunchKernelGGL(k_brief_one, dim3((unsigned)((cap + kBriefOneChunk - 1u) / kBriefOneChunk)), dim3(256), brieft_lds_bytes(p->brieft), s, p->d_blur,
+            hipLaunchKernelGGL(k_brief_one, dim3((unsigned)((cap + kBriefOneChunk - 1u) / kBriefOneChunk)), dim3(kBriefOneThreads), brieft_lds_bytes(p->brieft), s, p->d_blur,
                                p->d_blur_rowc, p->pyr, p->brieft, p->d_seg_counts, p->d_seg_before, p->d_seg, p->d_counts, p->d_corners,
                                (uint32_t)cap, p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin}, static_cast<uint32_t*>(dc),
                                static_cast<CornerData*>(dk), static_cast<CornerDescriptor*>(dd), p->d_single_done, seq);

@@ -155,6 +155,42 @@ __device__ __forceinline__ float gauss7(const float (&t)[7]) {
     return acc;
 }
 
+// fl32(a + b) and fl32(a * k) with a, b binary16 halves of registers (SA, SB: 0 = low half, 1 = high half) and k binary32:
+// v_fma_mix_f32 converts its binary16 sources on the way in (exactly), so the sum is the binary32 sum of the converted
+// values and the product their binary32 product, each rounded once -- without the two v_cvt_f32_f16 in front.
+template <int SA, int SB>
+__device__ __forceinline__ float add_hh(uint32_t a, uint32_t b, float one) {
+    float d;
+    if constexpr (SA == 0 && SB == 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(one), "v"(b));
+    if constexpr (SA == 1 && SB == 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(one), "v"(b));
+    if constexpr (SA == 0 && SB == 1) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(one), "v"(b));
+    if constexpr (SA == 1 && SB == 1) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(one), "v"(b));
+    return d;
+}
+template <int SA>
+__device__ __forceinline__ float mul_h(uint32_t a, float k, float zero) {
+    float d;
+    if constexpr (SA == 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(k), "v"(zero));
+    if constexpr (SA == 1) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(k), "v"(zero));
+    return d;
+}
+// gauss7() on seven binary16 taps that sit in register halves (w_i, half S_i): the same roundings, no conversions.
+// (The product with +0 added is the rounded product: grey values are never negative.)
+template <int S0, int S1, int S2, int S3, int S4, int S5, int S6>
+__device__ __forceinline__ float gauss7_h(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, uint32_t w6,
+                                          float one, float zero) {
+    float acc = mul_h<S3>(w3, kGauss[0], zero);
+    const float p1 = add_hh<S2, S4>(w2, w4, one), p2 = add_hh<S1, S5>(w1, w5, one), p3 = add_hh<S0, S6>(w0, w6, one);
+    const float t1 = kGauss[1] * p1;
+    acc = acc + t1;
+    const float t2 = kGauss[2] * p2;
+    acc = acc + t2;
+    const float t3 = kGauss[3] * p3;
+    acc = acc + t3;
+    return acc;
+}
+
+
 // One literal blur tap position (CRD-5): indices of the two texels and the lerp fraction.
 struct BlurTap {
     int i0, i1;

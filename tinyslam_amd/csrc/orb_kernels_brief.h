@@ -65,9 +65,9 @@ __device__ __forceinline__ uint32_t push_gt(uint32_t word, uint32_t a, uint32_t 
 // blockIdx; the single-frame kernel k_brief_one: its own chunk).  lds_raw: brieft_lds_bytes() of dynamic LDS.
 // The frame's blur row constants into LDS, 18 zero rows in front of every level and 26 behind it (BriefTGeom::row_base).
 __device__ __forceinline__ void brief_t_stage_rows(uint16_t* rows, const uint16_t* __restrict__ src, const Pyramid& pyr,
-                                                   const BriefTGeom& bg, uint32_t tid) {
+                                                   const BriefTGeom& bg, uint32_t tid, uint32_t n_threads = kBriefTThreads) {
     uint32_t m = 0;
-    for (uint32_t i = tid; i < bg.rows_padded; i += kBriefTThreads) {
+    for (uint32_t i = tid; i < bg.rows_padded; i += n_threads) {
         while (m + 1u < pyr.depth && i + (uint32_t)kBriefHalo >= bg.row_base[m + 1u]) m++;  // level whose padded range holds i
         const uint32_t y = i - bg.row_base[m];  // wraps for the zero rows in front of the level
         rows[i] = y < pyr.h[m] ? src[pyr.row_off[m] + y] : (uint16_t)0;
@@ -219,14 +219,16 @@ constexpr int kNfPatchHalfs = kNfPatchRows * kNfPatchCols;
 // CHUNK: keypoints per workgroup (k_brief_one takes 64 so that a frame's ~450 such keypoints spread over 60 workgroups
 // instead of 15 -- a wave works through its share one memory round trip after the other).  n_known: the frame's stored
 // count when the caller has it (else ~0u: read from the prefix).
-template <int CHUNK = 256>
+// NW: waves of the workgroup (k_brief_nf: 4; k_brief_one: 8, so that a chunk's keypoints that are not flat take one turn).
+template <int CHUNK = 256, int NW = 4>
 __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, uint32_t n_known, const uint16_t* __restrict__ blur,
                                               const uint16_t* __restrict__ blur_rowc, const Pyramid& pyr, const BriefTGeom& bg,
                                               const uint32_t* __restrict__ seg_counts, const uint32_t* __restrict__ seg_before,
                                               const CornerData* __restrict__ corners, uint32_t cap,
                                               CornerDescriptor* __restrict__ descriptors, const BriefTables& tab,
                                               CornerDescriptor* __restrict__ host_descriptors = nullptr) {
-    __shared__ __attribute__((aligned(16))) uint16_t patches[4][kNfPatchHalfs];
+    static_assert(CHUNK <= 256 && NW >= 4, "the scan runs on the first four waves");
+    __shared__ __attribute__((aligned(16))) uint16_t patches[NW][kNfPatchHalfs];
     __shared__ uint4 recs[256];
     __shared__ float2 rot[256];  // (cos, sin) of the keypoint's angle code (CRD-10 table), fetched during the scan
     __shared__ uint16_t list[256];
@@ -260,8 +262,8 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
         }
     }
     const uint64_t m = __ballot(mine);
-    if (lane == 0u) wave_n[wave] = (uint32_t)__popcll(m);
-    recs[tid] = rec;
+    if (lane == 0u && wave < 4u) wave_n[wave] = (uint32_t)__popcll(m);
+    if (tid < 256u) recs[tid] = rec;
     __syncthreads();
     uint32_t start = 0, n_nf = 0;
 #pragma unroll
@@ -278,7 +280,7 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
     uint32_t pat[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) pat[e] = tab.pattern[64u * (uint32_t)e + lane];
-    for (uint32_t i = wave; i < n_nf; i += 4u) {
+    for (uint32_t i = wave; i < n_nf; i += (uint32_t)NW) {
         // the whole wave works on one keypoint: everything derived from its record is wave-uniform -- say so
         // (readfirstlane), so that it lives in scalar registers and the arithmetic on it runs on the scalar unit
         const uint32_t idx = __builtin_amdgcn_readfirstlane((uint32_t)list[i]);
@@ -414,7 +416,8 @@ __global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ b
 // keypoints that are not flat (one memory round trip each, per wave) spread over many workgroups.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBriefOneChunk = 64;
-__global__ __launch_bounds__(256) void k_brief_one(const uint16_t* __restrict__ blur, const uint16_t* __restrict__ blur_rowc, Pyramid pyr,
+constexpr int kBriefOneThreads = 512;  // the flat keypoints take the first wave, the others one wave each: eight of those per turn
+__global__ __launch_bounds__(kBriefOneThreads) void k_brief_one(const uint16_t* __restrict__ blur, const uint16_t* __restrict__ blur_rowc, Pyramid pyr,
                                                    BriefTGeom bg, const uint32_t* __restrict__ seg_counts,
                                                    uint32_t* __restrict__ seg_before, const CornerData* __restrict__ segments,
                                                    uint32_t* __restrict__ counts, CornerData* __restrict__ corners, uint32_t cap,
@@ -436,11 +439,11 @@ __global__ __launch_bounds__(256) void k_brief_one(const uint16_t* __restrict__ 
     uint32_t* const before = reinterpret_cast<uint32_t*>(lds_raw);             // k_brief_t's layout: [n_ent + 1] ...
     uint16_t* const rows = reinterpret_cast<uint16_t*>(before + n_ent + 1u);   // ... then [rows_padded]
     // raw counts in final order (class-major) into before[], all loads of the workgroup in flight together
-    for (uint32_t e = tid; e < n_ent; e += 256u) {
+    for (uint32_t e = tid; e < n_ent; e += (uint32_t)kBriefOneThreads) {
         const uint32_t cls = e / bg.n_slots, sl = e - cls * bg.n_slots;
         before[e] = seg_counts[sl * bg.n_classes + cls];
     }
-    brief_t_stage_rows(rows, blur_rowc, pyr, bg, tid);
+    brief_t_stage_rows(rows, blur_rowc, pyr, bg, tid, (uint32_t)kBriefOneThreads);
     __syncthreads();
     BRIEF_ONE_STAMP();
     if (tid < 64u) {  // k_slot_prefix, by wave 0 of every workgroup: exclusive prefix of the stored counts, in place
@@ -467,13 +470,17 @@ __global__ __launch_bounds__(256) void k_brief_one(const uint16_t* __restrict__ 
     __syncthreads();  // the chunk's records are in the final list: brief_nf_body reads them
     BRIEF_ONE_STAMP();
     const uint32_t n_stored = before[n_ent];
-    brief_nf_body<kBriefOneChunk>(0u, chunk, n_stored, blur, blur_rowc, pyr, bg, seg_counts, seg_before, corners, cap, descriptors, tab,
+    brief_nf_body<kBriefOneChunk, kBriefOneThreads / 64>(0u, chunk, n_stored, blur, blur_rowc, pyr, bg, seg_counts, seg_before, corners, cap, descriptors, tab,
                                   host_descriptors);
-    // ---- completion, for a host that polls instead of synchronising the stream: every wave's stores to host memory are
-    // performed (system-scope fence) before its workgroup counts itself done; the last workgroup publishes the sequence number
-    // behind the counter, in a cache line of its own, and clears the count for the next call.
+    // ---- completion, for a host that polls instead of synchronising the stream: every wave waits until its stores have been
+    // acknowledged (the staging arrays are uncached host memory: an acknowledged store has left for the host, no cache holds
+    // it) before its workgroup counts itself done; the last workgroup publishes the sequence number behind them, in a cache
+    // line of its own, with the one system-scope release of the launch, and clears the count for the next call.  (A
+    // system-scope fence in EVERY workgroup writes the L2 back 128 times: k_brief_one 22 -> 28 us, and 37 / 57 us with 256 / 512
+    // workgroups.)
     BRIEF_ONE_STAMP();
-    __threadfence_system();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's loads and stores are done
     __syncthreads();
     BRIEF_ONE_STAMP();
 #ifdef TINYORB_STAMPS
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(256) void k_brief_one(const uint16_t* __restrict__ 
         for (int i = 0; i < 5; i++) host_count[(chunk ? 6 : 1) + i] = (uint32_t)(st[i + 1] - st[i]);
 #endif
     if (tid == 0u) {
-        const uint32_t prev = __hip_atomic_fetch_add(done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t prev = __hip_atomic_fetch_add(done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev + 1u == gridDim.x) {
             __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(host_count + 16, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

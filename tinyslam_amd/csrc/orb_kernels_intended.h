@@ -41,7 +41,7 @@ struct IGeom {
     uint32_t seg_cap;    // records per tile segment
     uint32_t arc;        // 9..16
     uint32_t nms;        // 0 / 1
-    uint32_t phase_mask; // timing experiments only: bit0 B1, bit1 S1, bit2 S2, bit3 S3+S4, bit4 C0
+    uint32_t phase_mask; // timing experiments only: bit0 B1, bit1 S1, bit2 S2, bit3 S3+S4, bit4 C0, bit5 G
     // Detector domain and guard.  intended (IM-4): the level itself, 16 < x < w - 16, 16 < y < h - 16.
     // literal == 1 (the reference's algorithm with the opt-in arc / NMS): the reference's
     // dispatch grid of the octave (8-rounded, may exceed the level) and its level-0 guard at every octave (fast.wgsl:77,
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     // read from the level's first / last row, which this band stages whenever it needs them; columns outside the
     // level are filled in place first (the detector's guard keeps it 16 texels away from them).  The X pass's output
     // (22 rows) of one column HALF of the tile at a time borrows the queues' storage: 7 KB at tw = 320.
-    if (geo.blur) {
+    if (geo.blur && (geo.phase_mask & 32u)) {
         uint16_t* const mid = queue_a;
         const bool left_edge = cx0 == 0, right_edge = cx0 + TW + 3 > w;  // uniform; the right apron of a tile may cross the edge without the tile reaching it
         if (left_edge || right_edge) {
@@ -340,6 +340,8 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
             __syncthreads();
         }
         const int HW = TW >> 1, Q = HW >> 2, P2 = HW >> 1;  // half width (multiple of 4), its quads, its column pairs
+        float one = 1.0f, zero = 0.0f;
+        asm volatile("" : "+v"(one), "+v"(zero));  // operands of v_fma_mix_f32, kept in registers
         const float inv_q = 1.0f / (float)Q, inv_p2 = 1.0f / (float)P2;
         uint16_t* const plane = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
         for (int c0 = 0; c0 < tw; c0 += HW) {  // uniform
@@ -350,19 +352,12 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
                 const half_t* p = grey + __mul24(lyc, LS) + kIPad + c0 + x - 4;
                 const uint2 q0 = *reinterpret_cast<const uint2*>(p), q1 = *reinterpret_cast<const uint2*>(p + 4),
                             q2 = *reinterpret_cast<const uint2*>(p + 8);
-                const uint32_t wds[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
-                float f[12];
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    f[2 * k] = from_half(bits_half((uint16_t)(wds[k] & 0xffffu)));
-                    f[2 * k + 1] = from_half(bits_half((uint16_t)(wds[k] >> 16)));
-                }
-                uint16_t o[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) {  // output column x + c: taps f[c + 1 .. c + 7]
-                    const float t[7] = {f[c + 1], f[c + 2], f[c + 3], f[c + 4], f[c + 5], f[c + 6], f[c + 7]};
-                    o[c] = half_bits(to_half(gauss7(t)));
-                }
+                // halfs 0..11 = columns x-4 .. x+7; output column x + c takes halfs c+1 .. c+7 (gauss7_h: no conversions)
+                const uint32_t o0 = half_bits(to_half(gauss7_h<1, 0, 1, 0, 1, 0, 1>(q0.x, q0.y, q0.y, q1.x, q1.x, q1.y, q1.y, one, zero)));
+                const uint32_t o1 = half_bits(to_half(gauss7_h<0, 1, 0, 1, 0, 1, 0>(q0.y, q0.y, q1.x, q1.x, q1.y, q1.y, q2.x, one, zero)));
+                const uint32_t o2 = half_bits(to_half(gauss7_h<1, 0, 1, 0, 1, 0, 1>(q0.y, q1.x, q1.x, q1.y, q1.y, q2.x, q2.x, one, zero)));
+                const uint32_t o3 = half_bits(to_half(gauss7_h<0, 1, 0, 1, 0, 1, 0>(q1.x, q1.x, q1.y, q1.y, q2.x, q2.x, q2.y, one, zero)));
+                const uint32_t o[4] = {o0, o1, o2, o3};
                 *reinterpret_cast<uint2*>(&mid[__mul24(r, HW) + x]) = make_uint2(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16));
             }
             __syncthreads();
@@ -371,19 +366,14 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
                 const int rg = (int)(((float)i + 0.5f) * inv_p2), x = (i - __mul24(rg, P2)) * 2, r0 = rg * 8;
                 const int gx = cx0 + c0 + x;
                 if (gx >= w) continue;
-                float lo[14], hi[14];
+                uint32_t v[14];  // column x in the low halves, x + 1 in the high halves
 #pragma unroll
-                for (int k = 0; k < 14; k++) {
-                    const uint32_t v = *reinterpret_cast<const uint32_t*>(&mid[__mul24(r0 + k, HW) + x]);
-                    lo[k] = from_half(bits_half((uint16_t)(v & 0xffffu)));
-                    hi[k] = from_half(bits_half((uint16_t)(v >> 16)));
-                }
+                for (int k = 0; k < 14; k++) v[k] = *reinterpret_cast<const uint32_t*>(&mid[__mul24(r0 + k, HW) + x]);
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const int gy = y0 + r0 + k;
-                    const float ta[7] = {lo[k], lo[k + 1], lo[k + 2], lo[k + 3], lo[k + 4], lo[k + 5], lo[k + 6]};
-                    const float tb[7] = {hi[k], hi[k + 1], hi[k + 2], hi[k + 3], hi[k + 4], hi[k + 5], hi[k + 6]};
-                    const uint32_t oa = half_bits(to_half(gauss7(ta))), ob = half_bits(to_half(gauss7(tb)));
+                    const uint32_t oa = half_bits(to_half(gauss7_h<0, 0, 0, 0, 0, 0, 0>(v[k], v[k + 1], v[k + 2], v[k + 3], v[k + 4], v[k + 5], v[k + 6], one, zero)));
+                    const uint32_t ob = half_bits(to_half(gauss7_h<1, 1, 1, 1, 1, 1, 1>(v[k], v[k + 1], v[k + 2], v[k + 3], v[k + 4], v[k + 5], v[k + 6], one, zero)));
                     if (gy < h) {
                         uint16_t* out = plane + (size_t)(uint32_t)(__mul24(gy, w) + gx);
                         if (gx + 1 < w && (w & 1) == 0)
