@@ -64,6 +64,10 @@ def parse_args(argv=None):
                     help="ranks = one process per GPU over torch.distributed (the driver's contract); node = ONE process "
                          "driving all GPUs through the orb_node_* C ABI (what a Rust host binds), pipelined collate, no "
                          "torch.distributed")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="N = 1 only: consecutive batches alternate between this many programs, each on a stream of its own, so "
+                         "that the tail of one batch's kernels overlaps the head of the next (default 1: one program, one stream "
+                         "-- the line the roofline figures are accounted on)")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the single-frame latency figure (profiling runs)")
     ap.add_argument("--preheat-ms", type=float, default=300.0,
                     help="untimed steps run for this long before the W warm-up steps, so that the clocks are up (the "
@@ -303,6 +307,10 @@ def run_rank(args):
                       node.as_tensor(d_desc, (B, MAX_FEATURES, 8), "<i4", dev)))
     prog.batch_select_output(0)
     state = {"k": 0, "pending": None, "gathered_bytes": 0}
+    # --in-flight n (N = 1): n programs (each with its own planes and lists) on n streams, batch k on program k % n
+    fly = max(1, args.in_flight) if world == 1 else 1
+    fly_progs = [prog] + [orb.OrbProgram(cfg).init() for _ in range(fly - 1)]
+    fly_streams = [torch.cuda.Stream(device=dev) for _ in range(fly)] if fly > 1 else []
     free = [None, None]
     compute_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
@@ -383,7 +391,12 @@ def run_rank(args):
         for b0, nb in batches:
             ptr = frames_t.data_ptr() + b0 * frame_bytes
             if world == 1:
-                prog.extract_batch_device(ptr, nb)
+                if fly > 1 and not state.get("serial"):
+                    i = state["k"] % fly
+                    fly_progs[i].extract_batch_device(ptr, nb, stream=fly_streams[i].cuda_stream)
+                    state["k"] += 1
+                else:
+                    prog.extract_batch_device(ptr, nb)
                 continue
             slot = state["k"] & 1
             prog.batch_select_output(slot)
@@ -448,6 +461,7 @@ def run_rank(args):
     state["gathered_bytes"] = 0
     prog.profile_enable(True)
     prog.profile_reset()
+    state["serial"] = True  # --in-flight n: the per-kernel figures come from one program on one stream (no kernel shares the chip)
     profiled = timed(args.steps)  # same K steps with HIP events around every launch
     prof = prog.profile()
     prog.profile_enable(False)
@@ -586,6 +600,7 @@ def run_rank(args):
                        "hierarchy_depth": DEPTH, "max_features": MAX_FEATURES, "threshold": THRESHOLD, "mode": args.mode,
                        "input": args.input,
                        "pipeline": "staged" if args.staged else "default",
+                       "batches_in_flight": fly,
                        "collate": ("none: results stay sharded on their GPUs" if args.collate == "none" else
                                    "RCCL gather of every batch to rank 0, overlapped with the next batch's kernels") if world > 1 else "none (1 GPU)"},
             "repeats_ms_per_step": [r / args.steps * 1e3 for r in repeats],

@@ -293,6 +293,11 @@ int orb_level_size(const OrbProgram *p, uint32_t level, uint32_t *width, uint32_
 /* Device scalar helpers, so the tests can pin CRD-3 / CRD-9 on the GPU itself (host arrays). */
 int orb_debug_f32_to_f16(OrbProgram *p, const float *src, uint16_t *dst, size_t n);
 int orb_debug_angle_code(OrbProgram *p, const float *cy, const float *cx, uint32_t *dst, size_t n);
+/* The program's table of the BRIEF pattern rotated by every angle code (brief.wgsl:50-57 evaluated once per code instead
+ * of once per keypoint): codes x 256 tests x {a, b} int16 BYTE offsets 2 * (ry * pitch + rx) into a window of binary16 texels,
+ * stored [code][lane 0..63][test lane + 64 e, e = 0..3][a, b].  Writes min(n_entries, codes * 512) values; *codes and *pitch
+ * (either may be NULL) say what the table was built for. */
+int orb_debug_rot_table(OrbProgram *p, int16_t *dst, size_t n_entries, uint32_t *codes, uint32_t *pitch);
 
 /* ---- measurement ---- */
 #define ORB_KERNEL_COUNT 20

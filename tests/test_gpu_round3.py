@@ -174,3 +174,34 @@ def test_configs4_full_size_eight_ranks(tinyorb, oracle, monkeypatch):
             ref = oracle.extract(rgba, depth=2, threshold=THR)
             lo, hi = int(offsets[f]), int(offsets[f + 1])
             _assert_frame_equal(oracle, ref, int(counts[f]), kp[lo:hi], desc[lo:hi])
+
+
+@pytest.mark.parametrize("intended", [False, True])
+def test_rotated_pattern_table_equals_numpy(tinyorb, intended):
+    """k_rot_table (brief.wgsl:50-57 / IM-6 evaluated once per angle code instead of once per keypoint): every entry of
+    the program's table against NumPy binary32 arithmetic -- cos/sin of code / 1000 correctly rounded (CRD-10), every
+    product and sum rounded on its own, truncation -- for all 3142 (6284) codes x 256 tests x 2 points."""
+    from oracle import orb_numpy as on
+    flags = (tinyorb.ORB_FLAG_INTENDED | tinyorb.ORB_FLAG_NMS) if intended else 0
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(320, 240), max_features=1024, hierarchy_depth=2, initial_threshold=THR,
+                            flags=flags, fast_arc=9 if intended else 0)
+    with tinyorb.OrbProgram(cfg) as prog:
+        table, pitch = prog.rot_table()
+    codes = table.shape[0]
+    assert codes == (6284 if intended else 3142) and pitch == (368 if intended else 48)
+    F = np.float32
+    theta = np.arange(codes, dtype=np.float32) / F(1000.0)
+    ct = np.cos(theta.astype(np.float64)).astype(np.float32)
+    st = np.sin(theta.astype(np.float64)).astype(np.float32)
+    for j in range(256):
+        ax, ay, bx, by = (F(v) for v in on.PATTERN[j])
+        if intended:
+            rax, ray = ct * ax + (-st) * ay, st * ax + ct * ay
+            rbx, rby = ct * bx + (-st) * by, st * bx + ct * by
+        else:
+            rax, ray = ct * ax + st * ay, (-st) * ax + ct * ay
+            rbx, rby = ct * bx + st * by, (-st) * bx + ct * by
+        oa = 2 * (np.trunc(ray).astype(np.int64) * pitch + np.trunc(rax).astype(np.int64))
+        ob = 2 * (np.trunc(rby).astype(np.int64) * pitch + np.trunc(rbx).astype(np.int64))
+        assert np.array_equal(table[:, j & 63, j >> 6, 0].astype(np.int64), oa), "test %d point a" % j
+        assert np.array_equal(table[:, j & 63, j >> 6, 1].astype(np.int64), ob), "test %d point b" % j

@@ -120,6 +120,7 @@ struct OrbProgram {
     uint32_t* d_pattern = nullptr;
     float* d_cos = nullptr;
     float* d_sin = nullptr;
+    uint4* d_rot = nullptr;  // the pattern rotated by every angle code (k_rot_table), for k_brief_nf or k_brief_i
     unsigned long long* d_stamps = nullptr;  // TINYORB_STAMPS=1: phase cycle sums of k_front (2 x 16 slots)
 
     // host staging of the single-frame API (orb.rs:216-218 staging buffers)
@@ -308,7 +309,7 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
     }
     {  // orb.rs:523-534
         LaunchScope ls(p, s, KID_BRIEF);
-        BriefTables tab{p->d_pattern, p->d_cos, p->d_sin};
+        BriefTables tab{p->d_pattern, p->d_cos, p->d_sin, p->d_rot};
         uint32_t bx = (cap + 127u) / 128u;  // ~32 keypoints per wave at a full frame
         if (bx > 64u) bx = 64u;
         if (bx < 1u) bx = 1u;
@@ -427,7 +428,7 @@ int launch_brief(OrbProgram* p, hipStream_t s, uint32_t n, const RowsGeom& rows_
                  const uint16_t* d_blur_rowc, const uint32_t* seg_counts, uint32_t* seg_before, const CornerData* seg,
                  uint32_t* d_counts, CornerData* d_corners, CornerDescriptor* d_desc) {
     const uint32_t cap = p->cfg.max_features;
-    const BriefTables tab{p->d_pattern, p->d_cos, p->d_sin};
+    const BriefTables tab{p->d_pattern, p->d_cos, p->d_sin, p->d_rot};
     const bool use_t = p->use_brief_t;
     {
         LaunchScope ls(p, s, KID_PREFIX);
@@ -642,9 +643,11 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
         LaunchScope ls(p, s, KID_BRIEF_I);
         IBriefGeom bgl = bg;
         bgl.xcd_swizzle = (n % 8u == 0u) ? 1u : 0u;
+        bgl.phase_mask = 3u;
+        if (const char* e = getenv("TINYORB_BRIEF_I_MASK")) bgl.phase_mask = (uint32_t)atoi(e);
         hipLaunchKernelGGL(k_brief_i, dim3(bg.group_base[D] * n), dim3(kIBriefThreads), p->ibrief_lds, s, p->d_blur, pyr, bgl,
                            p->d_iseg_counts, p->d_iseg_before, p->d_thr_key, p->d_iseg, p->d_iseg_scores, p->d_corners, cap,
-                           p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin});
+                           p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin, p->d_rot});
     }
     HIP_TRY(p, hipGetLastError());
     p->planes_valid = true;
@@ -1148,6 +1151,15 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     CREATE_TRY(hipMemcpy(p->d_pattern, ORB_BRIEF_PATTERN, 1024, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(p->d_cos, ORB_COS_BITS, ORB_ANGLE_STEPS_FULL * 4, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(p->d_sin, ORB_SIN_BITS, ORB_ANGLE_STEPS_FULL * 4, hipMemcpyHostToDevice));
+    {   // the pattern rotated by every angle code, for the consumer this program has: k_brief_i's window (intended, full circle) or
+        // k_brief_nf's patch (the reference's codes 0..3141)
+        const uint32_t n_codes = p->fused_i ? (uint32_t)ORB_ANGLE_STEPS_FULL : (uint32_t)ORB_ANGLE_STEPS;
+        const int pitch = p->fused_i ? (int)p->itiles.pitch : kNfPatchCols;
+        CREATE_TRY(hipMalloc(&p->d_rot, (size_t)n_codes * 64u * sizeof(uint4)));
+        hipLaunchKernelGGL(k_rot_table, dim3(n_codes), dim3(64), 0, p->stream, p->d_pattern, p->d_cos, p->d_sin, pitch, p->fused_i ? 1 : 0, p->d_rot);
+        CREATE_TRY(hipGetLastError());
+        CREATE_TRY(hipStreamSynchronize(p->stream));
+    }
     if (p->fused && getenv("TINYORB_STAMPS")) {  // diagnostic builds only (tools/stamps.py)
         CREATE_TRY(hipMalloc(&p->d_stamps, 32 * sizeof(unsigned long long)));
         CREATE_TRY(hipMemset(p->d_stamps, 0, 32 * sizeof(unsigned long long)));
@@ -1201,6 +1213,7 @@ void orb_program_destroy(OrbProgram* p) {
     (void)hipFree(p->d_pattern);
     (void)hipFree(p->d_cos);
     (void)hipFree(p->d_sin);
+    if (p->d_rot) (void)hipFree(p->d_rot);
     (void)hipFree(p->d_stamps);
     if (p->h_count) (void)hipHostFree(p->h_count);
     if (p->d_single_done) (void)hipFree(p->d_single_done);
@@ -1296,7 +1309,7 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
             LaunchScope ls(p, s, KID_BRIEF_ONE);
             hipLaunchKernelGGL(k_brief_one, dim3((unsigned)((cap + kBriefOneChunk - 1u) / kBriefOneChunk)), dim3(kBriefOneThreads), brieft_lds_bytes(p->brieft), s, p->d_blur,
                                p->d_blur_rowc, p->pyr, p->brieft, p->d_seg_counts, p->d_seg_before, p->d_seg, p->d_counts, p->d_corners,
-                               (uint32_t)cap, p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin}, static_cast<uint32_t*>(dc),
+                               (uint32_t)cap, p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin, p->d_rot}, static_cast<uint32_t*>(dc),
                                static_cast<CornerData*>(dk), static_cast<CornerDescriptor*>(dd), p->d_single_done, seq);
         }
         HIP_TRY(p, hipGetLastError());
@@ -1822,6 +1835,19 @@ int orb_debug_angle_code(OrbProgram* p, const float* cy, const float* cx, uint32
     (void)hipFree(d_cx);
     (void)hipFree(d_dst);
     if (e != hipSuccess) return fail(p, ORB_EHIP, "debug_angle_code: %s", hipGetErrorString(e));
+    return ORB_OK;
+}
+
+int orb_debug_rot_table(OrbProgram* p, int16_t* dst, size_t n_entries, uint32_t* codes, uint32_t* pitch) {
+    if (!p) return ORB_EINVAL;
+    if (!p->d_rot) return fail(p, ORB_ESTATE, "this program has no rotated-pattern table");
+    const uint32_t n_codes = p->fused_i ? (uint32_t)ORB_ANGLE_STEPS_FULL : (uint32_t)ORB_ANGLE_STEPS;
+    if (codes) *codes = n_codes;
+    if (pitch) *pitch = p->fused_i ? p->itiles.pitch : (uint32_t)kNfPatchCols;
+    const size_t n = std::min(n_entries, (size_t)n_codes * 512u);
+    if (n && !dst) return fail(p, ORB_EINVAL, "dst is NULL");
+    HIP_TRY(p, hipSetDevice(p->device));
+    if (n) HIP_TRY(p, hipMemcpy(dst, p->d_rot, n * sizeof(int16_t), hipMemcpyDeviceToHost));
     return ORB_OK;
 }
 

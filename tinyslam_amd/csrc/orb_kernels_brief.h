@@ -219,6 +219,42 @@ constexpr int kNfPatchHalfs = kNfPatchRows * kNfPatchCols;
 // CHUNK: keypoints per workgroup (k_brief_one takes 64 so that a frame's ~450 such keypoints spread over 60 workgroups
 // instead of 15 -- a wave works through its share one memory round trip after the other).  n_known: the frame's stored
 // count when the caller has it (else ~0u: read from the prefix).
+// ---------------------------------------------------------------------------------------------
+// The rotated pattern of every angle code (BriefTables::rot), built once per program.  A wave that describes one keypoint
+// used to rotate its lanes' eight points itself -- 16 products, 8 sums and 8 truncations per lane and keypoint, a
+// third of k_brief_nf's vector instructions and two thirds of k_brief_i's -- although the result depends on nothing
+// but the angle code: one block per code evaluates brief.wgsl:50-57 (or IM-6's R(+theta)) with the kernels' own
+// arithmetic (every product and sum rounded on its own, truncation) and stores each lane's eight points as byte offsets
+// into the consumer's window.  3142 (6284) codes x 1 KB.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_rot_table(const uint32_t* __restrict__ pattern, const float* __restrict__ cos_tab,
+                                                  const float* __restrict__ sin_tab, int pitch, int intended, uint4* __restrict__ out) {
+    const uint32_t code = blockIdx.x, lane = threadIdx.x;
+    const float ct = cos_tab[code], st = sin_tab[code], nst = -st;
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const uint32_t pk = pattern[64u * (uint32_t)e + lane];
+        const float pax = (float)(int8_t)(pk & 255u), pay = (float)(int8_t)((pk >> 8) & 255u);
+        const float pbx = (float)(int8_t)((pk >> 16) & 255u), pby = (float)(int8_t)(pk >> 24);
+        float rax, ray, rbx, rby;
+        if (intended) {  // R(+theta) p = (ct*x - st*y, st*x + ct*y), IM-6
+            const float a0 = ct * pax, a1 = nst * pay, a2 = st * pax, a3 = ct * pay;
+            const float b0 = ct * pbx, b1 = nst * pby, b2 = st * pbx, b3 = ct * pby;
+            rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+        } else {  // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y), brief.wgsl:38-54
+            const float a0 = ct * pax, a1 = st * pay, a2 = nst * pax, a3 = ct * pay;
+            const float b0 = ct * pbx, b1 = st * pby, b2 = nst * pbx, b3 = ct * pby;
+            rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+        }
+        const int oa = 2 * ((int)ray * pitch + (int)rax), ob = 2 * ((int)rby * pitch + (int)rbx);  // vec2i() truncates
+        w[e] = ((uint32_t)oa & 0xffffu) | ((uint32_t)ob << 16);
+    }
+    out[(size_t)code * 64u + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ int rot_a(uint32_t w) { return (int)(int16_t)(w & 0xffffu); }  // byte offset of point a
+__device__ __forceinline__ int rot_b(uint32_t w) { return (int)w >> 16; }                  // ... of point b
+
 // NW: waves of the workgroup (k_brief_nf: 4; k_brief_one: 8, so that a chunk's keypoints that are not flat take one turn).
 template <int CHUNK = 256, int NW = 4>
 __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, uint32_t n_known, const uint16_t* __restrict__ blur,
@@ -230,7 +266,6 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
     static_assert(CHUNK <= 256 && NW >= 4, "the scan runs on the first four waves");
     __shared__ __attribute__((aligned(16))) uint16_t patches[NW][kNfPatchHalfs];
     __shared__ uint4 recs[256];
-    __shared__ float2 rot[256];  // (cos, sin) of the keypoint's angle code (CRD-10 table), fetched during the scan
     __shared__ uint16_t list[256];
     __shared__ uint32_t wave_n[4];
     // per-level geometry: indexing the by-value kernel arguments with a run-time level is a global load from the
@@ -256,10 +291,6 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
         rec = *reinterpret_cast<const uint4*>(&corners[(size_t)frame * cap + kk]);
         const uint32_t l = min(rec.w, pyr.depth - 1u);
         mine = !(rec.x >= (uint32_t)kBriefHalo && rec.x < lv[l][5]);
-        if (mine) {
-            const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS - 1));
-            rot[tid] = make_float2(tab.cos_tab[code], tab.sin_tab[code]);
-        }
     }
     const uint64_t m = __ballot(mine);
     if (lane == 0u && wave < 4u) wave_n[wave] = (uint32_t)__popcll(m);
@@ -277,9 +308,6 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
 
     uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)frame * cap + k0);
     uint16_t* const patch = patches[wave];
-    uint32_t pat[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) pat[e] = tab.pattern[64u * (uint32_t)e + lane];
     for (uint32_t i = wave; i < n_nf; i += (uint32_t)NW) {
         // the whole wave works on one keypoint: everything derived from its record is wave-uniform -- say so
         // (readfirstlane), so that it lives in scalar registers and the arithmetic on it runs on the scalar unit
@@ -292,21 +320,10 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
         const int qa = (int)__builtin_amdgcn_readfirstlane(lv[lvl][2]);
         const uint16_t* rowc = blur_rowc + (size_t)frame * pyr.row_stride + __builtin_amdgcn_readfirstlane(lv[lvl][3]);
         const uint16_t* plane = blur + (size_t)frame * pyr.stride + __builtin_amdgcn_readfirstlane(lv[lvl][4]);
-        const float2 cs = rot[idx];
-        const float ct = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, cs.x)));
-        const float st = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, cs.y)));
-        const float nst = -st;
-        int dxa[4], dya[4], dxb[4], dyb[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
-            const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
-            // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y), brief.wgsl:38-54
-            const float a0 = ct * pax, a1 = st * pay, a2 = nst * pax, a3 = ct * pay;
-            const float b0 = ct * pbx, b1 = st * pby, b2 = nst * pbx, b3 = ct * pby;
-            const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
-            dxa[e] = (int)rax, dya[e] = (int)ray, dxb[e] = (int)rbx, dyb[e] = (int)rby;  // vec2i() truncates
-        }
+        // this lane's eight rotated points (brief.wgsl:50-57), from the table of the keypoint's angle code: issued here, used
+        // behind the patch fill
+        const uint4 tt = tab.rot[(size_t)min(r.z, (uint32_t)(ORB_ANGLE_STEPS - 1)) * 64u + lane];
+        const uint32_t tw[4] = {tt.x, tt.y, tt.z, tt.w};
         uint64_t bal[4];
         if ((w & 1) == 0) {
             // ---- patch in LDS: rows y-18..y+18, columns c0..c0+47 with c0 = (x - 18) rounded down to 8.  A piece
@@ -357,10 +374,11 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int xo = (int)r.x - c0;  // 18..25
+            const uint8_t* const centre = reinterpret_cast<const uint8_t*>(patch + kBriefHalo * kNfPatchCols + xo);  // the keypoint's texel
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const uint32_t va = patch[(dya[e] + kBriefHalo) * kNfPatchCols + xo + dxa[e]];
-                const uint32_t vb = patch[(dyb[e] + kBriefHalo) * kNfPatchCols + xo + dxb[e]];
+                const uint32_t va = *reinterpret_cast<const uint16_t*>(centre + rot_a(tw[e]));
+                const uint32_t vb = *reinterpret_cast<const uint16_t*>(centre + rot_b(tw[e]));
                 bal[e] = __ballot(va > vb);  // non-negative f16: bit patterns order like the values (brief.wgsl:62)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next keypoint's fill overwrites what was just sampled
@@ -371,10 +389,14 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
             const uint32_t rowv = (gy >= 0 && gy < h && lane < 37u) ? (uint32_t)rowc[gy] : 0u;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const int xa = (int)r.x + dxa[e], ya = (int)r.y + dya[e];
-                const int xb = (int)r.x + dxb[e], yb = (int)r.y + dyb[e];
-                uint32_t va = (uint32_t)__shfl((int)rowv, dya[e] + kBriefHalo);  // 0 when the row is outside the level
-                uint32_t vb = (uint32_t)__shfl((int)rowv, dyb[e] + kBriefHalo);
+                // the table holds 2 * (dy * kNfPatchCols + dx) with |dx| < kNfPatchCols / 2: take it apart again
+                const int oa = rot_a(tw[e]) >> 1, ob = rot_b(tw[e]) >> 1;
+                const int dya = (oa + kNfPatchCols / 2 + 64 * kNfPatchCols) / kNfPatchCols - 64, dxa = oa - dya * kNfPatchCols;
+                const int dyb = (ob + kNfPatchCols / 2 + 64 * kNfPatchCols) / kNfPatchCols - 64, dxb = ob - dyb * kNfPatchCols;
+                const int xa = (int)r.x + dxa, ya = (int)r.y + dya;
+                const int xb = (int)r.x + dxb, yb = (int)r.y + dyb;
+                uint32_t va = (uint32_t)__shfl((int)rowv, dya + kBriefHalo);  // 0 when the row is outside the level
+                uint32_t vb = (uint32_t)__shfl((int)rowv, dyb + kBriefHalo);
                 const bool ina = xa >= 0 && xa < w && ya >= 0 && ya < h;
                 const bool inb = xb >= 0 && xb < w && yb >= 0 && yb < h;
                 if (!ina)

@@ -572,28 +572,49 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     if (*overflow == 0u) {
         const uint32_t n = *list_count;
         if (geo.nms && n > 1u) {
-            // all n * n ordered pairs spread over the workgroup: pair p = (i, j) clears keep[i] (queue C's storage,
-            // C is in the list by now) when corner j is an 8-neighbour of corner i that beats it
-            uint16_t* const keep = queue_c;
-            for (uint32_t i = (uint32_t)tid; i < n; i += NT) keep[i] = 1u;
+            // The corners sorted by region row (a counting sort in the storage of queues B and C, both drained by now): a corner
+            // then meets only the corners of its own and the two neighbouring rows -- about ten of them where all n * n ordered
+            // pairs spread over the workgroup were 3 600 tests per tile (n ~ 60), a tenth of the kernel's instructions.
+            constexpr int kRows = 20;  // region rows 0 .. R + 1 (the tile's rows and its 1-px apron)
+            uint32_t* const row_cnt = reinterpret_cast<uint32_t*>(queue_b);  // [kRows]
+            uint32_t* const row_start = row_cnt + kRows;                     // [kRows + 1]
+            uint16_t* const sorted = reinterpret_cast<uint16_t*>(row_start + kRows + 1);  // [kIList] corner indices, row by row
+            uint16_t* const slot_of = queue_c;                                // [kIList]
+            static_assert((2 * kRows + 1) * 4 + kIList * 2 <= kIQueueB * 2 && kIList <= kIQueueC, "NMS scratch does not fit queues B and C");
+            if (tid < kRows) row_cnt[tid] = 0u;
             __syncthreads();
-            const uint32_t n_pairs = n * n;
-            const float inv_n = 1.0f / (float)n;
-            for (uint32_t p = (uint32_t)tid; p < n_pairs; p += NT) {
-                const uint32_t i = (uint32_t)(((float)p + 0.5f) * inv_n), j = p - i * n;
-                const uint32_t pi = list_pos[i], pj = list_pos[j];
-                const int dy = (int)(pj >> 9) - (int)(pi >> 9), dx = (int)(pj & 511u) - (int)(pi & 511u);
-                if (j != i && dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1) {
-                    const float s = list_score[i], t = list_score[j];
-                    const bool later = dy > 0 || (dy == 0 && dx > 0);
-                    if (t > s || (t == s && !later)) keep[i] = 0u;
+            for (uint32_t i = (uint32_t)tid; i < n; i += NT) slot_of[i] = (uint16_t)atomicAdd(&row_cnt[min((uint32_t)list_pos[i] >> 9, (uint32_t)(kRows - 1))], 1u);
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t acc = 0;
+                for (int r = 0; r < kRows; r++) {
+                    row_start[r] = acc;
+                    acc += row_cnt[r];
                 }
+                row_start[kRows] = acc;
             }
+            __syncthreads();
+            for (uint32_t i = (uint32_t)tid; i < n; i += NT) sorted[row_start[min((uint32_t)list_pos[i] >> 9, (uint32_t)(kRows - 1))] + slot_of[i]] = (uint16_t)i;
             __syncthreads();
             for (uint32_t i = (uint32_t)tid; i < n; i += NT) {
                 const uint32_t pi = list_pos[i];
-                const int x = cx0 + (int)(pi & 511u) - kIPad, gy = y0 - 1 + (int)(pi >> 9);
-                if (keep[i] && in_core(x, gy)) append((uint32_t)x, (uint32_t)gy, (uint32_t)list_ang[i], list_score[i]);
+                const int ri = (int)(pi >> 9), ci = (int)(pi & 511u);
+                const float sc = list_score[i];
+                bool keep = true;
+                for (int rr = max(ri - 1, 0); rr <= min(ri + 1, kRows - 1); rr++) {
+                    const uint32_t q1 = row_start[rr + 1];
+                    for (uint32_t q = row_start[rr]; q < q1; q++) {
+                        const uint32_t j = sorted[q];
+                        const int dx = (int)(list_pos[j] & 511u) - ci, dy = rr - ri;
+                        if (j != i && dx >= -1 && dx <= 1) {
+                            const float t = list_score[j];
+                            const bool later = dy > 0 || (dy == 0 && dx > 0);
+                            if (t > sc || (t == sc && !later)) keep = false;
+                        }
+                    }
+                }
+                const int x = cx0 + ci - kIPad, gy = y0 - 1 + ri;
+                if (keep && in_core(x, gy)) append((uint32_t)x, (uint32_t)gy, (uint32_t)list_ang[i], sc);
             }
         } else {
             for (uint32_t i = (uint32_t)tid; i < n; i += NT) {
@@ -750,6 +771,7 @@ struct IBriefGeom {
     uint32_t group_base[kMaxLevels + 1];  // first stack of each level; [depth] = stacks per frame
     uint32_t pitch;        // LDS row pitch in halfs: kITileW + 2 * kIBriefApronX
     uint32_t xcd_swizzle;  // all stacks of a frame on one XCD: its blur planes stay in that L2
+    uint32_t phase_mask;   // timing experiments only: bit0 the window is staged, bit1 the keypoints are described
 };
 
 __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __restrict__ blur, Pyramid pyr,
@@ -763,8 +785,10 @@ __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __re
     constexpr int NT = kIBriefThreads, NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) uint16_t win[];  // up to kIBriefRowsMax x pitch
     __shared__ uint4 kept_rec[256];
-    __shared__ float2 kept_rot[256];  // (cos, sin) of the kept keypoint's angle code, fetched by the thread that keeps it
     __shared__ uint32_t wave_kept[4];
+    __shared__ uint32_t kept_k[256];                   // final index of the kept keypoint
+    __shared__ uint32_t tile_first[kIBriefStack];     // kept entries of the chunk in front of the tile's first entry
+    __shared__ uint32_t tile_run[kIBriefStack];       // kept entries of the tile in earlier chunks
     const uint32_t n_groups = bg.group_base[pyr.depth];
     uint32_t group, frame;
     if (bg.xcd_swizzle) {
@@ -791,6 +815,7 @@ __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __re
     const int tw = min((int)bg.tw[lvl], w - ct * (int)bg.tw[lvl]);
     const int pitch = (int)bg.pitch;
     const uint16_t* plane = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
+    if (bg.phase_mask & 1u)
     {   // stage the window in 8-texel groups; five 16-byte loads per thread are in flight (unconditional, from
         // clamped addresses), groups that straddle the level's edge are patched texel by texel
         const int groups = (tw + 2 * kIBriefApronX + 7) >> 3;
@@ -836,31 +861,37 @@ __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __re
     const unsigned long long kth = thr_key[frame];
     CornerData* out_kp = corners + (size_t)frame * cap;
     uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)frame * cap);
-    // this lane's four tests (l, 64+l, 128+l, 192+l) of the pattern, as binary32 once per workgroup
-    float pfx[8], pfy[8];  // [2e] = point a, [2e+1] = point b of test e
+    // The stack's tiles as ONE list: entry c of the concatenated segments belongs to tile t (c in [o_t, o_t + n_t)), and a kept
+    // entry's final index is seg_before[tile] + its rank among the tile's kept entries (segment order).  Chunks of 256
+    // entries: the first four waves decide "kept" and compact records and final indices into kept_rec / kept_k, then all
+    // eight waves describe them.  (Tile by tile -- a dependent global load, three barriers and one or two turns of the
+    // waves per tile -- the kernel spent its time waiting: 0.13 ms of its 0.57 with neither window nor keypoints.)
+    uint32_t n_t[kIBriefStack], o_t[kIBriefStack + 1], before_t[kIBriefStack];
+    o_t[0] = 0;
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const uint32_t pk = tab.pattern[64u * (uint32_t)e + lane];
-        pfx[2 * e] = (float)(int8_t)(pk & 255u);
-        pfy[2 * e] = (float)(int8_t)((pk >> 8) & 255u);
-        pfx[2 * e + 1] = (float)(int8_t)((pk >> 16) & 255u);
-        pfy[2 * e + 1] = (float)(int8_t)(pk >> 24);
+    for (int t = 0; t < kIBriefStack; t++) {
+        const size_t sidx = sidx0 + (size_t)min(t, nb - 1) * bg.n_ct[lvl];
+        n_t[t] = t < nb ? min(seg_counts[sidx], bg.seg_cap) : 0u;
+        before_t[t] = seg_before[sidx];
+        o_t[t + 1] = o_t[t] + n_t[t];
     }
-    for (int t = 0; t < nb; t++) {  // tile by tile: final index = seg_before[tile] + rank among its kept entries
-        const size_t sidx = sidx0 + (size_t)t * bg.n_ct[lvl];
-        const uint32_t n = min(seg_counts[sidx], bg.seg_cap);
-        const CornerData* seg = segments + sidx * bg.seg_cap;
-        const float* ssc = seg_scores + sidx * bg.seg_cap;
-        uint32_t base = seg_before[sidx];
-        // chunks of 256 entries: the first four waves decide "kept" and compact the records (in segment order)
-        // into kept_rec, then all eight waves describe them
-        for (uint32_t j0 = 0; j0 < n; j0 += 256u) {
-            const uint32_t j = j0 + tid;
+    const uint32_t n_all = o_t[kIBriefStack];
+    if (tid < (uint32_t)kIBriefStack) tile_run[tid] = 0u;
+    {
+        for (uint32_t c0 = 0; c0 < n_all; c0 += 256u) {
+            const uint32_t c = c0 + tid;
             uint4 rec = make_uint4(0u, 0u, 0u, 0u);
             bool kept = false;
-            if (tid < 256u && j < n) {
-                rec = *reinterpret_cast<const uint4*>(&seg[j]);
-                kept = kth == 0ull || select_key(rec, ssc[j]) >= kth;
+            uint32_t t = 0;
+            if (tid < 256u && c < n_all) {
+#pragma unroll
+                for (int q = 1; q < kIBriefStack; q++) t += c >= o_t[q] ? 1u : 0u;
+                uint32_t ot = o_t[0];
+#pragma unroll
+                for (int q = 1; q < kIBriefStack; q++) ot = t == (uint32_t)q ? o_t[q] : ot;
+                const size_t at = (sidx0 + (size_t)t * bg.n_ct[lvl]) * bg.seg_cap + (c - ot);
+                rec = *reinterpret_cast<const uint4*>(&segments[at]);
+                kept = kth == 0ull || select_key(rec, seg_scores[at]) >= kth;
             }
             const uint64_t mask = __ballot(kept);
             __syncthreads();  // previous chunk's kept_rec consumed; (first chunk) the window is complete
@@ -869,44 +900,76 @@ __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __re
             uint32_t off = 0;
             for (uint32_t k = 0; k < wv && k < 4u; k++) off += wave_kept[k];
             const uint32_t chunk_total = wave_kept[0] + wave_kept[1] + wave_kept[2] + wave_kept[3];
+            const uint32_t pfx = off + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));  // kept entries of the chunk before this one
+            uint32_t ot = o_t[0], nt = n_t[0], bt = before_t[0];
+#pragma unroll
+            for (int q = 1; q < kIBriefStack; q++) {
+                ot = t == (uint32_t)q ? o_t[q] : ot;
+                nt = t == (uint32_t)q ? n_t[q] : nt;
+                bt = t == (uint32_t)q ? before_t[q] : bt;
+            }
+            const bool mine = tid < 256u && c < n_all;
+            if (mine && c == max(ot, c0)) tile_first[t] = pfx;  // the tile's first entry in this chunk
+            __syncthreads();
             if (kept) {
-                // the table look-up happens here, 256 at a time, not as a memory round trip in front of every keypoint
-                const uint32_t at = off + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                const uint32_t code = min(rec.z, (uint32_t)(ORB_ANGLE_STEPS_FULL - 1));
-                kept_rec[at] = rec;
-                kept_rot[at] = make_float2(tab.cos_tab[code], tab.sin_tab[code]);
+                kept_rec[pfx] = rec;
+                kept_k[pfx] = bt + tile_run[t] + (pfx - tile_first[t]);
             }
             __syncthreads();
-            for (uint32_t r = wv; r < chunk_total; r += NW) {
-                const uint32_t k = base + r;
-                if (k >= cap) break;  // indices only grow
-                const uint4 kr = kept_rec[r];
-                const float2 cs = kept_rot[r];
-                const float ct_ = cs.x, st = cs.y, nst = -st;
-                // LDS index of the keypoint inside the window (wave-uniform); a sample adds dy * pitch + dx
-                const int kbase = __builtin_amdgcn_readfirstlane(((int)kr.y - wy0) * pitch + ((int)kr.x - wx0));
-                uint64_t bal[4];
+            if (mine && (c + 1u == ot + nt || tid == 255u)) tile_run[t] += pfx + (kept ? 1u : 0u) - tile_first[t];  // the tile's last entry in this chunk
+            auto rot_of = [&](uint32_t r) {
+                const uint32_t code = min((uint32_t)__builtin_amdgcn_readfirstlane(kept_rec[r].z), (uint32_t)(ORB_ANGLE_STEPS_FULL - 1));
+                return tab.rot[(size_t)code * 64u + lane];
+            };
+            // U keypoints per wave and turn: a keypoint is a chain of latencies (record from LDS, table entry from L2, eight
+            // samples from LDS, ballots), not arithmetic -- with one at a time the kernel waited 60 % of its wave-cycles at four
+            // waves per SIMD (the window leaves room for two workgroups per CU).  The chains of U keypoints are independent.
+            constexpr uint32_t U = 4;
+            uint4 tt_next[U];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    int idx[2];
+            for (uint32_t u = 0; u < U; u++) tt_next[u] = wv + u * NW < chunk_total ? rot_of(wv + u * NW) : make_uint4(0u, 0u, 0u, 0u);
+            for (uint32_t r = wv; r < chunk_total && (bg.phase_mask & 2u); r += NW * U) {
+                uint4 kr[U], tt[U];
+                uint32_t kk[U];
+                bool ok[U];  // wave-uniform
 #pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        // R(+theta) p = (ct*x - st*y, st*x + ct*y), products and sums rounded on their own (IM-6)
-                        const float p0 = ct_ * pfx[2 * e + q], p1 = nst * pfy[2 * e + q];
-                        const float p2 = st * pfx[2 * e + q], p3 = ct_ * pfy[2 * e + q];
-                        const float rx = p0 + p1, ry = p2 + p3;
-                        idx[q] = kbase + __mul24((int)ry, pitch) + (int)rx;
-                    }
-                    bal[e] = __ballot((uint32_t)win[idx[0]] > (uint32_t)win[idx[1]]);  // non-negative f16: bit patterns order like the values
+                for (uint32_t u = 0; u < U; u++) {
+                    const uint32_t ru = r + u * NW;
+                    kr[u] = kept_rec[min(ru, 255u)];
+                    kk[u] = kept_k[min(ru, 255u)];
+                    ok[u] = ru < chunk_total && kk[u] < cap;  // past the capacity: dropped (IM-8's cut keeps the list below it)
+                    tt[u] = tt_next[u];
                 }
-                if (lane < 8u) {
-                    const uint64_t srcw = lane < 2u ? bal[0] : (lane < 4u ? bal[1] : (lane < 6u ? bal[2] : bal[3]));
-                    out_desc[(size_t)k * 8u + lane] = (uint32_t)(srcw >> ((lane & 1u) * 32u));
-                } else if (lane == 8u) {
-                    *reinterpret_cast<uint4*>(&out_kp[k]) = kr;
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++)
+                    if (r + (U + u) * NW < chunk_total) tt_next[u] = rot_of(r + (U + u) * NW);
+                uint64_t bal[U][4];
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) {
+                    const uint32_t tw[4] = {tt[u].x, tt[u].y, tt[u].z, tt[u].w};
+                    // the keypoint's texel inside the window (wave-uniform); a sample adds 2 * (dy * pitch + dx) bytes
+                    const int kbase = ok[u] ? __builtin_amdgcn_readfirstlane(((int)kr[u].y - wy0) * pitch + ((int)kr[u].x - wx0)) : 0;
+                    const uint8_t* const centre = reinterpret_cast<const uint8_t*>(win + kbase);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int oa = ok[u] ? rot_a(tw[e]) : 0, ob = ok[u] ? rot_b(tw[e]) : 0;
+                        const uint32_t va = *reinterpret_cast<const uint16_t*>(centre + oa);
+                        const uint32_t vb = *reinterpret_cast<const uint16_t*>(centre + ob);
+                        bal[u][e] = __ballot(va > vb);  // non-negative f16: bit patterns order like the values
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) {
+                    if (!ok[u]) continue;
+                    const uint32_t k = kk[u];
+                    if (lane < 8u) {
+                        const uint64_t srcw = lane < 2u ? bal[u][0] : (lane < 4u ? bal[u][1] : (lane < 6u ? bal[u][2] : bal[u][3]));
+                        out_desc[(size_t)k * 8u + lane] = (uint32_t)(srcw >> ((lane & 1u) * 32u));
+                    } else if (lane == 8u) {
+                        *reinterpret_cast<uint4*>(&out_kp[k]) = kr[u];
+                    }
                 }
             }
-            base += chunk_total;
         }
     }
 }

@@ -507,6 +507,10 @@ struct BriefTables {
     const uint32_t* pattern;  // 256 x packed (ax, ay, bx, by) int8
     const float* cos_tab;     // ORB_ANGLE_STEPS_FULL entries (the reference's codes use the first ORB_ANGLE_STEPS)
     const float* sin_tab;
+    // The pattern rotated by every angle code, for the wave-per-keypoint kernels (k_rot_table, orb_kernels_brief.h):
+    // rot[code * 64 + lane] = 8 x int16 = BYTE offsets of points a, b of tests lane, 64 + lane, 128 + lane, 192 + lane
+    // into a window of f16 texels around the keypoint (2 * (ry * pitch + rx); pitch: k_brief_nf's patch, k_brief_i's window).
+    const uint4* rot;
 };
 
 __device__ __forceinline__ float level_load(const uint16_t* lvl, uint32_t w, uint32_t h, int x, int y) {

@@ -42,7 +42,7 @@ EXPORTS = [
     "orb_write_input_image", "orb_set_threshold", "orb_extract_corners", "orb_read_corners",
     "orb_read_descriptors", "orb_extract_batch_device", "orb_extract_batch_host", "orb_batch_sync",
     "orb_batch_counts", "orb_batch_read", "orb_batch_select_output", "orb_batch_device_buffers", "orb_level_size",
-    "orb_debug_read_plane", "orb_debug_f32_to_f16", "orb_debug_angle_code", "orb_profile_enable",
+    "orb_debug_read_plane", "orb_debug_f32_to_f16", "orb_debug_angle_code", "orb_debug_rot_table", "orb_profile_enable",
     "orb_profile_reset", "orb_profile_get", "orb_synth_frames_device", "orb_copy_to_host", "orb_debug_stamps",
     "orb_match_consecutive", "orb_match_read", "orb_corner_level0_xy",
     "orb_batch_read_all", "orb_batch_compact_device", "orb_host_alloc", "orb_host_free", "orb_stream_sync",
@@ -142,6 +142,7 @@ def load_library(path=None):
     L.orb_debug_read_plane.argtypes = [vp, u32, ctypes.c_int, u32, vp, sz]
     L.orb_debug_f32_to_f16.argtypes = [vp, vp, vp, sz]
     L.orb_debug_angle_code.argtypes = [vp, vp, vp, vp, sz]
+    L.orb_debug_rot_table.argtypes = [vp, vp, sz, vp, vp]
     L.orb_match_consecutive.argtypes = [vp, u32, vp]
     L.orb_match_read.argtypes = [vp, u32, vp, ctypes.c_size_t]
     L.orb_profile_enable.argtypes = [vp, ctypes.c_int]
@@ -490,6 +491,14 @@ class OrbProgram:
         out = np.zeros(cy.shape, dtype=np.uint32)
         self._check(self._lib.orb_debug_angle_code(self._handle(), _ptr(cy), _ptr(cx), _ptr(out), cy.size))
         return out
+
+    def rot_table(self):
+        """The rotated-pattern table as (int16 array [codes, 64, 4, 2] of byte offsets, pitch)."""
+        codes, pitch = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        self._check(self._lib.orb_debug_rot_table(self._handle(), None, 0, ctypes.byref(codes), ctypes.byref(pitch)))
+        out = np.zeros((codes.value, 64, 4, 2), dtype=np.int16)
+        self._check(self._lib.orb_debug_rot_table(self._handle(), _ptr(out), out.size, None, None))
+        return out, pitch.value
 
     def profile_enable(self, on=True):
         self._check(self._lib.orb_profile_enable(self._handle(), 1 if on else 0))

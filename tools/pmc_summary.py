@@ -8,10 +8,15 @@ import sys
 import pandas as pd
 
 src = sys.argv[1]
-KERNELS = ("k_front<true>", "k_front<false>", "k_brief_rows", "k_slot_prefix", "k_front_y", "k_compact", "k_brief_t", "k_brief_nfb", "k_brief_nf")
+KERNELS = ("k_front<true>", "k_front<false>", "k_brief_rows", "k_slot_prefix", "k_front_y", "k_compact", "k_brief_t", "k_brief_nfb", "k_brief_nf",
+           "k_front_i<true>", "k_front_i<false>", "k_brief_i", "k_select_i", "k_gauss")
 
 
 def short(name):
+    if "k_front_i<true" in name or "k_front_i<(bool)1" in name:
+        return "k_front_i<true>"
+    if "k_front_i<" in name:
+        return "k_front_i<false>"
     if "k_front<true" in name:
         return "k_front<true>"
     if "k_front<false" in name:
