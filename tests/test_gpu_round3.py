@@ -205,3 +205,23 @@ def test_rotated_pattern_table_equals_numpy(tinyorb, intended):
         ob = 2 * (np.trunc(rby).astype(np.int64) * pitch + np.trunc(rbx).astype(np.int64))
         assert np.array_equal(table[:, j & 63, j >> 6, 0].astype(np.int64), oa), "test %d point a" % j
         assert np.array_equal(table[:, j & 63, j >> 6, 1].astype(np.int64), ob), "test %d point b" % j
+
+
+def test_single_frame_staging_is_complete_when_the_call_returns(tinyorb, oracle):
+    """orb_extract_corners returns when the polled completion word arrives, not after a stream synchronisation: everything
+    k_brief_one wrote to the pinned staging arrays must be there by then.  A large frame (19 500 keypoints, 1024 workgroups
+    over all XCDs), 60 calls in a row, every result against the first (which is checked against the oracle) -- plain stores
+    to the staging arrays lost this race once in a few dozen calls; they are system-scope stores now."""
+    W, H, cap = 2048, 2200, 1 << 16
+    rgba = oracle.synth_frame(W, H, 31)
+    ref = oracle.extract(rgba, depth=2, threshold=THR, max_features=cap)
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=cap, hierarchy_depth=2, initial_threshold=THR)
+    with tinyorb.OrbProgram(cfg) as prog:
+        total, corners, desc = prog.extract(rgba)
+        _assert_frame_equal(oracle, ref, total, corners, desc)
+        c0, d0 = _sorted(corners, desc)
+        for it in range(60):
+            t, c, d = prog.extract(rgba)
+            assert t == total, "call %d: counter %d" % (it, t)
+            c, d = _sorted(c, d)
+            assert np.array_equal(c, c0) and np.array_equal(d, d0), "call %d: staging arrays incomplete" % it

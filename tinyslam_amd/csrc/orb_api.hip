@@ -437,7 +437,7 @@ int launch_brief(OrbProgram* p, hipStream_t s, uint32_t n, const RowsGeom& rows_
     }
     if (use_t) {
         const BriefTGeom& tg = p->brieft;
-        const dim3 grid(n, (cap + 255u) / 256u);
+        const dim3 grid(n, (cap + (uint32_t)kBriefNfChunk - 1u) / (uint32_t)kBriefNfChunk);  // k_brief_nf's
         {
             LaunchScope ls(p, s, KID_BRIEF_T);
             hipLaunchKernelGGL(k_brief_t<kBriefTWaves>, dim3(n, (cap + kBriefTThreads - 1u) / kBriefTThreads), dim3(kBriefTThreads),

@@ -56,6 +56,13 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
     return (uint32_t)v;
 }
 
+// Stores into the pinned host staging arrays of the single-frame call (k_brief_one).  Plain vector stores: the workgroup's
+// system-scope release in front of its completion count is what makes them visible to the polling host.  (Measured and
+// dropped: stores with the scope bits set, sc0 sc1 -- written through one by one, k_brief_one 20 -> 113 us at 720p --, and
+// __hip_atomic_store at system scope, issued lane by lane as 8-byte PCIe packets: 740 us.)
+__device__ __forceinline__ void store_host_u32(uint32_t* p, uint32_t v) { *p = v; }
+__device__ __forceinline__ void store_host_16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+
 // word = (word << 1) | (a > b), a and b non-negative f16 bit patterns (they order like the values, brief.wgsl:62)
 __device__ __forceinline__ uint32_t push_gt(uint32_t word, uint32_t a, uint32_t b) {
     return __builtin_amdgcn_alignbit(word, b - a, 31);  // bit 31 of (b - a) is set iff a > b
@@ -129,7 +136,7 @@ __device__ __forceinline__ void brief_t_body(uint8_t* lds_raw, uint32_t frame, u
     const uint4 rec = *reinterpret_cast<const uint4*>(
         &segments[(((size_t)frame * bg.n_slots + slot) * bg.n_classes + cls) * bg.seg_cap + (k - before[lo])]);
     *reinterpret_cast<uint4*>(&corners[(size_t)frame * cap + k]) = rec;  // final list = the lists back to back
-    if (host_corners) *reinterpret_cast<uint4*>(&host_corners[k]) = rec;
+    if (host_corners) store_host_16(&host_corners[k], rec);
     const uint32_t lvl = min(rec.w, pyr.depth - 1u);
     if (!(rec.x >= (uint32_t)kBriefHalo && rec.x < lv[lvl][0])) return;  // not flat: k_brief_nf takes it
 
@@ -153,9 +160,8 @@ __device__ __forceinline__ void brief_t_body(uint8_t* lds_raw, uint32_t frame, u
         o[0] = make_uint4(d[0], d[1], d[2], d[3]);
         o[1] = make_uint4(d[4], d[5], d[6], d[7]);
         if (host_descriptors) {
-            uint4* const ho = reinterpret_cast<uint4*>(host_descriptors + k);
-            ho[0] = make_uint4(d[0], d[1], d[2], d[3]);
-            ho[1] = make_uint4(d[4], d[5], d[6], d[7]);
+            store_host_16(reinterpret_cast<uint4*>(host_descriptors + k), make_uint4(d[0], d[1], d[2], d[3]));
+            store_host_16(reinterpret_cast<uint4*>(host_descriptors + k) + 1, make_uint4(d[4], d[5], d[6], d[7]));
         }
         return;
     }
@@ -184,9 +190,8 @@ __device__ __forceinline__ void brief_t_body(uint8_t* lds_raw, uint32_t frame, u
     o[0] = make_uint4(d[0], d[1], d[2], d[3]);
     o[1] = make_uint4(d[4], d[5], d[6], d[7]);
     if (host_descriptors) {
-        uint4* const ho = reinterpret_cast<uint4*>(host_descriptors + k);
-        ho[0] = make_uint4(d[0], d[1], d[2], d[3]);
-        ho[1] = make_uint4(d[4], d[5], d[6], d[7]);
+        store_host_16(reinterpret_cast<uint4*>(host_descriptors + k), make_uint4(d[0], d[1], d[2], d[3]));
+        store_host_16(reinterpret_cast<uint4*>(host_descriptors + k) + 1, make_uint4(d[4], d[5], d[6], d[7]));
     }
 }
 
@@ -413,17 +418,18 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
         if (lane < 8u) {
             const uint64_t src = lane < 2u ? bal[0] : (lane < 4u ? bal[1] : (lane < 6u ? bal[2] : bal[3]));
             out_desc[(size_t)idx * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
-            if (host_descriptors) reinterpret_cast<uint32_t*>(host_descriptors + k0)[(size_t)idx * 8u + lane] = (uint32_t)(src >> ((lane & 1u) * 32u));
+            if (host_descriptors) store_host_u32(reinterpret_cast<uint32_t*>(host_descriptors + k0) + (size_t)idx * 8u + lane, (uint32_t)(src >> ((lane & 1u) * 32u)));
         }
     }
 }
 
+constexpr int kBriefNfChunk = 64;  // keypoints of the final list a workgroup scans
 __global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ blur, const uint16_t* __restrict__ blur_rowc,
                                                   Pyramid pyr, BriefTGeom bg, const uint32_t* __restrict__ seg_counts,
                                                   const uint32_t* __restrict__ seg_before,
                                                   const CornerData* __restrict__ corners, uint32_t cap,
                                                   CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
-    brief_nf_body(blockIdx.x, blockIdx.y, ~0u, blur, blur_rowc, pyr, bg, seg_counts, seg_before, corners, cap, descriptors, tab);  // frame = fast index, as above
+    brief_nf_body<kBriefNfChunk>(blockIdx.x, blockIdx.y, ~0u, blur, blur_rowc, pyr, bg, seg_counts, seg_before, corners, cap, descriptors, tab);  // frame = fast index, as above
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -481,7 +487,10 @@ __global__ __launch_bounds__(kBriefOneThreads) void k_brief_one(const uint16_t* 
         }
         if (tid == 0u) {
             before[n_ent] = carry;  // stored keypoints of the frame
-            if (chunk == 0u) counts[0] = total, *host_count = total;
+            if (chunk == 0u) {
+                counts[0] = total;
+                store_host_u32(host_count, total);
+            }
         }
     }
     BRIEF_ONE_STAMP();
@@ -494,12 +503,13 @@ __global__ __launch_bounds__(kBriefOneThreads) void k_brief_one(const uint16_t* 
     const uint32_t n_stored = before[n_ent];
     brief_nf_body<kBriefOneChunk, kBriefOneThreads / 64>(0u, chunk, n_stored, blur, blur_rowc, pyr, bg, seg_counts, seg_before, corners, cap, descriptors, tab,
                                   host_descriptors);
-    // ---- completion, for a host that polls instead of synchronising the stream: every wave waits until its stores have been
-    // acknowledged (the staging arrays are uncached host memory: an acknowledged store has left for the host, no cache holds
-    // it) before its workgroup counts itself done; the last workgroup publishes the sequence number behind them, in a cache
-    // line of its own, with the one system-scope release of the launch, and clears the count for the next call.  (A
-    // system-scope fence in EVERY workgroup writes the L2 back 128 times: k_brief_one 22 -> 28 us, and 37 / 57 us with 256 / 512
-    // workgroups.)
+    // ---- completion, for a host that polls instead of synchronising the stream.  Every wave's stores are ordered in front of
+    // the barrier (workgroup-scope release), then ONE lane of the workgroup releases at system scope -- buffer_wbl2 sc0 sc1: what
+    // the workgroup wrote leaves this XCD's L2 for the host -- before the workgroup counts itself done; the last workgroup
+    // publishes the sequence number, in a cache line of its own, and clears the count for the next call.  (All 512 threads
+    // fencing: k_brief_one 22 -> 28 us, and 37 / 57 us with 256 / 512 workgroups.  No system-scope release per workgroup, only the
+    // last one's: 3 us faster and wrong -- the other XCDs' L2s are not written back by it, and one call in some thousands
+    // returned before the counter had arrived.)
     BRIEF_ONE_STAMP();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's loads and stores are done
@@ -510,6 +520,8 @@ __global__ __launch_bounds__(kBriefOneThreads) void k_brief_one(const uint16_t* 
         for (int i = 0; i < 5; i++) host_count[(chunk ? 6 : 1) + i] = (uint32_t)(st[i + 1] - st[i]);
 #endif
     if (tid == 0u) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: buffer_wbl2 sc0 sc1 ...
+        __builtin_amdgcn_s_waitcnt(0);                 // ... and its completion (hipcc leaves the wait out in front of a relaxed atomic)
         const uint32_t prev = __hip_atomic_fetch_add(done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev + 1u == gridDim.x) {
             __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -761,6 +761,7 @@ __global__ __launch_bounds__(1024) void k_select_i(const uint32_t* __restrict__ 
 // each tile are dealt to the eight waves round-robin, one wave64 per keypoint, lane l evaluates tests l, 64+l,
 // 128+l, 192+l.
 constexpr int kIBriefStack = 4;
+constexpr bool kIBriefTable = true;  // rotated points from BriefTables::rot (false: computed per keypoint, for A/B measurements)
 constexpr int kIBriefThreads = 512;
 constexpr int kIBriefRowsMax = kFrontRows * kIBriefStack + 2 * kBriefHalo;  // 100
 constexpr int kIBriefApronX = 24;                                            // >= 18, multiple of 8
@@ -866,6 +867,11 @@ __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __re
     // entries: the first four waves decide "kept" and compact records and final indices into kept_rec / kept_k, then all
     // eight waves describe them.  (Tile by tile -- a dependent global load, three barriers and one or two turns of the
     // waves per tile -- the kernel spent its time waiting: 0.13 ms of its 0.57 with neither window nor keypoints.)
+    uint32_t pat[4] = {0u, 0u, 0u, 0u};
+    if constexpr (!kIBriefTable) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) pat[e] = tab.pattern[64u * (uint32_t)e + lane];
+    }
     uint32_t n_t[kIBriefStack], o_t[kIBriefStack + 1], before_t[kIBriefStack];
     o_t[0] = 0;
 #pragma unroll
@@ -919,7 +925,24 @@ __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __re
             if (mine && (c + 1u == ot + nt || tid == 255u)) tile_run[t] += pfx + (kept ? 1u : 0u) - tile_first[t];  // the tile's last entry in this chunk
             auto rot_of = [&](uint32_t r) {
                 const uint32_t code = min((uint32_t)__builtin_amdgcn_readfirstlane(kept_rec[r].z), (uint32_t)(ORB_ANGLE_STEPS_FULL - 1));
-                return tab.rot[(size_t)code * 64u + lane];
+                if constexpr (kIBriefTable) {
+                    return tab.rot[(size_t)code * 64u + lane];
+                } else {  // the rotation on the spot (k_rot_table's arithmetic): no table traffic, 24 more vector instructions per test
+                    const float ct = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
+                    uint32_t w[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const uint32_t pk = pat[e];
+                        const float pax = (float)(int8_t)(pk & 255u), pay = (float)(int8_t)((pk >> 8) & 255u);
+                        const float pbx = (float)(int8_t)((pk >> 16) & 255u), pby = (float)(int8_t)(pk >> 24);
+                        const float a0 = ct * pax, a1 = nst * pay, a2 = st * pax, a3 = ct * pay;
+                        const float b0 = ct * pbx, b1 = nst * pby, b2 = st * pbx, b3 = ct * pby;
+                        const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+                        const int oa = 2 * ((int)ray * pitch + (int)rax), ob = 2 * ((int)rby * pitch + (int)rbx);
+                        w[e] = ((uint32_t)oa & 0xffffu) | ((uint32_t)ob << 16);
+                    }
+                    return make_uint4(w[0], w[1], w[2], w[3]);
+                }
             };
             // U keypoints per wave and turn: a keypoint is a chain of latencies (record from LDS, table entry from L2, eight
             // samples from LDS, ballots), not arithmetic -- with one at a time the kernel waited 60 % of its wave-cycles at four

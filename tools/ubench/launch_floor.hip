@@ -26,7 +26,9 @@ int main() {
     hipHostGetDevicePointer((void**)&d, h, 0);
     *h = 0;
     const int N = 2000;
-    for (int mode = 0; mode < 6; mode++) {
+    hipEvent_t ev;
+    hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    for (int mode = 0; mode < 9; mode++) {
         double t = 0;
         uint32_t seq = 0;
         for (int i = 0; i < N + 50; i++) {
@@ -38,11 +40,15 @@ int main() {
                 case 2: hipLaunchKernelGGL(k_null, dim3(64), dim3(256), 0, s, nullptr, 0u); hipLaunchKernelGGL(k_null, dim3(64), dim3(256), 0, s, nullptr, 0u); hipStreamSynchronize(s); break;
                 case 3: hipLaunchKernelGGL(k_null, dim3(64), dim3(256), 0, s, nullptr, 0u); hipLaunchKernelGGL(k_null, dim3(64), dim3(256), 0, s, d, seq); while (*(volatile uint32_t*)h != seq) {} break;
                 case 4: hipLaunchKernelGGL(k_spin, dim3(64), dim3(256), 0, s, 10000u); hipLaunchKernelGGL(k_spin, dim3(64), dim3(256), 0, s, 10000u); hipStreamSynchronize(s); break;
+                case 6: hipLaunchKernelGGL(k_null, dim3(64), dim3(256), 0, s, nullptr, 0u); while (hipStreamQuery(s) == hipErrorNotReady) {} break;
+                case 7: hipLaunchKernelGGL(k_null, dim3(64), dim3(256), 0, s, nullptr, 0u); hipEventRecord(ev, s); while (hipEventQuery(ev) == hipErrorNotReady) {} break;
+                case 8: hipLaunchKernelGGL(k_null, dim3(64), dim3(256), 0, s, nullptr, 0u); hipLaunchKernelGGL(k_null, dim3(64), dim3(256), 0, s, nullptr, 0u); while (hipStreamQuery(s) == hipErrorNotReady) {} break;
                 case 5: hipLaunchKernelGGL(k_spin, dim3(64), dim3(256), 0, s, 10000u); hipLaunchKernelGGL(k_spin, dim3(64), dim3(256), 0, s2, 10000u); hipStreamSynchronize(s); hipStreamSynchronize(s2); break;
             }
         }
         const char* names[] = {"1 launch + hipStreamSynchronize", "1 launch + host flag polled", "2 launches + hipStreamSynchronize", "2 launches + host flag polled",
-                               "2 x 10 us kernels, one stream, sync", "2 x 10 us kernels, two streams, 2 syncs"};
+                               "2 x 10 us kernels, one stream, sync", "2 x 10 us kernels, two streams, 2 syncs",
+                               "1 launch + hipStreamQuery spin", "1 launch + event + hipEventQuery spin", "2 launches + hipStreamQuery spin"};
         printf("%-44s %7.2f us\n", names[mode], (now() - t) / N);
     }
     return 0;
