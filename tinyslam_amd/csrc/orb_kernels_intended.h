@@ -213,35 +213,42 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     if (L0) {
         // RGBA quads; BT.601 luminance of input(x, y) (IM-1) -- or the reference's 0.229 weight on the mirrored row
         // (grayscale.wgsl:16-38); the tile's own pixels also go to the grey plane (for the blur kernel)
+        // A thread keeps its quad column and walks down the rows (k_front's phase A): the mirrored byte offset, the LDS offset
+        // and the row are computed once and stepped; buffer loads with the frame as the buffer -- a row above or below the image
+        // has an offset past the frame (or a negative one = huge) and reads zeros, which are staged like any other row and
+        // never read by a guarded pixel (the literal setting wants zeros there, Q8; phase G maps such rows to the edge row).
         const int q0 = max(cx0 / 4 - 2, 0), q1 = min((cx0 + tw) / 4 + 2, w / 4);
-        const int per_row = q1 - q0;
-        const float inv_per_row = 1.0f / (float)per_row;
-        const int n_items = kIRows * per_row;
+        const int per_row = q1 - q0;                       // <= kITileW / 4 + 4 quads: at least two rows per pass
+        const int rpp = NT / per_row;
+        const int ty = (int)(((float)tid + 0.5f) * (1.0f / (float)per_row)), tx = tid - __mul24(ty, per_row);
+        const bool lane_ok = ty < rpp;
         const uint8_t* src0 = frames + (size_t)frame * frame_bytes;
+        const __amdgpu_buffer_rsrc_t frame_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src0), 0, (int)frame_bytes, kBufferWord3Raw);
         uint16_t* plane0 = gray_f + pyr.off[0];
+        const int q = q0 + tx;
+        int gy_w = y0 - kIApron + ty;
+        uint32_t off_w = (uint32_t)(__mul24(lit ? h - 1 - gy_w : gy_w, w) + q * 4) * 4u;  // input row: mirrored in the literal setting
+        const uint32_t off_step = (uint32_t)(__mul24(lit ? -rpp : rpp, w) * 4);
+        int dst_w = __mul24(ty, LS) + kIPad + (q * 4 - cx0);
+        const int dst_step = rpp * LS;
+        const bool own_col = q * 4 >= cx0 && q * 4 < cx0 + tw;
         constexpr int U = 4;
-        for (int ib = tid; ib < n_items; ib += NT * U) {
+        for (int lyb = ty; lyb < kIRows; lyb += rpp * U) {
             uint4 v[U];
-            int dst[U], pix[U];  // LDS half index of the quad (-1: skip); pixel offset in the grey plane (-1: apron)
+            int dst[U], gys[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int i = ib + u * NT;
-                const int ic = min(i, n_items - 1);
-                const int ly = (int)(((float)ic + 0.5f) * inv_per_row);
-                const int q = q0 + (ic - __mul24(ly, per_row));
-                const int gy = y0 - kIApron + ly;
-                const bool ok = i < n_items && gy >= 0 && gy < h;
-                dst[u] = ok ? __mul24(ly, LS) + kIPad + (q * 4 - cx0) : -1;
-                const bool own = ly >= kIApron && ly < kIApron + R && q * 4 >= cx0 && q * 4 < cx0 + tw;
-                const int gyc = min(max(gy, 0), h - 1);
-                const int off = __mul24(gyc, w) + q * 4;                      // grey plane: row gy
-                const int src = __mul24(lit ? h - 1 - gyc : gyc, w) + q * 4;  // input: mirrored row in the literal mode
-                pix[u] = own && geo.store_grey ? off : -1;
-                v[u] = *reinterpret_cast<const uint4*>(src0 + (size_t)((uint32_t)src * 4u));
+                v[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(frame_rsrc, (int)off_w, 0, 0));
+                dst[u] = dst_w;
+                gys[u] = gy_w;
+                off_w += off_step;
+                dst_w += dst_step;
+                gy_w += rpp;
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if (dst[u] >= 0) {
+                const int ly = lyb + u * rpp;
+                if (lane_ok && ly < kIRows) {
                     // on texel pairs, as in k_front (packed binary32 instructions, one packed conversion per pair)
                     uint2 out;
                     if (lit) {
@@ -252,7 +259,8 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
                         out.y = luminance_pair_f16<true>(v[u].z, v[u].w);
                     }
                     *reinterpret_cast<uint2*>(grey + dst[u]) = out;
-                    if (pix[u] >= 0) *reinterpret_cast<uint2*>(plane0 + (size_t)(uint32_t)pix[u]) = out;
+                    if (geo.store_grey && own_col && ly >= kIApron && ly < kIApron + R && gys[u] < h)
+                        *reinterpret_cast<uint2*>(plane0 + (size_t)(uint32_t)(__mul24(gys[u], w) + q * 4)) = out;
                 }
             }
         }
@@ -343,11 +351,12 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
         float one = 1.0f, zero = 0.0f;
         asm volatile("" : "+v"(one), "+v"(zero));  // operands of v_fma_mix_f32, kept in registers
         const float inv_q = 1.0f / (float)Q, inv_p2 = 1.0f / (float)P2;
+        const int xrpp = NT / Q, xty = (int)(((float)tid + 0.5f) * inv_q), xtx = tid - __mul24(xty, Q);  // X pass: rows per turn, this thread's row phase and quad
         uint16_t* const plane = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
         for (int c0 = 0; c0 < tw; c0 += HW) {  // uniform
             // X pass: item = 4 consecutive columns of one row; inputs x-3 .. x+6 from three 8-byte reads
-            for (int i = tid; i < kIGaussRows * Q; i += NT) {
-                const int r = (int)(((float)i + 0.5f) * inv_q), x = (i - __mul24(r, Q)) * 4;
+            for (int r = xty; r < kIGaussRows && xty < xrpp; r += xrpp) {  // a thread keeps its quad column and walks down the rows
+                const int x = xtx * 4;
                 const int lyc = min(max(y0 - 3 + r, 0), h - 1) - y0 + kIApron;
                 const half_t* p = grey + __mul24(lyc, LS) + kIPad + c0 + x - 4;
                 const uint2 q0 = *reinterpret_cast<const uint2*>(p), q1 = *reinterpret_cast<const uint2*>(p + 4),
@@ -361,20 +370,22 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
                 *reinterpret_cast<uint2*>(&mid[__mul24(r, HW) + x]) = make_uint2(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16));
             }
             __syncthreads();
-            // Y pass: item = 2 columns x 8 rows from 14 rows of the X pass
-            for (int i = tid; i < 2 * P2; i += NT) {
-                const int rg = (int)(((float)i + 0.5f) * inv_p2), x = (i - __mul24(rg, P2)) * 2, r0 = rg * 8;
+            // Y pass: item = 2 columns x 6, 5 or 5 rows (three row groups: 240 items for the 256 threads at tw = 320; two groups
+            // of eight rows kept 160 busy) from 12 or 11 rows of the X pass
+            for (int i = tid; i < 3 * P2; i += NT) {
+                const int rg = (int)(((float)i + 0.5f) * inv_p2), x = (i - __mul24(rg, P2)) * 2;
+                const int r0 = rg == 0 ? 0 : 5 * rg + 1, n_rows = rg == 0 ? 6 : 5;
                 const int gx = cx0 + c0 + x;
                 if (gx >= w) continue;
-                uint32_t v[14];  // column x in the low halves, x + 1 in the high halves
+                uint32_t v[12];  // column x in the low halves, x + 1 in the high halves
 #pragma unroll
-                for (int k = 0; k < 14; k++) v[k] = *reinterpret_cast<const uint32_t*>(&mid[__mul24(r0 + k, HW) + x]);
+                for (int k = 0; k < 12; k++) v[k] = *reinterpret_cast<const uint32_t*>(&mid[__mul24(min(r0 + k, kIGaussRows - 1), HW) + x]);
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < 6; k++) {
                     const int gy = y0 + r0 + k;
                     const uint32_t oa = half_bits(to_half(gauss7_h<0, 0, 0, 0, 0, 0, 0>(v[k], v[k + 1], v[k + 2], v[k + 3], v[k + 4], v[k + 5], v[k + 6], one, zero)));
                     const uint32_t ob = half_bits(to_half(gauss7_h<1, 1, 1, 1, 1, 1, 1>(v[k], v[k + 1], v[k + 2], v[k + 3], v[k + 4], v[k + 5], v[k + 6], one, zero)));
-                    if (gy < h) {
+                    if (k < n_rows && gy < h) {
                         uint16_t* out = plane + (size_t)(uint32_t)(__mul24(gy, w) + gx);
                         if (gx + 1 < w && (w & 1) == 0)
                             *reinterpret_cast<uint32_t*>(out) = oa | (ob << 16);
