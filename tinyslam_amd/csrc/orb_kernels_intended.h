@@ -819,58 +819,88 @@ __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __re
     const int band0 = (int)(rel / bg.n_ct[lvl]) * kIBriefStack, ct = (int)(rel % bg.n_ct[lvl]);
     const int nb = min(kIBriefStack, (int)bg.n_bands[lvl] - band0);  // tiles in this stack
     const size_t sidx0 = (size_t)frame * bg.n_slots + bg.slot_base[lvl] + (size_t)band0 * bg.n_ct[lvl] + ct;
-    uint32_t total = 0;
-    for (int t = 0; t < nb; t++) total += min(seg_counts[sidx0 + (size_t)t * bg.n_ct[lvl]], bg.seg_cap);
-    if (total == 0u) return;  // uniform
+    // The stack's tiles as ONE list (see below): counts, list starts and the cut's key first -- one memory round trip --, then the
+    // first chunk's records, whose round trip runs under the staging of the window.
+    uint32_t n_t[kIBriefStack], o_t[kIBriefStack + 1], before_t[kIBriefStack];
+    o_t[0] = 0;
+#pragma unroll
+    for (int t = 0; t < kIBriefStack; t++) {
+        const size_t sidx = sidx0 + (size_t)min(t, nb - 1) * bg.n_ct[lvl];
+        n_t[t] = t < nb ? min(seg_counts[sidx], bg.seg_cap) : 0u;
+        before_t[t] = seg_before[sidx];
+        o_t[t + 1] = o_t[t] + n_t[t];
+    }
+    const unsigned long long kth = thr_key[frame];
+    const uint32_t n_all = o_t[kIBriefStack];
+    if (n_all == 0u) return;  // uniform
+    static_assert(kIBriefStack == 4, "tile_of / entry_of spell out four tiles");
+    const uint32_t o1 = o_t[1], o2 = o_t[2], o3 = o_t[3];
+    auto tile_of = [o1, o2, o3](uint32_t c) { return (c >= o1 ? 1u : 0u) + (c >= o2 ? 1u : 0u) + (c >= o3 ? 1u : 0u); };
+    const size_t seg_stride = (size_t)bg.n_ct[lvl] * bg.seg_cap, seg_base = sidx0 * bg.seg_cap;
+    auto entry_of = [o1, o2, o3, seg_stride, seg_base](uint32_t c, uint32_t t) {  // where entry c of the concatenated list lies in the segment arrays
+        const uint32_t ot = t == 0u ? 0u : (t == 1u ? o1 : (t == 2u ? o2 : o3));
+        return seg_base + (size_t)t * seg_stride + (c - ot);
+    };
+    uint4 rec_first = make_uint4(0u, 0u, 0u, 0u);
+    float score_first = 0.0f;
+    if (tid < 256u && tid < n_all) {
+        const size_t at = entry_of(tid, tile_of(tid));
+        rec_first = *reinterpret_cast<const uint4*>(&segments[at]);
+        score_first = seg_scores[at];
+    }
     const int w = (int)pyr.w[lvl], h = (int)pyr.h[lvl];
     const int wy0 = band0 * kFrontRows - kBriefHalo, wx0 = ct * (int)bg.tw[lvl] - kIBriefApronX;
     const int tw = min((int)bg.tw[lvl], w - ct * (int)bg.tw[lvl]);
     const int pitch = (int)bg.pitch;
     const uint16_t* plane = blur + (size_t)frame * pyr.stride + pyr.off[lvl];
     if (bg.phase_mask & 1u)
-    {   // stage the window in 8-texel groups; five 16-byte loads per thread are in flight (unconditional, from
-        // clamped addresses), groups that straddle the level's edge are patched texel by texel
-        const int groups = (tw + 2 * kIBriefApronX + 7) >> 3;
-        const int n_items = (nb * kFrontRows + 2 * kBriefHalo) * groups;
-        const float inv_groups = 1.0f / (float)groups;
-        const bool vec_ok = (w & 7) == 0 && w >= 8;
+    {   // Stage the window in 8-texel groups.  A thread keeps its column group and walks down the rows (k_front's phase A): what
+        // kind of group it is -- inside the level (one 16-byte buffer load with the level's plane as the buffer: a row above or
+        // below the level has an offset outside it and reads zeros), outside (zeros, no load) or across its edge (texel by
+        // texel) -- is decided once, a step is three additions; five loads per thread are in flight.
+        const int groups = (tw + 2 * kIBriefApronX + 7) >> 3;  // <= 46
+        const int n_rows = nb * kFrontRows + 2 * kBriefHalo;
+        const int rpp = NT / groups;
+        const int ty = (int)(((float)tid + 0.5f) * (1.0f / (float)groups)), tx = (int)tid - __mul24(ty, groups);
+        const int gx = wx0 + tx * 8;
+        const bool lane_ok = ty < rpp;
+        const bool inside = (w & 7) == 0 && gx >= 0 && gx + 8 <= w, outside = gx + 8 <= 0 || gx >= w;
+        const __amdgpu_buffer_rsrc_t plane_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t*>(plane), 0, (int)((uint32_t)w * (uint32_t)h * 2u), kBufferWord3Raw);
+        int gy_w = wy0 + ty;
+        uint32_t off_w = (uint32_t)(__mul24(gy_w, w) + (inside ? gx : 0)) * 2u;
+        const uint32_t off_step = (uint32_t)__mul24(rpp, w) * 2u;
+        int dst_w = __mul24(ty, pitch) + tx * 8;
+        const int dst_step = rpp * pitch;
         constexpr int U = 5;
-        for (int ib = (int)tid; ib < n_items; ib += NT * U) {
+        for (int rb = ty; rb < n_rows; rb += rpp * U) {
             uint4 v[U];
-            int dst[U], gxs[U], gys[U];
+            int dst[U], gys[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int i = min(ib + u * NT, n_items - 1);
-                const int r = (int)(((float)i + 0.5f) * inv_groups);
-                const int c = (i - __mul24(r, groups)) * 8;
-                gys[u] = wy0 + r;
-                gxs[u] = wx0 + c;
-                dst[u] = (ib + u * NT) < n_items ? __mul24(r, pitch) + c : -1;
-                const int gyc = min(max(gys[u], 0), h - 1), gxc = vec_ok ? min(max(gxs[u], 0), w - 8) : 0;
-                v[u] = vec_ok ? *reinterpret_cast<const uint4*>(plane + (size_t)(uint32_t)(__mul24(gyc, w) + gxc))
-                              : make_uint4(0u, 0u, 0u, 0u);
+                v[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (inside) v[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc, (int)off_w, 0, 0));
+                dst[u] = dst_w;
+                gys[u] = gy_w;
+                off_w += off_step;
+                dst_w += dst_step;
+                gy_w += rpp;
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if (dst[u] < 0) continue;
-                const int gy = gys[u], gx = gxs[u];
-                uint4 o = make_uint4(0u, 0u, 0u, 0u);
-                if (gy >= 0 && gy < h && gx + 8 > 0 && gx < w) {
-                    if (vec_ok && gx >= 0 && gx + 8 <= w) {
-                        o = v[u];
-                    } else {
-                        const uint16_t* row = plane + (size_t)(uint32_t)__mul24(gy, w);
-                        uint32_t e[8];
+                if (!(lane_ok && rb + u * rpp < n_rows)) continue;
+                uint4 o = v[u];
+                if (!inside && !outside && gys[u] >= 0 && gys[u] < h) {  // the level's edge runs through the group (or its rows are not 16-byte aligned)
+                    const uint16_t* row = plane + (size_t)(uint32_t)__mul24(gys[u], w);
+                    uint32_t e[8];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) e[k] = (gx + k >= 0 && gx + k < w) ? (uint32_t)row[gx + k] : 0u;
-                        o = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-                    }
+                    for (int k = 0; k < 8; k++) e[k] = (gx + k >= 0 && gx + k < w) ? (uint32_t)row[gx + k] : 0u;
+                    o = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
                 }
                 *reinterpret_cast<uint4*>(&win[dst[u]]) = o;
             }
         }
     }
-    const unsigned long long kth = thr_key[frame];
     CornerData* out_kp = corners + (size_t)frame * cap;
     uint32_t* out_desc = reinterpret_cast<uint32_t*>(descriptors + (size_t)frame * cap);
     // The stack's tiles as ONE list: entry c of the concatenated segments belongs to tile t (c in [o_t, o_t + n_t)), and a kept
@@ -883,32 +913,22 @@ __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __re
 #pragma unroll
         for (int e = 0; e < 4; e++) pat[e] = tab.pattern[64u * (uint32_t)e + lane];
     }
-    uint32_t n_t[kIBriefStack], o_t[kIBriefStack + 1], before_t[kIBriefStack];
-    o_t[0] = 0;
-#pragma unroll
-    for (int t = 0; t < kIBriefStack; t++) {
-        const size_t sidx = sidx0 + (size_t)min(t, nb - 1) * bg.n_ct[lvl];
-        n_t[t] = t < nb ? min(seg_counts[sidx], bg.seg_cap) : 0u;
-        before_t[t] = seg_before[sidx];
-        o_t[t + 1] = o_t[t] + n_t[t];
-    }
-    const uint32_t n_all = o_t[kIBriefStack];
     if (tid < (uint32_t)kIBriefStack) tile_run[tid] = 0u;
     {
         for (uint32_t c0 = 0; c0 < n_all; c0 += 256u) {
             const uint32_t c = c0 + tid;
-            uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+            uint4 rec = rec_first;
+            float score = score_first;
             bool kept = false;
             uint32_t t = 0;
             if (tid < 256u && c < n_all) {
-#pragma unroll
-                for (int q = 1; q < kIBriefStack; q++) t += c >= o_t[q] ? 1u : 0u;
-                uint32_t ot = o_t[0];
-#pragma unroll
-                for (int q = 1; q < kIBriefStack; q++) ot = t == (uint32_t)q ? o_t[q] : ot;
-                const size_t at = (sidx0 + (size_t)t * bg.n_ct[lvl]) * bg.seg_cap + (c - ot);
-                rec = *reinterpret_cast<const uint4*>(&segments[at]);
-                kept = kth == 0ull || select_key(rec, seg_scores[at]) >= kth;
+                t = tile_of(c);
+                if (c0 != 0u) {  // (the first chunk's records were fetched in front of the window)
+                    const size_t at = entry_of(c, t);
+                    rec = *reinterpret_cast<const uint4*>(&segments[at]);
+                    score = seg_scores[at];
+                }
+                kept = kth == 0ull || select_key(rec, score) >= kth;
             }
             const uint64_t mask = __ballot(kept);
             __syncthreads();  // previous chunk's kept_rec consumed; (first chunk) the window is complete
