@@ -124,7 +124,7 @@ struct OrbProgram {
     unsigned long long* d_stamps = nullptr;  // TINYORB_STAMPS=1: phase cycle sums of k_front (2 x 16 slots)
 
     // host staging of the single-frame API (orb.rs:216-218 staging buffers)
-    uint32_t* h_count = nullptr;      // pinned: [0] the raw counter of the last single-frame extract, [16] its completion sequence number (own cache line)
+    uint32_t* h_count = nullptr;      // pinned: [0] the raw counter of the last single-frame extract, [kSingleDoneWord] its completion sequence number (own cache line)
     uint32_t* d_single_done = nullptr;  // workgroups of k_brief_one that have finished (the last one publishes the sequence number and clears it)
     uint32_t single_seq = 0;
     CornerData* h_corners = nullptr;
@@ -1164,8 +1164,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         CREATE_TRY(hipMalloc(&p->d_stamps, 32 * sizeof(unsigned long long)));
         CREATE_TRY(hipMemset(p->d_stamps, 0, 32 * sizeof(unsigned long long)));
     }
-    CREATE_TRY(hipHostMalloc(&p->h_count, 32 * sizeof(uint32_t), hipHostMallocDefault));
-    memset(p->h_count, 0, 32 * sizeof(uint32_t));
+    CREATE_TRY(hipHostMalloc(&p->h_count, kSingleCountWords * sizeof(uint32_t), hipHostMallocDefault));
+    memset(p->h_count, 0, kSingleCountWords * sizeof(uint32_t));
     CREATE_TRY(hipMalloc(&p->d_single_done, sizeof(uint32_t)));
     CREATE_TRY(hipMemset(p->d_single_done, 0, sizeof(uint32_t)));
     CREATE_TRY(hipHostMalloc(&p->h_corners, cap * sizeof(CornerData), hipHostMallocDefault));
@@ -1320,7 +1320,7 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
         // 20 ms (a faulted kernel never publishes) and a stream synchronisation reports what happened.
         bool seen = false;
         if (!p->profiling && !getenv("TINYORB_SINGLE_SYNC")) {
-            const volatile uint32_t* const done = p->h_count + 16;
+            const volatile uint32_t* const done = p->h_count + kSingleDoneWord;
             const auto t0 = std::chrono::steady_clock::now();
             for (uint32_t spins = 0; !(seen = __atomic_load_n(done, __ATOMIC_ACQUIRE) == seq); spins++)
                 if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;

@@ -444,6 +444,9 @@ __global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ b
 // keypoints that are not flat (one memory round trip each, per wave) spread over many workgroups.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBriefOneChunk = 64;
+// the pinned counter block of the single-frame call: word 0 = the raw counter (orb.rs:550-556), word kSingleDoneWord = the completion
+// sequence number, in a cache line of its own (words 1..10: k_brief_one's stamps in the diagnostic build)
+constexpr int kSingleCountWords = 32, kSingleDoneWord = 16;
 constexpr int kBriefOneThreads = 512;  // the flat keypoints take the first wave, the others one wave each: eight of those per turn
 __global__ __launch_bounds__(kBriefOneThreads) void k_brief_one(const uint16_t* __restrict__ blur, const uint16_t* __restrict__ blur_rowc, Pyramid pyr,
                                                    BriefTGeom bg, const uint32_t* __restrict__ seg_counts,
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(kBriefOneThreads) void k_brief_one(const uint16_t* 
         const uint32_t prev = __hip_atomic_fetch_add(done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev + 1u == gridDim.x) {
             __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(host_count + 16, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_count + kSingleDoneWord, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
