@@ -965,6 +965,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 for (const void* f : fronts)
                     CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_pair<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
+                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_pair<8, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
             }
         }
     }
@@ -1271,10 +1272,10 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
         // Three launches per frame: one k_front per level, then k_brief_one -- slot prefix, both BRIEF kernels and the
         // write to host staging in one (a dependent launch costs 6-10 us whatever it does, and this call is the
         // reference's only shape).
-        // Levels 0 and 1 in ONE launch when level 1 can build its rows from the frame (k_front_pair): RGBA input, level 1 an
+        // Levels 0 and 1 in ONE launch when level 1 can build its rows from the frame (k_front_pair): RGBA or Y8 input, level 1 an
         // exact half of a level 0 whose width is a multiple of 8, both on full-width bands of 8 rows (the latency shape).
         const Pyramid& py = p->pyr;
-        const bool pair_ok = py.depth >= 2u && !p->input_y8 && py.w[0] == 2u * py.w[1] && py.h[0] == 2u * py.h[1] && (py.w[0] & 7u) == 0u &&
+        const bool pair_ok = py.depth >= 2u && py.w[0] == 2u * py.w[1] && py.h[0] == 2u * py.h[1] && (py.w[0] & 7u) == 0u &&
                              p->tile_w_lvl[0] == 0u && p->tile_w_lvl[1] == 0u && p->band_rows_lvl[0] == 8u && p->band_rows_lvl[1] == 8u &&
                              !p->d_stamps && !getenv("TINYORB_SINGLE_SERIAL");
         if (pair_ok) {
@@ -1296,8 +1297,12 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
             if (lds > p->max_lds) return fail(p, ORB_EINVAL, "internal: k_front_pair needs %u bytes of LDS", lds);
             {
                 LaunchScope ls(p, s, KID_FUSED_L0);
-                hipLaunchKernelGGL((k_front_pair<8, 8>), dim3(g[0].n_bands + g[1].n_bands), dim3(kFrontThreadsL0), lds, s, p->d_input,
-                                   p->frame_bytes, p->d_gray, p->d_blur, p->d_blur_rowc, py, g[0], g[1], p->threshold, p->d_seg_counts, p->d_seg);
+                if (p->input_y8)
+                    hipLaunchKernelGGL((k_front_pair<8, 8, true>), dim3(g[0].n_bands + g[1].n_bands), dim3(kFrontThreadsL0), lds, s, p->d_input,
+                                       p->frame_bytes, p->d_gray, p->d_blur, p->d_blur_rowc, py, g[0], g[1], p->threshold, p->d_seg_counts, p->d_seg);
+                else
+                    hipLaunchKernelGGL((k_front_pair<8, 8>), dim3(g[0].n_bands + g[1].n_bands), dim3(kFrontThreadsL0), lds, s, p->d_input,
+                                       p->frame_bytes, p->d_gray, p->d_blur, p->d_blur_rowc, py, g[0], g[1], p->threshold, p->d_seg_counts, p->d_seg);
             }
             if (py.depth > 2u)
                 if (int rc = run_fused_range(p, p->d_input, 0, 1, s, false, 2u)) return rc;

@@ -264,7 +264,7 @@ __device__ __forceinline__ void segment_append(bool is_corner, uint32_t x, uint3
 // UA: the general level-0 variant (RGBA or Y8) -- a width that is not a multiple of 4 (rows only 4-byte aligned: texel by texel loads, a
 //     partial last quad) and/or a level 1 that is not an exact half (FrontGeom::store_grey: the band also stores its grey rows).
 // TILED: column tiles (FrontGeom::tiled).  With TILED = false every tile expression below folds to the full-width form.
-// SRC (level 1 only): the band builds its grey rows from the RGBA frame itself -- luminance of the 2x2 blocks, then the mip
+// SRC (level 1 only): the band builds its grey rows from the frame itself (RGBA, or Y8 bytes through the typed buffer) -- luminance of the 2x2 blocks, then the mip
 //     (CRD-1..4, the arithmetic of phases A and C0) -- instead of reading the mip level 0's launch writes: the two launches
 //     of a single frame then do not depend on each other (orb_extract_corners runs them side by side).
 // NTO: threads of the workgroup when they are not the level's usual number (k_front_pair runs level 1 on 1024).
@@ -293,17 +293,17 @@ __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4)
 // Levels 0 and 1 of ONE frame in one launch (the reference's call shape, orb.rs:469-557: one blocking call per frame, where a
 // dependent launch costs more than the work it starts): blocks [0, n0) are level 0's bands, the rest level 1's, which build
 // their grey rows from the frame itself (SRC) and so wait for nothing.  1024 threads for both.
-template <int RB0, int RB1>
+template <int RB0, int RB1, bool Y8 = false>
 __global__ __launch_bounds__(kFrontThreadsL0) void k_front_pair(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                               uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                                               uint16_t* __restrict__ blur_rowc, Pyramid pyr, FrontGeom geo0,
                                                               FrontGeom geo1, float thr, uint32_t* __restrict__ seg_counts,
                                                               CornerData* __restrict__ segments) {
     if (blockIdx.x < geo0.n_bands)
-        front_body<true, false, RB0, false, false, false>(blockIdx.x, frames, frame_bytes, gray, blur, blur_rowc, pyr, geo0, thr, seg_counts, segments);
+        front_body<true, Y8, RB0, false, false, false>(blockIdx.x, frames, frame_bytes, gray, blur, blur_rowc, pyr, geo0, thr, seg_counts, segments);
     else
-        front_body<false, false, RB1, false, false, true, kFrontThreadsL0>(blockIdx.x - geo0.n_bands, frames, frame_bytes, gray, blur, blur_rowc,
-                                                                          pyr, geo1, thr, seg_counts, segments);
+        front_body<false, Y8, RB1, false, false, true, kFrontThreadsL0>(blockIdx.x - geo0.n_bands, frames, frame_bytes, gray, blur, blur_rowc,
+                                                                       pyr, geo1, thr, seg_counts, segments);
 }
 
 // Band slots of a frame: one per kFrontRows-row band per level, in level order.
