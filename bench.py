@@ -53,6 +53,10 @@ def parse_args(argv=None):
                     help="N > 1: what the gather to rank 0 carries -- 40-byte transport records packed back to back, or "
                          "the 48-byte record slabs padded to the fullest frame (round 1's form); none = the results stay "
                          "sharded on their GPUs (a consumer that runs where the frames were extracted): kernels only")
+    ap.add_argument("--force-collate", action="store_true",
+                    help="N = 1: run the N > 1 collate all the same -- process group of one rank (\"nccl\" = RCCL), counters "
+                         "all_gathered, records through the exact-size all_to_all (a send to itself), expansion on rank 0 -- "
+                         "so that a one-GPU box executes the RCCL path the multi-GPU runs take")
     ap.add_argument("--staged", action="store_true", help="force the one-kernel-per-stage pipeline")
     ap.add_argument("--input", choices=("rgba", "y8"), default="rgba",
                     help="rgba = the reference's input (the headline); y8 = the opt-in one-byte-per-pixel variant "
@@ -269,10 +273,17 @@ def run_rank(args):
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     backend = None
-    if world > 1:
+    collating = world > 1 or args.force_collate  # every batch goes through the collate to rank 0
+    if collating:
         # "nccl" is RCCL on ROCm.  TINYORB_DIST_BACKEND=gloo only exists to rehearse the N > 1 code path
         # on a one-GPU box (several ranks sharing device 0, which RCCL refuses).
         backend = os.environ.get("TINYORB_DIST_BACKEND", "nccl")
+        if world == 1 and "MASTER_ADDR" not in os.environ:  # --force-collate without a launcher: a group of one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -306,57 +317,43 @@ def run_rank(args):
         views.append((node.as_tensor(d_counts, (B,), "<i4", dev), node.as_tensor(d_corners, (B, MAX_FEATURES, 4), "<i4", dev),
                       node.as_tensor(d_desc, (B, MAX_FEATURES, 8), "<i4", dev)))
     prog.batch_select_output(0)
-    state = {"k": 0, "pending": None, "gathered_bytes": 0}
+    state = {"k": 0, "pending": None, "gathered_bytes": 0, "expected_bytes": 0}
     # --in-flight n (N = 1): n programs (each with its own planes and lists) on n streams, batch k on program k % n
-    fly = max(1, args.in_flight) if world == 1 else 1
+    fly = max(1, args.in_flight) if not collating else 1
     fly_progs = [prog] + [orb.OrbProgram(cfg).init() for _ in range(fly - 1)]
     fly_streams = [torch.cuda.Stream(device=dev) for _ in range(fly)] if fly > 1 else []
     free = [None, None]
-    compute_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    compute_stream = torch.cuda.Stream(device=dev) if collating else None
+    comm_stream = torch.cuda.Stream(device=dev) if collating else None
 
     # N > 1, transport collate: per output set a buffer for this rank's packed 40-byte records
-    transport = world > 1 and args.collate == "transport"
+    transport = collating and args.collate == "transport"
     tbuf = [torch.empty((B * MAX_FEATURES, node.TRANSPORT_WORDS), dtype=torch.int32, device=dev) for _ in range(2)] if transport else None
 
-    # N > 1, transport form: the lagged collator (no host stall per batch) and, on rank 0, the two record arrays of a
-    # whole job per output set, allocated once
+    # N > 1, transport form: the lagged exact-size collator (no host stall per batch, no byte too many) and, on rank 0,
+    # the two record arrays of a whole job per output set, allocated once
     collator = node.TransportCollator(B, MAX_FEATURES, dev) if transport else None
     all_records = world * B * MAX_FEATURES
     corners_all = [torch.empty((all_records, 4), dtype=torch.int32, device=dev) for _ in range(2)] if transport and rank == 0 else None
     desc_all = [torch.empty((all_records, 8), dtype=torch.int32, device=dev) for _ in range(2)] if transport and rank == 0 else None
     state["ticket"] = None
     state["host_s"] = 0.0
-    state["regathers"] = 0
 
-    def expand(info, merged, stride):
-        """Rank 0: transport records of every rank -> the reference's two record arrays, frames of the job in order."""
-        totals = info["totals"]
-        first = np.concatenate([[0], np.cumsum(totals)])
-        sl = info["slot"]
-        prog.unpack_transport(merged.data_ptr(), [r * stride for r in range(world)], totals, first[:-1],
-                              corners_all[sl].data_ptr(), desc_all[sl].data_ptr(), stream=comm_stream.cuda_stream)
-        state["last"] = (sl, torch.from_numpy(info["counts_all"]), first, corners_all[sl], desc_all[sl])
-
-    def finish_ticket():
-        """Batch k-1, one batch later: its counters are on the host; expand it on rank 0.  Should the lagged size of its
-        gather have been too small (the frames changed a lot from one batch to the next), gather it again, exactly."""
+    def exchange_ticket():
+        """Batch k-1, one batch later: its counters are on the host, so its records move now, exactly sized, and rank 0
+        expands them into the reference's two record arrays, frames of the job in order."""
         if state["ticket"] is None:
             return
-        info = collator.finish(state["ticket"])
+        before = collator.bytes_exchanged
+        info = collator.exchange(state["ticket"])
         state["ticket"] = None
-        if info["complete"]:
-            if rank == 0:
-                expand(info, info["merged"], collator.s_cap)
-            return
-        state["regathers"] += 1
-        sl = info["slot"]
-        out = node.collate_transport_to_root(views[sl][0], tbuf[sl], MAX_FEATURES)
-        if out is not None:
-            _, totals, merged = out
-            info["totals"] = totals
-            expand(info, merged, merged.shape[1])
-            state["gathered_bytes"] += merged.numel() * 4
+        state["gathered_bytes"] += collator.bytes_exchanged - before
+        state["expected_bytes"] += 4 * node.TRANSPORT_WORDS * sum(info["totals"])
+        if rank == 0:
+            sl, first = info["slot"], np.asarray(info["first"], dtype=np.uint64)
+            prog.unpack_transport(info["merged"].data_ptr(), first[:-1], info["totals"], first[:-1],
+                                  corners_all[sl].data_ptr(), desc_all[sl].data_ptr(), stream=comm_stream.cuda_stream)
+            state["last"] = (sl, torch.from_numpy(info["counts_all"]), first, corners_all[sl], desc_all[sl])
 
     def collate(pending):
         slot, done, nb = pending
@@ -364,13 +361,11 @@ def run_rank(args):
         t_host = time.perf_counter()
         with torch.cuda.stream(comm_stream):
             if transport:
-                finish_ticket()  # the batch before: sizes this batch's gather
+                exchange_ticket()  # the batch before: its counters are on the host, its records move now
                 comm_stream.wait_event(done)  # the kernels that wrote this output set
                 cs = comm_stream.cuda_stream
                 prog.batch_pack_transport(slot, B, tbuf[slot].data_ptr(), B * MAX_FEATURES, stream=cs)
-                before = collator.bytes_gathered
                 state["ticket"] = collator.submit(slot, counts_t, tbuf[slot])
-                state["gathered_bytes"] += collator.bytes_gathered - before
             elif args.collate == "padded":
                 comm_stream.wait_event(done)
                 out = node.collate_to_root(counts_t, corners_t, desc_t, MAX_FEATURES)
@@ -379,7 +374,7 @@ def run_rank(args):
             else:  # none: nothing leaves the GPU
                 comm_stream.wait_event(done)
             free[slot] = torch.cuda.Event()
-            free[slot].record(comm_stream)  # the gather has read this output set
+            free[slot].record(comm_stream)  # the pack (transport) or the gather has read this output set
         state["host_s"] += time.perf_counter() - t_host
 
     def step():
@@ -390,7 +385,7 @@ def run_rank(args):
         same number of collates (an empty shard tail still takes part with zero counts)."""
         for b0, nb in batches:
             ptr = frames_t.data_ptr() + b0 * frame_bytes
-            if world == 1:
+            if not collating:
                 if fly > 1 and not state.get("serial"):
                     i = state["k"] % fly
                     fly_progs[i].extract_batch_device(ptr, nb, stream=fly_streams[i].cuda_stream)
@@ -414,18 +409,18 @@ def run_rank(args):
             state["k"] += 1
 
     def flush():
-        if world > 1 and state["pending"] is not None:
+        if collating and state["pending"] is not None:
             collate(state["pending"])
             state["pending"] = None
         if transport:
             with torch.cuda.stream(comm_stream):
-                finish_ticket()
+                exchange_ticket()
 
     def fence():
         flush()
         prog.batch_sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if collating:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -436,7 +431,7 @@ def run_rank(args):
             step()
         fence()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
+        if collating:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -472,7 +467,7 @@ def run_rank(args):
     # strong mode every batch is visited once more, outside any timed region)
     stored_local, counts_first = 0.0, None
     for b0, nb in batches:
-        if len(batches) > 1 or world > 1:
+        if len(batches) > 1 or collating:
             prog.batch_select_output(0)
             prog.extract_batch_device(frames_t.data_ptr() + b0 * frame_bytes, nb)
         c = prog.batch_counts(nb)
@@ -480,27 +475,27 @@ def run_rank(args):
             counts_first = c.copy()
         stored_local += float(np.minimum(c, MAX_FEATURES).sum())
     kp = torch.tensor([stored_local], dtype=torch.float64, device=dev)
-    if world > 1:
+    if collating:
         dist.all_reduce(kp, op=dist.ReduceOp.SUM)
     kp_per_step = float(kp.item())
 
     # collate alone (N > 1): the same gather, serialised, to price the links into rank 0
     collate_info = None
-    if world > 1:
+    if collating:
         fence()
         prog.batch_select_output(0)
         prog.extract_batch_device(frames_t.data_ptr(), batches[0][1] if batches else 0, stream=compute_stream.cuda_stream)
         done = torch.cuda.Event()
         done.record(compute_stream)
         fence()
-        state["gathered_bytes"] = 0
+        state["gathered_bytes"] = state["expected_bytes"] = 0
         n_rep = 10
         t0 = time.perf_counter()
         for _ in range(n_rep):
             collate((0, done, batches[0][1]))
         if transport:
             with torch.cuda.stream(comm_stream):
-                finish_ticket()
+                exchange_ticket()
         torch.cuda.synchronize()
         dist.barrier()
         dt = time.perf_counter() - t0
@@ -520,17 +515,22 @@ def run_rank(args):
         collate_info = {"form": args.collate, "bytes_per_keypoint": 40 if transport else 48, "root_check": root_check,
                         "bytes_gathered_per_batch": per, "bytes_from_peers_per_batch": from_peers,
                         "ms_alone_per_batch": dt / n_rep * 1e3, "gbs_into_root": from_peers / (dt / n_rep) / 1e9,
-                        "gbs_per_link": from_peers / (dt / n_rep) / 1e9 / (world - 1),
+                        "gbs_per_link": from_peers / (dt / n_rep) / 1e9 / max(world - 1, 1),
                         "bytes_gathered_per_step_timed": gathered_per_step, "backend": backend,
-                        "host_ms_per_batch": collate_host_ms, "regathers": state["regathers"],
-                        "how": ("lagged: the gather of batch k is sized by batch k-1's totals (+25 %), the counters are read on the "
-                                "host one batch late; buffers allocated once" if transport else "padded slabs")}
+                        "host_ms_per_batch": collate_host_ms,
+                        "exact": bool(transport and state["gathered_bytes"] == state["expected_bytes"]),
+                        "how": ("exact and lagged: batch k's counters are all_gathered and copied to pinned host memory when it "
+                                "is packed; one batch later every rank reads the same totals S_r and one all_to_all_single with "
+                                "split sizes moves exactly sum(S_r) x 40 bytes into rank 0; buffers allocated once"
+                                if transport else "padded slabs")}
+        if world == 1:
+            collate_info["forced"] = "N = 1 with --force-collate: the group has one rank, the exchange is a send to itself"
 
     # device-resident in -> host-resident out (N = 1): every batch is packed on the device (orb_batch_pack) and fetched
     # into pinned host memory by two exact-size DMA copies on a second stream (orb_batch_fetch) while the next batch
     # computes; two output sets, two host buffers
     host_out = None
-    if world == 1 and not args.no_host_out and batches:
+    if world == 1 and not collating and not args.no_host_out and batches:
         copy_stream = torch.cuda.Stream(device=dev)
         cs = torch.cuda.current_stream(dev)
         hbs = [orb.HostBatch(B, B * MAX_FEATURES) for _ in range(2)]
@@ -602,7 +602,8 @@ def run_rank(args):
                        "pipeline": "staged" if args.staged else "default",
                        "batches_in_flight": fly,
                        "collate": ("none: results stay sharded on their GPUs" if args.collate == "none" else
-                                   "RCCL gather of every batch to rank 0, overlapped with the next batch's kernels") if world > 1 else "none (1 GPU)"},
+                                   "RCCL exchange of every batch to rank 0 (exact sizes), overlapped with the next batch's kernels")
+                                  if collating else "none (1 GPU)"},
             "repeats_ms_per_step": [r / args.steps * 1e3 for r in repeats],
             "min_ms_per_step": min(repeats) / args.steps * 1e3, "max_ms_per_step": max(repeats) / args.steps * 1e3,
             "mkeypoints_per_s": kp_per_step * args.steps / elapsed / 1e6,
@@ -625,7 +626,7 @@ def run_rank(args):
                                                                         initial_threshold=THRESHOLD, device=dev_index))
         print(json.dumps(out), flush=True)
     prog.close()
-    if world > 1:
+    if collating:
         dist.barrier()
         dist.destroy_process_group()
 

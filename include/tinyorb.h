@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TINYORB_ABI_VERSION 3
+#define TINYORB_ABI_VERSION 4
 
 /* status codes (the reference panics instead: orb.rs:553 unwrap, label look-ups) */
 #define ORB_OK 0
@@ -227,7 +227,10 @@ void *orb_program_stream(OrbProgram *p);
 typedef struct OrbNode OrbNode;
 /* options->device is ignored (devices[] decides); options->max_batch is the largest shard of one device;
  * ORB_FLAG_DOUBLE_OUTPUT is implied.  ORB_FLAG_INPUT_Y8 nodes take one byte per pixel, as their programs do.
- * TINYORB_NODE_LOOPBACK=1 in the environment (tests): devices may repeat and the exchange uses device copies, not RCCL. */
+ * TINYORB_NODE_LOOPBACK in the environment (tests): 1 = devices may repeat and the exchange uses device copies, not RCCL;
+ * 2 = every rank on ONE device and the exchange through RCCL all the same: a one-rank communicator over that device, each
+ * rank's records sent to the communicator's own rank (ncclSend + ncclRecv in one group; with n_devices == 1 rank 0's own
+ * records take that way too) -- how a one-GPU box executes the RCCL code. */
 int orb_node_create(const int *devices, int n_devices, const OrbConfig *config, const OrbOptions *options, OrbNode **out);
 void orb_node_destroy(OrbNode *node);
 const char *orb_node_last_error(const OrbNode *node);
@@ -256,6 +259,12 @@ int orb_node_collate_end(OrbNode *node, uint32_t *counts, uint64_t *offsets, voi
 int orb_node_collate(OrbNode *node, uint32_t *counts, uint64_t *offsets, void **corners_dev, void **descriptors_dev);
 /* Jobs extracted and not yet ended (0..2). */
 int orb_node_pending(const OrbNode *node);
+/* How the records of ranks >= 1 reach the first device: "rccl" (ncclSend/ncclRecv between devices), "rccl-self"
+ * (TINYORB_NODE_LOOPBACK=2), "copies" (TINYORB_NODE_LOOPBACK=1) or "none" (one device, nothing to exchange); and the
+ * number of ncclSend + ncclRecv pairs enqueued so far.  A failure in the middle of an enqueue sequence (HIP or RCCL) takes
+ * the node out of service: every later extract / collate returns ORB_ESTATE -- destroy it and create a new one. */
+const char *orb_node_exchange_backend(const OrbNode *node);
+uint64_t orb_node_rccl_pairs(const OrbNode *node);
 /* Copies the records of the job ended last to the host; capacity in records. */
 int orb_node_read_collated(OrbNode *node, CornerData *corners, CornerDescriptor *descriptors, size_t capacity);
 

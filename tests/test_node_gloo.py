@@ -165,6 +165,23 @@ def test_transport_collate_world1():
         dist.destroy_process_group()
 
 
+def _collator_batches(world, B):
+    """Five batches of very different sizes (an empty rank, a full one, a frame over the capacity)."""
+    rng = np.random.RandomState(7)
+    return [rng.randint(0, 4, size=(world, B)), rng.randint(0, 3, size=(world, B)), np.full((world, B), 9),
+            np.stack([np.zeros(B, dtype=np.int64)] + [rng.randint(0, 5, size=B) for _ in range(world - 1)]),
+            rng.randint(0, 9, size=(world, B))]
+
+
+def _collator_records(k, rank, total, rows):
+    """Transport records of batch k on `rank`: word 0 numbers them, word 9 mixes batch, rank and index; -1 behind them."""
+    rec = torch.full((rows, 10), -1, dtype=torch.int32)
+    idx = torch.arange(total, dtype=torch.int32)
+    rec[:total, 0] = idx + 1000 * k + 100 * rank
+    rec[:total, 9] = idx * 7 + k * 31 + rank
+    return rec
+
+
 def _worker_collator(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -172,58 +189,74 @@ def _worker_collator(rank, world, port, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tinyslam_amd import node
     B, cap = 3, 8
-    col = node.TransportCollator(B, cap, "cpu", headroom=1.0, slack=0)
-    rng = np.random.RandomState(7)
-    # four batches; the third holds far more than the second did: its lagged size is too small and says so
-    all_counts = [rng.randint(0, 4, size=(world, B)), rng.randint(0, 3, size=(world, B)),
-                  np.full((world, B), 9), rng.randint(0, 5, size=(world, B))]
+    col = node.TransportCollator(B, cap, "cpu")
+    all_counts = _collator_batches(world, B)
+    bufs = [None, None]  # the caller's two transport buffers, reused every other batch as in bench.py
     log, pending = [], None
     for k, cnt in enumerate(all_counts):
+        if pending is not None:  # batch k-1: its counters went to the host a whole batch ago; its records move now
+            info = col.exchange(pending)
+            log.append((k - 1, info, None if info["merged"] is None else info["merged"].numpy().copy(), col.bytes_exchanged))
         mine = torch.tensor(cnt[rank], dtype=torch.int32)
         total = int(np.minimum(cnt[rank], cap).sum())
-        records = torch.full((B * cap, 10), -1, dtype=torch.int32)
-        records[:total] = (torch.arange(total, dtype=torch.int32) + 1000 * k + 100 * rank).unsqueeze(1)
-        if pending is not None:  # batch k-1: its counters went to the host a whole batch ago
-            log.append((k - 1, col.finish(pending)))
-        pending = col.submit(k & 1, mine, records)
-    log.append((len(all_counts) - 1, col.finish(pending)))
+        bufs[k & 1] = _collator_records(k, rank, total, B * cap)  # overwrites batch k-2's records: they have been exchanged
+        pending = col.submit(k & 1, mine, bufs[k & 1])
+    info = col.exchange(pending)
+    log.append((len(all_counts) - 1, info, None if info["merged"] is None else info["merged"].numpy().copy(), col.bytes_exchanged))
     if rank == 0:
         out = {}
-        for k, info in log:
+        for k, info, merged, nbytes in log:
             out["counts%d" % k] = info["counts_all"]
             out["totals%d" % k] = np.array(info["totals"])
-            out["complete%d" % k] = np.array(info["complete"])
-            out["s_used%d" % k] = np.array(info["s_used"])
-        # the landing area of the last two batches is still intact (two slots)
-        for k, info in log[-2:]:
-            out["merged%d" % k] = info["merged"].numpy().copy()
+            out["first%d" % k] = np.array(info["first"])
+            out["merged%d" % k] = merged
+            out["bytes%d" % k] = np.array(nbytes)
         np.savez(out_path, **out)
+    else:
+        assert all(m is None for _, _, m, _ in log) and col.bytes_exchanged == 0
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_lagged_transport_collator_world2(tmp_path):
-    """TransportCollator over gloo: the gather of batch k is sized by batch k-1's totals, the counters are read one batch
-    late, an undersized gather is reported (never silently truncated), buffers are reused across batches."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_exact_lagged_transport_collator(tmp_path, world):
+    """TransportCollator over gloo: the counters of batch k are read one batch late and size its exchange EXACTLY -- rank 0
+    receives sum(S_r) records, back to back in rank order, record for record what the ranks held, whatever batches k-1
+    and k+1 looked like (empty ranks, full ranks, a frame over the capacity); buffers are reused across batches."""
     out_path = str(tmp_path / "collator.npz")
-    mp.spawn(_worker_collator, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    mp.spawn(_worker_collator, args=(world, _free_port(), out_path), nprocs=world, join=True)
     got = np.load(out_path)
-    rng = np.random.RandomState(7)
-    B, cap, world = 3, 8, 2
-    all_counts = [rng.randint(0, 4, size=(world, B)), rng.randint(0, 3, size=(world, B)),
-                  np.full((world, B), 9), rng.randint(0, 5, size=(world, B))]
-    s_fix = B * cap
+    B, cap = 3, 8
+    all_counts = _collator_batches(world, B)
+    bytes_so_far = 0
     for k, cnt in enumerate(all_counts):
         assert np.array_equal(got["counts%d" % k], cnt.reshape(-1))
         totals = np.minimum(cnt, cap).sum(axis=1)
         assert np.array_equal(got["totals%d" % k], totals)
-        assert int(got["s_used%d" % k]) == s_fix
-        assert bool(got["complete%d" % k]) == (totals.max() <= s_fix)
-        s_fix = min(B * cap, max(int(totals.max()), 1))
-    assert bool(got["complete0"]) and bool(got["complete1"]) and not bool(got["complete2"])
-    for k in (2, 3):
-        totals = np.minimum(all_counts[k], cap).sum(axis=1)
+        assert np.array_equal(got["first%d" % k], np.concatenate([[0], np.cumsum(totals)]))
+        merged = got["merged%d" % k]
+        assert merged.shape == (int(totals.sum()), 10)  # not a record more
+        bytes_so_far += int(totals.sum()) * 40
+        assert int(got["bytes%d" % k]) == bytes_so_far  # exactly sum(S_r) x 40 bytes per batch
+        at = 0
         for r in range(world):
-            n = min(int(totals[r]), int(got["s_used%d" % k]))
-            want = np.arange(n, dtype=np.int32) + 1000 * k + 100 * r
-            assert np.array_equal(got["merged%d" % k][r, :n, 0], want)
+            want = _collator_records(k, r, int(totals[r]), int(totals[r])).numpy()
+            assert np.array_equal(merged[at:at + int(totals[r])], want), (k, r)
+            at += int(totals[r])
+
+
+def test_exact_collator_world1():
+    """A group of one rank: the exchange is a send to itself (what `bench.py --gpus 1 --force-collate` runs over RCCL)."""
+    from tinyslam_amd import node
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    try:
+        col = node.TransportCollator(3, 8, "cpu")
+        rec = _collator_records(0, 0, 14, 24)
+        t = col.submit(0, torch.tensor([3, 11, 3], dtype=torch.int32), rec)  # 11 is cut to the capacity 8
+        info = col.exchange(t)
+        assert info["totals"] == [14] and info["first"] == [0, 14] and torch.equal(info["merged"], rec[:14])
+        assert col.bytes_exchanged == 14 * 40
+        with pytest.raises(ValueError):  # fewer records than the counters say: refused, never padded
+            col.exchange(col.submit(1, torch.tensor([8, 8, 8], dtype=torch.int32), rec[:10]))
+    finally:
+        dist.destroy_process_group()

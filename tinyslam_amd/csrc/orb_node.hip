@@ -18,6 +18,12 @@
 // Buffers: two output sets and two wire buffers per device (slot k % 2), three collated result buffers on rank 0
 // (k % 3: a result stays valid while the next two jobs are extracted), all ordered by events.
 // librccl is opened with dlopen on first use, so a single-GPU user of libtinyorb never loads it.
+//
+// Three ways to move the records (NodeXchg): RCCL between distinct devices (the product), device copies between ranks
+// that share a device (TINYORB_NODE_LOOPBACK=1, tests), and RCCL on ONE device (TINYORB_NODE_LOOPBACK=2): a one-rank
+// communicator over the device, every rank's transport records sent to the communicator's own rank by ncclSend + ncclRecv
+// inside the same group the multi-device path uses -- with n == 1 rank 0's own records take that way too --, so that a
+// one-GPU box executes the RCCL code (dlopen, symbols, communicator, grouped point-to-point, stream ordering).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -49,6 +55,8 @@ struct Rccl {
 
 thread_local std::string g_node_create_error;
 
+enum NodeXchg { XCHG_RCCL = 0, XCHG_COPIES = 1, XCHG_RCCL_SELF = 2 };
+
 constexpr int kSlots = 2;      // output sets / wire buffers / pinned counter sets
 constexpr int kCollSlots = 3;  // collated result buffers on rank 0
 
@@ -73,10 +81,13 @@ struct OrbNode {
     size_t frame_bytes = 0;
     Rccl rccl;
     std::vector<ncclComm_t> comms;
-    bool loopback = false;  // TINYORB_NODE_LOOPBACK=1: the exchange runs as device copies, not RCCL (see orb_node_create)
+    int xchg = XCHG_RCCL;   // how the records move (NodeXchg; TINYORB_NODE_LOOPBACK, see orb_node_create)
+    int first_sender = 1;   // ranks [first_sender, n) pack transport records and send them; 0 only with XCHG_RCCL_SELF and n == 1
+    uint64_t rccl_pairs = 0;  // ncclSend + ncclRecv pairs enqueued so far
+    bool failed = false;      // an enqueue failed half-way: the pipeline state is unknown, every further job is refused
     // per slot (job k uses slot k % kSlots) and rank
-    std::vector<void*> d_wire[kSlots];         // 40-byte transport records (tinyorb.h): rank r >= 1 its own [max_batch * cap]
-                                               // to send, rank 0 the received ones [(n - 1) * max_batch * cap] (null when n == 1)
+    std::vector<void*> d_send[kSlots];         // 40-byte transport records (tinyorb.h) of a sending rank [max_batch * cap]; null for the others
+    void* d_recv[kSlots] = {nullptr, nullptr}; // rank 0: the received ones [(n - first_sender) * max_batch * cap] (null without senders)
     std::vector<uint32_t*> h_counts[kSlots];   // pinned [max_batch]: raw per-frame counters of the rank's shard
     std::vector<uint64_t*> h_offsets[kSlots];  // pinned [max_batch + 1]: exclusive prefix of the stored counts
     std::vector<hipEvent_t> ev_kernels[kSlots], ev_pack[kSlots], ev_xchg[kSlots];
@@ -148,13 +159,16 @@ int load_rccl(OrbNode* node) {
 }
 
 int ensure_comms(OrbNode* node) {
-    if (node->loopback || node->n == 1 || !node->comms.empty()) return ORB_OK;
+    if (node->xchg == XCHG_COPIES || !node->comms.empty()) return ORB_OK;
+    if (node->xchg == XCHG_RCCL && node->n == 1) return ORB_OK;  // nothing to exchange: a single-GPU node never loads librccl
     if (int rc = load_rccl(node)) return rc;
-    node->comms.assign(node->n, nullptr);
-    ncclResult_t r = node->rccl.CommInitAll(node->comms.data(), node->n, node->devices.data());
+    // XCHG_RCCL_SELF: every rank lives on devices[0]; ONE communicator of one rank over it, all transfers are sends to self
+    const int n_comm = node->xchg == XCHG_RCCL_SELF ? 1 : node->n;
+    node->comms.assign(n_comm, nullptr);
+    ncclResult_t r = node->rccl.CommInitAll(node->comms.data(), n_comm, node->devices.data());
     if (r != ncclSuccess) {
         node->comms.clear();
-        return nfail(node, ORB_EHIP, "ncclCommInitAll over %d devices failed: %s", node->n,
+        return nfail(node, ORB_EHIP, "ncclCommInitAll over %d device(s) failed: %s", n_comm,
                      node->rccl.GetErrorString ? node->rccl.GetErrorString(r) : "rccl error");
     }
     return ORB_OK;
@@ -186,10 +200,32 @@ T* dev_ptr(T* host) {
     return static_cast<T*>(d);
 }
 
+// After a failure in the middle of an enqueue sequence the events, output sets and wire buffers no longer match what
+// the job queue says.  Drain every stream, drop the outstanding jobs and refuse further ones: the caller cannot retry
+// into a half-enqueued job (destroy the node and create a new one).
+int poison(OrbNode* node, int rc) {
+    node->failed = true;
+    for (int r = 0; r < node->n; r++) {
+        if (hipSetDevice(node->devices[r]) != hipSuccess) continue;
+        (void)hipStreamSynchronize(node->streams[r]);
+        (void)hipStreamSynchronize(node->pack_streams[r]);
+        (void)hipStreamSynchronize(node->xchg_streams[r]);
+    }
+    (void)hipGetLastError();
+    node->jobs.clear();
+    return rc;
+}
+
+int check_alive(OrbNode* node) {
+    if (!node->failed) return ORB_OK;
+    const std::string why = node->err;
+    return nfail(node, ORB_ESTATE, "node unusable after an earlier failure (%s)", why.c_str());
+}
+
 // The exchange of one job: exact-size transfers rank r -> rank 0, then the expansion behind rank 0's own records.
 // An RCCL error inside the group still closes the group (a communicator left in an open group hangs the next call).
 int enqueue_exchange(OrbNode* node, NodeJob& job) {
-    const int n = node->n, slot = job.slot;
+    const int n = node->n, slot = job.slot, s0 = node->first_sender;
     const uint32_t B = node->max_batch;
     const size_t cap = node->cfg.max_features;
     const Rccl& R = node->rccl;
@@ -199,26 +235,30 @@ int enqueue_exchange(OrbNode* node, NodeJob& job) {
         if (rank_records[r] > (uint64_t)B * cap) return nfail(node, ORB_EHIP, "internal: rank %d reports %llu records", r, (unsigned long long)rank_records[r]);
         rank_offset[r + 1] = rank_offset[r] + rank_records[r];
     }
-    std::vector<uint64_t> wire_first(n, 0), wire_count(n, 0), dst_first(n, 0);
+    // run i of the landing area = sender s0 + i
+    const int n_send = n - s0;
+    std::vector<uint64_t> wire_first(n_send > 0 ? n_send : 1, 0), wire_count(n_send > 0 ? n_send : 1, 0), dst_first(n_send > 0 ? n_send : 1, 0);
     uint64_t at = 0;
-    for (int r = 1; r < n; r++) {
-        wire_first[r - 1] = at, wire_count[r - 1] = rank_records[r], dst_first[r - 1] = rank_offset[r];
+    for (int r = s0; r < n; r++) {
+        wire_first[r - s0] = at, wire_count[r - s0] = rank_records[r], dst_first[r - s0] = rank_offset[r];
         at += rank_records[r];
     }
-    if (n > 1 && at > 0) {
-        // every sender's exchange stream waits for its pack; rank 0's wire buffer is reused in stream order
-        for (int r = 1; r < n; r++) {
+    if (n_send > 0 && at > 0) {
+        const bool self = node->xchg == XCHG_RCCL_SELF;
+        // every sender's exchange stream waits for its pack; the landing area is reused in stream order.  On one device with
+        // one communicator (self) everything goes through rank 0's exchange stream.
+        for (int r = s0; r < n; r++) {
             if (rank_records[r] == 0) continue;
             NODE_HIP(node, hipSetDevice(node->devices[r]));
-            NODE_HIP(node, hipStreamWaitEvent(node->xchg_streams[r], node->ev_pack[slot][r], 0));
+            NODE_HIP(node, hipStreamWaitEvent(node->xchg_streams[self ? 0 : r], node->ev_pack[slot][r], 0));
         }
-        if (node->loopback) {
-            for (int r = 1; r < n; r++) {
+        if (node->xchg == XCHG_COPIES) {
+            for (int r = s0; r < n; r++) {
                 if (rank_records[r] == 0) continue;
                 const size_t bytes = (size_t)rank_records[r] * ORB_TRANSPORT_RECORD_BYTES;
-                uint8_t* const landing = static_cast<uint8_t*>(node->d_wire[slot][0]) + (size_t)wire_first[r - 1] * ORB_TRANSPORT_RECORD_BYTES;
+                uint8_t* const landing = static_cast<uint8_t*>(node->d_recv[slot]) + (size_t)wire_first[r - s0] * ORB_TRANSPORT_RECORD_BYTES;
                 NODE_HIP(node, hipSetDevice(node->devices[r]));
-                NODE_HIP(node, hipMemcpyAsync(landing, node->d_wire[slot][r], bytes, hipMemcpyDefault, node->xchg_streams[r]));
+                NODE_HIP(node, hipMemcpyAsync(landing, node->d_send[slot][r], bytes, hipMemcpyDefault, node->xchg_streams[r]));
                 NODE_HIP(node, hipEventRecord(node->ev_xchg[slot][r], node->xchg_streams[r]));
                 node->xchg_set[slot][r] = 1;
                 NODE_HIP(node, hipSetDevice(node->devices[0]));
@@ -227,31 +267,34 @@ int enqueue_exchange(OrbNode* node, NodeJob& job) {
         } else {
             ncclResult_t bad = ncclSuccess;
             const char* what = "";
+            if (self) NODE_HIP(node, hipSetDevice(node->devices[0]));
             ncclResult_t g = R.GroupStart();
             if (g != ncclSuccess) return nfail(node, ORB_EHIP, "ncclGroupStart failed: %s", R.GetErrorString ? R.GetErrorString(g) : "rccl error");
-            for (int r = 1; r < n && bad == ncclSuccess; r++) {
+            for (int r = s0; r < n && bad == ncclSuccess; r++) {
                 if (rank_records[r] == 0) continue;
                 const size_t bytes = (size_t)rank_records[r] * ORB_TRANSPORT_RECORD_BYTES;
-                uint8_t* const landing = static_cast<uint8_t*>(node->d_wire[slot][0]) + (size_t)wire_first[r - 1] * ORB_TRANSPORT_RECORD_BYTES;
-                bad = R.Send(node->d_wire[slot][r], bytes, ncclUint8, 0, node->comms[r], node->xchg_streams[r]);
+                uint8_t* const landing = static_cast<uint8_t*>(node->d_recv[slot]) + (size_t)wire_first[r - s0] * ORB_TRANSPORT_RECORD_BYTES;
+                // self: the one-rank communicator's peer 0 is itself; sends and receives of a group match in order
+                bad = R.Send(node->d_send[slot][r], bytes, ncclUint8, 0, node->comms[self ? 0 : r], node->xchg_streams[self ? 0 : r]);
                 what = "ncclSend";
                 if (bad != ncclSuccess) break;
-                bad = R.Recv(landing, bytes, ncclUint8, r, node->comms[0], node->xchg_streams[0]);
+                bad = R.Recv(landing, bytes, ncclUint8, self ? 0 : r, node->comms[0], node->xchg_streams[0]);
                 what = "ncclRecv";
+                if (bad == ncclSuccess) node->rccl_pairs++;
             }
             g = R.GroupEnd();  // always: the group must not stay open
             if (bad != ncclSuccess) return nfail(node, ORB_EHIP, "%s failed: %s", what, R.GetErrorString ? R.GetErrorString(bad) : "rccl error");
             if (g != ncclSuccess) return nfail(node, ORB_EHIP, "ncclGroupEnd failed: %s", R.GetErrorString ? R.GetErrorString(g) : "rccl error");
-            for (int r = 1; r < n; r++) {
+            for (int r = s0; r < n; r++) {
                 if (rank_records[r] == 0) continue;
                 NODE_HIP(node, hipSetDevice(node->devices[r]));
-                NODE_HIP(node, hipEventRecord(node->ev_xchg[slot][r], node->xchg_streams[r]));  // the wire buffer is free again
+                NODE_HIP(node, hipEventRecord(node->ev_xchg[slot][r], node->xchg_streams[self ? 0 : r]));  // the send buffer is free again
                 node->xchg_set[slot][r] = 1;
             }
         }
         NODE_HIP(node, hipSetDevice(node->devices[0]));
         NODE_ORB(node, node->progs[0],
-                 orb_unpack_transport(node->progs[0], node->d_wire[slot][0], (uint32_t)(n - 1), wire_first.data(), wire_count.data(),
+                 orb_unpack_transport(node->progs[0], node->d_recv[slot], (uint32_t)n_send, wire_first.data(), wire_count.data(),
                                       dst_first.data(), node->d_coll_c[job.coll], node->d_coll_d[job.coll], node->xchg_streams[0]));
     }
     NODE_HIP(node, hipSetDevice(node->devices[0]));
@@ -269,14 +312,15 @@ int begin_oldest(OrbNode* node) {
             break;
         }
     if (!job) return nfail(node, ORB_ESTATE, "collate_begin: no extracted job is waiting for its exchange");
-    if (int rc = ensure_comms(node)) return rc;
+    if (int rc = ensure_comms(node)) return rc;  // nothing enqueued yet: the job stays, the caller may retry
     // the only host wait of the pipeline: the counters of THIS job (its kernels + pack; the next job is already queued)
     for (int r = 0; r < node->n; r++) {
         if (job->shard_n[r] == 0) continue;
         NODE_HIP(node, hipSetDevice(node->devices[r]));
         NODE_HIP(node, hipEventSynchronize(node->ev_pack[job->slot][r]));
     }
-    return enqueue_exchange(node, *job);
+    if (int rc = enqueue_exchange(node, *job)) return poison(node, rc);
+    return ORB_OK;
 }
 
 }  // namespace
@@ -288,6 +332,14 @@ const char* orb_node_last_error(const OrbNode* node) { return node ? node->err.c
 int orb_node_device_count(const OrbNode* node) { return node ? node->n : 0; }
 
 int orb_node_pending(const OrbNode* node) { return node ? (int)node->jobs.size() : 0; }
+
+const char* orb_node_exchange_backend(const OrbNode* node) {
+    if (!node) return "";
+    if (node->n - node->first_sender <= 0) return "none";
+    return node->xchg == XCHG_COPIES ? "copies" : node->xchg == XCHG_RCCL_SELF ? "rccl-self" : "rccl";
+}
+
+uint64_t orb_node_rccl_pairs(const OrbNode* node) { return node ? node->rccl_pairs : 0u; }
 
 OrbProgram* orb_node_program(OrbNode* node, int rank) {
     return (node && rank >= 0 && rank < node->n) ? node->progs[rank] : nullptr;
@@ -311,7 +363,8 @@ void orb_node_destroy(OrbNode* node) {
         if (r < (int)node->devices.size()) (void)hipSetDevice(node->devices[r]);
         if (r < (int)node->comms.size() && node->comms[r]) (void)node->rccl.CommDestroy(node->comms[r]);
         for (int s = 0; s < kSlots; s++) {
-            if (r < (int)node->d_wire[s].size()) (void)hipFree(node->d_wire[s][r]);
+            if (r < (int)node->d_send[s].size()) (void)hipFree(node->d_send[s][r]);
+            if (r == 0) (void)hipFree(node->d_recv[s]);
             if (r < (int)node->h_counts[s].size() && node->h_counts[s][r]) (void)hipHostFree(node->h_counts[s][r]);
             if (r < (int)node->h_offsets[s].size() && node->h_offsets[s][r]) (void)hipHostFree(node->h_offsets[s][r]);
             if (r < (int)node->ev_kernels[s].size() && node->ev_kernels[s][r]) (void)hipEventDestroy(node->ev_kernels[s][r]);
@@ -337,17 +390,23 @@ int orb_node_create(const int* devices, int n_devices, const OrbConfig* config, 
     *out = nullptr;
     if (!devices || n_devices <= 0 || n_devices > 64) return nfail(nullptr, ORB_EINVAL, "need 1..64 devices");
     if (!config) return nfail(nullptr, ORB_EINVAL, "config is NULL");
-    // TINYORB_NODE_LOOPBACK=1 (test facility): the records of the ranks move by device copies instead of RCCL, and a
-    // device may be listed more than once -- the whole n > 1 data path (shards, transport records, offsets, expansion
-    // on rank 0, the pipeline's events) can then run on one GPU, which RCCL refuses.
+    // TINYORB_NODE_LOOPBACK (test facility; the head of this file): 1 = the records of the ranks move by device copies
+    // instead of RCCL and a device may be listed more than once -- the whole n > 1 data path (shards, transport records,
+    // offsets, expansion on rank 0, the pipeline's events) can then run on one GPU, which RCCL refuses; 2 = the same ranks
+    // on ONE device, but the records move through RCCL: a one-rank communicator, ncclSend/ncclRecv to itself.
     const char* lb = getenv("TINYORB_NODE_LOOPBACK");
-    const bool loopback = lb && atoi(lb) != 0;
-    for (int a = 0; a < n_devices && !loopback; a++)
-        for (int b = a + 1; b < n_devices; b++)
-            if (devices[a] == devices[b]) return nfail(nullptr, ORB_EINVAL, "device %d listed twice", devices[a]);
+    const int xchg = lb ? atoi(lb) : 0;
+    if (xchg < 0 || xchg > 2) return nfail(nullptr, ORB_EINVAL, "TINYORB_NODE_LOOPBACK must be 0, 1 or 2");
+    for (int a = 0; a < n_devices; a++)
+        for (int b = a + 1; b < n_devices; b++) {
+            if (xchg == XCHG_RCCL && devices[a] == devices[b]) return nfail(nullptr, ORB_EINVAL, "device %d listed twice", devices[a]);
+            if (xchg == XCHG_RCCL_SELF && devices[a] != devices[b])
+                return nfail(nullptr, ORB_EINVAL, "TINYORB_NODE_LOOPBACK=2 runs every rank on one device (got %d and %d)", devices[a], devices[b]);
+        }
     OrbNode* node = new (std::nothrow) OrbNode();
     if (!node) return nfail(nullptr, ORB_EINVAL, "out of host memory");
-    node->loopback = loopback;
+    node->xchg = xchg;
+    node->first_sender = (xchg == XCHG_RCCL_SELF && n_devices == 1) ? 0 : 1;
     node->n = n_devices;
     node->devices.assign(devices, devices + n_devices);
     node->cfg = *config;
@@ -381,13 +440,15 @@ int orb_node_create(const int* devices, int n_devices, const OrbConfig* config, 
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&xs, hipStreamNonBlocking);
         node->pack_streams.push_back(ps);
         node->xchg_streams.push_back(xs);
-        const size_t wire_records = (r == 0 ? (size_t)(n_devices - 1) : 1u) * B * cap;  // rank 0 receives, the others send
+        const size_t send_records = r >= node->first_sender ? B * cap : 0u;
+        const size_t recv_records = r == 0 ? (size_t)(n_devices - node->first_sender) * B * cap : 0u;  // rank 0 receives
         for (int s = 0; s < kSlots; s++) {
             void* wire = nullptr;
             uint32_t* hc = nullptr;
             uint64_t* ho = nullptr;
             hipEvent_t ek = nullptr, ep = nullptr, ex = nullptr;
-            if (e == hipSuccess && wire_records) e = hipMalloc(&wire, wire_records * (size_t)ORB_TRANSPORT_RECORD_BYTES);
+            if (e == hipSuccess && send_records) e = hipMalloc(&wire, send_records * (size_t)ORB_TRANSPORT_RECORD_BYTES);
+            if (e == hipSuccess && recv_records) e = hipMalloc(&node->d_recv[s], recv_records * (size_t)ORB_TRANSPORT_RECORD_BYTES);
             if (e == hipSuccess) e = hipHostMalloc(&hc, B * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocPortable);
             if (e == hipSuccess) e = hipHostMalloc(&ho, (B + 1u) * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocPortable);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ek, hipEventDisableTiming);
@@ -395,7 +456,7 @@ int orb_node_create(const int* devices, int n_devices, const OrbConfig* config, 
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ex, hipEventDisableTiming);
             if (hc) memset(hc, 0, B * sizeof(uint32_t));
             if (ho) memset(ho, 0, (B + 1u) * sizeof(uint64_t));
-            node->d_wire[s].push_back(wire);
+            node->d_send[s].push_back(wire);
             node->h_counts[s].push_back(hc);
             node->h_offsets[s].push_back(ho);
             node->ev_kernels[s].push_back(ek);
@@ -421,8 +482,7 @@ int orb_node_create(const int* devices, int n_devices, const OrbConfig* config, 
 }
 
 // Stage 1 of a job: the kernels of every shard, and behind them the packing of its results (see the head of this file).
-static int submit_job(OrbNode* node, const uint8_t* const* frames_dev, const uint8_t* frames_pinned, uint32_t n_frames) {
-    if (int rc = check_job(node, n_frames)) return rc;
+static int enqueue_job(OrbNode* node, const uint8_t* const* frames_dev, const uint8_t* frames_pinned, uint32_t n_frames) {
     NodeJob job;
     job.n_frames = n_frames;
     job.slot = (int)(node->job_seq % (uint64_t)kSlots);
@@ -436,7 +496,6 @@ static int submit_job(OrbNode* node, const uint8_t* const* frames_dev, const uin
         const uint32_t m = hi - lo;
         job.shard_n[r] = m;
         if (m == 0) continue;
-        if (frames_dev && !frames_dev[r]) return nfail(node, ORB_EINVAL, "frames_dev[%d] is NULL", r);
         OrbProgram* const prog = node->progs[r];
         NODE_HIP(node, hipSetDevice(node->devices[r]));
         NODE_ORB(node, prog, orb_batch_select_output(prog, (uint32_t)slot));
@@ -452,14 +511,14 @@ static int submit_job(OrbNode* node, const uint8_t* const* frames_dev, const uin
         uint32_t* const dc = dev_ptr(node->h_counts[slot][r]);
         uint64_t* const dof = dev_ptr(node->h_offsets[slot][r]);
         if (!dc || !dof) return nfail(node, ORB_EHIP, "pinned counters are not visible to device %d", node->devices[r]);
-        if (r == 0) {  // rank 0's own records go straight to the head of the collated arrays
+        if (r < node->first_sender) {  // rank 0's own records go straight to the head of the collated arrays
             NODE_ORB(node, prog, orb_batch_compact_device(prog, m, dc, dof, node->d_coll_c[job.coll], node->d_coll_d[job.coll],
                                                           B * cap, ps));
         } else {       // the others pack 40-byte transport records; the wire buffer was last read by the sends two jobs back
             if (node->xchg_set[slot][r]) NODE_HIP(node, hipStreamWaitEvent(ps, node->ev_xchg[slot][r], 0));
             void* d_counts = nullptr;
             NODE_ORB(node, prog, orb_batch_device_buffers(prog, &d_counts, nullptr, nullptr));
-            NODE_ORB(node, prog, orb_batch_pack_transport(prog, (uint32_t)slot, m, node->d_wire[slot][r], B * cap, dof, ps));
+            NODE_ORB(node, prog, orb_batch_pack_transport(prog, (uint32_t)slot, m, node->d_send[slot][r], B * cap, dof, ps));
             NODE_HIP(node, hipMemcpyAsync(node->h_counts[slot][r], d_counts, m * sizeof(uint32_t), hipMemcpyDeviceToHost, ps));
         }
         NODE_HIP(node, hipEventRecord(node->ev_pack[slot][r], ps));
@@ -467,6 +526,20 @@ static int submit_job(OrbNode* node, const uint8_t* const* frames_dev, const uin
     }
     node->jobs.push_back(std::move(job));
     node->job_seq++;
+    return ORB_OK;
+}
+
+// Everything that can be refused is refused before the first enqueue; a failure after that leaves devices with work the
+// job queue does not know about, so it takes the node out of service (poison).
+static int submit_job(OrbNode* node, const uint8_t* const* frames_dev, const uint8_t* frames_pinned, uint32_t n_frames) {
+    if (int rc = check_alive(node)) return rc;
+    if (int rc = check_job(node, n_frames)) return rc;
+    for (int r = 0; r < node->n && frames_dev; r++) {
+        uint32_t lo, hi;
+        shard_range(n_frames, node->n, r, &lo, &hi);
+        if (hi > lo && !frames_dev[r]) return nfail(node, ORB_EINVAL, "frames_dev[%d] is NULL", r);
+    }
+    if (int rc = enqueue_job(node, frames_dev, frames_pinned, n_frames)) return poison(node, rc);
     return ORB_OK;
 }
 
@@ -479,6 +552,7 @@ int orb_node_extract_batch(OrbNode* node, const uint8_t* const* frames_dev, uint
 int orb_node_extract_batch_host(OrbNode* node, const uint8_t* frames_host, uint32_t n_frames) {
     if (!node) return ORB_EINVAL;
     if (!frames_host) return nfail(node, ORB_EINVAL, "frames_host is NULL");
+    if (int rc = check_alive(node)) return rc;
     if (int rc = check_job(node, n_frames)) return rc;
     // Every shard goes up in 16-frame chunks from the caller's array, pinned in place for the duration of the uploads,
     // on its device's copy stream while the kernels of the chunks already there run (orb_extract_batch_pinned): all
@@ -497,11 +571,13 @@ int orb_node_extract_batch_host(OrbNode* node, const uint8_t* frames_host, uint3
 
 int orb_node_collate_begin(OrbNode* node) {
     if (!node) return ORB_EINVAL;
+    if (int rc = check_alive(node)) return rc;
     return begin_oldest(node);
 }
 
 int orb_node_collate_end(OrbNode* node, uint32_t* counts, uint64_t* offsets, void** corners_dev, void** descriptors_dev) {
     if (!node) return ORB_EINVAL;
+    if (int rc = check_alive(node)) return rc;
     if (node->jobs.empty()) return nfail(node, ORB_ESTATE, "collate before extract_batch");
     if (!node->jobs.front().exchanging)
         if (int rc = begin_oldest(node)) return rc;

@@ -112,70 +112,85 @@ def collate_transport_to_root(counts: torch.Tensor, records: torch.Tensor, cap: 
 
 
 class TransportCollator:
-    """The transport collate without a host stall per batch (bench.py, N > 1).
+    """The transport collate without a host stall per batch and without a byte too many (bench.py, N > 1).
 
-    `collate_transport_to_root` needs the counters on the host before it can size the gather: one `.tolist()` per batch,
-    which at half a millisecond per batch makes the Python thread, not the links, the limiter.  Here the size of batch
-    k's gather comes from what batch k-1 held: every rank sends its first `s_fix` records (`s_fix` = the largest rank
-    total seen last time plus a quarter, at most the capacity), the all-gathered counters travel to pinned host memory
-    by an asynchronous copy, and they are looked at one batch later -- when they have long arrived -- by `finish()`,
-    which returns what the root needs to expand batch k-1 and says whether `s_fix` was too small for it (then the
-    caller gathers that batch again, exactly: `collate_transport_to_root`; every rank sees the same counters, so every
-    rank takes the same decision).  Buffers are allocated once.
+    What sizes the exchange of a batch is its per-frame counters, and they are on the device.  Reading them there and
+    then (`collate_transport_to_root`: all_gather + `.tolist()`) stalls the Python thread once per half-millisecond
+    batch; sizing the exchange from the batch before (round 3: the largest rank total plus a quarter) never stalls but
+    over-sends -- and into rank 0, where the links of a node meet, bytes are what the collate costs.  So the two halves
+    of a batch's collate are one batch apart:
+
+        submit(k)    all_gather of batch k's counters, their asynchronous copy to pinned host memory; batch k's transport
+                     records stay where they are (the caller's buffer of output set k % slots);
+        exchange(k)  one batch later, when the counters have long arrived: every rank reads the same totals S_0..S_{G-1}
+                     and the records move in ONE all_to_all_single with split sizes -- rank r sends exactly S_r records to
+                     `dst` and nothing to anybody else, `dst` receives them back to back in rank order (with the "nccl"
+                     backend that is one group of ncclSend/ncclRecv, every peer on its own xGMI link into `dst`; the
+                     root's own records take the same call, a copy inside its HBM).
 
         if ticket is not None:
-            info = col.finish(ticket)              # batch k-1: its counters are on the host by now; sizes batch k's gather
-        ticket = col.submit(slot, counts, records)  # batch k: enqueue only
-    """
+            info = col.exchange(ticket)             # batch k-1: exact sizes, enqueue only
+        ticket = col.submit(slot, counts, records)  # batch k
+
+    `bytes_exchanged` counts what `dst` received: the sum of S_r x 40 bytes, exactly.  Buffers are allocated once; a
+    slot's records and landing area are reused `slots` batches later, in stream order."""
 
     def __init__(self, n_frames: int, cap: int, device, dst: int = 0, group: Optional[dist.ProcessGroup] = None,
-                 headroom: float = 1.25, slack: int = 1024, slots: int = 2):
+                 slots: int = 2):
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.B, self.cap, self.dst, self.group, self.headroom, self.slack = n_frames, cap, dst, group, headroom, slack
+        self.B, self.cap, self.dst, self.group = n_frames, cap, dst, group
         self.s_cap = n_frames * cap          # records a rank can hold
-        self.s_fix = self.s_cap              # records per rank in the next gather (no history yet: everything)
         self.device = torch.device(device)
         pin = self.device.type == "cuda"
         self.counts_all = [torch.empty(self.world * n_frames, dtype=torch.int32, device=self.device) for _ in range(slots)]
         self.h_counts = [torch.empty(self.world * n_frames, dtype=torch.int32, pin_memory=pin) for _ in range(slots)]
         self.copied = [None] * slots         # event behind the counters' copy to the host
-        self.merged = [None] * slots         # root: (world, s_cap, 10) landing area per slot, allocated on first use
-        self.bytes_gathered = 0
+        self.records = [None] * slots        # the rank's transport records of the batch in this slot
+        self.merged = [None] * slots         # root: (world * s_cap, 10) landing area per slot, allocated on first use
+        self.bytes_exchanged = 0
 
     def submit(self, slot: int, counts: torch.Tensor, records: torch.Tensor):
-        """Enqueues batch `slot`'s exchange on the current stream: all_gather of the counters, their copy to pinned host
-        memory, one gather of the first s_fix records of every rank.  Returns the ticket (slot, s_fix used)."""
-        s_use = self.s_fix
+        """Enqueues the first half of batch `slot`'s collate on the current stream: all_gather of the counters and their
+        copy to pinned host memory.  `records` (this rank's transport records, the first sum(min(counts, cap)) rows
+        valid) must stay untouched until `exchange` has been enqueued for the returned ticket."""
         chunks = list(self.counts_all[slot].chunk(self.world))
         dist.all_gather(chunks, counts, group=self.group)
         self.h_counts[slot].copy_(self.counts_all[slot], non_blocking=True)
         if self.device.type == "cuda":
             self.copied[slot] = torch.cuda.Event()
             self.copied[slot].record()
-        payload = records[:s_use]
-        if payload.shape[0] < s_use:  # a buffer sized for this rank alone
-            pad = records.new_zeros((s_use, records.shape[1]))
-            pad[:payload.shape[0]] = payload
-            payload = pad
-        bufs = None
-        if self.rank == self.dst:
-            if self.merged[slot] is None:
-                self.merged[slot] = torch.empty((self.world, self.s_cap, records.shape[1]), dtype=records.dtype, device=records.device)
-            bufs = [self.merged[slot][r, :s_use] for r in range(self.world)]  # contiguous leading slices
-            self.bytes_gathered += self.world * s_use * records.shape[1] * records.element_size()
-        dist.gather(payload, bufs, dst=self.dst, group=self.group)
-        return (slot, s_use)
+        self.records[slot] = records
+        return slot
 
-    def finish(self, ticket):
-        """Host side of a submitted batch, one batch later: the counters (on the host by now), every rank's total, and
-        whether the gather carried all of them.  Also sets the size of the next gather."""
-        slot, s_used = ticket
+    def exchange(self, ticket):
+        """Second half, one batch later: reads the counters (on the host by now), and enqueues the exact-size exchange.
+        Returns {"slot", "counts_all" (numpy, G*B raw counters in frame order), "totals" [S_0..S_{G-1}], "first"
+        (exclusive prefix of the totals, G+1 entries), "merged" (root: (sum S, 10) view, rank r's records are rows
+        first[r]..first[r+1]; other ranks None)}."""
+        slot = ticket
         if self.copied[slot] is not None:
             self.copied[slot].synchronize()
         counts_all = self.h_counts[slot].numpy().copy()
         totals = [int(t) for t in counts_all.clip(max=self.cap).reshape(self.world, -1).sum(axis=1)]
-        complete = max(totals) <= s_used
-        self.s_fix = min(self.s_cap, max(int(max(totals) * self.headroom) + self.slack, 1))
-        return {"slot": slot, "counts_all": counts_all, "totals": totals, "complete": complete, "s_used": s_used,
-                "merged": self.merged[slot] if self.rank == self.dst else None}
+        first = [0]
+        for t in totals:
+            first.append(first[-1] + t)
+        records = self.records[slot]
+        words = records.shape[1]
+        mine = totals[self.rank]
+        if records.shape[0] < mine:
+            raise ValueError("rank %d holds %d transport records, its counters say %d" % (self.rank, records.shape[0], mine))
+        in_splits = [mine if r == self.dst else 0 for r in range(self.world)]
+        if self.rank == self.dst:
+            if self.merged[slot] is None:
+                self.merged[slot] = torch.empty((self.world * self.s_cap, words), dtype=records.dtype, device=records.device)
+            out = self.merged[slot][:first[-1]]
+            out_splits = totals
+            self.bytes_exchanged += first[-1] * words * records.element_size()
+        else:
+            out = records.new_empty((0, words))
+            out_splits = [0] * self.world
+        dist.all_to_all_single(out, records[:mine], output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+        return {"slot": slot, "counts_all": counts_all, "totals": totals, "first": first,
+                "merged": out if self.rank == self.dst else None}

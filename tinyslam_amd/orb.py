@@ -51,7 +51,7 @@ EXPORTS = [
     "orb_node_create", "orb_node_destroy", "orb_node_last_error", "orb_node_device_count", "orb_node_program",
     "orb_node_shard", "orb_node_extract_batch", "orb_node_extract_batch_host", "orb_node_collate",
     "orb_node_read_collated", "orb_node_collate_begin", "orb_node_collate_end", "orb_node_pending",
-    "orb_extract_batch_pinned", "orb_upload_sync",
+    "orb_extract_batch_pinned", "orb_upload_sync", "orb_node_exchange_backend", "orb_node_rccl_pairs",
 ]
 
 
@@ -182,9 +182,13 @@ def load_library(path=None):
     L.orb_node_collate_begin.argtypes = [vp]
     L.orb_node_collate_end.argtypes = [vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.orb_node_pending.argtypes = [vp]
+    L.orb_node_exchange_backend.argtypes = [vp]
+    L.orb_node_exchange_backend.restype = ctypes.c_char_p
+    L.orb_node_rccl_pairs.argtypes = [vp]
+    L.orb_node_rccl_pairs.restype = ctypes.c_uint64
     L.orb_extract_batch_pinned.argtypes = [vp, vp, u32]
     L.orb_upload_sync.argtypes = [vp]
-    if L.orb_abi_version() != 3:
+    if L.orb_abi_version() != 4:
         raise OrbError(ORB_EINVAL, "libtinyorb ABI version mismatch")
     if path == LIB_PATH:
         _lib = L
@@ -620,6 +624,14 @@ class OrbNode:
 
     def pending(self):
         return self._lib.orb_node_pending(self._h)
+
+    def exchange_backend(self):
+        """'rccl', 'rccl-self' (TINYORB_NODE_LOOPBACK=2), 'copies' (TINYORB_NODE_LOOPBACK=1) or 'none' (one device)."""
+        return self._lib.orb_node_exchange_backend(self._h).decode()
+
+    def rccl_pairs(self):
+        """ncclSend + ncclRecv pairs this node has enqueued so far."""
+        return int(self._lib.orb_node_rccl_pairs(self._h))
 
     def read_collated(self, total):
         corners = np.zeros(total, dtype=CORNER_DTYPE)
