@@ -252,7 +252,7 @@ def run_node(args):
                 out["cpu_baseline"] = cpu_baseline(n_cpu, counts[:B], intended=args.mode == "intended", y8=args.input == "y8")
     if args.mode == "literal" and not args.staged and not args.no_single_frame:
         out["single_frame_us"] = single_frame_latency(orb, cfg_kwargs)
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 def run_rank(args):
@@ -624,16 +624,40 @@ def run_rank(args):
                 # the reference's only call shape (orb.rs:469-557): one blocking extract per frame, microseconds per call
                 out["single_frame_us"] = single_frame_latency(orb, dict(max_features=MAX_FEATURES, hierarchy_depth=DEPTH,
                                                                         initial_threshold=THRESHOLD, device=dev_index))
-        print(json.dumps(out), flush=True)
+        emit(out)
     prog.close()
     if collating:
         dist.barrier()
         dist.destroy_process_group()
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  librccl prints a version banner on stdout when a communicator is
+    created (RCCL 2.26/2.27: "RCCL version : ...", five lines, no switch for it), so the process keeps a private
+    duplicate of stdout for the result line and points file descriptor 1 at stderr for everything else."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(out):
+    line = (json.dumps(out) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
+
+
 def main():
     args = parse_args()
     if args.host == "node":
+        claim_stdout()
         return run_node(args)  # one process for all GPUs: nothing to launch
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not started by torch.distributed.run: spawn the ranks ourselves -- before torch, libtinyorb or anything else
@@ -641,6 +665,7 @@ def main():
         # or exec workers; this one only waits and relays the exit status)
         from tinyslam_amd import launch
         sys.exit(launch.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    claim_stdout()
     run_rank(args)
 
 
