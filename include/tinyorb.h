@@ -74,8 +74,23 @@ typedef struct OrbOptions {
     uint32_t flags;       /* ORB_FLAG_* */
     uint32_t fast_arc;    /* 0 -> 12 (the reference's FAST-12, fast.wgsl:56-60; 9 with ORB_FLAG_INTENDED);
                            * 9..16: corner = run of >= fast_arc */
-    uint32_t reserved[4];
+    /* Two things the reference's WGSL leaves to the adapter it runs on, as switches (the defaults, 0 and 0, are the
+     * canonical decisions CRD-6 / CRD-5 of SURVEY.md 8a; until a dump from the reference itself pins them --
+     * rust/dump_config0, tools/pin_oracle.py -- a caller who knows the adapter can follow it).  For the reference's
+     * detector only (RGBA or Y8 input): refused together with ORB_FLAG_INTENDED, ORB_FLAG_NMS or a fast_arc other
+     * than 12, which have no reference behaviour to follow. */
+    uint32_t oob_policy;          /* ORB_OOB_*: what a textureLoad OUTSIDE the addressed level returns (fast.wgsl:78,86,103
+                                   * at octaves >= 1, whose guard uses the level-0 size; brief.wgsl:59-60) */
+    uint32_t sampler_weight_bits; /* 0: bilinear weights are the exact binary32 fractions; n = 1..23: a sampler that holds
+                                   * them in n fractional bits, rounded to nearest, halves up (8 is common): the blur's
+                                   * lerps (gaussian_blur_x.wgsl:53-58) and the blit of an odd-sized level (blit.wgsl:35) */
+    uint32_t reserved[2];
 } OrbOptions;
+
+#define ORB_OOB_ZERO 0u  /* 0.0 -- Vulkan robust image access; naga: image_load = Unchecked on such devices */
+#define ORB_OOB_CLAMP 1u /* every coordinate clamped into [0, size - 1] */
+#define ORB_OOB_UMIN 2u  /* naga's `Restrict` policy as its SPIR-V writer emits it: min(coordinate AS UNSIGNED, size - 1) --
+                          * a negative coordinate lands on the LAST column / row of the level */
 
 #define ORB_FLAG_STAGED 1u        /* force the one-kernel-per-stage pipeline (cross-check of the fused path) */
 #define ORB_FLAG_DOUBLE_OUTPUT 2u /* two sets of output slabs: batch k+1 computes while batch k is collated */

@@ -67,16 +67,25 @@ def grayscale_y8(y8):
     return to_f16_bits(img.astype(np.float32) / F(255.0))
 
 
-def _lerp_axis_coords(n_dst, n_src):
+def _weight(frac, wbits):
+    """A bilinear sampler's weight held in `wbits` fractional bits, halves up (0: the exact binary32 fraction, CRD-5)."""
+    frac = np.asarray(frac, dtype=np.float32)
+    if not wbits:
+        return frac
+    scale = F(2 ** wbits)
+    return (np.floor(frac * scale + F(0.5)) / scale).astype(np.float32)
+
+
+def _lerp_axis_coords(n_dst, n_src, wbits=0):
     s = (np.arange(n_dst, dtype=np.float32) + F(0.5)) * (F(n_src) / F(n_dst)) - F(0.5)
     s0 = np.floor(s)
-    frac = (s - s0).astype(np.float32)
+    frac = _weight((s - s0).astype(np.float32), wbits)
     i0 = np.clip(s0.astype(np.int64), 0, n_src - 1)
     i1 = np.clip(s0.astype(np.int64) + 1, 0, n_src - 1)
     return i0, i1, frac
 
 
-def mip(src_bits):
+def mip(src_bits, wbits=0):
     """blit.wgsl: bilinear sample of the previous level at each target texel centre."""
     src = from_f16_bits(src_bits)
     hs, ws = src.shape
@@ -85,8 +94,8 @@ def mip(src_bits):
         top = src[0::2, 0::2] + src[0::2, 1::2]
         bot = src[1::2, 0::2] + src[1::2, 1::2]
         return to_f16_bits((top + bot) * F(0.25))
-    x0, x1, fx = _lerp_axis_coords(wd, ws)
-    y0, y1, fy = _lerp_axis_coords(hd, hs)
+    x0, x1, fx = _lerp_axis_coords(wd, ws, wbits)
+    y0, y1, fy = _lerp_axis_coords(hd, hs, wbits)
     a, b = src[np.ix_(y0, x0)], src[np.ix_(y0, x1)]
     c, d = src[np.ix_(y1, x0)], src[np.ix_(y1, x1)]
     top = a + fx[None, :] * (b - a)
@@ -94,7 +103,7 @@ def mip(src_bits):
     return to_f16_bits(top + fy[:, None] * (bot - top))
 
 
-def blur_pass(src_bits):
+def blur_pass(src_bits, wbits=0):
     """gaussian_blur_x.wgsl used for BOTH passes (orb.rs:399-402); offsets in UV units; flipped v."""
     src = from_f16_bits(src_bits)[::-1, :]
     h, w = src.shape
@@ -104,7 +113,7 @@ def blur_pass(src_bits):
     for off, wgt in zip(BLUR_OFF, BLUR_WGT):
         coord = (u + off) * fw - F(0.5)
         c0 = np.floor(coord)
-        frac = (coord - c0).astype(np.float32)
+        frac = _weight((coord - c0).astype(np.float32), wbits)
         i0 = np.clip(c0.astype(np.int64), 0, w - 1)
         i1 = np.clip(c0.astype(np.int64) + 1, 0, w - 1)
         t0, t1 = src[:, i0], src[:, i1]
@@ -148,17 +157,26 @@ def atan2f(y, x):
     return r.astype(np.float32)
 
 
-def _load(level, xs, ys):
-    """textureLoad with out-of-level coordinates returning 0 (CRD-6)."""
+def _load(level, xs, ys, oob="zero"):
+    """textureLoad.  Outside the level: 0 ("zero", CRD-6), each coordinate clamped into the level ("clamp"), or naga's
+    Restrict policy, min(unsigned(coordinate), size - 1) -- a negative coordinate wraps to a huge unsigned one and lands
+    on the LAST column / row ("umin")."""
     h, w = level.shape
-    ok = (xs >= 0) & (ys >= 0) & (xs < w) & (ys < h)
-    out = np.zeros(np.broadcast(xs, ys).shape, dtype=np.float32)
-    xs_b, ys_b = np.broadcast_arrays(xs, ys)
-    out[ok] = level[ys_b[ok], xs_b[ok]]
-    return out
+    xs_b, ys_b = np.broadcast_arrays(np.asarray(xs, dtype=np.int64), np.asarray(ys, dtype=np.int64))
+    if oob == "zero":
+        ok = (xs_b >= 0) & (ys_b >= 0) & (xs_b < w) & (ys_b < h)
+        out = np.zeros(xs_b.shape, dtype=np.float32)
+        out[ok] = level[ys_b[ok], xs_b[ok]]
+        return out
+    if oob == "clamp":
+        return level[np.clip(ys_b, 0, h - 1), np.clip(xs_b, 0, w - 1)].astype(np.float32)
+    assert oob == "umin"
+    ux = np.minimum(xs_b.astype(np.int32).view(np.uint32), np.uint32(w - 1)).astype(np.int64)
+    uy = np.minimum(ys_b.astype(np.int32).view(np.uint32), np.uint32(h - 1)).astype(np.int64)
+    return level[uy, ux].astype(np.float32)
 
 
-def fast(gray_levels_bits, threshold):
+def fast(gray_levels_bits, threshold, oob="zero"):
     """fast.wgsl compute_fast over all octaves; returns (x, y, angle, octave) rows in raster order."""
     thr = F(threshold)
     H0, W0 = gray_levels_bits[0].shape
@@ -178,11 +196,11 @@ def fast(gray_levels_bits, threshold):
         if not guard.any():
             continue
         gx, gy = gx[guard], gy[guard]
-        c = _load(lvl, gx, gy)
+        c = _load(lvl, gx, gy, oob)
         over = np.zeros(gx.shape, dtype=np.int32)
         under = np.zeros(gx.shape, dtype=np.int32)
         for dx, dy in RING4:
-            diff = _load(lvl, gx + dx, gy + dy) - c
+            diff = _load(lvl, gx + dx, gy + dy, oob) - c
             over += diff > thr
             under += (~(diff > thr)) & (diff < -thr)
         cand = (over >= 3) | (under >= 3)
@@ -192,7 +210,7 @@ def fast(gray_levels_bits, threshold):
         cx = np.zeros(gx.shape, dtype=np.float32)
         cy = np.zeros(gx.shape, dtype=np.float32)
         for i, (dx, dy) in enumerate(RING16):
-            v = _load(lvl, gx + dx, gy + dy)
+            v = _load(lvl, gx + dx, gy + dy, oob)
             diff = v - c
             cx = cx + v * F(dx)
             cy = cy + v * F(dy)
@@ -209,7 +227,7 @@ def fast(gray_levels_bits, threshold):
     return np.array(rows, dtype=np.uint32).reshape(-1, 4)
 
 
-def brief(blur_levels_bits, corners):
+def brief(blur_levels_bits, corners, oob="zero"):
     """brief.wgsl: rotated BRIEF-256; returns uint32 (n, 8)."""
     corners = np.asarray(corners, dtype=np.uint32).reshape(-1, 4)
     n = corners.shape[0]
@@ -233,23 +251,24 @@ def brief(blur_levels_bits, corners):
         for octv, lvl in enumerate(levels):
             sel = corners[:, 3] == octv
             if sel.any():
-                va[sel] = _load(lvl, tax[sel], tay[sel])
-                vb[sel] = _load(lvl, tbx[sel], tby[sel])
+                va[sel] = _load(lvl, tax[sel], tay[sel], oob)
+                vb[sel] = _load(lvl, tbx[sel], tby[sel], oob)
         out[:, j >> 5] |= ((va > vb).astype(np.uint32) << np.uint32(j & 31))
     return out
 
 
-def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, y8=False):
-    """orb.rs:469-557 stage order (y8: the frame is a one-byte-per-pixel Y plane)."""
+def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, y8=False, oob="zero", weight_bits=0):
+    """orb.rs:469-557 stage order (y8: the frame is a one-byte-per-pixel Y plane).  oob / weight_bits: the two
+    implementation-defined switches (out-of-level loads, sampler weight precision); defaults = CRD-6 / CRD-5."""
     gray = [grayscale_y8(rgba) if y8 else grayscale(rgba)]
     for _ in range(1, depth):
-        gray.append(mip(gray[-1]))
-    tmp = [blur_pass(g) for g in gray]
-    blur = [blur_pass(t) for t in tmp]
-    kps = fast(gray, threshold)
+        gray.append(mip(gray[-1], weight_bits))
+    tmp = [blur_pass(g, weight_bits) for g in gray]
+    blur = [blur_pass(t, weight_bits) for t in tmp]
+    kps = fast(gray, threshold, oob)
     total = kps.shape[0]
     kps = kps[:max_features]
-    desc = brief(blur, kps)
+    desc = brief(blur, kps, oob)
     return dict(total=total, corners=kps, descriptors=desc, gray=gray, blur=blur)
 
 

@@ -176,8 +176,21 @@ static uint32_t clamp_idx(int64_t i, uint32_t n) {
     return (uint32_t)i;
 }
 
+/* Implementation-defined point: the weight a sampler gives the second texel of a bilinear pair.  WGSL
+ * leaves the filter's precision to the adapter; GPUs commonly hold it in 8 fractional bits.  bits == 0: the exact
+ * binary32 fraction (CRD-5); bits == n: the fraction rounded to the nearest multiple of 2^-n (halves up). */
+static float sampler_weight(float f, uint32_t bits) {
+    if (bits == 0 || bits > 23) return f;
+    float s = (float)(1u << bits);
+    return floorf(f * s + 0.5f) / s; /* s is a power of two: product and quotient are exact */
+}
+
 void orc_mip(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint32_t wd, uint32_t hd) {
-    if (ws == 2 * wd && hs == 2 * hd) {
+    orc_mip_impl(src, ws, hs, dst, wd, hd, 0);
+}
+
+void orc_mip_impl(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint32_t wd, uint32_t hd, uint32_t wbits) {
+    if (ws == 2 * wd && hs == 2 * hd) { /* weights are exactly 1/2 at any precision */
         for (uint32_t y = 0; y < hd; y++)
             for (uint32_t x = 0; x < wd; x++) {
                 float a = orc_f16_to_f32(src[(size_t)(2 * y) * ws + 2 * x]);
@@ -196,12 +209,12 @@ void orc_mip(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint3
     for (uint32_t y = 0; y < hd; y++) {
         float sy = ((float)y + 0.5f) * ry - 0.5f;
         float fy0 = floorf(sy);
-        float fy = sy - fy0;
+        float fy = sampler_weight(sy - fy0, wbits);
         uint32_t y0 = clamp_idx((int64_t)fy0, hs), y1 = clamp_idx((int64_t)fy0 + 1, hs);
         for (uint32_t x = 0; x < wd; x++) {
             float sx = ((float)x + 0.5f) * rx - 0.5f;
             float fx0 = floorf(sx);
-            float fx = sx - fx0;
+            float fx = sampler_weight(sx - fx0, wbits);
             uint32_t x0 = clamp_idx((int64_t)fx0, ws), x1 = clamp_idx((int64_t)fx0 + 1, ws);
             float a = orc_f16_to_f32(src[(size_t)y0 * ws + x0]);
             float b = orc_f16_to_f32(src[(size_t)y0 * ws + x1]);
@@ -228,7 +241,9 @@ static const float BLUR_OFFSETS[4] = {-2.2273038885157046f, -0.4391873198428642f
 static const float BLUR_WEIGHTS[4] = {0.13748623236806098f, 0.5037756553768409f, 0.32748695702046415f,
                                       0.031251155234634016f};
 
-void orc_blur_pass(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst) {
+void orc_blur_pass(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst) { orc_blur_pass_impl(src, w, h, dst, 0); }
+
+void orc_blur_pass_impl(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, uint32_t wbits) {
     float fw = (float)w;
     for (uint32_t y = 0; y < h; y++) {
         const uint16_t *row = src + (size_t)(h - 1 - y) * w; /* flipped v, sampled at the row centre */
@@ -239,7 +254,7 @@ void orc_blur_pass(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst) {
                 float uo = u + BLUR_OFFSETS[i];
                 float coord = uo * fw - 0.5f;
                 float c0 = floorf(coord);
-                float f = coord - c0;
+                float f = sampler_weight(coord - c0, wbits);
                 uint32_t i0 = clamp_idx((int64_t)c0, w), i1 = clamp_idx((int64_t)c0 + 1, w);
                 float t0 = orc_f16_to_f32(row[i0]);
                 float t1 = orc_f16_to_f32(row[i1]);
@@ -260,14 +275,39 @@ static const int RING4[4][2] = {{3, 0}, {-3, 0}, {0, 3}, {0, -3}}; /* fast.wgsl:
 static const int RING16[16][2] = {{-3, 0}, {-3, -1}, {-2, -2}, {-1, -3}, {0, -3}, {1, -3}, {2, -2}, {3, -1},
                                   {3, 0},  {3, 1},   {2, 2},   {1, 3},   {0, 3},  {-1, 3}, {-2, 2}, {-3, 1}};
 
-/* textureLoad of one mip level; outside the level -> 0 (CRD-6). */
-static float level_load(const uint16_t *pyr, const orc_pyramid_t *lay, uint32_t lvl, int64_t x, int64_t y) {
-    if (x < 0 || y < 0 || x >= (int64_t)lay->w[lvl] || y >= (int64_t)lay->h[lvl]) return 0.0f;
+/* textureLoad of one mip level.  Implementation-defined point: what a load OUTSIDE the level returns
+ * (fast.wgsl:78,86,103 at octaves >= 1, whose guard uses the level-0 size; brief.wgsl:59-60 for samples that leave the
+ * level).  WGSL allows either of two behaviours and naga 0.20 picks by adapter (wgpu-hal's Vulkan backend: image_load =
+ * Unchecked when the device has robustImageAccess, else Restrict):
+ *   ORC_OOB_ZERO   the load returns 0 (Vulkan robust image access) -- CRD-6, the default;
+ *   ORC_OOB_CLAMP  every coordinate is clamped into [0, size - 1] on its own;
+ *   ORC_OOB_UMIN   naga's `Restrict` as its SPIR-V writer emits it: min(coordinate AS UNSIGNED, size - 1), so a
+ *                  negative coordinate lands on the level's LAST column / row, not its first. */
+static float level_load_p(const uint16_t *pyr, const orc_pyramid_t *lay, uint32_t lvl, int64_t x, int64_t y, uint32_t oob) {
+    const int64_t w = (int64_t)lay->w[lvl], h = (int64_t)lay->h[lvl];
+    if (x < 0 || y < 0 || x >= w || y >= h) {
+        if (oob == ORC_OOB_ZERO) return 0.0f;
+        if (oob == ORC_OOB_CLAMP) {
+            x = x < 0 ? 0 : (x >= w ? w - 1 : x);
+            y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+        } else {
+            x = (x < 0 || x >= w) ? w - 1 : x;
+            y = (y < 0 || y >= h) ? h - 1 : y;
+        }
+    }
     return orc_f16_to_f32(pyr[lay->offset[lvl] + (size_t)y * lay->w[lvl] + (size_t)x]);
+}
+static float level_load(const uint16_t *pyr, const orc_pyramid_t *lay, uint32_t lvl, int64_t x, int64_t y) {
+    return level_load_p(pyr, lay, lvl, x, y, ORC_OOB_ZERO);
 }
 
 void orc_fast(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, orc_corner_t *out, uint32_t cap,
               uint32_t *total) {
+    orc_fast_impl(pyr, lay, threshold, ORC_OOB_ZERO, out, cap, total);
+}
+
+void orc_fast_impl(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, uint32_t oob, orc_corner_t *out,
+                   uint32_t cap, uint32_t *total) {
     uint32_t count = 0;
     uint32_t W0 = lay->w[0], H0 = lay->h[0];
     uint32_t lim_x = W0 - 16u, lim_y = H0 - 16u; /* textureDimensions(texture) is the level-0 size; u32 wrap kept */
@@ -277,10 +317,10 @@ void orc_fast(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, or
         for (uint32_t gy = 0; gy < gh; gy++)
             for (uint32_t gx = 0; gx < gw; gx++) {
                 if (!(gx > 16u && gy > 16u && gx < lim_x && gy < lim_y)) continue; /* fast.wgsl:77 */
-                float c = level_load(pyr, lay, oct, gx, gy);
+                float c = level_load_p(pyr, lay, oct, gx, gy, oob);
                 uint32_t num_over = 0, num_under = 0;
                 for (int i = 0; i < 4; i++) { /* fast.wgsl:85-93 */
-                    float v = level_load(pyr, lay, oct, (int64_t)gx + RING4[i][0], (int64_t)gy + RING4[i][1]);
+                    float v = level_load_p(pyr, lay, oct, (int64_t)gx + RING4[i][0], (int64_t)gy + RING4[i][1], oob);
                     float diff = v - c;
                     if (diff > threshold)
                         num_over++;
@@ -291,7 +331,7 @@ void orc_fast(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, or
                 uint32_t is_over = 0, is_under = 0;
                 float cx = 0.0f, cy = 0.0f;
                 for (int i = 0; i < 16; i++) { /* fast.wgsl:102-113 */
-                    float v = level_load(pyr, lay, oct, (int64_t)gx + RING16[i][0], (int64_t)gy + RING16[i][1]);
+                    float v = level_load_p(pyr, lay, oct, (int64_t)gx + RING16[i][0], (int64_t)gy + RING16[i][1], oob);
                     float diff = v - c;
                     float px = v * (float)RING16[i][0];
                     float py = v * (float)RING16[i][1];
@@ -326,6 +366,11 @@ void orc_fast(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, or
  * ---------------------------------------------------------------------------------------- */
 void orc_brief(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
                orc_descriptor_t *out) {
+    orc_brief_impl(blur_pyr, lay, corners, n, ORC_OOB_ZERO, out);
+}
+
+void orc_brief_impl(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
+                    uint32_t oob, orc_descriptor_t *out) {
     for (uint32_t fidx = 0; fidx < n; fidx++) {
         const orc_corner_t *k = &corners[fidx];
         uint32_t oct = k->octave;
@@ -348,8 +393,8 @@ void orc_brief(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_cor
                 int64_t tby = (int64_t)(int32_t)rby + (int64_t)(int32_t)k->y;
                 float va = 0.0f, vb = 0.0f;
                 if (oct < lay->depth) {
-                    va = level_load(blur_pyr, lay, oct, tax, tay);
-                    vb = level_load(blur_pyr, lay, oct, tbx, tby);
+                    va = level_load_p(blur_pyr, lay, oct, tax, tay, oob);
+                    vb = level_load_p(blur_pyr, lay, oct, tbx, tby, oob);
                 }
                 if (va > vb) bits |= 1u << i; /* brief.wgsl:62-64 */
             }
@@ -374,25 +419,38 @@ void orc_grayscale_y8(const uint8_t *y8, uint32_t W, uint32_t H, uint16_t *gray)
     }
 }
 
+static const orc_impl_t ORC_IMPL_DEFAULT = {ORC_OOB_ZERO, 0};
+
 static int extract_impl(const uint8_t *frame, int y8, uint32_t W, uint32_t H, uint32_t depth, float threshold,
-                        uint32_t max_features, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total,
-                        uint16_t *gray_pyr, uint16_t *blur_pyr);
+                        uint32_t max_features, const orc_impl_t *impl, orc_corner_t *corners, orc_descriptor_t *descriptors,
+                        uint32_t *total, uint16_t *gray_pyr, uint16_t *blur_pyr);
+
+int orc_extract_impl(const uint8_t *frame, int y8, uint32_t W, uint32_t H, uint32_t depth, float threshold,
+                     uint32_t max_features, const orc_impl_t *impl, orc_corner_t *corners, orc_descriptor_t *descriptors,
+                     uint32_t *total, uint16_t *gray_pyr, uint16_t *blur_pyr) {
+    if (impl && (impl->oob > ORC_OOB_UMIN || impl->sampler_weight_bits > 23)) return -1;
+    return extract_impl(frame, y8, W, H, depth, threshold, max_features, impl ? impl : &ORC_IMPL_DEFAULT, corners, descriptors,
+                        total, gray_pyr, blur_pyr);
+}
 
 int orc_extract(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, float threshold, uint32_t max_features,
                 orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total, uint16_t *gray_pyr,
                 uint16_t *blur_pyr) {
-    return extract_impl(rgba, 0, W, H, depth, threshold, max_features, corners, descriptors, total, gray_pyr, blur_pyr);
+    return extract_impl(rgba, 0, W, H, depth, threshold, max_features, &ORC_IMPL_DEFAULT, corners, descriptors, total, gray_pyr,
+                        blur_pyr);
 }
 
 int orc_extract_y8(const uint8_t *y8, uint32_t W, uint32_t H, uint32_t depth, float threshold, uint32_t max_features,
                    orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total, uint16_t *gray_pyr,
                    uint16_t *blur_pyr) {
-    return extract_impl(y8, 1, W, H, depth, threshold, max_features, corners, descriptors, total, gray_pyr, blur_pyr);
+    return extract_impl(y8, 1, W, H, depth, threshold, max_features, &ORC_IMPL_DEFAULT, corners, descriptors, total, gray_pyr,
+                        blur_pyr);
 }
 
 static int extract_impl(const uint8_t *rgba, int y8, uint32_t W, uint32_t H, uint32_t depth, float threshold,
-                        uint32_t max_features, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total,
-                        uint16_t *gray_pyr, uint16_t *blur_pyr) {
+                        uint32_t max_features, const orc_impl_t *impl, orc_corner_t *corners, orc_descriptor_t *descriptors,
+                        uint32_t *total, uint16_t *gray_pyr, uint16_t *blur_pyr) {
+    const uint32_t wbits = impl->sampler_weight_bits, oob = impl->oob;
     if (!rgba || !W || !H || depth < 1 || depth > ORC_MAX_LEVELS || !total) return -1;
     orc_pyramid_t lay;
     orc_pyramid_layout(W, H, depth, &lay);
@@ -410,13 +468,13 @@ static int extract_impl(const uint8_t *rgba, int y8, uint32_t W, uint32_t H, uin
     else
         orc_grayscale(rgba, W, H, gray);
     for (uint32_t m = 1; m < depth; m++)
-        orc_mip(gray + lay.offset[m - 1], lay.w[m - 1], lay.h[m - 1], gray + lay.offset[m], lay.w[m], lay.h[m]);
-    for (uint32_t m = 0; m < depth; m++) orc_blur_pass(gray + lay.offset[m], lay.w[m], lay.h[m], tmp + lay.offset[m]);
-    for (uint32_t m = 0; m < depth; m++) orc_blur_pass(tmp + lay.offset[m], lay.w[m], lay.h[m], blur + lay.offset[m]);
+        orc_mip_impl(gray + lay.offset[m - 1], lay.w[m - 1], lay.h[m - 1], gray + lay.offset[m], lay.w[m], lay.h[m], wbits);
+    for (uint32_t m = 0; m < depth; m++) orc_blur_pass_impl(gray + lay.offset[m], lay.w[m], lay.h[m], tmp + lay.offset[m], wbits);
+    for (uint32_t m = 0; m < depth; m++) orc_blur_pass_impl(tmp + lay.offset[m], lay.w[m], lay.h[m], blur + lay.offset[m], wbits);
     uint32_t count = 0;
-    orc_fast(gray, &lay, threshold, corners, max_features, &count);
+    orc_fast_impl(gray, &lay, threshold, oob, corners, max_features, &count);
     uint32_t stored = count < max_features ? count : max_features;
-    if (descriptors) orc_brief(blur, &lay, corners, stored, descriptors);
+    if (descriptors) orc_brief_impl(blur, &lay, corners, stored, oob, descriptors);
     *total = count;
     if (gray_pyr) memcpy(gray_pyr, gray, lay.total * sizeof(uint16_t));
     if (blur_pyr) memcpy(blur_pyr, blur, lay.total * sizeof(uint16_t));

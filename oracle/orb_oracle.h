@@ -79,6 +79,35 @@ int orc_extract(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, flo
                 orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *total, uint16_t *gray_pyr,
                 uint16_t *blur_pyr);
 
+/* ---- implementation-defined behaviour as switches.  The reference's WGSL leaves two things to the adapter that can
+ * change keypoints and descriptor bits; until a dump from the reference itself pins them
+ * (tools/pin_oracle.py, rust/dump_config0), the restatement can be run either way:
+ *   oob                   what textureLoad returns outside the addressed level (fast.wgsl:78,86,103; brief.wgsl:59-60):
+ *                         ORC_OOB_ZERO 0 (robust image access; CRD-6, the default), ORC_OOB_CLAMP each coordinate clamped
+ *                         into the level, ORC_OOB_UMIN naga's `Restrict` policy as min(unsigned(coordinate), size - 1):
+ *                         negative coordinates land on the LAST column / row.
+ *   sampler_weight_bits   precision of a bilinear sampler's weights (gaussian_blur_x.wgsl:53-58; blit.wgsl:35 for odd
+ *                         sizes): 0 = the exact binary32 fraction (CRD-5, the default), n = 1..23: the fraction rounded
+ *                         to n fractional bits, halves up (8 is what GPUs commonly implement).
+ * The defaults are what every other entry of this header computes. */
+#define ORC_OOB_ZERO 0u
+#define ORC_OOB_CLAMP 1u
+#define ORC_OOB_UMIN 2u
+typedef struct {
+    uint32_t oob;
+    uint32_t sampler_weight_bits;
+} orc_impl_t;
+void orc_mip_impl(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint32_t wd, uint32_t hd, uint32_t wbits);
+void orc_blur_pass_impl(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, uint32_t wbits);
+void orc_fast_impl(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, uint32_t oob, orc_corner_t *out,
+                   uint32_t cap, uint32_t *total);
+void orc_brief_impl(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
+                    uint32_t oob, orc_descriptor_t *out);
+/* orc_extract / orc_extract_y8 (y8 != 0) with the switches; impl == NULL: the defaults. */
+int orc_extract_impl(const uint8_t *frame, int y8, uint32_t W, uint32_t H, uint32_t depth, float threshold,
+                     uint32_t max_features, const orc_impl_t *impl, orc_corner_t *corners, orc_descriptor_t *descriptors,
+                     uint32_t *total, uint16_t *gray_pyr, uint16_t *blur_pyr);
+
 /* ---- opt-in extensions (NOT in the reference, no parity target: the definitions
  * below are the build's own and are pinned only by the NumPy restatement and the GPU tests) ----
  * arc: a corner needs a circular run of >= arc ring pixels (9..16) all brighter or all darker than the centre by

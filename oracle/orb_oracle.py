@@ -73,6 +73,10 @@ def lib():
         L.orc_extract.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, u32p, vp, vp]
         L.orc_extract_y8.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, u32p, vp, vp]
         L.orc_extract.restype = ctypes.c_int
+        L.orc_extract_impl.argtypes = [vp, ctypes.c_int, u32, u32, u32, f32, u32, vp, vp, vp, u32p, vp, vp]
+        L.orc_extract_impl.restype = ctypes.c_int
+        L.orc_mip_impl.argtypes = [vp, u32, u32, vp, u32, u32, u32]
+        L.orc_blur_pass_impl.argtypes = [vp, u32, u32, vp, u32]
         L.orc_extract_ex.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, vp, u32p]
         L.orc_extract_ex.restype = ctypes.c_int
         L.orc_extract_intended.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, vp, u32p, vp, vp]
@@ -151,26 +155,36 @@ def grayscale(rgba):
     return out
 
 
-def mip(src, wd=None, hd=None):
+def mip(src, wd=None, hd=None, weight_bits=0):
     src = np.ascontiguousarray(src, dtype=np.uint16)
     hs, ws = src.shape
     wd = max(1, ws >> 1) if wd is None else wd
     hd = max(1, hs >> 1) if hd is None else hd
     out = np.empty((hd, wd), dtype=np.uint16)
-    lib().orc_mip(_ptr(src), ws, hs, _ptr(out), wd, hd)
+    lib().orc_mip_impl(_ptr(src), ws, hs, _ptr(out), wd, hd, int(weight_bits))
     return out
 
 
-def blur_pass(src):
+def blur_pass(src, weight_bits=0):
     src = np.ascontiguousarray(src, dtype=np.uint16)
     h, w = src.shape
     out = np.empty((h, w), dtype=np.uint16)
-    lib().orc_blur_pass(_ptr(src), w, h, _ptr(out))
+    lib().orc_blur_pass_impl(_ptr(src), w, h, _ptr(out), int(weight_bits))
     return out
 
 
-def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=False):
-    """Whole frame.  Returns dict(total, corners[structured], descriptors[u32 (n,8)], gray, blur)."""
+# The implementation-defined switches of orb_oracle.h (orc_impl_t): what a textureLoad outside the level returns, and the
+# precision of a bilinear sampler's weights.  The defaults are CRD-6 / CRD-5.
+OOB_POLICIES = {"zero": 0, "clamp": 1, "umin": 2}
+
+
+def _impl(oob, weight_bits):
+    return (ctypes.c_uint32 * 2)(OOB_POLICIES[oob] if isinstance(oob, str) else int(oob), int(weight_bits))
+
+
+def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=False, oob="zero", weight_bits=0, y8=False):
+    """Whole frame.  Returns dict(total, corners[structured], descriptors[u32 (n,8)], gray, blur).
+    oob / weight_bits: the implementation-defined switches (orc_impl_t); y8: a one-byte-per-pixel frame."""
     rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
     H, W = rgba.shape[:2]
     corners = np.zeros(max_features, dtype=CORNER_DTYPE)
@@ -179,11 +193,12 @@ def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=Fal
     _, ntex = level_dims(W, H, depth)
     gray = np.zeros(ntex, dtype=np.uint16) if planes else None
     blur = np.zeros(ntex, dtype=np.uint16) if planes else None
-    rc = lib().orc_extract(_ptr(rgba), W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
-                           _ptr(corners), _ptr(desc), ctypes.byref(total),
-                           _ptr(gray) if planes else None, _ptr(blur) if planes else None)
+    impl = _impl(oob, weight_bits)
+    rc = lib().orc_extract_impl(_ptr(rgba), 1 if y8 else 0, W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
+                                ctypes.cast(impl, ctypes.c_void_p), _ptr(corners), _ptr(desc), ctypes.byref(total),
+                                _ptr(gray) if planes else None, _ptr(blur) if planes else None)
     if rc != 0:
-        raise ValueError("orc_extract: invalid arguments")
+        raise ValueError("orc_extract_impl: invalid arguments")
     n = min(total.value, max_features)
     return dict(total=total.value, corners=corners[:n], descriptors=desc[:n], gray=gray, blur=blur)
 
@@ -196,8 +211,10 @@ def grayscale_y8(y8):
     return out
 
 
-def extract_y8(y8, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=False):
+def extract_y8(y8, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=False, oob="zero", weight_bits=0):
     """Y8 input variant (one byte per pixel; not in the reference's code, see orb_oracle.c)."""
+    if oob != "zero" or weight_bits:
+        return extract(y8, depth, threshold, max_features, planes, oob, weight_bits, y8=True)
     y8 = np.ascontiguousarray(y8, dtype=np.uint8)
     H, W = y8.shape[:2]
     corners = np.zeros(max_features, dtype=CORNER_DTYPE)

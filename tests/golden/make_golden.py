@@ -50,6 +50,22 @@ Y8_CASES = [
 ]
 
 
+# The implementation-defined switches (oracle/orb_oracle.h, orc_impl_t; include/tinyorb.h, OrbOptions::oob_policy /
+# sampler_weight_bits): name, W, H, depth, seed, flags, oob, weight bits.  Frames chosen so that the switch changes the
+# result (keypoints at octaves >= 1 near the level's edge, samples that leave the level -- for s45 one with a negative
+# coordinate, where clamp and umin part --, lerp weights of the blur and of the odd-sized blit).  Kept in tests/golden/impl/.
+IMPL_CASES = [
+    ("m320x240_d3_s45_clamp_w0", 320, 240, 3, 45, 15, "clamp", 0),
+    ("m320x240_d3_s45_umin_w0", 320, 240, 3, 45, 15, "umin", 0),
+    ("m320x240_d3_s45_zero_w8", 320, 240, 3, 45, 15, "zero", 8),
+    ("m320x240_d3_s45_umin_w8", 320, 240, 3, 45, 15, "umin", 8),
+    ("m333x211_d4_s41_zero_w8", 333, 211, 4, 41, 15, "zero", 8),
+    ("m333x211_d4_s41_clamp_w8", 333, 211, 4, 41, 15, "clamp", 8),
+    ("m640x480_d2_s41_clamp_w0", 640, 480, 2, 41, 15, "clamp", 0),
+    ("m640x480_d2_config1_umin_w8", 640, 480, 2, 1, 7, "umin", 8),  # BASELINE.json configs[0]'s frame under the other reading
+]
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -79,6 +95,31 @@ def main():
             corners=np.stack([corners[k] for k in ("x", "y", "angle", "octave")], 1).astype(np.uint32),
             descriptors=desc.astype(np.uint32))
         print(name, "total", ref["total"])
+    os.makedirs(os.path.join(HERE, "impl"), exist_ok=True)
+    for name, W, H, depth, seed, flags, oob, wbits in IMPL_CASES:
+        rgba = orb_oracle.synth_frame(W, H, seed, flags)
+        ref = orb_oracle.extract(rgba, depth=depth, threshold=THR, max_features=8192, planes=True, oob=oob, weight_bits=wbits)
+        alt = orb_numpy.extract(rgba, depth=depth, threshold=THR, max_features=8192, oob=oob, weight_bits=wbits)
+        base = orb_oracle.extract(rgba, depth=depth, threshold=THR, max_features=8192)
+        kc = np.stack([ref["corners"][k] for k in ("x", "y", "angle", "octave")], 1)
+        assert ref["total"] == alt["total"] and np.array_equal(kc, alt["corners"])
+        assert np.array_equal(ref["descriptors"], alt["descriptors"])
+        assert ref["total"] != base["total"] or not np.array_equal(ref["descriptors"], base["descriptors"]), "the switch changes nothing here"
+        dims, _ = orb_oracle.level_dims(W, H, depth)
+        blur_sha = []
+        for m, (w, h, off) in enumerate(dims):
+            b = ref["blur"][off:off + w * h]
+            assert np.array_equal(b, alt["blur"][m].ravel())
+            blur_sha.append(sha(b))
+        corners, desc = orb_oracle.sort_keypoints(ref["corners"], ref["descriptors"])
+        np.savez_compressed(
+            os.path.join(HERE, "impl", name + ".npz"),
+            params=np.array([W, H, depth, seed, flags, 8192, orb_oracle.OOB_POLICIES[oob], wbits], dtype=np.int64), threshold=THR,
+            rgba_sha256=sha(rgba), blur_sha256=np.array(blur_sha), total=np.int64(ref["total"]),
+            total_default=np.int64(base["total"]),
+            corners=np.stack([corners[k] for k in ("x", "y", "angle", "octave")], 1).astype(np.uint32),
+            descriptors=desc.astype(np.uint32))
+        print(name, "total", ref["total"], "(default switches:", base["total"], ")")
     os.makedirs(os.path.join(HERE, "y8"), exist_ok=True)
     for name, W, H, depth, seed, flags in Y8_CASES:
         y8 = orb_oracle.synth_frame_y8(W, H, seed, flags)

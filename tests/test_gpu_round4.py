@@ -86,3 +86,121 @@ def test_bench_ranks_path_collates_through_nccl_world1():
     kp = rec["keypoints_per_frame"] * 32
     assert abs(col["bytes_gathered_per_batch"] - 40 * kp) < 1e-6 * 40 * kp + 1
     assert rec["n_gpus"] == 1 and rec["value"] > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# The implementation-defined switches (include/tinyorb.h OrbOptions::oob_policy / sampler_weight_bits): the committed
+# fixtures straight against the GPU, then shapes x policies against the oracle -- fused and staged kernels, the batch and
+# the single-frame entries, Y8 input, the wave-per-keypoint BRIEF fallback.
+# ---------------------------------------------------------------------------------------------
+import glob
+import hashlib
+
+_IMPL = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "impl", "*.npz")))
+
+
+def _impl_program(tinyorb, W, H, depth, oob, wbits, flags=0, max_batch=1, cap=8192, thr=THR):
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=cap, hierarchy_depth=depth, initial_threshold=thr,
+                            max_batch=max_batch, flags=flags, oob_policy=oob, sampler_weight_bits=wbits)
+    return tinyorb.OrbProgram(cfg).init()
+
+
+@pytest.mark.parametrize("path", _IMPL, ids=[os.path.basename(p) for p in _IMPL])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_impl_switch_fixture_on_gpu(tinyorb, path, flags):
+    """No oracle code runs here: the fixture holds the expected keypoints, descriptors and blur planes."""
+    g = np.load(path)
+    W, H, depth, seed, syn_flags, cap, oob, wbits = (int(v) for v in g["params"])
+    with _impl_program(tinyorb, W, H, depth, oob, wbits, flags=flags, cap=cap, thr=float(g["threshold"])) as prog:
+        assert prog.pipeline() == ("staged" if flags else "fused")
+        dev = prog.synth_frames_device(1, seed, syn_flags)
+        rgba = prog.copy_to_host(dev, W * H * 4)
+        assert hashlib.sha256(rgba.tobytes()).hexdigest() == str(g["rgba_sha256"])
+        prog.extract_batch_device(dev, 1)
+        total = int(prog.batch_counts(1)[0])
+        assert total == int(g["total"])
+        corners, desc = prog.batch_read(0, total)
+        c, d = _sorted(corners, desc)
+        assert np.array_equal(np.stack([c[k] for k in ("x", "y", "angle", "octave")], 1), g["corners"])
+        assert np.array_equal(d, g["descriptors"])
+        for m in range(depth):
+            b = prog.read_plane(tinyorb.ORB_PLANE_BLUR, m)
+            assert hashlib.sha256(b.tobytes()).hexdigest() == str(g["blur_sha256"][m])
+
+
+@pytest.mark.parametrize("W,H,depth,seed", [(320, 240, 3, 45), (333, 211, 4, 41), (1282, 96, 2, 17), (200, 97, 3, 7), (640, 360, 2, 3),
+                                            (44, 36, 3, 12), (1241, 376, 3, 14), (2052, 80, 2, 6), (4100, 72, 2, 5)])
+@pytest.mark.parametrize("oob,wbits", [("clamp", 0), ("umin", 8), ("zero", 8), ("clamp", 4)])
+def test_impl_switches_match_oracle(tinyorb, oracle, W, H, depth, seed, oob, wbits):
+    """Every out-of-level policy and a sampler weight precision on shapes that take different kernels (bands of 64..8 rows,
+    odd widths and halvings: k_mip and the general level-0 variant, column tiles), fused and staged, through the batch
+    entry and through the reference's six calls."""
+    rgba = oracle.synth_frame(W, H, seed)
+    ref = oracle.extract(rgba, depth=depth, threshold=THR, planes=True, oob=oob, weight_bits=wbits)
+    dims, _ = oracle.level_dims(W, H, depth)
+    for flags in (0, 1):
+        with _impl_program(tinyorb, W, H, depth, tinyorb.OOB_POLICIES[oob], wbits, flags=flags) as prog:
+            total, corners, desc = prog.extract(rgba)  # write_input_image + extract_corners + the two reads
+            _assert_frame_equal(oracle, ref, total, corners, desc)
+            for m, (w, h, off) in enumerate(dims):
+                b = prog.read_plane(tinyorb.ORB_PLANE_BLUR, m)
+                assert np.array_equal(b.ravel(), ref["blur"][off:off + w * h]), "blur level %d" % m
+
+
+def test_impl_switches_batch_y8_and_brief_fallback(tinyorb, oracle, monkeypatch):
+    """A batch of Y8 frames under clamp + 8-bit weights; then the same RGBA frames with the wave-per-keypoint BRIEF kernel
+    forced (k_brief_rows, the fallback for frames whose row constants do not fit k_brief_t's LDS staging)."""
+    W, H, B = 320, 240, 5
+    y8 = np.stack([oracle.synth_frame_y8(W, H, 800 + i) for i in range(B)])
+    with _impl_program(tinyorb, W, H, 3, tinyorb.ORB_OOB_CLAMP, 8, flags=tinyorb.ORB_FLAG_INPUT_Y8, max_batch=B) as prog:
+        prog.extract_batch_host(y8)
+        counts = prog.batch_counts(B)
+        for i in range(B):
+            ref = oracle.extract_y8(y8[i], depth=3, threshold=THR, oob="clamp", weight_bits=8)
+            _assert_frame_equal(oracle, ref, int(counts[i]), *prog.batch_read(i, min(int(counts[i]), 8192)))
+    monkeypatch.setenv("TINYORB_BRIEF_ROWS", "1")
+    frames = np.stack([oracle.synth_frame(W, H, 45 + i) for i in range(B)])
+    for oob in ("umin", "clamp"):
+        with _impl_program(tinyorb, W, H, 3, tinyorb.OOB_POLICIES[oob], 0, max_batch=B) as prog:
+            prog.extract_batch_host(frames)
+            counts = prog.batch_counts(B)
+            for i in range(B):
+                ref = oracle.extract(frames[i], depth=3, threshold=THR, oob=oob)
+                _assert_frame_equal(oracle, ref, int(counts[i]), *prog.batch_read(i, min(int(counts[i]), 8192)))
+
+
+def test_impl_switches_are_refused_with_the_extensions(tinyorb):
+    """The switches follow the reference's adapter; the build's own extensions have no reference behaviour to follow."""
+    for kw in (dict(flags=tinyorb.ORB_FLAG_INTENDED), dict(flags=tinyorb.ORB_FLAG_NMS), dict(fast_arc=9)):
+        for sw in (dict(oob_policy=tinyorb.ORB_OOB_CLAMP), dict(sampler_weight_bits=8)):
+            with pytest.raises(tinyorb.OrbError) as e:
+                tinyorb.OrbProgram(tinyorb.OrbConfig(tinyorb.Extent3d(320, 240), **kw, **sw)).init()
+            assert e.value.code == tinyorb.ORB_EINVAL
+    for sw in (dict(oob_policy=3), dict(sampler_weight_bits=24)):
+        with pytest.raises(tinyorb.OrbError):
+            tinyorb.OrbProgram(tinyorb.OrbConfig(tinyorb.Extent3d(320, 240), **sw)).init()
+
+
+_REF_DUMPS = sorted(d for d in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "reference_dump*"))
+                    if os.path.exists(os.path.join(d, "total.npy")))
+
+
+@pytest.mark.skipif(not _REF_DUMPS, reason="no dump of the reference (tests/golden/reference_dump*/): parity unpinned")
+@pytest.mark.parametrize("dump", _REF_DUMPS or [None])
+def test_reference_dump_on_gpu(tinyorb, dump):
+    """The GPU path against the REFERENCE's own output (rust/dump_config0), with no oracle code in between: counter, sorted
+    keypoints and descriptor bits, under the default switches."""
+    total = int(np.load(os.path.join(dump, "total.npy")))
+    corners = np.load(os.path.join(dump, "corners.npy")).astype(np.uint32).reshape(-1, 4)
+    desc = np.load(os.path.join(dump, "descriptors.npy")).astype(np.uint32).reshape(-1, 8)
+    W, H, depth, seed, syn_flags, cap = (int(v) for v in np.load(os.path.join(dump, "params.npy")))
+    order = np.lexsort((corners[:, 0], corners[:, 1], corners[:, 3]))
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=cap, hierarchy_depth=depth, initial_threshold=THR)
+    with tinyorb.OrbProgram(cfg).init() as prog:
+        dev = prog.synth_frames_device(1, seed, syn_flags)
+        prog.extract_batch_device(dev, 1)
+        got_total = int(prog.batch_counts(1)[0])
+        assert got_total == total
+        c, d = _sorted(*prog.batch_read(0, min(total, cap)))
+        assert np.array_equal(np.stack([c[k] for k in ("x", "y", "angle", "octave")], 1), corners[order])
+        assert np.array_equal(d, desc[order])

@@ -66,6 +66,8 @@ struct OrbProgram {
     uint32_t max_batch = 1;
     float threshold = 0.f;
     uint32_t arc = 12;  // FAST arc length (opt-in extension, 9..16)
+    uint32_t oob = kOobZero;  // OrbOptions::oob_policy
+    float wq = 0.0f;          // OrbOptions::sampler_weight_bits as 2^bits (0: exact weights)
     // opt-in NMS (staged pipeline): provisional detections + score planes
     uint32_t cap_prov = 0;
     uint32_t* d_prov_counts = nullptr;
@@ -252,7 +254,7 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
     for (uint32_t m = 1; m < D; m++) {  // orb.rs:413-429
         LaunchScope ls(p, s, KID_MIP);
         dim3 grid((pyr.w[m] + 63u) / 64u, (pyr.h[m] + 4u * kMipRows - 1u) / (4u * kMipRows), n);
-        hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, p->d_gray, pyr, m, (float)pyr.w[m - 1] / (float)pyr.w[m], (float)pyr.h[m - 1] / (float)pyr.h[m]);
+        hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, s, p->d_gray, pyr, m, (float)pyr.w[m - 1] / (float)pyr.w[m], (float)pyr.h[m - 1] / (float)pyr.h[m], p->wq);
     }
     for (uint32_t m = 0; m < D; m++) {  // orb.rs:432-466 (both passes)
         LaunchScope ls(p, s, KID_BLUR);
@@ -263,7 +265,7 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
         }
         dim3 grid(pyr.h[m], 1, n);
         size_t lds = (size_t)pyr.w[m] * 2u * sizeof(uint16_t);
-        hipLaunchKernelGGL(k_blur_rows, grid, dim3(256), lds, s, p->d_gray, p->d_blur, pyr, m);
+        hipLaunchKernelGGL(k_blur_rows, grid, dim3(256), lds, s, p->d_gray, p->d_blur, pyr, m, p->wq);
     }
     const bool nms = (p->opt.flags & ORB_FLAG_NMS) != 0u;
     const uint32_t im = p->intended ? 1u : 0u;
@@ -285,7 +287,7 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
                                    nms ? p->d_score_planes : (float*)nullptr, p->score_layout);
             else
                 hipLaunchKernelGGL(k_fast, grid, dim3(16, 16), 0, s, p->d_gray, pyr, oct, gw, gh, p->threshold, p->arc, im,
-                                   p->d_counts, p->d_corners, cap, (float*)nullptr, (float*)nullptr, p->score_layout);
+                                   p->d_counts, p->d_corners, cap, (float*)nullptr, (float*)nullptr, p->score_layout, p->oob);
         }
         width /= 2u;
         height /= 2u;
@@ -314,7 +316,7 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
         if (bx > 64u) bx = 64u;
         if (bx < 1u) bx = 1u;
         hipLaunchKernelGGL(k_brief, dim3(bx, 1, n), dim3(256), 0, s, p->d_blur, pyr, p->d_counts, p->d_corners, cap,
-                           p->d_desc, tab, im);
+                           p->d_desc, tab, im, p->oob);
     }
     HIP_TRY(p, hipGetLastError());
     p->planes_valid = true;
@@ -418,6 +420,7 @@ bool brieft_geometry(const OrbProgram* p, const RowsGeom& rg, uint32_t n_classes
         rows += p->pyr.h[m] + 2u * (uint32_t)kBriefHalo + 8u;
     }
     g.rows_padded = rows;
+    g.oob = p->oob;
     *out = g;
     if (getenv("TINYORB_BRIEF_ROWS")) return false;  // A/B and cross-check: the wave-per-keypoint kernel
     return rg.n_slots >= 1u && rg.n_slots * n_classes <= kBriefTMaxSlots && rows <= kBriefTMaxRows;
@@ -445,11 +448,16 @@ int launch_brief(OrbProgram* p, hipStream_t s, uint32_t n, const RowsGeom& rows_
                                d_desc, tab);
         }
         LaunchScope ls(p, s, KID_BRIEF_NF);
-        hipLaunchKernelGGL(k_brief_nf, grid, dim3(256), 0, s, d_blur, d_blur_rowc, p->pyr, tg, seg_counts, seg_before, d_corners,
-                           cap, d_desc, tab);
+        if (p->oob != kOobZero)
+            hipLaunchKernelGGL(k_brief_nf<true>, grid, dim3(256), 0, s, d_blur, d_blur_rowc, p->pyr, tg, seg_counts, seg_before, d_corners,
+                               cap, d_desc, tab);
+        else
+            hipLaunchKernelGGL(k_brief_nf<false>, grid, dim3(256), 0, s, d_blur, d_blur_rowc, p->pyr, tg, seg_counts, seg_before, d_corners,
+                               cap, d_desc, tab);
     } else {
         LaunchScope ls(p, s, KID_BRIEF_ROWS);
         RowsGeom rg = rows_geom;
+        rg.oob = p->oob;
         rg.split = 1u;  // small batches: several workgroups per band slot so that the chip still sees ~2000 of them
         while (rg.split < 16u && rg.n_slots * n * rg.split < 2048u) rg.split *= 2u;
         hipLaunchKernelGGL(k_brief_rows, dim3(rg.n_slots * rg.split, n), dim3(256), 0, s, d_blur, d_blur_rowc, p->pyr, rg,
@@ -488,7 +496,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
             hipStream_t sm = s;
             LaunchScope ls(p, sm, KID_MIP);  // inexact reduction (odd source size): generic bilinear blit
             dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 4u * kMipRows - 1u) / (4u * kMipRows), n);
-            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, sm, d_gray, pyr, lvl, (float)pyr.w[lvl - 1] / (float)pyr.w[lvl], (float)pyr.h[lvl - 1] / (float)pyr.h[lvl]);
+            hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, sm, d_gray, pyr, lvl, (float)pyr.w[lvl - 1] / (float)pyr.w[lvl], (float)pyr.h[lvl - 1] / (float)pyr.h[lvl], p->wq);
         }
         FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n, p->band_rows_lvl[lvl], p->tile_w_lvl[lvl]);
         hipStream_t s_lvl = s;
@@ -498,6 +506,8 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         g.seg_cap = p->bands.seg_cap;
         g.n_classes = p->seg_classes;
         g.stamps = p->d_stamps;
+        g.oob = p->oob;
+        g.wq = p->wq;
         g.store_grey = (lvl == 0 && D > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) ? 1u : 0u;
         if (g.n_bands * (g.tiled ? g.n_ct : 1u) != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: band count mismatch at level %u", lvl);
@@ -798,6 +808,12 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         ((options->flags & (ORB_FLAG_INTENDED | ORB_FLAG_NMS)) || (options->fast_arc != 0 && options->fast_arc != 12)))
         return fail(nullptr, ORB_EINVAL, "ORB_FLAG_INPUT_Y8 is defined for the reference's detector only (no "
                                          "ORB_FLAG_INTENDED, ORB_FLAG_NMS or fast_arc other than 12)");
+    if (options && (options->oob_policy > ORB_OOB_UMIN || options->sampler_weight_bits > 23u))
+        return fail(nullptr, ORB_EINVAL, "oob_policy must be ORB_OOB_ZERO / _CLAMP / _UMIN and sampler_weight_bits 0..23");
+    if (options && (options->oob_policy != ORB_OOB_ZERO || options->sampler_weight_bits != 0u) &&
+        ((options->flags & (ORB_FLAG_INTENDED | ORB_FLAG_NMS)) || (options->fast_arc != 0 && options->fast_arc != 12)))
+        return fail(nullptr, ORB_EINVAL, "oob_policy / sampler_weight_bits follow the reference's adapter: they are defined for the "
+                                         "reference's detector only (no ORB_FLAG_INTENDED, ORB_FLAG_NMS or fast_arc other than 12)");
     if (options && (options->flags & ORB_FLAG_INTENDED) && (W > 16384u || H > 16384u))
         return fail(nullptr, ORB_EINVAL, "ORB_FLAG_INTENDED needs W, H <= 16384 (14-bit coordinates in the top-K key)");
 
@@ -811,6 +827,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     p->intended = (p->opt.flags & ORB_FLAG_INTENDED) != 0u;
     p->input_y8 = (p->opt.flags & ORB_FLAG_INPUT_Y8) != 0u;
     p->arc = p->opt.fast_arc ? p->opt.fast_arc : (p->intended ? 9u : 12u);
+    p->oob = p->opt.oob_policy;
+    p->wq = p->opt.sampler_weight_bits ? (float)(1u << p->opt.sampler_weight_bits) : 0.0f;
     p->frame_bytes = (size_t)W * H * (p->input_y8 ? 1u : 4u);
     layout_pyramid(W, H, config->hierarchy_depth, &p->pyr);
 
@@ -1268,7 +1286,7 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
     const bool direct = !getenv("TINYORB_SINGLE_MEMCPY") && hipHostGetDevicePointer(&dc, p->h_count, 0) == hipSuccess &&
                         hipHostGetDevicePointer(&dk, p->h_corners, 0) == hipSuccess &&
                         hipHostGetDevicePointer(&dd, p->h_desc, 0) == hipSuccess;
-    if (direct && p->fused && p->use_brief_t && !getenv("TINYORB_SINGLE_SPLIT")) {
+    if (direct && p->fused && p->use_brief_t && p->oob == kOobZero && !getenv("TINYORB_SINGLE_SPLIT")) {  // k_brief_one is built for the default policy
         // Three launches per frame: one k_front per level, then k_brief_one -- slot prefix, both BRIEF kernels and the
         // write to host staging in one (a dependent launch costs 6-10 us whatever it does, and this call is the
         // reference's only shape).
@@ -1292,6 +1310,7 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
                 g[lvl].seg_cap = p->bands.seg_cap;
                 g[lvl].n_classes = p->seg_classes;
                 g[lvl].xcd_swizzle = 0u;
+                g[lvl].wq = p->wq;
                 lds = std::max(lds, front_lds_bytes(g[lvl]));
             }
             if (lds > p->max_lds) return fail(p, ORB_EINVAL, "internal: k_front_pair needs %u bytes of LDS", lds);

@@ -196,20 +196,36 @@ struct BlurTap {
     int i0, i1;
     float f;
 };
-__host__ __device__ __forceinline__ BlurTap blur_tap(uint32_t x, uint32_t w, float off) {
+// wq: 0 = the exact binary32 fraction (CRD-5); 2^n = a sampler that holds its weights in n fractional bits -- the
+// fraction rounded to the nearest multiple of 2^-n, halves up (OrbOptions::sampler_weight_bits; scaling by a power of
+// two is exact).
+__host__ __device__ __forceinline__ float sampler_weight(float f, float wq) {
+    return wq != 0.0f ? __builtin_floorf(f * wq + 0.5f) / wq : f;
+}
+__host__ __device__ __forceinline__ BlurTap blur_tap(uint32_t x, uint32_t w, float off, float wq = 0.0f) {
     float fw = (float)w;
     float u = ((float)x + 0.5f) / fw;
     float uo = u + off;
     float coord = uo * fw - 0.5f;
     float c0 = __builtin_floorf(coord);
     BlurTap t;
-    t.f = coord - c0;
+    t.f = sampler_weight(coord - c0, wq);
     int i = (int)c0;
     int hi = (int)w - 1;
     t.i0 = i < 0 ? 0 : (i > hi ? hi : i);
     int j = i + 1;
     t.i1 = j < 0 ? 0 : (j > hi ? hi : j);
     return t;
+}
+
+// What a textureLoad outside the addressed level returns is implementation-defined (fast.wgsl:78,86,103 at
+// octaves >= 1, brief.wgsl:59-60): OrbOptions::oob_policy.  kOobZero: 0 (Vulkan robust image access; the default);
+// kOobClamp: every coordinate clamped into the level; kOobUmin: naga's `Restrict` as its SPIR-V writer emits it,
+// min(unsigned(coordinate), size - 1) -- a negative coordinate lands on the LAST column / row.
+constexpr uint32_t kOobZero = 0u, kOobClamp = 1u, kOobUmin = 2u;
+__host__ __device__ __forceinline__ int oob_index(int i, int n, uint32_t policy) {  // policy != kOobZero
+    if (policy == kOobClamp) return i < 0 ? 0 : (i >= n ? n - 1 : i);
+    return (i < 0 || i >= n) ? n - 1 : i;
 }
 
 // Synthetic-frame hash; byte-identical to the recipe the tests hold (checked on the GPU).

@@ -31,6 +31,7 @@ struct BriefTGeom {
     uint32_t qa[kMaxLevels];
     uint32_t row_base[kMaxLevels];  // index of row 0 of the level in the padded LDS row array
     uint32_t rows_padded;           // entries of that array
+    uint32_t oob;                   // OrbOptions::oob_policy: what a sample outside the level reads (brief.wgsl:59-60; kOobZero: 0)
 };
 
 __host__ __device__ inline uint32_t brieft_lds_bytes(const BriefTGeom& g) {
@@ -77,7 +78,10 @@ __device__ __forceinline__ void brief_t_stage_rows(uint16_t* rows, const uint16_
     for (uint32_t i = tid; i < bg.rows_padded; i += n_threads) {
         while (m + 1u < pyr.depth && i + (uint32_t)kBriefHalo >= bg.row_base[m + 1u]) m++;  // level whose padded range holds i
         const uint32_t y = i - bg.row_base[m];  // wraps for the zero rows in front of the level
-        rows[i] = y < pyr.h[m] ? src[pyr.row_off[m] + y] : (uint16_t)0;
+        uint16_t v = 0;  // CRD-6; with an out-of-level policy the padding rows repeat a row of the level (clamp: the nearest, umin: the last)
+        if (y < pyr.h[m]) v = src[pyr.row_off[m] + y];
+        else if (bg.oob != kOobZero) v = src[pyr.row_off[m] + (uint32_t)oob_index((int)y, (int)pyr.h[m], bg.oob)];
+        rows[i] = v;
     }
 }
 
@@ -261,7 +265,9 @@ __device__ __forceinline__ int rot_a(uint32_t w) { return (int)(int16_t)(w & 0xf
 __device__ __forceinline__ int rot_b(uint32_t w) { return (int)w >> 16; }                  // ... of point b
 
 // NW: waves of the workgroup (k_brief_nf: 4; k_brief_one: 8, so that a chunk's keypoints that are not flat take one turn).
-template <int CHUNK = 256, int NW = 4>
+// OOB: the program has an out-of-level policy other than "zero" (BriefTGeom::oob says which): pieces and samples outside
+// the level take a texel of the level instead of 0.  A template flag so that the default's code stays what it was.
+template <int CHUNK = 256, int NW = 4, bool OOB = false>
 __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, uint32_t n_known, const uint16_t* __restrict__ blur,
                                               const uint16_t* __restrict__ blur_rowc, const Pyramid& pyr, const BriefTGeom& bg,
                                               const uint32_t* __restrict__ seg_counts, const uint32_t* __restrict__ seg_before,
@@ -346,11 +352,19 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
                 const int p = (int)lane + 64 * rr;
                 const int pr = (int)(((float)p + 0.5f) * (1.0f / (float)kPiecesPerRow));
                 const int pc = p - pr * kPiecesPerRow;
-                const int gy = (int)r.y - kBriefHalo + pr, cx = c0 + 8 * pc;
+                const int gy0 = (int)r.y - kBriefHalo + pr, cx = c0 + 8 * pc;
+                const int gy = OOB ? oob_index(gy0, h, bg.oob) : gy0;  // OOB: a row outside the level reads a row of the level
                 const bool in = p < kPieces && gy >= 0 && gy < h && cx >= 0 && cx < w;
                 kind[rr] = !in ? 0 : (cx < qa ? 1 : (cx + 8 <= w ? 2 : 3));
                 where[rr] = p < kPieces ? pr * kNfPatchCols + 8 * pc : -1;
                 rcv[rr] = rowc[min(max(gy, 0), h - 1)];
+                if (OOB && p < kPieces && !(cx >= 0 && cx < w)) {
+                    // the whole piece lies left (cx <= -8) or right (cx >= w) of the level: one texel of row gy repeated -- its first
+                    // (clamp, left) or its last one (right; umin: left as well); a column below qa is the row constant
+                    const int xm = oob_index(cx, w, bg.oob);
+                    if (xm >= qa) rcv[rr] = plane[(size_t)(uint32_t)(__mul24(gy, w) + xm)];
+                    kind[rr] = 1;
+                }
                 // 4-byte aligned: even width, cx a multiple of 8
                 tv[rr] = *reinterpret_cast<const uint4*>(plane + (kind[rr] == 2 ? (size_t)(uint32_t)(__mul24(gy, w) + cx) : (size_t)0));
             }
@@ -365,11 +379,12 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
                 } else if (kind[rr] == 3) {  // width not a multiple of 8: the last piece of a row, texel by texel
                     const int p = (int)lane + 64 * rr;
                     const int pr = (int)(((float)p + 0.5f) * (1.0f / (float)kPiecesPerRow));
-                    const int gy = (int)r.y - kBriefHalo + pr, cx = c0 + 8 * (p - pr * kPiecesPerRow);
+                    const int gy0 = (int)r.y - kBriefHalo + pr, cx = c0 + 8 * (p - pr * kPiecesPerRow);
+                    const int gy = OOB ? oob_index(gy0, h, bg.oob) : gy0;
                     const uint16_t* src = plane + (size_t)(uint32_t)(__mul24(gy, w) + cx);
                     uint32_t t[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) t[q] = cx + q < w ? (uint32_t)src[q] : 0u;
+                    for (int q = 0; q < 8; q++) t[q] = cx + q < w ? (uint32_t)src[q] : (OOB ? (uint32_t)src[w - 1 - cx] : 0u);  // OOB: the row's last texel (cx >= qa here)
                     v = make_uint4(t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16));
                 }
                 if (where[rr] >= 0) *reinterpret_cast<uint4*>(&patch[where[rr]]) = v;
@@ -405,11 +420,11 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
                 const bool ina = xa >= 0 && xa < w && ya >= 0 && ya < h;
                 const bool inb = xb >= 0 && xb < w && yb >= 0 && yb < h;
                 if (!ina)
-                    va = 0u;
+                    va = OOB ? blur_sample_mapped(plane, rowc, w, h, qa, xa, ya, bg.oob) : 0u;
                 else if (xa >= qa)
                     va = plane[(size_t)(uint32_t)(__mul24(ya, w) + xa)];
                 if (!inb)
-                    vb = 0u;
+                    vb = OOB ? blur_sample_mapped(plane, rowc, w, h, qa, xb, yb, bg.oob) : 0u;
                 else if (xb >= qa)
                     vb = plane[(size_t)(uint32_t)(__mul24(yb, w) + xb)];
                 bal[e] = __ballot(va > vb);
@@ -424,12 +439,13 @@ __device__ __forceinline__ void brief_nf_body(uint32_t frame, uint32_t chunk, ui
 }
 
 constexpr int kBriefNfChunk = 64;  // keypoints of the final list a workgroup scans
+template <bool OOB = false>
 __global__ __launch_bounds__(256) void k_brief_nf(const uint16_t* __restrict__ blur, const uint16_t* __restrict__ blur_rowc,
                                                   Pyramid pyr, BriefTGeom bg, const uint32_t* __restrict__ seg_counts,
                                                   const uint32_t* __restrict__ seg_before,
                                                   const CornerData* __restrict__ corners, uint32_t cap,
                                                   CornerDescriptor* __restrict__ descriptors, BriefTables tab) {
-    brief_nf_body<kBriefNfChunk>(blockIdx.x, blockIdx.y, ~0u, blur, blur_rowc, pyr, bg, seg_counts, seg_before, corners, cap, descriptors, tab);  // frame = fast index, as above
+    brief_nf_body<kBriefNfChunk, 4, OOB>(blockIdx.x, blockIdx.y, ~0u, blur, blur_rowc, pyr, bg, seg_counts, seg_before, corners, cap, descriptors, tab);  // frame = fast index, as above
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -78,6 +78,8 @@ struct FrontGeom {
     uint32_t blur_q;      // columns [0, blur_q) of the final blur are one constant per row
     uint32_t n_var;       // w - blur_q: columns whose blur varies along the row (one BlurCol table entry each)
     unsigned long long* stamps;  // diagnostic runs only: 16 cycle sums per kernel flavour (else null)
+    uint32_t oob;         // OrbOptions::oob_policy (kOobZero / kOobClamp / kOobUmin): texels outside a level >= 1 in phase A
+    float wq;             // OrbOptions::sampler_weight_bits as 2^bits (0: exact lerp weights), for blur_tap()
 };
 
 // Tap positions of one column x >= blur_q of the literal blur (phase C): pass 2 at x lerps pass 1 at columns j0, j1
@@ -332,7 +334,16 @@ struct RowsGeom {
     uint32_t flat_end[kMaxLevels];  // qa - 18: a keypoint with 18 <= x < flat_end samples only columns in [0, qa)
     uint32_t qa[kMaxLevels];        // columns [0, qa) of the level's blur are the row constants
     uint32_t split;                 // workgroups per band slot (> 1 for small batches: more waves in flight)
+    uint32_t oob;                   // OrbOptions::oob_policy for samples that leave the level (brief.wgsl:59-60)
 };
+
+// One sample of the fused pipeline's blur under an out-of-level policy != kOobZero: the coordinates are mapped into the level,
+// columns below qa are the row constant, the rest is the stored tail.
+__device__ __forceinline__ uint32_t blur_sample_mapped(const uint16_t* plane, const uint16_t* rowc, int w, int h, int qa, int x, int y,
+                                                       uint32_t oob) {
+    const int xm = oob_index(x, w, oob), ym = oob_index(y, h, oob);
+    return xm < qa ? (uint32_t)rowc[ym] : (uint32_t)plane[(size_t)(uint32_t)(__mul24(ym, w) + xm)];
+}
 
 __global__ __launch_bounds__(256) void k_brief_rows(const uint16_t* __restrict__ blur,
                                                     const uint16_t* __restrict__ blur_rowc, Pyramid pyr, RowsGeom rg,
@@ -373,7 +384,8 @@ __global__ __launch_bounds__(256) void k_brief_rows(const uint16_t* __restrict__
         const uint32_t k = before + j;
         if (k >= cap) break;  // frame is full (indices only grow)
         const int gy = (int)rec.y - kBriefHalo + (int)lane;  // lanes 0..36 are the patch rows
-        const uint32_t rowv = (gy >= 0 && gy < h && lane < 37u) ? (uint32_t)rowc[gy] : 0u;
+        uint32_t rowv = (gy >= 0 && gy < h && lane < 37u) ? (uint32_t)rowc[gy] : 0u;
+        if (rg.oob != kOobZero && lane < 37u && !(gy >= 0 && gy < h)) rowv = rowc[oob_index(gy, h, rg.oob)];  // a row of the level instead of 0
         uint64_t bal[4];
         if (rec.x >= (uint32_t)kBriefHalo && rec.x < fe) {
             // ---- every sample column lies in [0, qa): only the rows of the rotated points matter
@@ -425,11 +437,11 @@ __global__ __launch_bounds__(256) void k_brief_rows(const uint16_t* __restrict__
                 const bool ina = xa >= 0 && xa < w && ya >= 0 && ya < h;
                 const bool inb = xb >= 0 && xb < w && yb >= 0 && yb < h;
                 if (!ina)
-                    va = 0u;
+                    va = rg.oob != kOobZero ? blur_sample_mapped(plane, rowc, w, h, qa, xa, ya, rg.oob) : 0u;
                 else if (xa >= qa)
                     va = plane[(size_t)(uint32_t)(__mul24(ya, w) + xa)];
                 if (!inb)
-                    vb = 0u;
+                    vb = rg.oob != kOobZero ? blur_sample_mapped(plane, rowc, w, h, qa, xb, yb, rg.oob) : 0u;
                 else if (xb >= qa)
                     vb = plane[(size_t)(uint32_t)(__mul24(yb, w) + xb)];
                 bal[e] = __ballot(va > vb);

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_grayscale_y8(const uint8_t* __restrict_
 constexpr int kMipRows = 4;  // target rows per thread
 // rx, ry: source/target size ratios of the generic case, (float)ws / (float)wd and (float)hs / (float)hd, divided once on the
 // host (IEEE binary32 division on both sides: the same value the kernel used to compute per thread).
-__global__ __launch_bounds__(256) void k_mip(uint16_t* __restrict__ gray, Pyramid pyr, uint32_t m, float rx, float ry) {
+__global__ __launch_bounds__(256) void k_mip(uint16_t* __restrict__ gray, Pyramid pyr, uint32_t m, float rx, float ry, float wq = 0.0f) {
     const uint32_t wd = pyr.w[m], hd = pyr.h[m], ws = pyr.w[m - 1], hs = pyr.h[m - 1];
     const uint32_t x = blockIdx.x * 64u + threadIdx.x;
     if (x >= wd) return;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_mip(uint16_t* __restrict__ gray, Pyrami
     }
     const float sx = ((float)x + 0.5f) * rx - 0.5f;
     const float fx0 = __builtin_floorf(sx);
-    const float fx = sx - fx0;
+    const float fx = sampler_weight(sx - fx0, wq);  // wq: OrbOptions::sampler_weight_bits (0: exact, CRD-4)
     const int ix = (int)fx0;
     const int x0 = min(max(ix, 0), (int)ws - 1), x1 = min(max(ix + 1, 0), (int)ws - 1);
     uint32_t ta[kMipRows], tb[kMipRows], tc[kMipRows], td[kMipRows];
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_mip(uint16_t* __restrict__ gray, Pyrami
         const uint32_t y = min(yb + 4u * (uint32_t)r, hd - 1u);  // rows past the level repeat the last one (not stored)
         const float sy = ((float)y + 0.5f) * ry - 0.5f;
         const float fy0 = __builtin_floorf(sy);
-        fy[r] = sy - fy0;
+        fy[r] = sampler_weight(sy - fy0, wq);
         const int iy = (int)fy0;
         const int y0 = min(max(iy, 0), (int)hs - 1), y1 = min(max(iy + 1, 0), (int)hs - 1);
         ta[r] = src[(size_t)y0 * ws + x0], tb[r] = src[(size_t)y0 * ws + x1];
@@ -125,11 +125,11 @@ __global__ __launch_bounds__(256) void k_mip(uint16_t* __restrict__ gray, Pyrami
 // One block = one row of one level of one frame; row and the f16-rounded intermediate in LDS.
 // grid: (h_level, 1, frames), dynamic LDS = 2 * w * 2 bytes.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float blur_point(const half_t* row, uint32_t x, uint32_t w) {
+__device__ __forceinline__ float blur_point(const half_t* row, uint32_t x, uint32_t w, float wq) {
     float acc = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        BlurTap t = blur_tap(x, w, kBlurOff[i]);
+        BlurTap t = blur_tap(x, w, kBlurOff[i], wq);
         float t0 = from_half(row[t.i0]), t1 = from_half(row[t.i1]);
         float d = t1 - t0;
         float s = t0 + t.f * d;
@@ -140,7 +140,7 @@ __device__ __forceinline__ float blur_point(const half_t* row, uint32_t x, uint3
 }
 
 __global__ __launch_bounds__(256) void k_blur_rows(const uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
-                                                   Pyramid pyr, uint32_t m) {
+                                                   Pyramid pyr, uint32_t m, float wq) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t w = pyr.w[m];
     half_t* row = reinterpret_cast<half_t*>(lds_raw);
@@ -149,9 +149,9 @@ __global__ __launch_bounds__(256) void k_blur_rows(const uint16_t* __restrict__ 
     const size_t base = (size_t)blockIdx.z * pyr.stride + pyr.off[m] + (size_t)y * w;
     for (uint32_t x = threadIdx.x; x < w; x += 256u) row[x] = bits_half(gray[base + x]);
     __syncthreads();
-    for (uint32_t x = threadIdx.x; x < w; x += 256u) tmp[x] = to_half(blur_point(row, x, w));
+    for (uint32_t x = threadIdx.x; x < w; x += 256u) tmp[x] = to_half(blur_point(row, x, w, wq));
     __syncthreads();
-    for (uint32_t x = threadIdx.x; x < w; x += 256u) blur[base + x] = half_bits(to_half(blur_point(tmp, x, w)));
+    for (uint32_t x = threadIdx.x; x < w; x += 256u) blur[base + x] = half_bits(to_half(blur_point(tmp, x, w, wq)));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint16_t* __restrict__ gray,
                                               uint32_t gw, uint32_t gh, float threshold, uint32_t arc,
                                               uint32_t intended, uint32_t* __restrict__ counts, CornerData* __restrict__ corners,
                                               uint32_t cap, float* __restrict__ scores_list,
-                                              float* __restrict__ score_planes, ScoreLayout sl) {
+                                              float* __restrict__ score_planes, ScoreLayout sl, uint32_t oob = kOobZero) {
     constexpr int T = 16, R = 3, S = T + 2 * R;
     __shared__ float tile[S][S + 1];
     const uint32_t w = pyr.w[oct], h = pyr.h[oct];
@@ -315,6 +315,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint16_t* __restrict__ gray,
         int gx = bx + tx - R, gy = by + ty - R;
         float v = 0.0f;
         if (gx >= 0 && gy >= 0 && gx < (int)w && gy < (int)h) v = from_half(bits_half(lvl[(size_t)gy * w + gx]));
+        else if (oob != kOobZero)  // OrbOptions::oob_policy: a texel of the level instead of 0 (CRD-6)
+            v = from_half(bits_half(lvl[(size_t)oob_index(gy, (int)h, oob) * w + (size_t)oob_index(gx, (int)w, oob)]));
         tile[ty][tx] = v;
     }
     __syncthreads();
@@ -513,22 +515,25 @@ struct BriefTables {
     const uint4* rot;
 };
 
-__device__ __forceinline__ float level_load(const uint16_t* lvl, uint32_t w, uint32_t h, int x, int y) {
-    if (x < 0 || y < 0 || x >= (int)w || y >= (int)h) return 0.0f;  // CRD-6
+__device__ __forceinline__ float level_load(const uint16_t* lvl, uint32_t w, uint32_t h, int x, int y, uint32_t oob = kOobZero) {
+    if (x < 0 || y < 0 || x >= (int)w || y >= (int)h) {
+        if (oob == kOobZero) return 0.0f;  // CRD-6
+        x = oob_index(x, (int)w, oob), y = oob_index(y, (int)h, oob);
+    }
     return from_half(bits_half(lvl[(size_t)y * w + x]));
 }
 
 // (s1, s2) = (st, -st): the reference's R(-theta); (-st, st): "intended" mode IM-6, R(+theta).
 __device__ __forceinline__ bool brief_test(uint32_t packed, float ct, float s1, float s2, int px, int py,
-                                           const uint16_t* lvl, uint32_t w, uint32_t h) {
+                                           const uint16_t* lvl, uint32_t w, uint32_t h, uint32_t oob = kOobZero) {
     const float ax = (float)(int8_t)(packed & 255u), ay = (float)(int8_t)((packed >> 8) & 255u);
     const float bx = (float)(int8_t)((packed >> 16) & 255u), by = (float)(int8_t)(packed >> 24);
     // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y)   brief.wgsl:38-54
     float a0 = ct * ax, a1 = s1 * ay, a2 = s2 * ax, a3 = ct * ay;
     float b0 = ct * bx, b1 = s1 * by, b2 = s2 * bx, b3 = ct * by;
     float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
-    const float va = level_load(lvl, w, h, (int)rax + px, (int)ray + py);  // vec2i() truncates, brief.wgsl:56-57
-    const float vb = level_load(lvl, w, h, (int)rbx + px, (int)rby + py);
+    const float va = level_load(lvl, w, h, (int)rax + px, (int)ray + py, oob);  // vec2i() truncates, brief.wgsl:56-57
+    const float vb = level_load(lvl, w, h, (int)rbx + px, (int)rby + py, oob);
     return va > vb;  // brief.wgsl:62
 }
 
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(256) void k_brief(const uint16_t* __restrict__ blur
                                                const uint32_t* __restrict__ counts,
                                                const CornerData* __restrict__ corners, uint32_t cap,
                                                CornerDescriptor* __restrict__ descriptors, BriefTables tab,
-                                               uint32_t intended) {
+                                               uint32_t intended, uint32_t oob = kOobZero) {
     const uint32_t f = blockIdx.z;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -558,10 +563,10 @@ __global__ __launch_bounds__(256) void k_brief(const uint16_t* __restrict__ blur
             const uint32_t w = pyr.w[oct], h = pyr.h[oct];
             const uint16_t* lvl = blur + (size_t)f * pyr.stride + pyr.off[oct];
             const int px = (int)rec.x, py = (int)rec.y;
-            b0 = __ballot(brief_test(p0, ct, st, nst, px, py, lvl, w, h));
-            b1 = __ballot(brief_test(p1, ct, st, nst, px, py, lvl, w, h));
-            b2 = __ballot(brief_test(p2, ct, st, nst, px, py, lvl, w, h));
-            b3 = __ballot(brief_test(p3, ct, st, nst, px, py, lvl, w, h));
+            b0 = __ballot(brief_test(p0, ct, st, nst, px, py, lvl, w, h, oob));
+            b1 = __ballot(brief_test(p1, ct, st, nst, px, py, lvl, w, h, oob));
+            b2 = __ballot(brief_test(p2, ct, st, nst, px, py, lvl, w, h, oob));
+            b3 = __ballot(brief_test(p3, ct, st, nst, px, py, lvl, w, h, oob));
         }
         if (lane < 8u) {
             const uint64_t src = lane < 2u ? b0 : (lane < 4u ? b1 : (lane < 6u ? b2 : b3));

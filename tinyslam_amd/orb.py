@@ -26,6 +26,8 @@ ORB_FLAG_DOUBLE_OUTPUT = 2
 ORB_FLAG_NMS = 4
 ORB_FLAG_INTENDED = 8
 ORB_FLAG_INPUT_Y8 = 16
+ORB_OOB_ZERO, ORB_OOB_CLAMP, ORB_OOB_UMIN = 0, 1, 2  # OrbOptions.oob_policy
+OOB_POLICIES = {"zero": ORB_OOB_ZERO, "clamp": ORB_OOB_CLAMP, "umin": ORB_OOB_UMIN}
 TRANSPORT_RECORD_WORDS = 10  # ORB_TRANSPORT_RECORD_BYTES / 4
 SYN_GRADIENT, SYN_BLOBS, SYN_WEDGES, SYN_NOISE = 1, 2, 4, 8
 SYN_ALL = 15
@@ -79,7 +81,8 @@ class _Config(ctypes.Structure):
 
 class _Options(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("max_batch", ctypes.c_uint32), ("flags", ctypes.c_uint32),
-                ("fast_arc", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 4)]
+                ("fast_arc", ctypes.c_uint32), ("oob_policy", ctypes.c_uint32), ("sampler_weight_bits", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32 * 2)]
 
 
 _lib = None
@@ -266,6 +269,9 @@ class OrbConfig:
     max_batch: int = 1
     flags: int = 0
     fast_arc: int = 0  # 0 -> 12 (reference; 9 with ORB_FLAG_INTENDED); 9..16 opt-in
+    # the two implementation-defined points of the reference's WGSL as switches (include/tinyorb.h, OrbOptions)
+    oob_policy: int = 0           # ORB_OOB_ZERO / ORB_OOB_CLAMP / ORB_OOB_UMIN: textureLoad outside the level
+    sampler_weight_bits: int = 0  # 0: exact bilinear weights; n: weights held in n fractional bits
 
 
 def _ptr(a):
@@ -293,7 +299,7 @@ class OrbProgram:
         c = self.config
         cfg = _Config(_Extent3d(c.image_size.width, c.image_size.height, c.image_size.depth_or_array_layers),
                       c.max_features, c.hierarchy_depth, float(np.float32(c.initial_threshold)))
-        opt = _Options(c.device, c.max_batch, c.flags, c.fast_arc)
+        opt = _Options(c.device, c.max_batch, c.flags, c.fast_arc, c.oob_policy, c.sampler_weight_bits)
         h = ctypes.c_void_p()
         rc = L.orb_program_create(ctypes.byref(cfg), ctypes.byref(opt), ctypes.byref(h))
         if rc != ORB_OK:
@@ -553,7 +559,7 @@ class OrbNode:
         c = self.config
         cfg = _Config(_Extent3d(c.image_size.width, c.image_size.height, c.image_size.depth_or_array_layers),
                       c.max_features, c.hierarchy_depth, float(np.float32(c.initial_threshold)))
-        opt = _Options(0, c.max_batch, c.flags, c.fast_arc)
+        opt = _Options(0, c.max_batch, c.flags, c.fast_arc, c.oob_policy, c.sampler_weight_bits)
         devs = (ctypes.c_int * len(self.devices))(*self.devices)
         h = ctypes.c_void_p()
         rc = L.orb_node_create(devs, len(self.devices), ctypes.byref(cfg), ctypes.byref(opt), ctypes.byref(h))
