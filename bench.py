@@ -35,6 +35,14 @@ W, H, DEPTH, MAX_FEATURES = 1280, 720, 2, 8192
 THRESHOLD = 20.0 / 255.0
 SEED0 = 1000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# --content: (synthetic-frame flags: 1 gradient, 2 blobs, 4 wedges, 8 noise; FAST threshold in 1/255)
+CONTENT = {"flat": (1, 20), "sparse": (5, 20), "default": (15, 20), "dense": (15, 16), "overflow": (15, 8)}
+
+
+def content_of(args):
+    """(synthetic-frame flags, threshold) of --content."""
+    flags, thr255 = CONTENT[args.content]
+    return flags, thr255 / 255.0
 
 
 def parse_args(argv=None):
@@ -57,6 +65,12 @@ def parse_args(argv=None):
                     help="N = 1: run the N > 1 collate all the same -- process group of one rank (\"nccl\" = RCCL), counters "
                          "all_gathered, records through the exact-size all_to_all (a send to itself), expansion on rank 0 -- "
                          "so that a one-GPU box executes the RCCL path the multi-GPU runs take")
+    ap.add_argument("--content", choices=tuple(CONTENT), default="default",
+                    help="what the synthetic frames hold (keypoints per 1280x720 frame in brackets): flat = the gradient alone [0]; "
+                         "sparse = gradient + wedges [~650]; default = gradient + blobs + wedges + noise at the reference threshold "
+                         "20/255 [~3.8 k, the headline]; dense = the same frames at threshold 16/255 [~7.7 k, just under "
+                         "max_features]; overflow = threshold 8/255 [~64 k detected, 8192 stored: the band queues overflow and "
+                         "every frame is cut at max_features]")
     ap.add_argument("--staged", action="store_true", help="force the one-kernel-per-stage pipeline")
     ap.add_argument("--input", choices=("rgba", "y8"), default="rgba",
                     help="rgba = the reference's input (the headline); y8 = the opt-in one-byte-per-pixel variant "
@@ -79,30 +93,31 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def cpu_baseline(n_sample, gpu_counts, intended=False, y8=False):
+def cpu_baseline(n_sample, gpu_counts, intended=False, y8=False, syn_flags=15, threshold=THRESHOLD):
     """Times oracle/ (the CPU restatement) on the first n_sample frames of the workload and checks that its per-frame
     counters equal the GPU's on those frames."""
     import numpy as np
     from oracle import orb_oracle
     orb_oracle.build()
-    cores = os.cpu_count() or 1
+    nproc = os.cpu_count() or 1          # what the box has
+    usable = nproc
     try:
-        cores = len(os.sched_getaffinity(0))
+        usable = len(os.sched_getaffinity(0))  # what this process may run on
     except AttributeError:
         pass
-    cores = min(cores, 16)  # the CPU share of a one-GPU box
+    cores = min(usable, 16)  # threads used: the CPU share of a one-GPU box
     gen = orb_oracle.synth_frame_y8 if y8 else orb_oracle.synth_frame  # ORB_SYN_Y8: integer luma of the same recipe
-    frames = np.stack([gen(W, H, SEED0 + i) for i in range(n_sample)])
+    frames = np.stack([gen(W, H, SEED0 + i, syn_flags) for i in range(n_sample)])
     t0 = time.perf_counter()
     if intended:
-        totals, _, _ = orb_oracle.extract_intended_batch(frames, depth=DEPTH, threshold=THRESHOLD, max_features=MAX_FEATURES,
+        totals, _, _ = orb_oracle.extract_intended_batch(frames, depth=DEPTH, threshold=threshold, max_features=MAX_FEATURES,
                                                          arc=9, nms=True, n_threads=cores)
     else:
-        totals, _, _ = orb_oracle.extract_batch(frames, depth=DEPTH, threshold=THRESHOLD, max_features=MAX_FEATURES,
+        totals, _, _ = orb_oracle.extract_batch(frames, depth=DEPTH, threshold=threshold, max_features=MAX_FEATURES,
                                                 n_threads=cores, y8=y8)
     dt = time.perf_counter() - t0
     m = min(n_sample, len(gpu_counts))
-    return {"value": n_sample / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": n_sample / dt, "unit": "frames/s", "cores": cores, "host_cpus": nproc, "host_cpus_usable": usable, "kind": "port",
             "sample": "%d of the bench's 1280x720 frames (seeds %d..), oracle/orb_oracle.c frame-parallel over %d "
                       "threads, %.1f s wall" % (n_sample, SEED0, cores, dt),
             "keypoints_per_frame": float(np.minimum(totals, MAX_FEATURES).mean()),
@@ -131,10 +146,23 @@ def roofline_of(args, prof, launches_frames, bytes_per_frame, profiled_s):
     tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.mode, args.input))
     if not os.path.exists(tpath):
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # the headline: literal mode, RGBA input
-    if os.path.exists(tpath):
+    # `traffic` is a committed measurement (rocprofv3 counter passes cannot run inside this process): it is only quoted when it
+    # was taken on exactly these kernels -- the stamp is a hash of csrc/ -- and on this workload; otherwise null, with the reason
+    if not os.path.exists(tpath):
+        roofline["traffic_note"] = "no counter pass committed for this mode / input"
+    else:
+        from tinyslam_amd import build as orb_build
         tj = json.load(open(tpath))
-        if (tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == frames_per_launch
-                and tj.get("input", "rgba") == args.input and tj.get("mode", "literal") == args.mode):
+        if args.content != "default":
+            roofline["traffic_note"] = "the committed counter pass is of --content default"
+        elif not (tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == frames_per_launch
+                  and tj.get("input", "rgba") == args.input and tj.get("mode", "literal") == args.mode):
+            roofline["traffic_note"] = "the committed counter pass is of another kernel or batch size"
+        elif tj.get("csrc_sha256") != orb_build.source_hash():
+            roofline["traffic_note"] = ("stale: %s was taken on other kernel sources (csrc hash %s..., tree %s...); re-run "
+                                        "tools/collect_profiles.sh" % (os.path.basename(tpath), str(tj.get("csrc_sha256"))[:12],
+                                                                       orb_build.source_hash()[:12]))
+        else:
             roofline["traffic"] = tj.get("hbm_bytes_per_launch")
             roofline["traffic_source"] = tj.get("source")
     return roofline
@@ -151,17 +179,48 @@ def workload_text(args, world, B, strong):
 
 
 def single_frame_latency(orb, cfg_kwargs, n=200):
-    """The reference's only call shape (orb.rs:469-557): one blocking extract_corners per frame.  Mean microseconds of
-    orb_extract_corners alone on a resident frame, 1280x720."""
+    """The reference's only call shape (orb.rs:469-557): one blocking extract_corners per frame, 1280x720.  Returns
+    (mean microseconds of orb_extract_corners alone on a resident frame, frames/s of the reference's loop write_input_image
+    -> extract_corners -> read_corners -> read_descriptors from a host frame, frames/s of the same loop with
+    orb_write_input_image_pinned uploading frame k + 1 under the kernels of frame k)."""
+    import numpy as np
     cfg = orb.OrbConfig(orb.Extent3d(W, H), max_batch=1, **cfg_kwargs)
     with orb.OrbProgram(cfg).init() as p1:
-        p1.synth_frames_device(1, SEED0)
+        dev = p1.synth_frames_device(1, SEED0)
         for _ in range(20):
             p1.extract_corners()
         t0 = time.perf_counter()
         for _ in range(n):
             p1.extract_corners()
-        return (time.perf_counter() - t0) / n * 1e6
+        extract_us = (time.perf_counter() - t0) / n * 1e6
+        frame = p1.copy_to_host(dev, W * H * 4)
+        corners = np.zeros(MAX_FEATURES, dtype=orb.CORNER_DTYPE)
+        desc = np.zeros((MAX_FEATURES, 8), dtype=np.uint32)
+
+        def six_calls(write):
+            for k in range(n + 10):
+                if k == 10:
+                    t0 = time.perf_counter()
+                write()
+                p1.extract_corners()
+                p1.read_corners(corners)
+                p1.read_descriptors(desc)
+            return n / (time.perf_counter() - t0)
+        blocking_fps = six_calls(lambda: p1.write_input_image(frame))
+        pins = [orb.PinnedArray((H, W, 4), np.uint8) for _ in range(2)]
+        for pn in pins:
+            pn.array[:] = frame.reshape(H, W, 4)
+        st = {"k": 0}
+
+        def write_ahead():  # frame k + 1 goes up while frame k is extracted (one image ahead)
+            p1.write_input_image_pinned(pins[st["k"] & 1].array)
+            st["k"] += 1
+        write_ahead()
+        ahead_fps = six_calls(write_ahead)
+        p1.upload_sync()
+        for pn in pins:
+            pn.close()
+        return extract_us, blocking_fps, ahead_fps
 
 
 def run_node(args):
@@ -176,7 +235,8 @@ def run_node(args):
         raise SystemExit("--host node runs the weak-scaling workload (one B-frame shard per GPU per step)")
     loop = os.environ.get("TINYORB_NODE_LOOPBACK", "0") not in ("", "0")
     devices = [0] * world if loop else list(range(world))
-    cfg_kwargs = dict(max_features=MAX_FEATURES, hierarchy_depth=DEPTH, initial_threshold=THRESHOLD,
+    syn_flags, threshold = content_of(args)
+    cfg_kwargs = dict(max_features=MAX_FEATURES, hierarchy_depth=DEPTH, initial_threshold=threshold,
                       flags=(orb.ORB_FLAG_STAGED if args.staged else 0)
                       | ((orb.ORB_FLAG_INTENDED | orb.ORB_FLAG_NMS) if args.mode == "intended" else 0)
                       | (orb.ORB_FLAG_INPUT_Y8 if args.input == "y8" else 0),
@@ -186,7 +246,7 @@ def run_node(args):
     F = B * world
     with orb.OrbNode(cfg, devices) as node:
         progs = [node.program(r) for r in range(world)]
-        ptrs = [progs[r].synth_frames_device(B, SEED0 + r * B) for r in range(world)]
+        ptrs = [progs[r].synth_frames_device(B, SEED0 + r * B, syn_flags) for r in range(world)]
         last = {}
 
         def steps(n):
@@ -230,10 +290,11 @@ def run_node(args):
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (gradient+blobs+wedges+noise, seeds %d.., generated on device)" % SEED0,
+            "data": "synthetic (%s, seeds %d.., generated on device)"
+                    % ("+".join(n for b, n in ((1, "gradient"), (2, "blobs"), (4, "wedges"), (8, "noise")) if syn_flags & b), SEED0),
             "config": {"workload": workload_text(args, world, B, False),
                        "frames_per_gpu_per_batch": B, "frames_per_step": F, "width": W, "height": H,
-                       "hierarchy_depth": DEPTH, "max_features": MAX_FEATURES, "threshold": THRESHOLD, "mode": args.mode,
+                       "hierarchy_depth": DEPTH, "max_features": MAX_FEATURES, "threshold": threshold, "content": args.content, "mode": args.mode,
                        "input": args.input, "pipeline": "staged" if args.staged else "default",
                        "host": "node: one process, orb_node_* C ABI, no torch.distributed"
                                + (" (TINYORB_NODE_LOOPBACK: %d ranks on device 0, device copies instead of RCCL)" % world if loop else ""),
@@ -249,9 +310,10 @@ def run_node(args):
         if world == 1:
             n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 128
             if n_cpu > 0:
-                out["cpu_baseline"] = cpu_baseline(n_cpu, counts[:B], intended=args.mode == "intended", y8=args.input == "y8")
-    if args.mode == "literal" and not args.staged and not args.no_single_frame:
-        out["single_frame_us"] = single_frame_latency(orb, cfg_kwargs)
+                out["cpu_baseline"] = cpu_baseline(n_cpu, counts[:B], intended=args.mode == "intended", y8=args.input == "y8",
+                                                   syn_flags=syn_flags, threshold=threshold)
+    if args.mode == "literal" and args.content == "default" and not args.staged and not args.no_single_frame:
+        out["single_frame_us"], out["single_frame_loop_fps"], out["single_frame_loop_pinned_fps"] = single_frame_latency(orb, cfg_kwargs)
     emit(out)
 
 
@@ -299,8 +361,9 @@ def run_rank(args):
     batches = [(b0, min(B, n_local - b0)) for b0 in range(0, n_local, B)]  # (first local frame, frames)
     job_frames = args.total_frames if strong else B * world
 
+    syn_flags, threshold = content_of(args)
     cfg = orb.OrbConfig(orb.Extent3d(W, H), max_features=MAX_FEATURES, hierarchy_depth=DEPTH,
-                        initial_threshold=THRESHOLD, device=dev_index, max_batch=B,
+                        initial_threshold=threshold, device=dev_index, max_batch=B,
                         flags=(orb.ORB_FLAG_STAGED if args.staged else 0) | orb.ORB_FLAG_DOUBLE_OUTPUT
                         | ((orb.ORB_FLAG_INTENDED | orb.ORB_FLAG_NMS) if args.mode == "intended" else 0)
                         | (orb.ORB_FLAG_INPUT_Y8 if args.input == "y8" else 0),
@@ -309,7 +372,7 @@ def run_rank(args):
     frame_bytes = W * H * (1 if args.input == "y8" else 4)
     frames_t = torch.empty(max(n_local, 1) * frame_bytes, dtype=torch.uint8, device=dev)  # this rank's shard, in HBM
     for b0, nb in batches:
-        prog.synth_frames_device(nb, SEED0 + lo + b0, frames_dev_ptr=frames_t.data_ptr() + b0 * frame_bytes)
+        prog.synth_frames_device(nb, SEED0 + lo + b0, syn_flags, frames_dev_ptr=frames_t.data_ptr() + b0 * frame_bytes)
     views = []
     for s_ in range(2):
         prog.batch_select_output(s_)
@@ -594,10 +657,11 @@ def run_rank(args):
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (gradient+blobs+wedges+noise, seeds %d.., generated on device)" % SEED0,
+            "data": "synthetic (%s, seeds %d.., generated on device)"
+                    % ("+".join(n for b, n in ((1, "gradient"), (2, "blobs"), (4, "wedges"), (8, "noise")) if syn_flags & b), SEED0),
             "config": {"workload": workload_text(args, world, B, strong),
                        "frames_per_gpu_per_batch": B, "frames_per_step": job_frames, "width": W, "height": H,
-                       "hierarchy_depth": DEPTH, "max_features": MAX_FEATURES, "threshold": THRESHOLD, "mode": args.mode,
+                       "hierarchy_depth": DEPTH, "max_features": MAX_FEATURES, "threshold": threshold, "content": args.content, "mode": args.mode,
                        "input": args.input,
                        "pipeline": "staged" if args.staged else "default",
                        "batches_in_flight": fly,
@@ -619,11 +683,12 @@ def run_rank(args):
         if world == 1:
             n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 128
             if n_cpu > 0:
-                out["cpu_baseline"] = cpu_baseline(n_cpu, counts_first, intended=args.mode == "intended", y8=args.input == "y8")
-            if args.mode == "literal" and args.input == "rgba" and not args.staged and not args.no_single_frame:
+                out["cpu_baseline"] = cpu_baseline(n_cpu, counts_first, intended=args.mode == "intended", y8=args.input == "y8",
+                                                   syn_flags=syn_flags, threshold=threshold)
+            if args.mode == "literal" and args.input == "rgba" and args.content == "default" and not args.staged and not args.no_single_frame:
                 # the reference's only call shape (orb.rs:469-557): one blocking extract per frame, microseconds per call
-                out["single_frame_us"] = single_frame_latency(orb, dict(max_features=MAX_FEATURES, hierarchy_depth=DEPTH,
-                                                                        initial_threshold=THRESHOLD, device=dev_index))
+                out["single_frame_us"], out["single_frame_loop_fps"], out["single_frame_loop_pinned_fps"] = single_frame_latency(
+                    orb, dict(max_features=MAX_FEATURES, hierarchy_depth=DEPTH, initial_threshold=THRESHOLD, device=dev_index))
         emit(out)
     prog.close()
     if collating:

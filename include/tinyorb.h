@@ -135,6 +135,14 @@ const char *orb_pipeline_note(const OrbProgram *p);
 /* ---- single-frame API, one call per reference method ---- */
 /* orb.rs:567-583 write_input_image: tightly packed RGBA8, rows of 4*width bytes (ORB_FLAG_INPUT_Y8: rows of width bytes). */
 int orb_write_input_image(OrbProgram *p, const uint8_t *bytes, size_t len);
+/* The same upload without the wait (orb.rs:567-583 returns after queue.write_texture, before the copy has happened): `bytes`
+ * lies in PINNED host memory (orb_host_alloc, or registered with the HIP runtime by the caller) and goes up on the program's
+ * copy stream; the call returns at once, orb_upload_sync() waits until the array may be reused.  Images are extracted in the
+ * order they were written, and ONE may be written ahead: a camera loop uploads frame k + 1 under the kernels of frame k --
+ *     write_pinned(f0);  loop { write_pinned(f[k+1]); extract_corners(&n) [frame k]; read_corners; read_descriptors; }
+ * A third write while two images wait returns ORB_ESTATE.  With nothing written since, extract_corners works on the last
+ * image again. */
+int orb_write_input_image_pinned(OrbProgram *p, const uint8_t *bytes_pinned, size_t len);
 /* orb.rs:585-589 set_threshold */
 int orb_set_threshold(OrbProgram *p, float threshold);
 /* orb.rs:469-557 extract_corners: runs the whole pipeline, blocks until the results are in

@@ -210,8 +210,11 @@ def test_rotated_pattern_table_equals_numpy(tinyorb, intended):
 def test_single_frame_staging_is_complete_when_the_call_returns(tinyorb, oracle):
     """orb_extract_corners returns when the polled completion word arrives, not after a stream synchronisation: everything
     k_brief_one wrote to the pinned staging arrays must be there by then.  A large frame (19 500 keypoints, 1024 workgroups
-    over all XCDs), 60 calls in a row, every result against the first (which is checked against the oracle) -- plain stores
-    to the staging arrays lost this race once in a few dozen calls; they are system-scope stores now."""
+    over all XCDs), 60 calls in a row, every result against the first (which is checked against the oracle).  The staging
+    arrays are written with plain stores; what makes them visible is the protocol behind them (orb_kernels_brief.h, the end of
+    k_brief_one): one lane per workgroup releases at system scope, then counts the workgroup done with an acquire-release
+    add at agent scope, and the workgroup that completes the count publishes the sequence number the host polls.  With only
+    the last workgroup releasing, one call in some thousands returned before the counter had arrived."""
     W, H, cap = 2048, 2200, 1 << 16
     rgba = oracle.synth_frame(W, H, 31)
     ref = oracle.extract(rgba, depth=2, threshold=THR, max_features=cap)

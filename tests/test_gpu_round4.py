@@ -204,3 +204,48 @@ def test_reference_dump_on_gpu(tinyorb, dump):
         c, d = _sorted(*prog.batch_read(0, min(total, cap)))
         assert np.array_equal(np.stack([c[k] for k in ("x", "y", "angle", "octave")], 1), corners[order])
         assert np.array_equal(d, desc[order])
+
+
+# ---------------------------------------------------------------------------------------------
+# orb_write_input_image_pinned: the reference's non-blocking upload (orb.rs:567-583), one image ahead
+# ---------------------------------------------------------------------------------------------
+def test_pinned_write_runs_one_image_ahead(tinyorb, oracle):
+    """A camera loop: frame k + 1 goes up on the copy stream while frame k is extracted.  Images come out in the order they
+    were written, each bit-equal to the oracle; a third write ahead is refused; a blocking write overwrites the newest
+    waiting image (the last write wins, as in the reference); with nothing written, extract works on the last image again."""
+    W, H, N = 640, 360, 7
+    frames = [oracle.synth_frame(W, H, 900 + i) for i in range(N)]
+    refs = [oracle.extract(f, depth=2, threshold=THR) for f in frames]
+    pins = [tinyorb.PinnedArray((H, W, 4), np.uint8) for _ in range(2)]
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), hierarchy_depth=2, initial_threshold=THR)
+
+    def result(prog):
+        total = prog.extract_corners()
+        n = min(total, 8192)
+        return total, prog.read_corners(np.zeros(n, dtype=tinyorb.CORNER_DTYPE)), prog.read_descriptors(np.zeros((n, 8), dtype=np.uint32))
+
+    with tinyorb.OrbProgram(cfg).init() as prog:
+        pins[0].array[:] = frames[0]
+        prog.write_input_image_pinned(pins[0].array)
+        for k in range(N):
+            if k + 1 < N:
+                prog.upload_sync()  # the pinned array of frame k - 1 ... k is free again
+                pins[(k + 1) & 1].array[:] = frames[k + 1]
+                prog.write_input_image_pinned(pins[(k + 1) & 1].array)  # under the kernels of frame k
+            _assert_frame_equal(oracle, refs[k], *result(prog))
+        _assert_frame_equal(oracle, refs[N - 1], *result(prog))  # nothing written since: the last image again
+        # two ahead is the limit
+        prog.write_input_image_pinned(pins[0].array)
+        prog.write_input_image_pinned(pins[1].array)
+        with pytest.raises(tinyorb.OrbError) as e:
+            prog.write_input_image_pinned(pins[0].array)
+        assert e.value.code == tinyorb.ORB_ESTATE
+        prog.upload_sync()
+        # a blocking write replaces the newest waiting image (pins[1]'s) and may be repeated
+        prog.write_input_image(frames[2])
+        prog.write_input_image(frames[3])
+        first = pins[0].array.copy()
+        _assert_frame_equal(oracle, oracle.extract(first, depth=2, threshold=THR), *result(prog))  # pins[0]'s image
+        _assert_frame_equal(oracle, refs[3], *result(prog))  # then the overwritten slot: frame 3
+    for pn in pins:
+        pn.close()

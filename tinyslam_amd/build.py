@@ -42,6 +42,19 @@ def _deps():
     return deps
 
 
+def source_hash():
+    """SHA-256 over the kernel and host sources of libtinyorb (csrc/*, include/tinyorb.h), in name order: stamps measurements that
+    belong to one state of the kernels (profiles/traffic*.json; bench.py refuses a stamp that is not the tree's)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc")))
+    files.append(os.path.join(os.path.dirname(PKG_DIR), "include", "tinyorb.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True

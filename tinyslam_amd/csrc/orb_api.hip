@@ -50,6 +50,10 @@ struct OrbProgram {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // chunked uploads of orb_extract_batch_host
     hipEvent_t order_event = nullptr;   // orders work on a caller's stream behind the last batch
+    // run_fused: a batch is cut into sub-ranges whose BRIEF kernels run on this side stream under the next sub-range's front kernels
+    hipStream_t brief_stream = nullptr;
+    std::vector<hipEvent_t> split_events;  // two per sub-range: front kernels done, BRIEF done
+    uint32_t batch_split = 0;              // sub-ranges per batch (0: not decided yet; 1: none)
     std::vector<hipEvent_t> upload_events;  // one per chunk of a chunked upload (reused)
     hipEvent_t upload_done = nullptr;       // behind the last host-to-device copy of the last host batch
     // orb_batch_pack / orb_batch_fetch: packed records of an output set on the device, its counters and offsets in pinned
@@ -99,6 +103,24 @@ struct OrbProgram {
     float* d_prov2_scores = nullptr;
 
     uint8_t* d_input = nullptr;  // max_batch frames (single-frame API, host batches, synth)
+    // single-frame API: up to two images may be written ahead of extract_corners (orb_write_input_image_pinned uploads frame
+    // k + 1 on the copy stream while frame k is extracted); slab 0 is d_input's first frame, slab 1 d_input_alt
+    uint8_t* d_input_alt = nullptr;
+    uint32_t in_last = 0;                 // slab of the image the last extract_corners worked on (and the next one will, if nothing is pending)
+    uint32_t in_pending = 0;              // images written and not yet extracted (0..2)
+    uint32_t in_queue[2] = {0u, 0u};      // their slabs, oldest first
+    hipEvent_t in_uploaded[2] = {nullptr, nullptr};  // behind the asynchronous upload into the slab
+    bool in_async[2] = {false, false};    // the slab's image came through the copy stream: extract_corners orders its kernels behind in_uploaded
+    // environment switches (experiments and cross-checks), read once when the program is created
+    struct {
+        bool single_memcpy = false, single_split = false, single_serial = false, single_sync = false;
+        bool no_swizzle = false, quiet = false;
+        int phase_mask = -1, brief_i_mask = -1, lds_pad = 0;
+    } env;
+    // device-visible addresses of the pinned single-frame staging arrays (resolved once)
+    uint32_t* dv_count = nullptr;
+    CornerData* dv_corners = nullptr;
+    CornerDescriptor* dv_desc = nullptr;
     uint16_t* d_gray = nullptr;  // max_batch x pyr.stride
     uint16_t* d_blur = nullptr;
     uint16_t* d_blur_rowc = nullptr;  // fused path: [max_batch][row_stride] blur row constants (columns < qa)
@@ -384,10 +406,12 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
         g.tmp_halfs = std::max<uint32_t>(2u * kFrontTmpRows * g.ts, (uint32_t)(sizeof(BlurCol) / 2u) * g.n_var);
         g.tmp_halfs = (g.tmp_halfs + 7u) & ~7u;
     }
+    {   // pre-test items of a band (tile): rows x ceil(dispatch columns / 16) at level 0, / 8 above (orb_front_body.inc, B1)
+        const uint32_t cols_t = g.tiled ? std::min(g.tw, gw) : gw, iw = lvl == 0 ? 16u : 8u;
+        g.ovf_words = (band_rows * ((cols_t + iw - 1u) / iw) + 31u) / 32u;
+    }
     g.n_classes = 1u;
-    g.phase_mask = 15u;
-    if (const char* e = getenv("TINYORB_PHASE_MASK")) g.phase_mask = (uint32_t)atoi(e);
-    if (const char* e = getenv("TINYORB_NO_SWIZZLE")) g.xcd_swizzle = atoi(e) ? 0u : g.xcd_swizzle;
+    g.phase_mask = 15u;  // run_fused_range applies the program's experiment switches (TINYORB_PHASE_MASK, TINYORB_NO_SWIZZLE)
     return g;
 }
 
@@ -506,6 +530,8 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         g.seg_cap = p->bands.seg_cap;
         g.n_classes = p->seg_classes;
         g.stamps = p->d_stamps;
+        if (p->env.phase_mask >= 0) g.phase_mask = (uint32_t)p->env.phase_mask;
+        if (p->env.no_swizzle) g.xcd_swizzle = 0u;
         g.oob = p->oob;
         g.wq = p->wq;
         g.store_grey = (lvl == 0 && D > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) ? 1u : 0u;
@@ -514,7 +540,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         if (!g.tiled && sizeof(BlurCol) * (size_t)g.n_var > 8u * (size_t)g.ts)  // the column table borrows the queues' storage
             return fail(p, ORB_EINVAL, "internal: blur column table of level %u does not fit", lvl);
         uint32_t lds = front_lds_bytes(g);
-        if (const char* e = getenv("TINYORB_LDS_PAD")) lds += (uint32_t)atoi(e);  // occupancy experiments only
+        lds += (uint32_t)p->env.lds_pad;  // TINYORB_LDS_PAD: occupancy experiments only
         if (lds > p->max_lds) return fail(p, ORB_EINVAL, "level %u needs %u bytes of LDS", lvl, lds);
         const dim3 grid(g.n_bands * (g.tiled ? g.n_ct : 1u) * n);
 #define FRONT_ARGS frames, p->frame_bytes, d_gray, d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg
@@ -558,7 +584,19 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         } else {
             LaunchScope ls(p, s_lvl, KID_FUSED_LN);
             const dim3 block(kFrontThreadsLN);
-            if (g.tiled) { FRONT_LAUNCH_TILED(false, false, false) }
+            if (p->oob != kOobZero) {  // texels outside the level follow OrbOptions::oob_policy: the OOBK instances
+#define FRONT_LAUNCH_OOB(TILED_)                                                                                              \
+    switch (p->band_rows_lvl[lvl]) {                                                                                          \
+        case 64: hipLaunchKernelGGL((k_front<false, false, 64, false, TILED_, false, true>), grid, block, lds, s_lvl, FRONT_ARGS); break; \
+        case 32: hipLaunchKernelGGL((k_front<false, false, 32, false, TILED_, false, true>), grid, block, lds, s_lvl, FRONT_ARGS); break; \
+        case 16: hipLaunchKernelGGL((k_front<false, false, 16, false, TILED_, false, true>), grid, block, lds, s_lvl, FRONT_ARGS); break; \
+        default: hipLaunchKernelGGL((k_front<false, false, 8, false, TILED_, false, true>), grid, block, lds, s_lvl, FRONT_ARGS); break;  \
+    }
+                if (g.tiled && p->band_rows_lvl[lvl] == 16u) hipLaunchKernelGGL((k_front<false, false, 16, false, true, false, true>), grid, block, lds, s_lvl, FRONT_ARGS);
+                else if (g.tiled) hipLaunchKernelGGL((k_front<false, false, 8, false, true, false, true>), grid, block, lds, s_lvl, FRONT_ARGS);
+                else { FRONT_LAUNCH_OOB(false) }
+#undef FRONT_LAUNCH_OOB
+            } else if (g.tiled) { FRONT_LAUNCH_TILED(false, false, false) }
             else { FRONT_LAUNCH(false, false) }
         }
 #undef FRONT_LAUNCH
@@ -572,10 +610,59 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
 }
 
 int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
-    // One launch per kernel for the whole batch.  Cutting the batch into chunks that alternate between two
-    // streams was measured (2/4/8 chunks: +5 %, +4 %, +6 % time): each kernel fills the chip on its own.
-    if (int rc = run_fused_range(p, frames, 0, n, s)) return rc;
-    p->planes_valid = true;  // except the level-0 grey plane, which the fused path keeps in LDS only
+    // One launch per kernel for the whole batch -- measured twice:
+    //  * round 1: the batch cut into chunks that run whole pipelines on two streams (front kernel against front kernel):
+    //    2 / 4 / 8 chunks + 5 %, + 4 %, + 6 % time;
+    //  * round 4 (TINYORB_BATCH_SPLIT=n, the code below; profiles/r04_split_ab.txt): the batch cut into n sub-ranges of
+    //    frames, the BRIEF kernels of sub-range i on a side stream under the front kernels of sub-range i + 1 on `s`,
+    //        s:      F0 ----- F1 ----- F2 ----- B2 -- (waits for B0, B1)
+    //        side:            B0 ----- B1 --
+    //    same kernels, buffers, results and output layout: 0.534 ms per 256 frames in one piece, 0.580 / 0.621 / 0.659 with
+    //    2 / 3 / 4 sub-ranges -- 45 us MORE per cut.  k_front's two workgroups per CU hold all of the CU's LDS and all eight
+    //    wave slots of its SIMDs, so a kernel from another queue gets a CU only when a band retires, and then competes with
+    //    the next band for it; k_brief_t is as bound by the vector units as k_front is (30.7 M wave instructions x 4 cycles /
+    //    1024 SIMDs = 0.057 ms against its 0.049), so it has nothing to give back while it runs beside it; and every
+    //    cross-queue dependency costs the two queues a signal round trip.  The default therefore stays one piece.
+    if (p->batch_split == 0u) {
+        const char* e = getenv("TINYORB_BATCH_SPLIT");
+        p->batch_split = e ? (uint32_t)std::max(1, atoi(e)) : 1u;
+    }
+    uint32_t parts = p->profiling ? 1u : p->batch_split;
+    while (parts > 1u && (n / parts) < 32u) parts--;  // a sub-range should still fill the chip several times over
+    if (parts <= 1u) {
+        if (int rc = run_fused_range(p, frames, 0, n, s)) return rc;
+        p->planes_valid = true;  // except the level-0 grey plane, which the fused path keeps in LDS only
+        return ORB_OK;
+    }
+    if (!p->brief_stream) HIP_TRY(p, hipStreamCreateWithFlags(&p->brief_stream, hipStreamNonBlocking));
+    while (p->split_events.size() < 2u * parts) {
+        hipEvent_t ev = nullptr;
+        HIP_TRY(p, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        p->split_events.push_back(ev);
+    }
+    // sub-ranges of (almost) equal size, multiples of 8 frames: a launch deals whole groups of 8 frames to the 8 XCDs
+    const uint32_t unit = 8u;
+    uint32_t f0 = 0;
+    for (uint32_t i = 0; i < parts; i++) {
+        uint32_t m = i + 1u == parts ? n - f0 : ((n * (i + 1u) / parts) / unit) * unit - f0;
+        const bool last = i + 1u == parts;
+        if (int rc = run_fused_range(p, frames, f0, m, s, last)) return rc;  // the last sub-range's BRIEF stays on s
+        if (!last) {
+            hipEvent_t front_done = p->split_events[2u * i], brief_done = p->split_events[2u * i + 1u];
+            HIP_TRY(p, hipEventRecord(front_done, s));
+            HIP_TRY(p, hipStreamWaitEvent(p->brief_stream, front_done, 0));
+            const size_t lists = (size_t)p->bands.n_slots * p->seg_classes;
+            launch_brief(p, p->brief_stream, m, p->rows, p->d_blur + (size_t)f0 * p->pyr.stride, p->d_blur_rowc + (size_t)f0 * p->pyr.row_stride,
+                         p->d_seg_counts + (size_t)f0 * lists, p->d_seg_before + (size_t)f0 * lists,
+                         p->d_seg + (size_t)f0 * lists * p->bands.seg_cap, p->d_counts + f0, p->d_corners + (size_t)f0 * p->cfg.max_features,
+                         p->d_desc + (size_t)f0 * p->cfg.max_features);
+            HIP_TRY(p, hipGetLastError());
+            HIP_TRY(p, hipEventRecord(brief_done, p->brief_stream));
+        }
+        f0 += m;
+    }
+    for (uint32_t i = 0; i + 1u < parts; i++) HIP_TRY(p, hipStreamWaitEvent(s, p->split_events[2u * i + 1u], 0));
+    p->planes_valid = true;
     return ORB_OK;
 }
 
@@ -618,8 +705,7 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
         g.seg_cap = bg.seg_cap;
         g.arc = p->arc;
         g.nms = (p->opt.flags & ORB_FLAG_NMS) ? 1u : 0u;
-        g.phase_mask = 63u;
-        if (const char* e = getenv("TINYORB_PHASE_MASK")) g.phase_mask = (uint32_t)atoi(e);
+        g.phase_mask = p->env.phase_mask >= 0 ? (uint32_t)p->env.phase_mask : 63u;
         g.literal = 0u;
         g.dw = pyr.w[lvl];
         g.dh = pyr.h[lvl];
@@ -653,8 +739,7 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
         LaunchScope ls(p, s, KID_BRIEF_I);
         IBriefGeom bgl = bg;
         bgl.xcd_swizzle = (n % 8u == 0u) ? 1u : 0u;
-        bgl.phase_mask = 3u;
-        if (const char* e = getenv("TINYORB_BRIEF_I_MASK")) bgl.phase_mask = (uint32_t)atoi(e);
+        bgl.phase_mask = p->env.brief_i_mask >= 0 ? (uint32_t)p->env.brief_i_mask : 3u;
         hipLaunchKernelGGL(k_brief_i, dim3(bg.group_base[D] * n), dim3(kIBriefThreads), p->ibrief_lds, s, p->d_blur, pyr, bgl,
                            p->d_iseg_counts, p->d_iseg_before, p->d_thr_key, p->d_iseg, p->d_iseg_scores, p->d_corners, cap,
                            p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin, p->d_rot});
@@ -831,6 +916,19 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     p->wq = p->opt.sampler_weight_bits ? (float)(1u << p->opt.sampler_weight_bits) : 0.0f;
     p->frame_bytes = (size_t)W * H * (p->input_y8 ? 1u : 4u);
     layout_pyramid(W, H, config->hierarchy_depth, &p->pyr);
+    {   // experiment / cross-check switches: the environment is read here and nowhere on a per-call path
+        auto on = [](const char* name) { const char* e = getenv(name); return e && *e && atoi(e) != 0; };
+        auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
+        p->env.single_memcpy = on("TINYORB_SINGLE_MEMCPY");
+        p->env.single_split = on("TINYORB_SINGLE_SPLIT");
+        p->env.single_serial = on("TINYORB_SINGLE_SERIAL");
+        p->env.single_sync = on("TINYORB_SINGLE_SYNC");
+        p->env.no_swizzle = on("TINYORB_NO_SWIZZLE");
+        p->env.quiet = getenv("TINYORB_QUIET") != nullptr;
+        p->env.phase_mask = num("TINYORB_PHASE_MASK", -1);
+        p->env.brief_i_mask = num("TINYORB_BRIEF_I_MASK", -1);
+        p->env.lds_pad = num("TINYORB_LDS_PAD", 0);
+    }
 
     auto bail = [&](int code) {
         g_create_error = p->err;
@@ -976,7 +1074,10 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
 #define FRONT_FN_TILED(R) reinterpret_cast<const void*>(&k_front<true, false, R, false, true>), reinterpret_cast<const void*>(&k_front<false, false, R, false, true>), \
                     reinterpret_cast<const void*>(&k_front<true, true, R, false, true>), reinterpret_cast<const void*>(&k_front<true, false, R, true, true>), \
                     reinterpret_cast<const void*>(&k_front<true, true, R, true, true>)
-                    FRONT_FN(64), FRONT_FN(32), FRONT_FN(16), FRONT_FN(8), FRONT_FN_TILED(16), FRONT_FN_TILED(8)
+                    FRONT_FN(64), FRONT_FN(32), FRONT_FN(16), FRONT_FN(8), FRONT_FN_TILED(16), FRONT_FN_TILED(8),
+#define FRONT_FN_OOB(R, T) reinterpret_cast<const void*>(&k_front<false, false, R, false, T, false, true>)
+                    FRONT_FN_OOB(64, false), FRONT_FN_OOB(32, false), FRONT_FN_OOB(16, false), FRONT_FN_OOB(8, false), FRONT_FN_OOB(16, true), FRONT_FN_OOB(8, true)
+#undef FRONT_FN_OOB
 #undef FRONT_FN
 #undef FRONT_FN_TILED
                 };
@@ -1097,7 +1198,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
             snprintf(why, sizeof why, "the band does not fit in %u bytes of LDS", p->max_lds);
         p->pipeline_note = std::string("staged pipeline (one kernel per reference stage, about 1/7 of the fused rate): ") + why;
         static bool warned = false;
-        if (!warned && !getenv("TINYORB_QUIET")) {
+        if (!warned && !p->env.quiet) {
             warned = true;
             fprintf(stderr, "libtinyorb: %s\n", p->pipeline_note.c_str());
         }
@@ -1189,6 +1290,17 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     CREATE_TRY(hipMemset(p->d_single_done, 0, sizeof(uint32_t)));
     CREATE_TRY(hipHostMalloc(&p->h_corners, cap * sizeof(CornerData), hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc(&p->h_desc, cap * sizeof(CornerDescriptor), hipHostMallocDefault));
+    {   // device-visible addresses of the staging arrays, once (null: the runtime cannot map them -> the three copies of orb.rs:537-547)
+        void *dc = nullptr, *dk = nullptr, *dd = nullptr;
+        if (hipHostGetDevicePointer(&dc, p->h_count, 0) == hipSuccess && hipHostGetDevicePointer(&dk, p->h_corners, 0) == hipSuccess &&
+            hipHostGetDevicePointer(&dd, p->h_desc, 0) == hipSuccess) {
+            p->dv_count = static_cast<uint32_t*>(dc);
+            p->dv_corners = static_cast<CornerData*>(dk);
+            p->dv_desc = static_cast<CornerDescriptor*>(dd);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
 #undef CREATE_TRY
     *out = p;
     return ORB_OK;
@@ -1198,12 +1310,16 @@ void orb_program_destroy(OrbProgram* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->brief_stream) (void)hipStreamSynchronize(p->brief_stream);
     for (auto& sp : p->pending) {
         (void)hipEventDestroy(sp.start);
         (void)hipEventDestroy(sp.stop);
     }
     for (auto e : p->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(p->d_input);
+    (void)hipFree(p->d_input_alt);
+    for (hipEvent_t ev : p->in_uploaded)
+        if (ev) (void)hipEventDestroy(ev);
     (void)hipFree(p->d_gray);
     (void)hipFree(p->d_blur);
     (void)hipFree(p->d_blur_rowc);
@@ -1240,6 +1356,8 @@ void orb_program_destroy(OrbProgram* p) {
     if (p->h_desc) (void)hipHostFree(p->h_desc);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
+    if (p->brief_stream) (void)hipStreamDestroy(p->brief_stream);
+    for (hipEvent_t ev : p->split_events) (void)hipEventDestroy(ev);
     if (p->order_event) (void)hipEventDestroy(p->order_event);
     for (hipEvent_t ev : p->upload_events) (void)hipEventDestroy(ev);
     if (p->upload_done) (void)hipEventDestroy(p->upload_done);
@@ -1253,14 +1371,59 @@ void orb_program_destroy(OrbProgram* p) {
     delete p;
 }
 
+// Slab an image written now goes to, and its place in the queue of images waiting for extract_corners (at most two: the
+// one being extracted next and the one uploaded under it).  With nothing pending the slab of the last extract is reused.
+// ahead = false (the blocking write, the reference's): the last write wins -- an image that is still waiting is overwritten,
+// the queue never grows past one.  ahead = true (orb_write_input_image_pinned): the image is queued behind a waiting one.
+static int claim_input_slab(OrbProgram* p, bool ahead, uint32_t* slab_out, uint8_t** dst) {
+    if (ahead && p->in_pending >= 2u)
+        return fail(p, ORB_ESTATE, "two images are already waiting for extract_corners");
+    if (int rc = ensure_input(p)) return rc;
+    uint32_t slab;
+    if (p->in_pending == 0u || ahead) {
+        slab = p->in_pending == 0u ? p->in_last : (p->in_queue[0] ^ 1u);
+        p->in_queue[p->in_pending++] = slab;
+    } else {
+        slab = p->in_queue[p->in_pending - 1u];  // overwrite the newest waiting image
+        if (p->in_async[slab]) HIP_TRY(p, hipEventSynchronize(p->in_uploaded[slab]));  // its upload must not land on top of this one
+    }
+    if (slab == 1u && !p->d_input_alt) HIP_TRY(p, hipMalloc(&p->d_input_alt, p->frame_bytes));
+    *slab_out = slab;
+    *dst = slab ? p->d_input_alt : p->d_input;
+    return ORB_OK;
+}
+
 int orb_write_input_image(OrbProgram* p, const uint8_t* bytes, size_t len) {
     if (!p) return ORB_EINVAL;
     if (!bytes || len != p->frame_bytes)
         return fail(p, ORB_EINVAL, "write_input_image: expected %zu bytes (4*W*H), got %zu", p->frame_bytes, len);
     HIP_TRY(p, hipSetDevice(p->device));
-    if (int rc = ensure_input(p)) return rc;
-    HIP_TRY(p, hipMemcpyAsync(p->d_input, bytes, len, hipMemcpyHostToDevice, p->stream));
+    uint32_t slab = 0;
+    uint8_t* dst = nullptr;
+    if (int rc = claim_input_slab(p, false, &slab, &dst)) return rc;
+    p->in_async[slab] = false;
+    HIP_TRY(p, hipMemcpyAsync(dst, bytes, len, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(p, hipStreamSynchronize(p->stream));  // the caller's slice may be reused right away
+    return ORB_OK;
+}
+
+int orb_write_input_image_pinned(OrbProgram* p, const uint8_t* bytes_pinned, size_t len) {
+    if (!p) return ORB_EINVAL;
+    if (!bytes_pinned || len != p->frame_bytes)
+        return fail(p, ORB_EINVAL, "write_input_image_pinned: expected %zu bytes, got %zu", p->frame_bytes, len);
+    HIP_TRY(p, hipSetDevice(p->device));
+    uint32_t slab = 0;
+    uint8_t* dst = nullptr;
+    if (int rc = claim_input_slab(p, true, &slab, &dst)) return rc;
+    if (!p->copy_stream) HIP_TRY(p, hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    if (!p->in_uploaded[slab]) HIP_TRY(p, hipEventCreateWithFlags(&p->in_uploaded[slab], hipEventDisableTiming));
+    if (!p->upload_done) HIP_TRY(p, hipEventCreateWithFlags(&p->upload_done, hipEventDisableTiming));
+    // The slab is free: the extract that last read it has returned (extract_corners blocks).  The copy runs on the copy
+    // stream, beside the kernels of the image extracted meanwhile; extract_corners orders its kernels behind it.
+    HIP_TRY(p, hipMemcpyAsync(dst, bytes_pinned, len, hipMemcpyHostToDevice, p->copy_stream));
+    HIP_TRY(p, hipEventRecord(p->in_uploaded[slab], p->copy_stream));
+    HIP_TRY(p, hipEventRecord(p->upload_done, p->copy_stream));  // orb_upload_sync(): the host array may be reused
+    p->in_async[slab] = true;
     return ORB_OK;
 }
 
@@ -1278,15 +1441,26 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
     if (int rc = ensure_input(p)) return rc;
     hipStream_t s = p->stream;
     const size_t cap = p->cfg.max_features;
+    // the oldest image written and not yet extracted; with none pending, the last one again (as the reference would)
+    uint32_t slab = p->in_last;
+    if (p->in_pending) {
+        slab = p->in_queue[0];
+        p->in_queue[0] = p->in_queue[1];
+        p->in_pending--;
+        p->in_last = slab;
+    }
+    const uint8_t* const d_in = slab ? p->d_input_alt : p->d_input;
+    if (p->in_async[slab]) {  // uploaded on the copy stream (orb_write_input_image_pinned)
+        HIP_TRY(p, hipStreamWaitEvent(s, p->in_uploaded[slab], 0));
+        p->in_async[slab] = false;
+    }
     // orb.rs:537-547: counter, corners and descriptors go to host staging, then block.  The reference copies the three
     // whole buffers; here a kernel writes the counter and the STORED records into the (pinned, device-visible) staging
     // memory: no size has to reach the host first, and 48 bytes per keypoint cross PCIe instead of 48 * max_features.
     // What lies behind the stored records in the staging arrays is stale, as it is in the reference's buffers.
-    void *dc = nullptr, *dk = nullptr, *dd = nullptr;
-    const bool direct = !getenv("TINYORB_SINGLE_MEMCPY") && hipHostGetDevicePointer(&dc, p->h_count, 0) == hipSuccess &&
-                        hipHostGetDevicePointer(&dk, p->h_corners, 0) == hipSuccess &&
-                        hipHostGetDevicePointer(&dd, p->h_desc, 0) == hipSuccess;
-    if (direct && p->fused && p->use_brief_t && p->oob == kOobZero && !getenv("TINYORB_SINGLE_SPLIT")) {  // k_brief_one is built for the default policy
+    void *dc = p->dv_count, *dk = p->dv_corners, *dd = p->dv_desc;
+    const bool direct = !p->env.single_memcpy && dc != nullptr;
+    if (direct && p->fused && p->use_brief_t && p->oob == kOobZero && !p->env.single_split) {  // k_brief_one is built for the default policy
         // Three launches per frame: one k_front per level, then k_brief_one -- slot prefix, both BRIEF kernels and the
         // write to host staging in one (a dependent launch costs 6-10 us whatever it does, and this call is the
         // reference's only shape).
@@ -1295,7 +1469,11 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
         const Pyramid& py = p->pyr;
         const bool pair_ok = py.depth >= 2u && py.w[0] == 2u * py.w[1] && py.h[0] == 2u * py.h[1] && (py.w[0] & 7u) == 0u &&
                              p->tile_w_lvl[0] == 0u && p->tile_w_lvl[1] == 0u && p->band_rows_lvl[0] == 8u && p->band_rows_lvl[1] == 8u &&
-                             !p->d_stamps && !getenv("TINYORB_SINGLE_SERIAL");
+                             !p->d_stamps && !p->env.single_serial &&
+                             // a band stages a row with one thread per four texels (level 1 from the frame: per four of ITS texels):
+                             // both rows must fit the 1024 threads, else no thread would stage anything (orb_front_body.inc)
+                             (py.w[0] >> 2) <= (uint32_t)kFrontThreadsL0 &&
+                             ((((std::max(py.w[1], ((py.w[0] / 2u + 7u) / 8u) * 8u) + 4u + 7u) & ~7u)) >> 2) <= (uint32_t)kFrontThreadsL0;
         if (pair_ok) {
             FrontGeom g[2];
             uint32_t width = py.w[0], height = py.h[0], lds = 0;
@@ -1311,21 +1489,24 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
                 g[lvl].n_classes = p->seg_classes;
                 g[lvl].xcd_swizzle = 0u;
                 g[lvl].wq = p->wq;
+                if (p->env.phase_mask >= 0) g[lvl].phase_mask = (uint32_t)p->env.phase_mask;
                 lds = std::max(lds, front_lds_bytes(g[lvl]));
             }
-            if (lds > p->max_lds) return fail(p, ORB_EINVAL, "internal: k_front_pair needs %u bytes of LDS", lds);
+            // a level-1 band stages a row with one thread per four texels, a level-0 band with one per quad (orb_front_body.inc)
+            if (lds > p->max_lds || ((g[1].ls - (uint32_t)kLdsPad) >> 2) > (uint32_t)kFrontThreadsL0 || (py.w[0] >> 2) > (uint32_t)kFrontThreadsL0)
+                return fail(p, ORB_EINVAL, "internal: k_front_pair does not fit this frame (%u bytes of LDS, %u columns)", lds, py.w[0]);
             {
                 LaunchScope ls(p, s, KID_FUSED_L0);
                 if (p->input_y8)
-                    hipLaunchKernelGGL((k_front_pair<8, 8, true>), dim3(g[0].n_bands + g[1].n_bands), dim3(kFrontThreadsL0), lds, s, p->d_input,
+                    hipLaunchKernelGGL((k_front_pair<8, 8, true>), dim3(g[0].n_bands + g[1].n_bands), dim3(kFrontThreadsL0), lds, s, d_in,
                                        p->frame_bytes, p->d_gray, p->d_blur, p->d_blur_rowc, py, g[0], g[1], p->threshold, p->d_seg_counts, p->d_seg);
                 else
-                    hipLaunchKernelGGL((k_front_pair<8, 8>), dim3(g[0].n_bands + g[1].n_bands), dim3(kFrontThreadsL0), lds, s, p->d_input,
+                    hipLaunchKernelGGL((k_front_pair<8, 8>), dim3(g[0].n_bands + g[1].n_bands), dim3(kFrontThreadsL0), lds, s, d_in,
                                        p->frame_bytes, p->d_gray, p->d_blur, p->d_blur_rowc, py, g[0], g[1], p->threshold, p->d_seg_counts, p->d_seg);
             }
             if (py.depth > 2u)
-                if (int rc = run_fused_range(p, p->d_input, 0, 1, s, false, 2u)) return rc;
-        } else if (int rc = run_fused_range(p, p->d_input, 0, 1, s, false)) {
+                if (int rc = run_fused_range(p, d_in, 0, 1, s, false, 2u)) return rc;
+        } else if (int rc = run_fused_range(p, d_in, 0, 1, s, false)) {
             return rc;
         }
         const uint32_t seq = ++p->single_seq ? p->single_seq : ++p->single_seq;  // never 0
@@ -1343,13 +1524,18 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
         // than the poll (tools/ubench/launch_floor.hip: 11.6 against 6.5 us for an empty launch).  The poll gives up after
         // 20 ms (a faulted kernel never publishes) and a stream synchronisation reports what happened.
         bool seen = false;
-        if (!p->profiling && !getenv("TINYORB_SINGLE_SYNC")) {
+        if (!p->profiling && !p->env.single_sync) {
             const volatile uint32_t* const done = p->h_count + kSingleDoneWord;
             const auto t0 = std::chrono::steady_clock::now();
             for (uint32_t spins = 0; !(seen = __atomic_load_n(done, __ATOMIC_ACQUIRE) == seq); spins++)
                 if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
         }
-        if (!seen) HIP_TRY(p, hipStreamSynchronize(s));
+        if (!seen) {
+            HIP_TRY(p, hipStreamSynchronize(s));
+            // not published within 20 ms (or polling is off): whatever happened, the launch is over now -- a launch that
+            // was cut short must not leave its workgroup count behind for the next call to add to
+            if (!p->profiling && !p->env.single_sync) HIP_TRY(p, hipMemsetAsync(p->d_single_done, 0, sizeof(uint32_t), s));
+        }
 #ifdef TINYORB_STAMPS
         if (getenv("TINYORB_PRINT_STAMPS")) {  // k_brief_one's joints, workgroups 0 and 24, in units of 10 ns
             fprintf(stderr, "k_brief_one stamps (load+stage, scan, flat body, other body, fence) x 10 ns:");
@@ -1364,7 +1550,7 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
         if (*corner_count > cap) return fail(p, ORB_ECAPACITY, "%u corners detected, max_features is %zu", *corner_count, cap);
         return ORB_OK;
     }
-    if (int rc = run_pipeline(p, p->d_input, 1, s)) return rc;
+    if (int rc = run_pipeline(p, d_in, 1, s)) return rc;
     if (direct) {
         p->last_batch = 1;
         p->last_stream = s;
@@ -1910,6 +2096,7 @@ int orb_synth_frames_device(OrbProgram* p, uint8_t* frames_dev, uint32_t n_frame
         if (n_frames > p->max_batch) return fail(p, ORB_EINVAL, "n_frames %u > max_batch %u", n_frames, p->max_batch);
         if (int rc = ensure_input(p)) return rc;
         frames_dev = p->d_input;
+        p->in_pending = 0u, p->in_last = 0u, p->in_async[0] = false;  // the program's own slab: what extract_corners works on next
     }
     const uint32_t W = p->pyr.w[0], H = p->pyr.h[0];
     if (p->input_y8) flags |= ORB_SYN_Y8;  // a Y8 program's frames are one byte per pixel

@@ -541,7 +541,10 @@ __global__ __launch_bounds__(kBriefOneThreads) void k_brief_one(const uint16_t* 
     if (tid == 0u) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: buffer_wbl2 sc0 sc1 ...
         __builtin_amdgcn_s_waitcnt(0);                 // ... and its completion (hipcc leaves the wait out in front of a relaxed atomic)
-        const uint32_t prev = __hip_atomic_fetch_add(done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The count is an acquire-release read-modify-write at agent scope: every workgroup's system-scope release above is
+        // ordered in front of its increment, and the workgroup that reads gridDim.x - 1 acquires all the others' -- the
+        // protocol is right by the memory model, not only by what gfx950 does (one lane per workgroup: nothing measurable).
+        const uint32_t prev = __hip_atomic_fetch_add(done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (prev + 1u == gridDim.x) {
             __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(host_count + kSingleDoneWord, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -78,7 +78,8 @@ struct FrontGeom {
     uint32_t blur_q;      // columns [0, blur_q) of the final blur are one constant per row
     uint32_t n_var;       // w - blur_q: columns whose blur varies along the row (one BlurCol table entry each)
     unsigned long long* stamps;  // diagnostic runs only: 16 cycle sums per kernel flavour (else null)
-    uint32_t oob;         // OrbOptions::oob_policy (kOobZero / kOobClamp / kOobUmin): texels outside a level >= 1 in phase A
+    uint32_t ovf_words;   // words of one bit set over the band's pre-test items (two sets in LDS: items whose survivors did not fit queue A)
+    uint32_t oob;         // OrbOptions::oob_policy (kOobZero / kOobClamp / kOobUmin); phase A of the levels >= 1 follows it through OOBK
     float wq;             // OrbOptions::sampler_weight_bits as 2^bits (0: exact lerp weights), for blur_tap()
 };
 
@@ -96,9 +97,10 @@ static_assert(sizeof(BlurCol) == 24, "BlurCol layout");
 __host__ __device__ inline uint32_t front_lds_bytes(const FrontGeom& g) {
     // grey rows + queues B/C (the blur column table lives there first: 24 B x n_var <= 8 B x ts, checked on the host)
     // + queue A + 5 counters + blur row constants (2 x rows float4)
+    // + two bit sets over the pre-test items (8 bytes per 32 items)
     if (g.tiled)  // the same, the shared storage sized for whichever of its two uses is larger, + the far grey columns of tile 0
-        return ((g.rows + 6) * g.ls + g.tmp_halfs) * 2u + kFrontQueue * 2u + 32u + 32u * g.rows + 8u * g.rows;
-    return ((g.rows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + kFrontQueue * 2u + 32u + 32u * g.rows;
+        return ((g.rows + 6) * g.ls + g.tmp_halfs) * 2u + kFrontQueue * 2u + 32u + 32u * g.rows + 8u * g.rows + 8u * g.ovf_words;
+    return ((g.rows + 6) * g.ls + 2 * kFrontTmpRows * g.ts) * 2u + kFrontQueue * 2u + 32u + 32u * g.rows + 8u * g.ovf_words;
 }
 
 // Typed buffer loads (the texture path converts): with DATA_FORMAT 8_8_8_8 / NUM_FORMAT UNORM a lane receives byte/255 of
@@ -269,10 +271,13 @@ __device__ __forceinline__ void segment_append(bool is_corner, uint32_t x, uint3
 // SRC (level 1 only): the band builds its grey rows from the frame itself (RGBA, or Y8 bytes through the typed buffer) -- luminance of the 2x2 blocks, then the mip
 //     (CRD-1..4, the arithmetic of phases A and C0) -- instead of reading the mip level 0's launch writes: the two launches
 //     of a single frame then do not depend on each other (orb_extract_corners runs them side by side).
+// OOBK (levels >= 1 only): the program has an out-of-level policy other than "zero" (OrbOptions::oob_policy): texels outside the
+//     level are staged as the level's last row / column instead of 0.  A template flag so that the default's code stays what it was
+//     (as a run-time branch it cost k_front<false> a register and 6 % of its time).
 // NTO: threads of the workgroup when they are not the level's usual number (k_front_pair runs level 1 on 1024).
 // The body lives in orb_front_body.inc and is emitted twice: front_body<...> (a device function, for k_front_pair) and
 // the kernel k_front<...> itself.
-template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false, bool TILED = false, bool SRC = false, int NTO = 0>
+template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false, bool TILED = false, bool SRC = false, int NTO = 0, bool OOBK = false>
 __device__ __forceinline__ void front_body(const uint32_t block_id, const uint8_t* __restrict__ frames, size_t frame_bytes,
                                            uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                            uint16_t* __restrict__ blur_rowc, const Pyramid pyr,
@@ -281,7 +286,7 @@ __device__ __forceinline__ void front_body(const uint32_t block_id, const uint8_
 #include "orb_front_body.inc"
 }
 
-template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false, bool TILED = false, bool SRC = false>
+template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false, bool TILED = false, bool SRC = false, bool OOBK = false>
 __global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                          uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                                          uint16_t* __restrict__ blur_rowc, Pyramid pyr,

@@ -54,6 +54,7 @@ EXPORTS = [
     "orb_node_shard", "orb_node_extract_batch", "orb_node_extract_batch_host", "orb_node_collate",
     "orb_node_read_collated", "orb_node_collate_begin", "orb_node_collate_end", "orb_node_pending",
     "orb_extract_batch_pinned", "orb_upload_sync", "orb_node_exchange_backend", "orb_node_rccl_pairs",
+    "orb_write_input_image_pinned",
 ]
 
 
@@ -130,6 +131,7 @@ def load_library(path=None):
     L.orb_program_destroy.argtypes = [vp]
     L.orb_program_destroy.restype = None
     L.orb_write_input_image.argtypes = [vp, vp, sz]
+    L.orb_write_input_image_pinned.argtypes = [vp, vp, sz]
     L.orb_set_threshold.argtypes = [vp, ctypes.c_float]
     L.orb_extract_corners.argtypes = [vp, ctypes.POINTER(u32)]
     L.orb_read_corners.argtypes = [vp, vp, sz]
@@ -341,6 +343,13 @@ class OrbProgram:
         a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray, memoryview))
                                  else np.asarray(data, dtype=np.uint8))
         self._check(self._lib.orb_write_input_image(self._handle(), _ptr(a), a.size))
+
+    def write_input_image_pinned(self, frame):
+        """orb_write_input_image_pinned: `frame` is a numpy view of PINNED memory (PinnedArray.array); asynchronous, one image
+        may be written ahead of extract_corners (upload_sync() waits until the array may be reused)."""
+        a = np.asarray(frame)
+        assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+        self._check(self._lib.orb_write_input_image_pinned(self._handle(), ctypes.c_void_p(a.ctypes.data), a.size))
 
     def set_threshold(self, threshold):
         """orb.rs:585"""

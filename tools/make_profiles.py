@@ -12,6 +12,8 @@ import sys
 import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tinyslam_amd import build as orb_build  # noqa: E402  (source_hash: no GPU, no compile)
 src_tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 tag = sys.argv[2] if len(sys.argv) > 2 else src_tag  # name of the committed files (one set per round)
 src = os.path.join(ROOT, "gpurun_out", src_tag)
@@ -64,6 +66,7 @@ traffic = {
     "kernel": bench["roofline"]["kernel"], "frames_per_launch": bench["roofline"]["frames_per_launch"],
     "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
     "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+    "csrc_sha256": orb_build.source_hash(),  # the kernels these counters were taken on (bench.py checks it)
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1` "
               "(profiles/%s_pmc_summary.csv); bytes = (2*FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE reads half of a wide "
               "coalesced stream on gfx950" % tag,
