@@ -332,7 +332,7 @@ int orb_debug_angle_code(OrbProgram *p, const float *cy, const float *cx, uint32
 int orb_debug_rot_table(OrbProgram *p, int16_t *dst, size_t n_entries, uint32_t *codes, uint32_t *pitch);
 
 /* ---- measurement ---- */
-#define ORB_KERNEL_COUNT 20
+#define ORB_KERNEL_COUNT 21
 /* When enabled every kernel launch is bracketed by hipEvents on its stream. */
 int orb_profile_enable(OrbProgram *p, int enable);
 int orb_profile_reset(OrbProgram *p);

@@ -60,14 +60,29 @@ pub mod orb {
         max_batch: u32,
         flags: u32,    // 0 = the reference's literal algorithm
         fast_arc: u32, // 0 = FAST-12
-        reserved: [u32; 4],
+        oob_policy: u32,          // ORB_OOB_ZERO / _CLAMP / _UMIN: textureLoad outside the level (0 = the default, CRD-6)
+        sampler_weight_bits: u32, // 0 = exact bilinear weights (CRD-5); n = weights held in n fractional bits
+        reserved: [u32; 2],
     }
+
+    /// The two points the reference's WGSL leaves to its adapter, as switches (`OrbOptions` of include/tinyorb.h).
+    /// `tools/pin_oracle.py check <dump>` says which setting a given adapter follows.
+    #[derive(Clone, Copy, Default)]
+    pub struct AdapterBehaviour {
+        pub oob_policy: u32,
+        pub sampler_weight_bits: u32,
+    }
+    pub const ORB_OOB_ZERO: u32 = 0;
+    pub const ORB_OOB_CLAMP: u32 = 1;
+    pub const ORB_OOB_UMIN: u32 = 2;
 
     extern "C" {
         fn orb_program_create(cfg: *const OrbConfigC, opt: *const OrbOptionsC, out: *mut *mut c_void) -> c_int;
         fn orb_program_destroy(p: *mut c_void);
         fn orb_last_error(p: *const c_void) -> *const c_char;
         fn orb_write_input_image(p: *mut c_void, bytes: *const u8, len: usize) -> c_int;
+        fn orb_write_input_image_pinned(p: *mut c_void, bytes_pinned: *const u8, len: usize) -> c_int;
+        fn orb_upload_sync(p: *mut c_void) -> c_int;
         fn orb_set_threshold(p: *mut c_void, threshold: f32) -> c_int;
         fn orb_extract_corners(p: *mut c_void, corner_count: *mut u32) -> c_int;
         fn orb_read_corners(p: *mut c_void, dst: *mut CornerData, n: usize) -> c_int;
@@ -79,6 +94,8 @@ pub mod orb {
 
     pub struct OrbProgram {
         pub config: OrbConfig,
+        /// what the reference's adapter does where WGSL leaves it open (default: zeros / exact weights)
+        pub adapter: AdapterBehaviour,
         handle: *mut c_void,
     }
 
@@ -86,7 +103,7 @@ pub mod orb {
         /// The reference builds `OrbProgram { config, compute, storage }` by struct literal; the wgpu
         /// objects are gone, so construction takes the config only.
         pub fn new(config: OrbConfig) -> Self {
-            Self { config, handle: std::ptr::null_mut() }
+            Self { config, adapter: AdapterBehaviour::default(), handle: std::ptr::null_mut() }
         }
 
         fn check(&self, rc: c_int) {
@@ -107,12 +124,31 @@ pub mod orb {
                 hierarchy_depth: self.config.hierarchy_depth,
                 initial_threshold: self.config.initial_threshold,
             };
-            let rc = unsafe { orb_program_create(&c, &OrbOptionsC::default(), &mut self.handle) };
+            let opt = OrbOptionsC {
+                oob_policy: self.adapter.oob_policy,
+                sampler_weight_bits: self.adapter.sampler_weight_bits,
+                ..Default::default()
+            };
+            let rc = unsafe { orb_program_create(&c, &opt, &mut self.handle) };
             self.check(rc);
         }
 
         pub fn write_input_image(&self, bytes: &[u8]) {
             self.check(unsafe { orb_write_input_image(self.handle, bytes.as_ptr(), bytes.len()) });
+        }
+
+        /// The reference's non-blocking upload (orb.rs:567-583 returns after `queue.write_texture`): `bytes` must lie in
+        /// pinned host memory (`orb_host_alloc`) and stay untouched until `upload_sync()`.  One image may be written
+        /// ahead of `extract_corners`, so a camera loop uploads frame k + 1 under the kernels of frame k.
+        ///
+        /// # Safety
+        /// `bytes` must point to `len` bytes of pinned memory that outlive the upload.
+        pub unsafe fn write_input_image_pinned(&self, bytes: *const u8, len: usize) {
+            self.check(orb_write_input_image_pinned(self.handle, bytes, len));
+        }
+
+        pub fn upload_sync(&self) {
+            self.check(unsafe { orb_upload_sync(self.handle) });
         }
 
         pub fn set_threshold(&self, threshold: f32) {
@@ -165,6 +201,8 @@ pub mod orb {
         fn orb_node_collate_end(node: *mut c_void, counts: *mut u32, offsets: *mut u64, corners_dev: *mut *mut c_void,
                                 descriptors_dev: *mut *mut c_void) -> c_int;
         fn orb_node_pending(node: *const c_void) -> c_int;
+        fn orb_node_exchange_backend(node: *const c_void) -> *const c_char;
+        fn orb_node_rccl_pairs(node: *const c_void) -> u64;
         fn orb_node_read_collated(node: *mut c_void, corners: *mut CornerData, descriptors: *mut CornerDescriptor,
                                   capacity: usize) -> c_int;
     }
@@ -258,6 +296,16 @@ pub mod orb {
 
         pub fn pending(&self) -> usize {
             unsafe { orb_node_pending(self.handle) as usize }
+        }
+
+        /// How the records of ranks >= 1 reach the first device: "rccl", "rccl-self", "copies" or "none".
+        pub fn exchange_backend(&self) -> String {
+            unsafe { std::ffi::CStr::from_ptr(orb_node_exchange_backend(self.handle)).to_string_lossy().into_owned() }
+        }
+
+        /// ncclSend + ncclRecv pairs this node has enqueued so far.
+        pub fn rccl_pairs(&self) -> u64 {
+            unsafe { orb_node_rccl_pairs(self.handle) }
         }
 
         fn collate(&self, n: u32) -> BatchResult {

@@ -27,12 +27,12 @@ using namespace orb;
 
 namespace {
 
-enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I, KID_MATCH, KID_COMPACT, KID_BRIEF_T, KID_BRIEF_NF, KID_PACK_T, KID_UNPACK_T, KID_BRIEF_ONE };
+enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I, KID_MATCH, KID_COMPACT, KID_BRIEF_T, KID_BRIEF_NF, KID_PACK_T, KID_UNPACK_T, KID_BRIEF_ONE, KID_FRONT_I_LN };
 const char* const kKernelNames[ORB_KERNEL_COUNT] = {"k_grayscale", "k_mip",      "k_blur_rows", "k_fast",       "k_brief",
                                                     "k_front_l0",  "k_front_ln", "k_synth",     "k_brief_rows", "k_slot_prefix",
-                                                    "k_front_i",   "k_select_i", "k_brief_i",   "k_match",      "k_compact",
+                                                    "k_front_i_l0", "k_select_i", "k_brief_i",   "k_match",      "k_compact",
                                                     "k_brief_t",   "k_brief_nf",  "k_compact_transport", "k_unpack_transport",
-                                                    "k_brief_one"};
+                                                    "k_brief_one", "k_front_i_ln"};
 
 thread_local std::string g_create_error;
 
@@ -717,7 +717,7 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
             return fail(p, ORB_EINVAL, "internal: tile count mismatch at level %u", lvl);
         if (g.blur && !ifront_gauss_fits(g.tw)) return fail(p, ORB_EINVAL, "internal: tile width %u too wide for the fused Gaussian", g.tw);
         const dim3 grid(g.n_bands * g.n_ct * n);
-        LaunchScope ls(p, s, KID_FRONT_I);
+        LaunchScope ls(p, s, lvl == 0 ? KID_FRONT_I : KID_FRONT_I_LN);  // level 0 (RGBA in) and the levels above are different launches: one id each
         if (lvl == 0)
             hipLaunchKernelGGL(k_front_i<true>, grid, dim3(kIThreads), ifront_lds_bytes(g), s, frames, p->frame_bytes,
                                p->d_gray, p->d_blur, pyr, g, p->threshold, p->d_iseg_counts, p->d_iseg, p->d_iseg_scores);
@@ -810,7 +810,7 @@ int run_fused_x(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
         if (g.n_bands * g.n_ct != bg.slot_base[lvl + 1] - bg.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: tile count mismatch at level %u", lvl);
         if (gw && gh) {
-            LaunchScope ls(p, s, KID_FRONT_I);
+            LaunchScope ls(p, s, lvl == 0 ? KID_FRONT_I : KID_FRONT_I_LN);  // level 0 (RGBA in) and the levels above are different launches: one id each
             const dim3 grid(g.n_bands * g.n_ct * n);
             if (lvl == 0)
                 hipLaunchKernelGGL(k_front_i<true>, grid, dim3(kIThreads), ifront_lds_bytes(g), s, frames, p->frame_bytes,

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("TINYORB_LIB") or os.path.join(os.path.dirname(os.path
 
 ORB_OK, ORB_EINVAL, ORB_EHIP, ORB_ECAPACITY, ORB_ESTATE = 0, 1, 2, 3, 4
 ORB_PLANE_GRAY, ORB_PLANE_BLUR = 0, 1
-ORB_KERNEL_COUNT = 20
+ORB_KERNEL_COUNT = 21
 ORB_FLAG_STAGED = 1
 ORB_FLAG_DOUBLE_OUTPUT = 2
 ORB_FLAG_NMS = 4
