@@ -188,6 +188,56 @@ __device__ __forceinline__ bool ring_is_corner(const half_t* ctr, int ls, float 
 // f16 below c - thr, none if that is not positive), folded into the same subtraction by complementing both sides.
 // Ring points i and i + 8 share a register: 8 packed subtractions whose sign bits are the mask, gathered in ring order
 // by a packed shift and a shift-or per register and one byte permute.
+// The smallest (over) / largest (under) f16 bit pattern t of a ring value v that passes the reference's strict test against centre
+// c -- fl32(v - c) > thr, resp. < -thr -- as the two constants of the packed comparison  ((t ^ m) - 1) - (v ^ m) < 0  (see
+// ring_is_corner_polar): tt = (t ^ m) - 1 and mm = m, each replicated in both halves of a word.  -1 for "nothing passes".
+__device__ __forceinline__ void polar_threshold(float c, float thr, bool over, uint32_t* tt, uint32_t* mm) {
+    const float sgn = over ? 1.0f : -1.0f;
+    const float s = __builtin_fmaf(sgn, thr, c);           // c + thr / c - thr (rounded: only a first guess)
+    const uint32_t h0 = half_bits(to_half(s));
+    const float d = from_half(bits_half((uint16_t)h0)) - c;  // exact
+    const bool pass = d * sgn > thr;                       // the candidate itself, by the reference's expression (CRD-7; +-d is exact)
+    const int isgn = over ? 1 : -1;
+    int t = (int)h0 + (pass ? 0 : isgn);                   // over: smallest v that passes; under: largest v that passes
+    if (!over && !(s > 0.0f)) t = -1;                      // nothing is darker than a non-positive bound
+    const uint32_t m = over ? 0u : 0xffffu;
+    const uint32_t tm1 = (uint32_t)(((t ^ (int)m) - 1) & 0xffff);
+    *tt = tm1 | (tm1 << 16);
+    *mm = m | (m << 16);
+}
+// 1 in each half of the result where that half of v passes (polar_threshold's constants)
+__device__ __forceinline__ uint32_t polar_pass2(uint32_t v, uint32_t tt, uint32_t mm) {
+    typedef short short2_t __attribute__((ext_vector_type(2)));
+    const short2_t df = __builtin_bit_cast(short2_t, tt) - __builtin_bit_cast(short2_t, v ^ mm);
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ushort2_t, df) >> (unsigned short)15);
+}
+// The 16-bit ring mask of one polarity (bit i <=> ring point i passes), exact, on packed 16-bit integers.
+__device__ __forceinline__ uint32_t ring_mask_polar(const half_t* ctr, int ls, float thr, bool over) {
+    uint32_t tt, mm;
+    polar_threshold(from_half(ctr[0]), thr, over, &tt, &mm);
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const ushort2_t v = {half_bits(ctr[kRingDy[j] * ls + kRingDx[j]]), half_bits(ctr[kRingDy[j + 8] * ls + kRingDx[j + 8]])};
+        const uint32_t sb = polar_pass2(__builtin_bit_cast(uint32_t, v), tt, mm);
+        acc = j == 0 ? sb : ((sb << j) | acc);
+    }
+    return __builtin_amdgcn_perm(0u, acc, 0x0c0c0200u);  // bits 0..7: ring 0..7, bits 8..15: ring 8..15
+}
+// Every second ring point (ring indices 0, 2, .., 14) of one polarity: bit i <=> ring point 2 i passes.
+__device__ __forceinline__ uint32_t even_ring_mask_polar(const half_t* ctr, int ls, float thr, bool over) {
+    uint32_t tt, mm;
+    polar_threshold(from_half(ctr[0]), thr, over, &tt, &mm);
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {  // even points j and j + 4 = ring points 2 j and 2 j + 8 share a register
+        const ushort2_t v = {half_bits(ctr[kRingDy[2 * j] * ls + kRingDx[2 * j]]), half_bits(ctr[kRingDy[2 * j + 8] * ls + kRingDx[2 * j + 8]])};
+        const uint32_t sb = polar_pass2(__builtin_bit_cast(uint32_t, v), tt, mm);
+        acc = j == 0 ? sb : ((sb << j) | acc);
+    }
+    return (acc & 15u) | ((acc >> 12) & 0xf0u);
+}
+
 __device__ __forceinline__ bool ring_is_corner_polar(const half_t* ctr, int ls, float thr, bool over) {
     const float c = from_half(ctr[0]);
     const float sgn = over ? 1.0f : -1.0f;

@@ -57,8 +57,9 @@ constexpr int kIGaussRows = kFrontRows + 6;  // rows of the X pass a tile's Y pa
 // the X pass's output of one column half of a tile lives in the queues' storage (phase G runs before the detector)
 __host__ __device__ inline bool ifront_gauss_fits(uint32_t tw) { return (uint32_t)kIGaussRows * (tw / 2u) <= (uint32_t)(kIQueueA + kIQueueB + kIQueueC); }
 
+constexpr int kINmsRows = 20;  // region rows 0 .. R + 1 (the tile's rows and its 1-px apron), plus two spare
 __host__ __device__ inline uint32_t ifront_lds_bytes(const IGeom& g) {
-    return kIRows * g.ls * 2u + (kIQueueA + kIQueueB + kIQueueC) * 2u + 32u;
+    return kIRows * g.ls * 2u + (kIQueueA + kIQueueB + kIQueueC) * 2u + 32u + 4u * (2u * kINmsRows + 2u);  // grey tile, queues, 8 counters, the NMS's row counters and row starts
 }
 
 __device__ __forceinline__ bool has_run_bits(uint32_t mask, uint32_t n_bits, uint32_t need) {
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int LS = (int)geo.ls, TW = (int)geo.tw;
     half_t* const grey = reinterpret_cast<half_t*>(lds_raw);  // kIRows x LS; LDS column kIPad <-> image column cx0
-    // 16-bit queue entries: [15] try brighter, [14] try darker, [13:9] region row (0 <-> y0-1), [8:0] LDS column.
+    // 16-bit queue entries: region row, item of the row, bit number of the item's survivor mask (see B1).
     // A: pre-test survivors; B: survivors of the even-ring filter; C: corners.  The corner list of the NMS
     // (position, angle, score) reuses A's storage once A has been drained.
     uint16_t* const queue_a = reinterpret_cast<uint16_t*>(grey + kIRows * LS);
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     uint32_t* const list_count = counters + 3;
     uint32_t* const c_count = counters + 4;   // corners appended by this tile
     uint32_t* const overflow = counters + 5;  // some queue was full: the tile is redone by the direct path
+    uint32_t* const nms_row_cnt = counters + 8;  // [kINmsRows] corners per region row (S3 counts, S4 sorts by them)
     uint16_t* const list_pos = queue_a;                                          // kIList
     uint16_t* const list_ang = queue_a + kIList;                                 // kIList
     float* const list_score = reinterpret_cast<float*>(queue_a + 2 * kIList);   // kIList (6 KB in all = A's storage)
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     float* const seg_sc = seg_scores + slot * geo.seg_cap;
     const uint32_t arc = geo.arc;
     const int apron = geo.nms ? 1 : 0;  // the NMS needs the scores of the pixels around the tile as well
-    if (tid < 8) counters[tid] = 0u;
+    if (tid < 8 + kINmsRows) counters[tid] = 0u;
 
     // =========================== A: grey rows [y0-4, y0+R+4) x columns [cx0-8, cx0+tw+8) ===========================
     if (L0) {
@@ -437,16 +439,21 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
         append((uint32_t)x, (uint32_t)gy, ang, s);
     };
 
-    // =========================== B1: compass pre-test, 8 px per item ===========================
+    // =========================== B1: compass pre-test, 16 px per item ===========================
+    // 16-bit queue entries (k_front's form): [14:10] region row (0 <-> y0-1), [9:5] item of the row (LDS column kIPad - 8 + 16 j),
+    // [4:0] bit number in the item's survivor mask: bit 16 h + front_mask_bit(k, under) = pixel 8 h + k of the item passed the
+    // pre-test of that polarity.  A pixel that passes both (possible below arc 12: two of the four compass points each way)
+    // has two entries; the stages behind test one polarity per entry, and a run of >= 9 of one polarity excludes the other.
     if (geo.phase_mask & 1u)
     // A run of `arc` ring positions holds at least arc / 4 of the four compass points: 3 for arc >= 12 (the
     // reference's shortcut), 2 for 9..11.  Conservative packed test as in k_front (selection network on the f16 bit
-    // patterns, packed-f16 compares against a threshold one ulp below RD16(thr)).
+    // patterns, packed-f16 compares against a threshold one ulp below RD16(thr)); what is done once per item -- index
+    // arithmetic, the region's edges, the slot reservation -- weighs half as much per pixel as with items of eight.
     {
         const bool need3 = arc >= 12u;
         const int r_lo = ry0 - (y0 - 1), r_hi = ry1 - (y0 - 1);          // region rows [r_lo, r_hi)
-        const int i_lo = (rx0 - cx0 + 8) >> 3, i_hi = (rx1 - 1 - cx0 + 8) >> 3;  // items: xl = 8 * i - 8
-        const int per_row = i_hi - i_lo + 1;
+        const int j_lo = (rx0 - cx0 + 8) >> 4, j_hi = (rx1 - 1 - cx0 + 8) >> 4;  // items: xl = 16 * j - 8
+        const int per_row = j_hi - j_lo + 1;
         const int n_items = (r_hi > r_lo && per_row > 0) ? (r_hi - r_lo) * per_row : 0;
         const float inv_per_row = 1.0f / (float)max(per_row, 1);
         uint32_t tb = half_bits(to_half(thr));
@@ -456,65 +463,72 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
         for (int i = tid; i < n_items; i += NT) {
             const int rr = (int)(((float)i + 0.5f) * inv_per_row);
             const int r = r_lo + rr;
-            const int xl = (i_lo + (i - __mul24(rr, per_row))) * 8 - 8;  // column inside the tile of the item's pixel 0
+            const int j = j_lo + (i - __mul24(rr, per_row));
+            const int xl = 16 * j - 8;  // column inside the tile of the item's pixel 0
             const int x = cx0 + xl;
-            const half_t* rowc = grey + __mul24(r + 3, LS) + kIPad + xl;
-            const uint2 qa = *reinterpret_cast<const uint2*>(rowc - 4);
-            const uint4 qb = *reinterpret_cast<const uint4*>(rowc);
-            const uint2 qc = *reinterpret_cast<const uint2*>(rowc + 8);
-            const uint4 qu = *reinterpret_cast<const uint4*>(rowc - 3 * LS);
-            const uint4 qd = *reinterpret_cast<const uint4*>(rowc + 3 * LS);
-            const uint32_t dw[8] = {qa.x, qa.y, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};
-            const uint32_t upw[4] = {qu.x, qu.y, qu.z, qu.w}, dnw[4] = {qd.x, qd.y, qd.z, qd.w};
-            uint32_t e_ovr[4], e_und[4];
+            const half_t* row16 = grey + __mul24(r + 3, LS) + kIPad + xl;
+            uint32_t cand = 0;  // bit 16 h + front_mask_bit(k, under): pixel 8 h + k survives
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const ushort2_t left = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 1], dw[j], 16));
-                const ushort2_t right = as_u16x2(__builtin_amdgcn_alignbit(dw[j + 4], dw[j + 3], 16));
-                const ushort2_t upp = as_u16x2(upw[j]), dwn = as_u16x2(dnw[j]);
-                const ushort2_t lo1 = __builtin_elementwise_min(left, right), hi1 = __builtin_elementwise_max(left, right);
-                const ushort2_t lo2 = __builtin_elementwise_min(upp, dwn), hi2 = __builtin_elementwise_max(upp, dwn);
-                const ushort2_t m1 = __builtin_elementwise_max(lo1, lo2), m2 = __builtin_elementwise_min(hi1, hi2);
-                const half2_t second_lo = __builtin_bit_cast(half2_t, __builtin_elementwise_min(m1, m2));
-                const half2_t second_hi = __builtin_bit_cast(half2_t, __builtin_elementwise_max(m1, m2));
-                const half2_t c2 = __builtin_bit_cast(half2_t, dw[j + 2]);
-                // >= 3 brighter <=> 2nd smallest beyond thr; >= 2 brighter <=> 2nd largest beyond thr (and mirrored)
-                const half2_t sel_over = need3 ? second_lo : second_hi, sel_under = need3 ? second_hi : second_lo;
-                const half2_t e_over = thr_lo2 - (sel_over - c2);    // negative  <=>  sel_over - c > thr_lo
-                const half2_t e_under = (sel_under - c2) + thr_lo2;  // negative  <=>  sel_under - c < -thr_lo
-                e_ovr[j] = __builtin_bit_cast(uint32_t, e_over);
-                e_und[j] = __builtin_bit_cast(uint32_t, e_under);
+            for (int hh = 0; hh < 2; hh++) {
+                const half_t* rowc = row16 + 8 * hh;
+                const uint2 qa = *reinterpret_cast<const uint2*>(rowc - 4);
+                const uint4 qb = *reinterpret_cast<const uint4*>(rowc);
+                const uint2 qc = *reinterpret_cast<const uint2*>(rowc + 8);
+                const uint4 qu = *reinterpret_cast<const uint4*>(rowc - 3 * LS);
+                const uint4 qd = *reinterpret_cast<const uint4*>(rowc + 3 * LS);
+                const uint32_t dw[8] = {qa.x, qa.y, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};
+                const uint32_t upw[4] = {qu.x, qu.y, qu.z, qu.w}, dnw[4] = {qd.x, qd.y, qd.z, qd.w};
+                uint32_t e_ovr[4], e_und[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const ushort2_t left = as_u16x2(__builtin_amdgcn_alignbit(dw[q + 1], dw[q], 16));
+                    const ushort2_t right = as_u16x2(__builtin_amdgcn_alignbit(dw[q + 4], dw[q + 3], 16));
+                    const ushort2_t upp = as_u16x2(upw[q]), dwn = as_u16x2(dnw[q]);
+                    const ushort2_t lo1 = __builtin_elementwise_min(left, right), hi1 = __builtin_elementwise_max(left, right);
+                    const ushort2_t lo2 = __builtin_elementwise_min(upp, dwn), hi2 = __builtin_elementwise_max(upp, dwn);
+                    const ushort2_t m1 = __builtin_elementwise_max(lo1, lo2), m2 = __builtin_elementwise_min(hi1, hi2);
+                    const half2_t second_lo = __builtin_bit_cast(half2_t, __builtin_elementwise_min(m1, m2));
+                    const half2_t second_hi = __builtin_bit_cast(half2_t, __builtin_elementwise_max(m1, m2));
+                    const half2_t c2 = __builtin_bit_cast(half2_t, dw[q + 2]);
+                    // >= 3 brighter <=> 2nd smallest beyond thr; >= 2 brighter <=> 2nd largest beyond thr (and mirrored)
+                    const half2_t sel_over = need3 ? second_lo : second_hi, sel_under = need3 ? second_hi : second_lo;
+                    const half2_t e_over = thr_lo2 - (sel_over - c2);    // negative  <=>  sel_over - c > thr_lo
+                    const half2_t e_under = (sel_under - c2) + thr_lo2;  // negative  <=>  sel_under - c < -thr_lo
+                    e_ovr[q] = __builtin_bit_cast(uint32_t, e_over);
+                    e_und[q] = __builtin_bit_cast(uint32_t, e_under);
+                }
+                uint32_t acc = 0;  // the sixteen sign bits as one 16-bit mask (k_front, B1)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t so = __builtin_bit_cast(uint32_t, as_u16x2(e_ovr[q]) >> (unsigned short)15);
+                    const uint32_t su = __builtin_bit_cast(uint32_t, as_u16x2(e_und[q]) >> (unsigned short)15);
+                    acc = q == 0 ? so : ((so << q) | acc);
+                    acc = (su << (4 + q)) | acc;
+                }
+                cand |= __builtin_amdgcn_perm(0u, acc, hh == 0 ? 0x0c0c0200u : 0x02000c0cu);
             }
-            auto gather_signs = [](const uint32_t (&e)[4]) {
-                const uint32_t p01 = __builtin_amdgcn_perm(e[1], e[0], 0x07050301u);
-                const uint32_t p23 = __builtin_amdgcn_perm(e[3], e[2], 0x07050301u);
-                return (p01 & 0x80808080u) | ((p23 & 0x80808080u) >> 4);  // pixel k at bit 8*(k&3) + (k<4 ? 7 : 3)
-            };
-            uint32_t c_over = gather_signs(e_ovr), c_under = gather_signs(e_und);
-            {   // pixels of the item outside [rx0, rx1)
+            {   // pixels of the item outside [rx0, rx1): only the first and the last item of a row
                 const int first = rx0 - x, past = rx1 - x;
-                if (first > 0 || past < 8) {
+                if (first > 0 || past < 16) {
                     uint32_t keep = 0;
 #pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        if (k >= first && k < past) keep |= 1u << (8 * (k & 3) + (k < 4 ? 7 : 3));
-                    c_over &= keep;
-                    c_under &= keep;
+                    for (int k = 0; k < 16; k++)
+                        if (k >= first && k < past) keep |= (front_mask_bit(k & 7, false) | front_mask_bit(k & 7, true)) << (16 * (k >> 3));
+                    cand &= keep;
                 }
             }
-            uint32_t cand = c_over | c_under;
             if (cand) {
-                uint32_t qs = lds_add_rtn(qa_count, (uint32_t)__builtin_popcount(cand));
-                while (cand) {
-                    const int p = __builtin_ctz(cand);
-                    cand &= cand - 1u;
-                    const int k = (p >> 3) | ((p & 4) ^ 4);
-                    if (qs < (uint32_t)kIQueueA)
-                        queue_a[qs] = (uint16_t)((((c_over >> p) & 1u) << 15) | (((c_under >> p) & 1u) << 14) |
-                                                 ((uint32_t)r << 9) | (uint32_t)(kIPad + xl + k));
-                    else
-                        *overflow = 1u;
-                    qs++;
+                const uint32_t n_cand = (uint32_t)__builtin_popcount(cand);
+                uint32_t qs = lds_add_rtn(qa_count, n_cand);
+                const uint32_t base = ((uint32_t)r << 10) | ((uint32_t)j << 5);
+                if (qs + n_cand <= (uint32_t)kIQueueA) {
+                    while (cand) {
+                        const uint32_t pbit = (uint32_t)__builtin_ctz(cand);
+                        cand &= cand - 1u;
+                        queue_a[qs++] = (uint16_t)(base | pbit);
+                    }
+                } else {
+                    *overflow = 1u;
                 }
             }
         }
@@ -522,12 +536,19 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     __syncthreads();
 
     auto locate = [&](uint32_t e, int* x, int* gy) -> const half_t* {
-        const int r = (int)((e >> 9) & 31u), col = (int)(e & 511u);
-        *x = cx0 + col - kIPad;
+        const int r = (int)((e >> 10) & 31u), j = (int)((e >> 5) & 31u);
+        const int k16 = (int)(((e & 3u) << 1) | ((e >> 3) & 1u) | ((e >> 1) & 8u));  // pixel of the item: front_mask_bit in [3:0], the half in [4]
+        const int xl = 16 * j - 8 + k16;
+        *x = cx0 + xl;
         *gy = y0 - 1 + r;
-        return grey + __mul24(r + 3, LS) + col;
+        return grey + __mul24(r + 3, LS) + kIPad + xl;
     };
+    auto is_over = [](uint32_t e) { return (e & 4u) == 0u; };  // polarity of the pre-test that passed
     // =========================== S1: even-ring filter, A -> B ===========================
+    // every second ring point: a run of `arc` ring positions contains arc / 2 consecutive ones of these eight (one polarity per
+    // entry: one exact v_fma_mix_f32 difference and one compare per point.  The packed 16-bit form of the literal kernel's
+    // 16-point test -- even_ring_mask_polar -- was measured here and is slower on eight points: finding the exact f16 threshold
+    // of the pixel costs as much as half of them: 0.144 against 0.120 ms per batch)
     if (geo.phase_mask & 2u) {
         const uint32_t need_even = arc >> 1;
         const uint32_t n_a = min(*qa_count, (uint32_t)kIQueueA);
@@ -535,7 +556,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
             const uint32_t e = queue_a[i];
             int x, gy;
             const half_t* ctr = locate(e, &x, &gy);
-            if (even_ring_filter(ctr, LS, thr, need_even, (e & 0x8000u) != 0u, (e & 0x4000u) != 0u)) {
+            if (even_ring_filter(ctr, LS, thr, need_even, is_over(e), !is_over(e))) {
                 const uint32_t qs = atomicAdd(qb_count, 1u);
                 if (qs < (uint32_t)kIQueueB)
                     queue_b[qs] = (uint16_t)e;
@@ -552,7 +573,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
             const uint32_t e = queue_b[i];
             int x, gy;
             const half_t* ctr = locate(e, &x, &gy);
-            if (ring_has_arc(ctr, LS, thr, arc, (e & 0x8000u) != 0u, (e & 0x4000u) != 0u)) {
+            if (has_run_16(ring_mask_polar(ctr, LS, thr, is_over(e)), arc)) {
                 const uint32_t qs = atomicAdd(qc_count, 1u);
                 if (qs < (uint32_t)kIQueueC)
                     queue_c[qs] = (uint16_t)e;
@@ -572,9 +593,12 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
             float s;
             uint32_t ang;
             ring_score_angle(ctr, LS, thr, arc, lit, &s, &ang);
-            list_pos[i] = (uint16_t)(e & 0x3fffu);
+            const uint32_t row = (uint32_t)(gy - (y0 - 1));
+            list_pos[i] = (uint16_t)((row << 9) | (uint32_t)(x - cx0 + kIPad));  // region row, LDS column
             list_ang[i] = (uint16_t)ang;
             list_score[i] = s;
+            // the corner's place among the corners of its region row (S4 sorts by row): queue B is drained by now
+            if (geo.nms) reinterpret_cast<uint16_t*>(queue_b)[i] = (uint16_t)atomicAdd(&nms_row_cnt[min(row, (uint32_t)(kINmsRows - 1))], 1u);
         }
         if (tid == 0) *list_count = n_c;
     }
@@ -586,25 +610,25 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
             // The corners sorted by region row (a counting sort in the storage of queues B and C, both drained by now): a corner
             // then meets only the corners of its own and the two neighbouring rows -- about ten of them where all n * n ordered
             // pairs spread over the workgroup were 3 600 tests per tile (n ~ 60), a tenth of the kernel's instructions.
-            constexpr int kRows = 20;  // region rows 0 .. R + 1 (the tile's rows and its 1-px apron)
-            uint32_t* const row_cnt = reinterpret_cast<uint32_t*>(queue_b);  // [kRows]
-            uint32_t* const row_start = row_cnt + kRows;                     // [kRows + 1]
-            uint16_t* const sorted = reinterpret_cast<uint16_t*>(row_start + kRows + 1);  // [kIList] corner indices, row by row
-            uint16_t* const slot_of = queue_c;                                // [kIList]
-            static_assert((2 * kRows + 1) * 4 + kIList * 2 <= kIQueueB * 2 && kIList <= kIQueueC, "NMS scratch does not fit queues B and C");
-            if (tid < kRows) row_cnt[tid] = 0u;
-            __syncthreads();
-            for (uint32_t i = (uint32_t)tid; i < n; i += NT) slot_of[i] = (uint16_t)atomicAdd(&row_cnt[min((uint32_t)list_pos[i] >> 9, (uint32_t)(kRows - 1))], 1u);
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t acc = 0;
-                for (int r = 0; r < kRows; r++) {
-                    row_start[r] = acc;
-                    acc += row_cnt[r];
+            constexpr int kRows = kINmsRows;
+            // Storage: slot_of (written by S3) at the head of queue B, the sorted indices in queue C, row_start behind the row counters.  Every wave
+            // derives the row prefix itself (lanes 0..kRows-1, a wave-wide scan) and writes the same values: no barrier for it.
+            const uint16_t* const slot_of = reinterpret_cast<const uint16_t*>(queue_b);         // [kIList]
+            uint32_t* const row_start = nms_row_cnt + kRows;                                    // [kRows + 1]
+            uint16_t* const sorted = queue_c;                                                   // [kIList] corner indices, row by row
+            static_assert(kIList <= kIQueueB && kIList <= kIQueueC, "NMS scratch does not fit queues B and C");
+            {
+                const uint32_t lane = (uint32_t)tid & 63u;
+                const uint32_t cnt = lane < (uint32_t)kRows ? nms_row_cnt[lane] : 0u;
+                uint32_t incl = cnt;
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+                    if ((int)lane >= d) incl += t;
                 }
-                row_start[kRows] = acc;
+                if (lane < (uint32_t)kRows) row_start[lane] = incl - cnt;
+                if (lane == (uint32_t)kRows - 1u) row_start[kRows] = incl;
             }
-            __syncthreads();
             for (uint32_t i = (uint32_t)tid; i < n; i += NT) sorted[row_start[min((uint32_t)list_pos[i] >> 9, (uint32_t)(kRows - 1))] + slot_of[i]] = (uint16_t)i;
             __syncthreads();
             for (uint32_t i = (uint32_t)tid; i < n; i += NT) {
