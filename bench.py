@@ -256,6 +256,8 @@ def run_node(args):
     frame_bytes = W * H * (1 if args.input == "y8" else 4)
     F = B * world
     with orb.OrbNode(cfg, devices) as node:
+        if args.collate == "none":  # results stay packed on the device that computed them (orb_node_set_results)
+            node.set_results(True)
         progs = [node.program(r) for r in range(world)]
         ptrs = [progs[r].synth_frames_device(B, SEED0 + r * B, syn_flags) for r in range(world)]
         last = {}
@@ -309,8 +311,10 @@ def run_node(args):
                        "input": args.input, "pipeline": "staged" if args.staged else "default",
                        "host": "node: one process, orb_node_* C ABI, no torch.distributed"
                                + (" (TINYORB_NODE_LOOPBACK: %d ranks on device 0, device copies instead of RCCL)" % world if loop else ""),
-                       "collate": "every job packed and collated on the first device (exact-size transport records), "
-                                  "overlapped with the next job's kernels"},
+                       "collate": ("none: every job's records packed on the device that computed them (orb_node_set_results)"
+                                   if args.collate == "none" else
+                                   "every job packed and collated on the first device (exact-size transport records), "
+                                   "overlapped with the next job's kernels")},
             "repeats_ms_per_step": [r / args.steps * 1e3 for r in repeats],
             "min_ms_per_step": min(repeats) / args.steps * 1e3, "max_ms_per_step": max(repeats) / args.steps * 1e3,
             "mkeypoints_per_s": kp_per_step * args.steps / elapsed / 1e6,

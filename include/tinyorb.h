@@ -288,7 +288,21 @@ int orb_node_pending(const OrbNode *node);
  * the node out of service: every later extract / collate returns ORB_ESTATE -- destroy it and create a new one. */
 const char *orb_node_exchange_backend(const OrbNode *node);
 uint64_t orb_node_rccl_pairs(const OrbNode *node);
-/* Copies the records of the job ended last to the host; capacity in records. */
+/* Where a job's results end up.  ORB_NODE_RESULTS_ROOT (default): collated on the first device, as described above.
+ * ORB_NODE_RESULTS_SHARDED: nothing is exchanged -- every rank packs the stored records of its shard back to back, in frame
+ * order, into buffers on ITS OWN device (for a consumer that runs where the frames were extracted, e.g. a matcher per GPU:
+ * with eight GPUs the collate into one device runs at the rate of its links, the kernels do not).  The three stages and their
+ * overlap stay; orb_node_collate_end fills counts[] and offsets[] as before (offsets[] keep counting across ranks: rank r's
+ * records are offsets[first frame of r] .. and lie at the start of its own buffer) and returns NULL record pointers;
+ * orb_node_shard_result hands out rank r's buffers of the job ended last (valid while the next two jobs are extracted).
+ * May only be changed while no job is outstanding. */
+#define ORB_NODE_RESULTS_ROOT 0
+#define ORB_NODE_RESULTS_SHARDED 1
+int orb_node_set_results(OrbNode *node, int where);
+int orb_node_shard_result(OrbNode *node, int rank, uint32_t *n_frames, uint64_t *n_records, void **corners_dev,
+                          void **descriptors_dev);
+/* Copies the records of the job ended last to the host (sharded results: rank by rank, i.e. still in frame order); capacity in
+ * records. */
 int orb_node_read_collated(OrbNode *node, CornerData *corners, CornerDescriptor *descriptors, size_t capacity);
 
 /* ---- descriptor matching (the SLAM stage that consumes this path's output; NOT in the

@@ -201,6 +201,9 @@ pub mod orb {
         fn orb_node_collate_end(node: *mut c_void, counts: *mut u32, offsets: *mut u64, corners_dev: *mut *mut c_void,
                                 descriptors_dev: *mut *mut c_void) -> c_int;
         fn orb_node_pending(node: *const c_void) -> c_int;
+        fn orb_node_set_results(node: *mut c_void, where_: c_int) -> c_int;
+        fn orb_node_shard_result(node: *mut c_void, rank: c_int, n_frames: *mut u32, n_records: *mut u64, corners_dev: *mut *mut c_void,
+                                 descriptors_dev: *mut *mut c_void) -> c_int;
         fn orb_node_exchange_backend(node: *const c_void) -> *const c_char;
         fn orb_node_rccl_pairs(node: *const c_void) -> u64;
         fn orb_node_read_collated(node: *mut c_void, corners: *mut CornerData, descriptors: *mut CornerDescriptor,
@@ -296,6 +299,22 @@ pub mod orb {
 
         pub fn pending(&self) -> usize {
             unsafe { orb_node_pending(self.handle) as usize }
+        }
+
+        /// Results collated on the first device (`false`, the default) or left packed on the device that computed them
+        /// (`true`: no exchange; `shard_result(rank)` hands out that rank's device buffers).  Only with no job outstanding.
+        pub fn set_results_sharded(&self, sharded: bool) {
+            let rc = unsafe { orb_node_set_results(self.handle, if sharded { 1 } else { 0 }) };
+            assert!(rc == 0, "tinyorb: orb_node_set_results failed");
+        }
+
+        /// (frames, records, device address of the corners, of the descriptors) of `rank` for the job ended last.
+        pub fn shard_result(&self, rank: i32) -> (u32, u64, *mut c_void, *mut c_void) {
+            let (mut nf, mut nr) = (0u32, 0u64);
+            let (mut c, mut d) = (std::ptr::null_mut(), std::ptr::null_mut());
+            let rc = unsafe { orb_node_shard_result(self.handle, rank, &mut nf, &mut nr, &mut c, &mut d) };
+            assert!(rc == 0, "tinyorb: orb_node_shard_result failed");
+            (nf, nr, c, d)
         }
 
         /// How the records of ranks >= 1 reach the first device: "rccl", "rccl-self", "copies" or "none".

@@ -249,3 +249,52 @@ def test_pinned_write_runs_one_image_ahead(tinyorb, oracle):
         _assert_frame_equal(oracle, refs[3], *result(prog))  # then the overwritten slot: frame 3
     for pn in pins:
         pn.close()
+
+
+def test_node_sharded_results_stay_on_their_devices(tinyorb, oracle, monkeypatch):
+    """orb_node_set_results(SHARDED): no exchange -- every rank packs its own records on its own device.  Three loopback ranks,
+    jobs streamed with two outstanding; rank by rank the records equal the oracle's, offsets keep counting across ranks,
+    switching back to the collated form gives the same bytes in one array, and changing the mode with a job outstanding is
+    refused."""
+    monkeypatch.setenv("TINYORB_NODE_LOOPBACK", "1")
+    W, H, CAP, B, RANKS = 320, 240, 2048, 4, 3
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=CAP, hierarchy_depth=2, initial_threshold=THR, max_batch=B)
+    sizes = [11, 5, 12]
+    jobs = [np.stack([oracle.synth_frame(W, H, 7000 + 20 * j + i) for i in range(n)]) for j, n in enumerate(sizes)]
+    with tinyorb.OrbNode(cfg, [0] * RANKS) as node:
+        node.set_results(True)
+        assert node.exchange_backend() == "copies"  # what an exchange WOULD use; none happens
+        p0 = node.program(0)
+        for k, frames in enumerate(jobs):
+            node.extract_batch_host(frames)
+            if k == 0:
+                with pytest.raises(tinyorb.OrbError):
+                    node.set_results(False)  # a job is outstanding
+            counts, offsets, c_ptr, d_ptr = node.collate(sizes[k])
+            assert c_ptr is None and d_ptr is None
+            frame = 0
+            for r in range(RANKS):
+                lo, hi = node.shard(sizes[k], r)
+                nf, nr, c_r, d_r = node.shard_result(r)
+                assert nf == hi - lo and nr == int(offsets[hi]) - int(offsets[lo])
+                kp = p0.copy_to_host(c_r, nr * 16).view(tinyorb.CORNER_DTYPE) if nr else np.zeros(0, tinyorb.CORNER_DTYPE)
+                ds = p0.copy_to_host(d_r, nr * 32).view(np.uint32).reshape(nr, 8) if nr else np.zeros((0, 8), np.uint32)
+                base = int(offsets[lo])
+                for f in range(lo, hi):
+                    ref = oracle.extract(frames[f], depth=2, threshold=THR, max_features=CAP)
+                    a, b = int(offsets[f]) - base, int(offsets[f + 1]) - base
+                    _assert_frame_equal(oracle, ref, int(counts[f]), kp[a:b], ds[a:b])
+                    frame += 1
+            assert frame == sizes[k]
+            all_kp, all_ds = node.read_collated(int(offsets[-1]))  # rank by rank = frame order
+        node.set_results(False)
+        node.extract_batch_host(jobs[-1])
+        counts2, offsets2, c_ptr, d_ptr = node.collate(sizes[-1])
+        assert c_ptr and np.array_equal(counts2, counts) and np.array_equal(offsets2, offsets)
+        kp2, ds2 = node.read_collated(int(offsets2[-1]))
+        # inside a frame the records of a band list are appended in the order the waves finish: compare frame by frame, sorted
+        for f in range(sizes[-1]):
+            a, b = int(offsets[f]), int(offsets[f + 1])
+            ca, da = _sorted(all_kp[a:b], all_ds[a:b])
+            cb, db = _sorted(kp2[a:b], ds2[a:b])
+            assert np.array_equal(ca, cb) and np.array_equal(da, db)

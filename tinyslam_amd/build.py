@@ -43,12 +43,14 @@ def _deps():
 
 
 def source_hash():
-    """SHA-256 over the kernel and host sources of libtinyorb (csrc/*, include/tinyorb.h), in name order: stamps measurements that
-    belong to one state of the kernels (profiles/traffic*.json; bench.py refuses a stamp that is not the tree's)."""
+    """SHA-256 over the sources that decide what the kernels do and how they are launched -- the kernel headers (csrc/*.h,
+    *.inc), orb_api.hip and the compiler flags -- in name order: stamps measurements that belong to one state of the kernels
+    (profiles/traffic*.json; bench.py refuses a stamp that is not the tree's).  The node layer (orb_node.hip) and the public
+    header hold no device code and are not part of it."""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc")))
-    files.append(os.path.join(os.path.dirname(PKG_DIR), "include", "tinyorb.h"))
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")) or f == "orb_api.hip")
+    h.update(" ".join(HIPCC_FLAGS).encode())
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())

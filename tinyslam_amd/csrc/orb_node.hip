@@ -29,6 +29,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -100,6 +101,12 @@ struct OrbNode {
     bool collated = false;                     // a job has been ended: read_collated has something to read
     uint64_t total_records = 0;
     int last_coll = 0;
+    // Sharded results (orb_node_set_results): nothing is exchanged, every rank packs its own records into buffers on ITS device
+    bool sharded = false;
+    std::vector<CornerData*> d_shard_c[kCollSlots];      // per rank [max_batch * cap]
+    std::vector<CornerDescriptor*> d_shard_d[kCollSlots];
+    std::vector<uint64_t> last_shard_records;            // of the job ended last, per rank
+    std::vector<uint32_t> last_shard_frames;
     std::string err;
 };
 
@@ -312,6 +319,10 @@ int begin_oldest(OrbNode* node) {
             break;
         }
     if (!job) return nfail(node, ORB_ESTATE, "collate_begin: no extracted job is waiting for its exchange");
+    if (node->sharded) {  // nothing to exchange: the job is complete when its packs are
+        job->exchanging = true;
+        return ORB_OK;
+    }
     if (int rc = ensure_comms(node)) return rc;  // nothing enqueued yet: the job stays, the caller may retry
     // the only host wait of the pipeline: the counters of THIS job (its kernels + pack; the next job is already queued)
     for (int r = 0; r < node->n; r++) {
@@ -376,6 +387,12 @@ void orb_node_destroy(OrbNode* node) {
         if (r < (int)node->xchg_streams.size() && node->xchg_streams[r]) (void)hipStreamDestroy(node->xchg_streams[r]);
         if (r < (int)node->progs.size()) orb_program_destroy(node->progs[r]);
     }
+    for (int c = 0; c < kCollSlots; c++)
+        for (size_t r = 0; r < node->d_shard_c[c].size(); r++) {
+            if (r < node->devices.size()) (void)hipSetDevice(node->devices[r]);
+            (void)hipFree(node->d_shard_c[c][r]);
+            if (r < node->d_shard_d[c].size()) (void)hipFree(node->d_shard_d[c][r]);
+        }
     if (!node->devices.empty()) (void)hipSetDevice(node->devices[0]);
     for (int c = 0; c < kCollSlots; c++) {
         (void)hipFree(node->d_coll_c[c]);
@@ -511,7 +528,10 @@ static int enqueue_job(OrbNode* node, const uint8_t* const* frames_dev, const ui
         uint32_t* const dc = dev_ptr(node->h_counts[slot][r]);
         uint64_t* const dof = dev_ptr(node->h_offsets[slot][r]);
         if (!dc || !dof) return nfail(node, ORB_EHIP, "pinned counters are not visible to device %d", node->devices[r]);
-        if (r < node->first_sender) {  // rank 0's own records go straight to the head of the collated arrays
+        if (node->sharded) {  // results stay where they were computed: every rank packs into its own buffers, nothing travels
+            NODE_ORB(node, prog, orb_batch_compact_device(prog, m, dc, dof, node->d_shard_c[job.coll][r], node->d_shard_d[job.coll][r],
+                                                          B * cap, ps));
+        } else if (r < node->first_sender) {  // rank 0's own records go straight to the head of the collated arrays
             NODE_ORB(node, prog, orb_batch_compact_device(prog, m, dc, dof, node->d_coll_c[job.coll], node->d_coll_d[job.coll],
                                                           B * cap, ps));
         } else {       // the others pack 40-byte transport records; the wire buffer was last read by the sends two jobs back
@@ -584,25 +604,40 @@ int orb_node_collate_end(OrbNode* node, uint32_t* counts, uint64_t* offsets, voi
     NodeJob& job = node->jobs.front();
     const int slot = job.slot;
     const size_t cap = node->cfg.max_features;
-    NODE_HIP(node, hipSetDevice(node->devices[0]));
-    if (job.shard_n[0]) NODE_HIP(node, hipEventSynchronize(node->ev_pack[slot][0]));  // rank 0's own records are in place
-    NODE_HIP(node, hipEventSynchronize(node->ev_xchg[slot][0]));                       // and everybody else's
+    if (node->sharded) {
+        for (int r = 0; r < node->n; r++) {
+            if (job.shard_n[r] == 0) continue;
+            NODE_HIP(node, hipSetDevice(node->devices[r]));
+            NODE_HIP(node, hipEventSynchronize(node->ev_pack[slot][r]));  // rank r's records are packed on its device
+        }
+    } else {
+        NODE_HIP(node, hipSetDevice(node->devices[0]));
+        if (job.shard_n[0]) NODE_HIP(node, hipEventSynchronize(node->ev_pack[slot][0]));  // rank 0's own records are in place
+        NODE_HIP(node, hipEventSynchronize(node->ev_xchg[slot][0]));                       // and everybody else's
+    }
     // frame-ordered counters and offsets for the caller
     uint64_t off = 0;
     uint32_t f_out = 0;
-    for (int r = 0; r < node->n; r++)
+    node->last_shard_records.assign(node->n, 0u);
+    node->last_shard_frames.assign(node->n, 0u);
+    for (int r = 0; r < node->n; r++) {
+        const uint64_t off_r = off;
         for (uint32_t f = 0; f < job.shard_n[r]; f++, f_out++) {
             const uint32_t raw = node->h_counts[slot][r][f];
             if (counts) counts[f_out] = raw;
             if (offsets) offsets[f_out] = off;
             off += raw < cap ? raw : cap;
         }
+        node->last_shard_records[r] = off - off_r;
+        node->last_shard_frames[r] = job.shard_n[r];
+    }
     if (offsets) offsets[f_out] = off;
     node->total_records = off;
     node->last_coll = job.coll;
     node->collated = true;
-    if (corners_dev) *corners_dev = node->d_coll_c[job.coll];
-    if (descriptors_dev) *descriptors_dev = node->d_coll_d[job.coll];
+    // sharded: there is no collated array -- the records of rank r lie on device r (orb_node_shard_result)
+    if (corners_dev) *corners_dev = node->sharded ? nullptr : (void*)node->d_coll_c[job.coll];
+    if (descriptors_dev) *descriptors_dev = node->sharded ? nullptr : (void*)node->d_coll_d[job.coll];
     node->jobs.pop_front();
     return ORB_OK;
 }
@@ -611,9 +646,56 @@ int orb_node_collate(OrbNode* node, uint32_t* counts, uint64_t* offsets, void** 
     return orb_node_collate_end(node, counts, offsets, corners_dev, descriptors_dev);  // begins the exchange if nobody has
 }
 
+int orb_node_set_results(OrbNode* node, int where) {
+    if (!node) return ORB_EINVAL;
+    if (int rc = check_alive(node)) return rc;
+    if (where != ORB_NODE_RESULTS_ROOT && where != ORB_NODE_RESULTS_SHARDED) return nfail(node, ORB_EINVAL, "results: ORB_NODE_RESULTS_ROOT or _SHARDED");
+    if (!node->jobs.empty()) return nfail(node, ORB_ESTATE, "set_results with %zu jobs outstanding", node->jobs.size());
+    if (where == ORB_NODE_RESULTS_SHARDED && node->d_shard_c[0].empty()) {
+        const size_t pack = (size_t)node->max_batch * node->cfg.max_features;
+        for (int c = 0; c < kCollSlots; c++) {
+            node->d_shard_c[c].assign(node->n, nullptr);
+            node->d_shard_d[c].assign(node->n, nullptr);
+        }
+        for (int c = 0; c < kCollSlots; c++)
+            for (int r = 0; r < node->n; r++) {
+                NODE_HIP(node, hipSetDevice(node->devices[r]));
+                NODE_HIP(node, hipMalloc(&node->d_shard_c[c][r], pack * sizeof(CornerData)));
+                NODE_HIP(node, hipMalloc(&node->d_shard_d[c][r], pack * sizeof(CornerDescriptor)));
+            }
+    }
+    node->sharded = where == ORB_NODE_RESULTS_SHARDED;
+    node->collated = false;
+    return ORB_OK;
+}
+
+int orb_node_shard_result(OrbNode* node, int rank, uint32_t* n_frames, uint64_t* n_records, void** corners_dev, void** descriptors_dev) {
+    if (!node || rank < 0 || rank >= node->n) return ORB_EINVAL;
+    if (!node->sharded) return nfail(node, ORB_ESTATE, "shard_result: the node collates on the first device (orb_node_set_results)");
+    if (!node->collated) return nfail(node, ORB_ESTATE, "shard_result before collate_end");
+    if (n_frames) *n_frames = node->last_shard_frames[rank];
+    if (n_records) *n_records = node->last_shard_records[rank];
+    if (corners_dev) *corners_dev = node->d_shard_c[node->last_coll][rank];
+    if (descriptors_dev) *descriptors_dev = node->d_shard_d[node->last_coll][rank];
+    return ORB_OK;
+}
+
 int orb_node_read_collated(OrbNode* node, CornerData* corners, CornerDescriptor* descriptors, size_t capacity) {
     if (!node) return ORB_EINVAL;
     if (!node->collated) return nfail(node, ORB_ESTATE, "read_collated before collate");
+    if (node->sharded) {  // convenience for tests and small jobs: rank by rank, in frame order
+        size_t at = 0;
+        for (int r = 0; r < node->n && at < capacity; r++) {
+            const size_t m = std::min<size_t>((size_t)node->last_shard_records[r], capacity - at);
+            if (m == 0) continue;
+            NODE_HIP(node, hipSetDevice(node->devices[r]));
+            if (corners) NODE_HIP(node, hipMemcpy(corners + at, node->d_shard_c[node->last_coll][r], m * sizeof(CornerData), hipMemcpyDeviceToHost));
+            if (descriptors)
+                NODE_HIP(node, hipMemcpy(descriptors + at, node->d_shard_d[node->last_coll][r], m * sizeof(CornerDescriptor), hipMemcpyDeviceToHost));
+            at += m;
+        }
+        return ORB_OK;
+    }
     const size_t m = node->total_records < capacity ? (size_t)node->total_records : capacity;
     NODE_HIP(node, hipSetDevice(node->devices[0]));
     if (corners && m) NODE_HIP(node, hipMemcpy(corners, node->d_coll_c[node->last_coll], m * sizeof(CornerData), hipMemcpyDeviceToHost));

@@ -54,7 +54,7 @@ EXPORTS = [
     "orb_node_shard", "orb_node_extract_batch", "orb_node_extract_batch_host", "orb_node_collate",
     "orb_node_read_collated", "orb_node_collate_begin", "orb_node_collate_end", "orb_node_pending",
     "orb_extract_batch_pinned", "orb_upload_sync", "orb_node_exchange_backend", "orb_node_rccl_pairs",
-    "orb_write_input_image_pinned",
+    "orb_write_input_image_pinned", "orb_node_set_results", "orb_node_shard_result",
 ]
 
 
@@ -187,6 +187,8 @@ def load_library(path=None):
     L.orb_node_collate_begin.argtypes = [vp]
     L.orb_node_collate_end.argtypes = [vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.orb_node_pending.argtypes = [vp]
+    L.orb_node_set_results.argtypes = [vp, ctypes.c_int]
+    L.orb_node_shard_result.argtypes = [vp, ctypes.c_int, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.orb_node_exchange_backend.argtypes = [vp]
     L.orb_node_exchange_backend.restype = ctypes.c_char_p
     L.orb_node_rccl_pairs.argtypes = [vp]
@@ -639,6 +641,16 @@ class OrbNode:
 
     def pending(self):
         return self._lib.orb_node_pending(self._h)
+
+    def set_results(self, sharded):
+        """Results collated on the first device (False, the default) or left packed on the device that computed them (True)."""
+        self._check(self._lib.orb_node_set_results(self._h, 1 if sharded else 0))
+
+    def shard_result(self, rank):
+        """Sharded results: (frames, records, device addresses of rank's packed corners / descriptors) of the job ended last."""
+        nf, nr, c, d = ctypes.c_uint32(), ctypes.c_uint64(), ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self._lib.orb_node_shard_result(self._h, rank, ctypes.byref(nf), ctypes.byref(nr), ctypes.byref(c), ctypes.byref(d)))
+        return nf.value, nr.value, c.value, d.value
 
     def exchange_backend(self):
         """'rccl', 'rccl-self' (TINYORB_NODE_LOOPBACK=2), 'copies' (TINYORB_NODE_LOOPBACK=1) or 'none' (one device)."""
