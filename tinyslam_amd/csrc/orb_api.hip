@@ -139,6 +139,7 @@ struct OrbProgram {
     BriefTGeom brieft{};       // thread-per-keypoint BRIEF of the fused literal pipelines (plain and arc/NMS)
     bool use_brief_t = false;
     uint32_t band_rows_lvl[kMaxLevels] = {0};  // band height of the plain fused path per level: kFrontRows or kFrontRowsWide (chosen at create)
+    uint32_t ln_threads[kMaxLevels] = {0};     // levels >= 1: threads of a band's workgroup, kFrontThreadsLN or kFrontThreadsLNBig (chosen at create)
     uint32_t tile_w_lvl[kMaxLevels] = {0};     // 0: full-width bands; else the level runs on column tiles of this width (k_front<..., TILED>)
     uint32_t seg_classes = 1;  // lists per band slot of the plain fused path: 2 with k_brief_t (angle code 0 / the rest)
     uint32_t* d_pattern = nullptr;
@@ -366,7 +367,7 @@ uint32_t front_bands(const Pyramid& pyr, uint32_t lvl, uint32_t band_rows) {
 
 // tile_w = 0: full-width bands; else column tiles of that width (rounded up to 8; FrontGeom::tiled)
 FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t gh, uint32_t n_frames,
-                         uint32_t band_rows = kFrontRows, uint32_t tile_w = 0) {
+                         uint32_t band_rows = kFrontRows, uint32_t tile_w = 0, uint32_t threads = 0) {
     FrontGeom g{};
     g.lvl = lvl;
     g.rows = band_rows;
@@ -406,8 +407,8 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
         g.tmp_halfs = std::max<uint32_t>(2u * kFrontTmpRows * g.ts, (uint32_t)(sizeof(BlurCol) / 2u) * g.n_var);
         g.tmp_halfs = (g.tmp_halfs + 7u) & ~7u;
     }
-    {   // pre-test items of a band (tile): rows x ceil(dispatch columns / 16) at level 0, / 8 above (orb_front_body.inc, B1)
-        const uint32_t cols_t = g.tiled ? std::min(g.tw, gw) : gw, iw = lvl == 0 ? 16u : 8u;
+    {   // pre-test items of a band (tile): rows x ceil(dispatch columns / 16) at level 0 and on 1024 threads, / 8 otherwise (orb_front_body.inc, B1)
+        const uint32_t cols_t = g.tiled ? std::min(g.tw, gw) : gw, iw = (lvl == 0 || threads == (uint32_t)kFrontThreadsLNBig) ? 16u : 8u;
         g.ovf_words = (band_rows * ((cols_t + iw - 1u) / iw) + 31u) / 32u;
     }
     g.n_classes = 1u;
@@ -522,7 +523,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
             dim3 grid((pyr.w[lvl] + 63u) / 64u, (pyr.h[lvl] + 4u * kMipRows - 1u) / (4u * kMipRows), n);
             hipLaunchKernelGGL(k_mip, grid, dim3(64, 4), 0, sm, d_gray, pyr, lvl, (float)pyr.w[lvl - 1] / (float)pyr.w[lvl], (float)pyr.h[lvl - 1] / (float)pyr.h[lvl], p->wq);
         }
-        FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n, p->band_rows_lvl[lvl], p->tile_w_lvl[lvl]);
+        FrontGeom g = front_geometry(pyr, lvl, gw ? gw : 8u, gh, n, p->band_rows_lvl[lvl], p->tile_w_lvl[lvl], p->ln_threads[lvl]);
         hipStream_t s_lvl = s;
         if (gw == 0) g.gh = 0;  // no FAST dispatch at this octave (orb.rs:511-515 with width 0)
         g.slot_base = p->bands.slot_base[lvl];
@@ -581,6 +582,15 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
                 FRONT_LAUNCH(true, false)
             }
 #undef FRONT_LAUNCH_UA
+        } else if (p->ln_threads[lvl] == (uint32_t)kFrontThreadsLNBig) {  // a level whose bands are large enough for level 0's shape (chosen at create)
+            LaunchScope ls(p, s_lvl, KID_FUSED_LN);
+            const dim3 block(kFrontThreadsLNBig);
+            switch (p->band_rows_lvl[lvl]) {
+                case 64: hipLaunchKernelGGL((k_front<false, false, 64, false, false, false, false, kFrontThreadsLNBig>), grid, block, lds, s_lvl, FRONT_ARGS); break;
+                case 32: hipLaunchKernelGGL((k_front<false, false, 32, false, false, false, false, kFrontThreadsLNBig>), grid, block, lds, s_lvl, FRONT_ARGS); break;
+                case 16: hipLaunchKernelGGL((k_front<false, false, 16, false, false, false, false, kFrontThreadsLNBig>), grid, block, lds, s_lvl, FRONT_ARGS); break;
+                default: hipLaunchKernelGGL((k_front<false, false, 8, false, false, false, false, kFrontThreadsLNBig>), grid, block, lds, s_lvl, FRONT_ARGS); break;
+            }
         } else {
             LaunchScope ls(p, s_lvl, KID_FUSED_LN);
             const dim3 block(kFrontThreadsLN);
@@ -980,17 +990,32 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                     // the tallest band of which two fit a CU; else the tallest that fits at all
                     uint32_t rows = 0, rows_lds = 0, fits = 0, fits_lds = 0, want = 0, want_lds = 0;
                     const uint32_t forced = force ? (uint32_t)atoi(force) : 0u;
-                    for (int cand : kFrontBandHeights) {
-                        if (std::max(w, gw) > (1u << front_x_bits(cand)) || std::max(w, gw) > (uint32_t)kFrontMaxWidthWide) continue;
-                        // levels >= 1 run on 512 threads: beyond about 16 k pixels a band only gets longer (measured at
-                        // 640 wide: 32 rows 4 % slower than 16; at 480 wide: 32 rows 16 % faster than 16)
-                        if (lvl > 0 && (uint32_t)cand * gw > 16384u && cand > kFrontRowsWide) continue;
-                        const uint32_t lds = front_lds_bytes(front_geometry(p->pyr, lvl, gw, gh, 1, (uint32_t)cand));
-                        if (lds > p->max_lds) continue;
-                        if (forced == (uint32_t)cand) want = (uint32_t)cand, want_lds = lds;
-                        if (!fits) fits = (uint32_t)cand, fits_lds = lds;
-                        if (!rows && 2u * lds <= p->max_lds) rows = (uint32_t)cand, rows_lds = lds;
+                    auto pick = [&](uint32_t threads) {
+                        rows = rows_lds = fits = fits_lds = want = want_lds = 0u;
+                        for (int cand : kFrontBandHeights) {
+                            if (std::max(w, gw) > (1u << front_x_bits(cand)) || std::max(w, gw) > (uint32_t)kFrontMaxWidthWide) continue;
+                            // levels >= 1: beyond about 32 pixels per thread a band only gets longer (at 512 threads: 640 wide, 32 rows
+                            // 4 % slower than 16; 480 wide, 32 rows 16 % faster than 16)
+                            if (lvl > 0 && (uint32_t)cand * gw > 32u * threads && cand > kFrontRowsWide) continue;
+                            const uint32_t lds = front_lds_bytes(front_geometry(p->pyr, lvl, gw, gh, 1, (uint32_t)cand, 0u, threads));
+                            if (lds > p->max_lds) continue;
+                            if (forced == (uint32_t)cand) want = (uint32_t)cand, want_lds = lds;
+                            if (!fits) fits = (uint32_t)cand, fits_lds = lds;
+                            if (!rows && 2u * lds <= p->max_lds) rows = (uint32_t)cand, rows_lds = lds;
+                        }
+                    };
+                    // Levels >= 1 take level 0's shape -- 1024 threads, sixteen-pixel pre-test items -- where a band of which two fit
+                    // a CU holds about as many pixels as level 0's at 1280 columns (18 k and more: 640 columns x 32 rows, 320 x 64,
+                    // 1280 x 16; measured at 720p, 640x480, 2560x1440: 5 ... 21 % off k_front<false>), and 512 threads otherwise
+                    // (480 columns: the tallest band that fits twice is 32 x 480 = 15 k pixels, 13 % slower on 1024 threads; 160
+                    // columns: 27 % slower).  Not for programs of one frame (flat bands), forced heights, tiles or an out-of-level
+                    // policy (those instances exist for 512 threads only).
+                    p->ln_threads[lvl] = (uint32_t)kFrontThreadsLN;
+                    if (lvl > 0 && p->max_batch > 1u && !forced && !getenv("TINYORB_TILE_W") && p->oob == kOobZero && !getenv("TINYORB_LN_512")) {
+                        pick((uint32_t)kFrontThreadsLNBig);
+                        if (rows != 0u && rows * gw >= 18432u) p->ln_threads[lvl] = (uint32_t)kFrontThreadsLNBig;
                     }
+                    if (p->ln_threads[lvl] != (uint32_t)kFrontThreadsLNBig) pick(lvl == 0 ? (uint32_t)kFrontThreadsL0 : (uint32_t)kFrontThreadsLN);
                     const bool two_per_cu = rows != 0u;
                     if (!rows) rows = fits, rows_lds = fits_lds;
                     // A program for one frame at a time (the reference's call shape) is after latency, not throughput: its 45 + 23
@@ -1075,6 +1100,9 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                     reinterpret_cast<const void*>(&k_front<true, true, R, false, true>), reinterpret_cast<const void*>(&k_front<true, false, R, true, true>), \
                     reinterpret_cast<const void*>(&k_front<true, true, R, true, true>)
                     FRONT_FN(64), FRONT_FN(32), FRONT_FN(16), FRONT_FN(8), FRONT_FN_TILED(16), FRONT_FN_TILED(8),
+#define FRONT_FN_BIG(R) reinterpret_cast<const void*>(&k_front<false, false, R, false, false, false, false, kFrontThreadsLNBig>)
+                    FRONT_FN_BIG(64), FRONT_FN_BIG(32), FRONT_FN_BIG(16), FRONT_FN_BIG(8),
+#undef FRONT_FN_BIG
 #define FRONT_FN_OOB(R, T) reinterpret_cast<const void*>(&k_front<false, false, R, false, T, false, true>)
                     FRONT_FN_OOB(64, false), FRONT_FN_OOB(32, false), FRONT_FN_OOB(16, false), FRONT_FN_OOB(8, false), FRONT_FN_OOB(16, true), FRONT_FN_OOB(8, true)
 #undef FRONT_FN_OOB

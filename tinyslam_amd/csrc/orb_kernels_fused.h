@@ -25,7 +25,10 @@
 namespace orb {
 
 constexpr int kFrontThreadsL0 = 1024;  // level 0: 16 waves per band, two bands per CU -> 8 waves/SIMD
-constexpr int kFrontThreadsLN = 512;
+constexpr int kFrontThreadsLN = 512;   // the levels above, by default; a level whose bands hold about 20 k pixels runs on kFrontThreadsLNBig threads
+constexpr int kFrontThreadsLNBig = 1024;  // with sixteen-pixel pre-test items -- level 0's shape (round 4: k_front<false> 0.0735 -> 0.0697 ms at
+                                          // 720p, 0.130 -> 0.102 for the 1280-wide level 1 of 2560x1440); narrow levels keep 512 threads (320x240: 0.051
+                                          // against 0.064 on 1024): the program decides per level when it is created (OrbProgram::ln_threads)
 constexpr int kFrontRows = 16;       // R: band height at 1280 columns (the bench shape); other widths: kFrontBandHeights, chosen per level at create
 constexpr int kFrontRowsWide = 8;    // the flattest band: 14 full-width rows of up to 4096 texels fit in LDS
 constexpr int kFrontTmpRows = 2;     // rows per blur chunk (double buffered)
@@ -336,13 +339,14 @@ __device__ __forceinline__ void front_body(const uint32_t block_id, const uint8_
 #include "orb_front_body.inc"
 }
 
-template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false, bool TILED = false, bool SRC = false, bool OOBK = false>
-__global__ __launch_bounds__(L0 ? kFrontThreadsL0 : kFrontThreadsLN, L0 ? 8 : 4) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
+// NTK: threads of the workgroup when not the level's default (levels >= 1: kFrontThreadsLNBig)
+template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false, bool TILED = false, bool SRC = false, bool OOBK = false, int NTK = 0>
+__global__ __launch_bounds__(NTK ? NTK : (L0 ? kFrontThreadsL0 : kFrontThreadsLN), (L0 || NTK == kFrontThreadsLNBig) ? 8 : 4) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                          uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                                          uint16_t* __restrict__ blur_rowc, Pyramid pyr,
                                                          FrontGeom geo, float thr, uint32_t* __restrict__ seg_counts,
                                                          CornerData* __restrict__ segments) {
-    constexpr int NTO = 0;
+    constexpr int NTO = NTK;
     const uint32_t block_id = blockIdx.x;
 #include "orb_front_body.inc"
 }
