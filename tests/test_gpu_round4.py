@@ -298,3 +298,31 @@ def test_node_sharded_results_stay_on_their_devices(tinyorb, oracle, monkeypatch
             ca, da = _sorted(all_kp[a:b], all_ds[a:b])
             cb, db = _sorted(kp2[a:b], ds2[a:b])
             assert np.array_equal(ca, cb) and np.array_equal(da, db)
+
+
+@pytest.mark.parametrize("W,H,depth", [(640, 480, 2), (640, 480, 4), (1280, 720, 3), (2560, 360, 3), (1241, 376, 3), (752, 480, 3), (1288, 200, 2),
+                                       (644, 300, 2), (1920, 264, 4)])
+def test_batch_programs_with_large_upper_level_bands(tinyorb, oracle, W, H, depth):
+    """A batch program runs a level >= 1 on 1024 threads with sixteen-pixel pre-test items where a band of which two fit a CU
+    holds 18 k pixels or more (k_front<false, ..., kFrontThreadsLNBig>; chosen per level at create): 64-row bands of 320 columns,
+    32 x 640, 16 x 1280 and the widths in between, deeper pyramids, a level that does not halve exactly.  Three frames per batch,
+    every frame against the oracle (planes of the levels >= 1 included); a dense frame exercises the detector's rounds there."""
+    B = 3
+    frames = np.stack([oracle.synth_frame(W, H, 8100 + i) for i in range(B)])
+    rng = np.random.default_rng(W + H)
+    frames[2, ..., :3] = ((rng.random((H, W, 1)) < 0.2) * 255).astype(np.uint8)  # salt and pepper: queues overflow
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), max_features=1 << 16, hierarchy_depth=depth, initial_threshold=THR, max_batch=B)
+    dims, _ = oracle.level_dims(W, H, depth)
+    with tinyorb.OrbProgram(cfg).init() as prog:
+        assert prog.pipeline() == "fused"
+        prog.extract_batch_host(frames)
+        counts = prog.batch_counts(B)
+        for i in range(B):
+            ref = oracle.extract(frames[i], depth=depth, threshold=THR, max_features=1 << 16, planes=True)
+            _assert_frame_equal(oracle, ref, int(counts[i]), *prog.batch_read(i, min(int(counts[i]), 1 << 16)))
+            for m, (w, h, off) in enumerate(dims):
+                if m > 0:
+                    g = prog.read_plane(tinyorb.ORB_PLANE_GRAY, m, frame=i)
+                    assert np.array_equal(g.ravel(), ref["gray"][off:off + w * h]), "gray level %d of frame %d" % (m, i)
+                b = prog.read_plane(tinyorb.ORB_PLANE_BLUR, m, frame=i)
+                assert np.array_equal(b.ravel(), ref["blur"][off:off + w * h]), "blur level %d of frame %d" % (m, i)

@@ -30,6 +30,8 @@ for case in range(n_cases):
     W = int(rng.integers(6, 120)) * 4 if rng.random() < 0.85 else int(rng.integers(25, 300))
     if rng.random() < 0.05:
         W = int(rng.integers(513, 600)) * 4  # 8-row bands
+    if rng.random() < 0.15:
+        W = int(rng.integers(160, 660)) * 4  # 640 .. 2636 columns: levels >= 1 whose bands hold 18 k pixels (1024-thread k_front<false>)
     H = int(rng.integers(24, 200)) if W <= 600 else int(rng.integers(24, 64))
     depth = int(rng.integers(1, 5))
     thr = float(np.float32(rng.choice([12, 20, 40]) / 255.0))
