@@ -225,8 +225,14 @@ pub mod orb {
     }
 
     impl OrbNode {
+        /// The constructor as it was before `flags` (round 2's signature): the reference's algorithm on RGBA frames.
+        pub fn with_defaults(devices: &[i32], config: &OrbConfig, max_batch: u32) -> Self {
+            Self::new(devices, config, max_batch, 0)
+        }
+
         /// `max_batch` = the largest shard one device may get (frames per job / devices, rounded up).
         /// `flags`: ORB_FLAG_* of include/tinyorb.h; with ORB_FLAG_INPUT_Y8 (16) frames are one byte per pixel.
+        /// (Round 3 added `flags`: callers of the three-argument form use `with_defaults`.)
         pub fn new(devices: &[i32], config: &OrbConfig, max_batch: u32, flags: u32) -> Self {
             let c = OrbConfigC {
                 image_size: Extent3dC {
