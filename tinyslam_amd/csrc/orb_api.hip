@@ -1083,10 +1083,12 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 for (uint32_t lvl = 0; lvl <= p->pyr.depth; lvl++) rg.slot_base[lvl] = bg.slot_base[lvl];
                 for (uint32_t lvl = 0; lvl < p->pyr.depth; lvl++) {
                     // columns [0, qa) of the level's blur are kept as one constant per row (k_front, phase C)
-                    const uint32_t qa = front_geometry(p->pyr, lvl, 8, 8, 1).blur_q & ~7u;
+                    const uint32_t q = front_geometry(p->pyr, lvl, 8, 8, 1).blur_q, qa = q & ~7u;
                     p->blur_qa[lvl] = qa;
                     rg.qa[lvl] = qa;
-                    rg.flat_end[lvl] = qa > (uint32_t)kBriefHalo ? qa - kBriefHalo : 0u;
+                    // a keypoint is "flat" when every sample column lies below Q, not only below qa: the stored columns [qa, Q) hold
+                    // the row constant too
+                    rg.flat_end[lvl] = q > (uint32_t)kBriefHalo ? q - kBriefHalo : 0u;
                 }
                 // The attribute belongs to the function on this device, not to the program: always raise it to the
                 // device's limit, so that a later, smaller program never lowers it under a live, larger one.
@@ -1184,7 +1186,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
             const uint32_t qa = fg.blur_q & ~7u;
             p->blur_qa[lvl] = qa;
             rg.qa[lvl] = qa;
-            rg.flat_end[lvl] = qa > (uint32_t)kBriefHalo ? qa - kBriefHalo : 0u;
+            rg.flat_end[lvl] = fg.blur_q > (uint32_t)kBriefHalo ? fg.blur_q - kBriefHalo : 0u;
         }
         bg.slot_base[p->pyr.depth] = slots;
         rg.slot_base[p->pyr.depth] = slots;

@@ -27,7 +27,7 @@ constexpr uint32_t kBriefTMaxRows = 12288;  // rows (all levels) + 36 per level,
 struct BriefTGeom {
     uint32_t n_slots, seg_cap;
     uint32_t n_classes;             // lists per band slot (FrontGeom::n_classes): 2 = angle code 0 / the rest
-    uint32_t flat_end[kMaxLevels];  // qa - 18
+    uint32_t flat_end[kMaxLevels];  // Q - 18 (Q = FrontGeom::blur_q: every column below it holds the row constant)
     uint32_t qa[kMaxLevels];
     uint32_t row_base[kMaxLevels];  // index of row 0 of the level in the padded LDS row array
     uint32_t rows_padded;           // entries of that array

@@ -390,7 +390,7 @@ constexpr int kBriefHalo = 18;  // |trunc(R(-theta) p)| <= 18 for every pattern 
 struct RowsGeom {
     uint32_t n_slots, seg_cap;
     uint32_t slot_base[kMaxLevels + 1];
-    uint32_t flat_end[kMaxLevels];  // qa - 18: a keypoint with 18 <= x < flat_end samples only columns in [0, qa)
+    uint32_t flat_end[kMaxLevels];  // Q - 18: a keypoint with 18 <= x < flat_end samples only columns in [0, Q), which all hold the row constant
     uint32_t qa[kMaxLevels];        // columns [0, qa) of the level's blur are the row constants
     uint32_t split;                 // workgroups per band slot (> 1 for small batches: more waves in flight)
     uint32_t oob;                   // OrbOptions::oob_policy for samples that leave the level (brief.wgsl:59-60)
