@@ -70,6 +70,8 @@ def lib():
         L.orc_blur_pass.argtypes = [vp, u32, u32, vp]
         L.orc_fast.argtypes = [vp, ctypes.POINTER(_Pyramid), f32, vp, u32, u32p]
         L.orc_brief.argtypes = [vp, ctypes.POINTER(_Pyramid), vp, u32, vp]
+        L.orc_brief_impl.argtypes = [vp, ctypes.POINTER(_Pyramid), vp, u32, u32, vp]
+        L.orc_brief_impl.restype = None
         L.orc_extract.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, u32p, vp, vp]
         L.orc_extract_y8.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, u32p, vp, vp]
         L.orc_extract.restype = ctypes.c_int
@@ -201,6 +203,23 @@ def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=Fal
         raise ValueError("orc_extract_impl: invalid arguments")
     n = min(total.value, max_features)
     return dict(total=total.value, corners=corners[:n], descriptors=desc[:n], gray=gray, blur=blur)
+
+
+def brief(blur_pyr, W, H, depth, corners, oob="zero"):
+    """Descriptors (n, 8) u32 of the given keypoints (CORNER_DTYPE: x, y, angle, octave) over a blur pyramid as `extract(...,
+    planes=True)["blur"]` returns it (orc_brief_impl: brief.wgsl:20-68 under an out-of-level policy).  tools/pin_oracle.py uses
+    it to ask what the restatement's descriptor is at an angle code somebody else computed."""
+    corners = np.ascontiguousarray(corners, dtype=CORNER_DTYPE)
+    blur_pyr = np.ascontiguousarray(blur_pyr, dtype=np.uint16)
+    lay, ntex = level_dims(W, H, depth)
+    assert blur_pyr.size == ntex
+    p = _Pyramid()
+    lib().orc_pyramid_layout(W, H, depth, ctypes.byref(p))
+    out = np.zeros((len(corners), 8), dtype=np.uint32)
+    if len(corners):
+        lib().orc_brief_impl(_ptr(blur_pyr), ctypes.byref(p), _ptr(corners), len(corners),
+                             OOB_POLICIES[oob] if isinstance(oob, str) else int(oob), _ptr(out))
+    return out
 
 
 def grayscale_y8(y8):

@@ -571,3 +571,39 @@ def test_pin_tool_names_the_setting_of_a_fabricated_dump(oracle, tmp_path):
     _, results, exact = pin_oracle.check(str(tmp_path))
     assert ("umin", 8) in exact and ("zero", 0) not in exact and ("zero", 8) not in exact and ("umin", 0) not in exact
     assert results[("zero", 0)]["descriptor_bits"] > 0
+
+
+def test_pin_tool_tells_an_atan2_difference_from_a_real_one(oracle, tmp_path):
+    """A dump fabricated from the restatement in which forty angle codes are one milliradian off and their descriptors are
+    the restatement's AT THOSE angles -- an adapter whose atan2 rounds the other way (CRD-9) -- is reported as pinned up to
+    atan2 under the right switches only; the same dump with one descriptor bit flipped at an agreeing angle is not."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pin_oracle
+    t, c, d, blur = pin_oracle.oracle_result("zero", 0, 2, 15, planes=True)
+    c, d = c.copy(), d.copy()
+    rng = np.random.default_rng(5)
+    pick = rng.choice(np.flatnonzero((c[:, 2] > 1) & (c[:, 2] < 3140)), size=40, replace=False)
+    c[pick, 2] += rng.choice(np.array([-1, 1]), size=40).astype(np.int64).astype(np.uint32)
+    d[pick] = pin_oracle.descriptors_at(blur, c[pick], "zero")
+    assert np.any(d[pick] != pin_oracle.oracle_result("zero", 0, 2, 15)[2][pick])  # the angle does move descriptor bits
+
+    def write(cc, dd):
+        np.save(tmp_path / "total.npy", np.uint32(t))
+        np.save(tmp_path / "corners.npy", cc)
+        np.save(tmp_path / "descriptors.npy", dd)
+        np.save(tmp_path / "params.npy", np.array([640, 480, 2, 2, 15, 8192], dtype=np.uint32))
+
+    write(c, d)
+    _, results, exact = pin_oracle.check(str(tmp_path))
+    assert not exact
+    r = results[("zero", 0)]
+    assert r["exact_up_to_atan2"] and r["angle_off_by_1"] == 40 and r["descriptor_bits_at_the_dumped_angle"] == 0
+    assert not results[("umin", 8)]["exact_up_to_atan2"]
+    assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 3
+    d2 = d.copy()
+    other = np.setdiff1d(np.arange(len(c)), pick)[7]
+    d2[other, 3] ^= np.uint32(1 << 11)
+    write(c, d2)
+    _, results, _ = pin_oracle.check(str(tmp_path))
+    assert not results[("zero", 0)]["exact_up_to_atan2"] and results[("zero", 0)]["descriptor_bits_where_angles_agree"] == 1
+    assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 1
