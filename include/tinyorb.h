@@ -13,7 +13,8 @@
  *
  * Threading: calls on one OrbProgram must be serialised by the caller; distinct programs are
  * independent (one program = one device + its streams), like one wgpu Device/Queue per
- * OrbProgram in the reference (orb.rs:47-51).
+ * OrbProgram in the reference (orb.rs:47-51), and may be created, used and destroyed from
+ * different host threads at the same time (tests/test_gpu_round4.py::test_programs_on_different_threads).
  */
 #ifndef TINYORB_H
 #define TINYORB_H

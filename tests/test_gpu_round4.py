@@ -326,3 +326,69 @@ def test_batch_programs_with_large_upper_level_bands(tinyorb, oracle, W, H, dept
                     assert np.array_equal(g.ravel(), ref["gray"][off:off + w * h]), "gray level %d of frame %d" % (m, i)
                 b = prog.read_plane(tinyorb.ORB_PLANE_BLUR, m, frame=i)
                 assert np.array_equal(b.ravel(), ref["blur"][off:off + w * h]), "blur level %d of frame %d" % (m, i)
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY.md 8b, threading: "different handles may be used from different threads"
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.timeout(300)
+def test_programs_on_different_threads(tinyorb, oracle):
+    """Four host threads, each with a program of its own (different sizes, modes and entry points: the single-frame calls,
+    the pinned upload, a batch) created, used and destroyed concurrently -- ctypes releases the GIL inside every call, so the
+    library's calls really overlap.  Every result bit-equal to the oracle; no call fails."""
+    import threading
+    jobs = [  # (W, H, depth, flags, kind)
+        (640, 360, 2, 0, "single"),
+        (320, 240, 3, 0, "pinned"),
+        (512, 256, 2, 0, "batch"),
+        (636, 200, 2, tinyorb.ORB_FLAG_STAGED, "single"),
+    ]
+    N = 6
+    work = []
+    for j, (W, H, depth, flags, kind) in enumerate(jobs):
+        frames = [oracle.synth_frame(W, H, 1200 + 10 * j + i) for i in range(N)]
+        work.append((frames, [oracle.extract(f, depth=depth, threshold=THR) for f in frames]))
+    errors = []
+    start = threading.Barrier(len(jobs))
+
+    def run(j):
+        W, H, depth, flags, kind = jobs[j]
+        frames, refs = work[j]
+        try:
+            start.wait()
+            for _ in range(2):  # create / destroy also overlap
+                cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), hierarchy_depth=depth, initial_threshold=THR, flags=flags,
+                                        max_batch=N if kind == "batch" else 1)
+                with tinyorb.OrbProgram(cfg).init() as prog:
+                    if kind == "batch":
+                        for _ in range(3):
+                            prog.extract_batch_host(np.stack(frames))
+                            counts = prog.batch_counts(N)
+                            for i in range(N):
+                                c, d = prog.batch_read(i, min(int(counts[i]), 8192))
+                                _assert_frame_equal(oracle, refs[i], int(counts[i]), c, d)
+                        continue
+                    pin = tinyorb.PinnedArray((H, W, 4), np.uint8) if kind == "pinned" else None
+                    for i in range(N):
+                        if pin is not None:
+                            pin.array[:] = frames[i]
+                            prog.write_input_image_pinned(pin.array)
+                        else:
+                            prog.write_input_image(frames[i])
+                        total = prog.extract_corners()
+                        n = min(total, 8192)
+                        _assert_frame_equal(oracle, refs[i], total, prog.read_corners(np.zeros(n, dtype=tinyorb.CORNER_DTYPE)),
+                                            prog.read_descriptors(np.zeros((n, 8), dtype=np.uint32)))
+                        if pin is not None:
+                            prog.upload_sync()
+                    if pin is not None:
+                        pin.close()
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((j, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(j,)) for j in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
