@@ -150,17 +150,31 @@ void orc_pyramid_layout(uint32_t W, uint32_t H, uint32_t depth, orc_pyramid_t *p
  *   texcoord = position*0.5+0.5 maps framebuffer row 0 to v = 1: output row y samples input row
  *   H-1-y at its texel centre (bilinear weight exactly 1, CRD-1); luminance per CRD-2.
  * ---------------------------------------------------------------------------------------- */
-void orc_grayscale(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray) {
+void orc_grayscale(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray) { orc_grayscale_impl(rgba, W, H, gray, 0); }
+
+/* Implementation-defined point (CRD-13): WGSL lets a shader compiler contract a product and a sum into one fused
+ * multiply-add, and `dot()` (grayscale.wgsl:36) has no evaluation order of its own -- GPU compilers commonly lower it to one
+ * multiply and a chain of fmas.  contract == 0: every product and sum rounded on its own, left to right (CRD-2, the
+ * default).  contract == 1: the contracting compiler, in source order -- r*wr, then fma(g, wg, .), then fma(b, wb, .); the
+ * alpha term is a * 0.0 = +0 and changes nothing. */
+void orc_grayscale_impl(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray, uint32_t contract) {
     for (uint32_t y = 0; y < H; y++) {
         const uint8_t *src = rgba + (size_t)(H - 1 - y) * W * 4;
         for (uint32_t x = 0; x < W; x++) {
             float r = orc_unorm8(src[4 * x + 0]);
             float g = orc_unorm8(src[4 * x + 1]);
             float b = orc_unorm8(src[4 * x + 2]);
-            float pr = 0.229f * r; /* grayscale.wgsl:36: 0.229, not 0.299 */
-            float pg = 0.587f * g;
-            float pb = 0.114f * b;
-            float lum = (pr + pg) + pb;
+            float lum;
+            if (contract) {
+                float t = 0.229f * r; /* grayscale.wgsl:36: 0.229, not 0.299 */
+                t = fmaf(g, 0.587f, t);
+                lum = fmaf(b, 0.114f, t);
+            } else {
+                float pr = 0.229f * r;
+                float pg = 0.587f * g;
+                float pb = 0.114f * b;
+                lum = (pr + pg) + pb;
+            }
             gray[(size_t)y * W + x] = orc_f32_to_f16(lum);
         }
     }
@@ -242,8 +256,13 @@ static const float BLUR_WEIGHTS[4] = {0.13748623236806098f, 0.5037756553768409f,
                                       0.031251155234634016f};
 
 void orc_blur_pass(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst) { orc_blur_pass_impl(src, w, h, dst, 0); }
-
 void orc_blur_pass_impl(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, uint32_t wbits) {
+    orc_blur_pass_impl2(src, w, h, dst, wbits, 0);
+}
+
+/* contract (CRD-13): `result += textureSample(..) * weight` (gaussian_blur_x.wgsl:58) as one fma per tap.  The bilinear
+ * filter itself is the sampler's arithmetic, not the shader's: it keeps CRD-5 (and the weight precision switch). */
+void orc_blur_pass_impl2(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, uint32_t wbits, uint32_t contract) {
     float fw = (float)w;
     for (uint32_t y = 0; y < h; y++) {
         const uint16_t *row = src + (size_t)(h - 1 - y) * w; /* flipped v, sampled at the row centre */
@@ -260,8 +279,12 @@ void orc_blur_pass_impl(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *d
                 float t1 = orc_f16_to_f32(row[i1]);
                 float d = t1 - t0;
                 float s = t0 + f * d;
-                float ws = s * BLUR_WEIGHTS[i];
-                acc = acc + ws;
+                if (contract) {
+                    acc = fmaf(s, BLUR_WEIGHTS[i], acc);
+                } else {
+                    float ws = s * BLUR_WEIGHTS[i];
+                    acc = acc + ws;
+                }
             }
             dst[(size_t)y * w + x] = orc_f32_to_f16(acc);
         }
@@ -371,6 +394,13 @@ void orc_brief(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_cor
 
 void orc_brief_impl(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
                     uint32_t oob, orc_descriptor_t *out) {
+    orc_brief_impl2(blur_pyr, lay, corners, n, oob, 0, out);
+}
+
+/* contract (CRD-13): `rotation_matrix * p` (brief.wgsl:53-54) is p.x * column 0 + p.y * column 1; contracted, the second
+ * term is fused onto the first product: (fma(st, y, ct*x), fma(ct, y, -st*x)). */
+void orc_brief_impl2(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
+                     uint32_t oob, uint32_t contract, orc_descriptor_t *out) {
     for (uint32_t fidx = 0; fidx < n; fidx++) {
         const orc_corner_t *k = &corners[fidx];
         uint32_t oct = k->octave;
@@ -387,6 +417,10 @@ void orc_brief_impl(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const or
                 float a0 = ct * ax, a1 = st * ay, a2 = nst * ax, a3 = ct * ay;
                 float b0 = ct * bx, b1 = st * by, b2 = nst * bx, b3 = ct * by;
                 float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+                if (contract) {
+                    rax = fmaf(st, ay, a0), ray = fmaf(ct, ay, a2);
+                    rbx = fmaf(st, by, b0), rby = fmaf(ct, by, b2);
+                }
                 int64_t tax = (int64_t)(int32_t)rax + (int64_t)(int32_t)k->x; /* vec2i() truncates */
                 int64_t tay = (int64_t)(int32_t)ray + (int64_t)(int32_t)k->y;
                 int64_t tbx = (int64_t)(int32_t)rbx + (int64_t)(int32_t)k->x;
@@ -419,7 +453,7 @@ void orc_grayscale_y8(const uint8_t *y8, uint32_t W, uint32_t H, uint16_t *gray)
     }
 }
 
-static const orc_impl_t ORC_IMPL_DEFAULT = {ORC_OOB_ZERO, 0};
+static const orc_impl_t ORC_IMPL_DEFAULT = {ORC_OOB_ZERO, 0, 0};
 
 static int extract_impl(const uint8_t *frame, int y8, uint32_t W, uint32_t H, uint32_t depth, float threshold,
                         uint32_t max_features, const orc_impl_t *impl, orc_corner_t *corners, orc_descriptor_t *descriptors,
@@ -428,7 +462,7 @@ static int extract_impl(const uint8_t *frame, int y8, uint32_t W, uint32_t H, ui
 int orc_extract_impl(const uint8_t *frame, int y8, uint32_t W, uint32_t H, uint32_t depth, float threshold,
                      uint32_t max_features, const orc_impl_t *impl, orc_corner_t *corners, orc_descriptor_t *descriptors,
                      uint32_t *total, uint16_t *gray_pyr, uint16_t *blur_pyr) {
-    if (impl && (impl->oob > ORC_OOB_UMIN || impl->sampler_weight_bits > 23)) return -1;
+    if (impl && (impl->oob > ORC_OOB_UMIN || impl->sampler_weight_bits > 23 || impl->contract > 1)) return -1;
     return extract_impl(frame, y8, W, H, depth, threshold, max_features, impl ? impl : &ORC_IMPL_DEFAULT, corners, descriptors,
                         total, gray_pyr, blur_pyr);
 }
@@ -450,7 +484,7 @@ int orc_extract_y8(const uint8_t *y8, uint32_t W, uint32_t H, uint32_t depth, fl
 static int extract_impl(const uint8_t *rgba, int y8, uint32_t W, uint32_t H, uint32_t depth, float threshold,
                         uint32_t max_features, const orc_impl_t *impl, orc_corner_t *corners, orc_descriptor_t *descriptors,
                         uint32_t *total, uint16_t *gray_pyr, uint16_t *blur_pyr) {
-    const uint32_t wbits = impl->sampler_weight_bits, oob = impl->oob;
+    const uint32_t wbits = impl->sampler_weight_bits, oob = impl->oob, contract = impl->contract;
     if (!rgba || !W || !H || depth < 1 || depth > ORC_MAX_LEVELS || !total) return -1;
     orc_pyramid_t lay;
     orc_pyramid_layout(W, H, depth, &lay);
@@ -466,15 +500,15 @@ static int extract_impl(const uint8_t *rgba, int y8, uint32_t W, uint32_t H, uin
     if (y8)
         orc_grayscale_y8(rgba, W, H, gray);
     else
-        orc_grayscale(rgba, W, H, gray);
+        orc_grayscale_impl(rgba, W, H, gray, contract);
     for (uint32_t m = 1; m < depth; m++)
         orc_mip_impl(gray + lay.offset[m - 1], lay.w[m - 1], lay.h[m - 1], gray + lay.offset[m], lay.w[m], lay.h[m], wbits);
-    for (uint32_t m = 0; m < depth; m++) orc_blur_pass_impl(gray + lay.offset[m], lay.w[m], lay.h[m], tmp + lay.offset[m], wbits);
-    for (uint32_t m = 0; m < depth; m++) orc_blur_pass_impl(tmp + lay.offset[m], lay.w[m], lay.h[m], blur + lay.offset[m], wbits);
+    for (uint32_t m = 0; m < depth; m++) orc_blur_pass_impl2(gray + lay.offset[m], lay.w[m], lay.h[m], tmp + lay.offset[m], wbits, contract);
+    for (uint32_t m = 0; m < depth; m++) orc_blur_pass_impl2(tmp + lay.offset[m], lay.w[m], lay.h[m], blur + lay.offset[m], wbits, contract);
     uint32_t count = 0;
     orc_fast_impl(gray, &lay, threshold, oob, corners, max_features, &count);
     uint32_t stored = count < max_features ? count : max_features;
-    if (descriptors) orc_brief_impl(blur, &lay, corners, stored, oob, descriptors);
+    if (descriptors) orc_brief_impl2(blur, &lay, corners, stored, oob, contract, descriptors);
     *total = count;
     if (gray_pyr) memcpy(gray_pyr, gray, lay.total * sizeof(uint16_t));
     if (blur_pyr) memcpy(blur_pyr, blur, lay.total * sizeof(uint16_t));

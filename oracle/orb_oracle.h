@@ -89,6 +89,11 @@ int orc_extract(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, flo
  *   sampler_weight_bits   precision of a bilinear sampler's weights (gaussian_blur_x.wgsl:53-58; blit.wgsl:35 for odd
  *                         sizes): 0 = the exact binary32 fraction (CRD-5, the default), n = 1..23: the fraction rounded
  *                         to n fractional bits, halves up (8 is what GPUs commonly implement).
+ *   contract              CRD-13: 0 = every binary32 product and sum of the shaders rounded on its own (CRD-2, -5, -10; the
+ *                         default); 1 = a shader compiler that contracts a product and the sum that follows it into one fused
+ *                         multiply-add, in source order -- WGSL permits it, and GPU compilers commonly lower `dot()`
+ *                         (grayscale.wgsl:36), `result += sample * weight` (gaussian_blur_x.wgsl:58) and matrix * vector
+ *                         (brief.wgsl:53-54) to fma chains.
  * The defaults are what every other entry of this header computes. */
 #define ORC_OOB_ZERO 0u
 #define ORC_OOB_CLAMP 1u
@@ -96,7 +101,12 @@ int orc_extract(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, flo
 typedef struct {
     uint32_t oob;
     uint32_t sampler_weight_bits;
+    uint32_t contract;
 } orc_impl_t;
+void orc_grayscale_impl(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray, uint32_t contract);
+void orc_blur_pass_impl2(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, uint32_t wbits, uint32_t contract);
+void orc_brief_impl2(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
+                     uint32_t oob, uint32_t contract, orc_descriptor_t *out);
 void orc_mip_impl(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint32_t wd, uint32_t hd, uint32_t wbits);
 void orc_blur_pass_impl(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, uint32_t wbits);
 void orc_fast_impl(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, uint32_t oob, orc_corner_t *out,

@@ -70,8 +70,10 @@ def lib():
         L.orc_blur_pass.argtypes = [vp, u32, u32, vp]
         L.orc_fast.argtypes = [vp, ctypes.POINTER(_Pyramid), f32, vp, u32, u32p]
         L.orc_brief.argtypes = [vp, ctypes.POINTER(_Pyramid), vp, u32, vp]
-        L.orc_brief_impl.argtypes = [vp, ctypes.POINTER(_Pyramid), vp, u32, u32, vp]
-        L.orc_brief_impl.restype = None
+        L.orc_brief_impl2.argtypes = [vp, ctypes.POINTER(_Pyramid), vp, u32, u32, u32, vp]
+        L.orc_brief_impl2.restype = None
+        L.orc_grayscale_impl.argtypes = [vp, u32, u32, vp, u32]
+        L.orc_blur_pass_impl2.argtypes = [vp, u32, u32, vp, u32, u32]
         L.orc_extract.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, u32p, vp, vp]
         L.orc_extract_y8.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, u32p, vp, vp]
         L.orc_extract.restype = ctypes.c_int
@@ -180,13 +182,13 @@ def blur_pass(src, weight_bits=0):
 OOB_POLICIES = {"zero": 0, "clamp": 1, "umin": 2}
 
 
-def _impl(oob, weight_bits):
-    return (ctypes.c_uint32 * 2)(OOB_POLICIES[oob] if isinstance(oob, str) else int(oob), int(weight_bits))
+def _impl(oob, weight_bits, contract=0):
+    return (ctypes.c_uint32 * 3)(OOB_POLICIES[oob] if isinstance(oob, str) else int(oob), int(weight_bits), int(contract))
 
 
-def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=False, oob="zero", weight_bits=0, y8=False):
+def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=False, oob="zero", weight_bits=0, y8=False, contract=0):
     """Whole frame.  Returns dict(total, corners[structured], descriptors[u32 (n,8)], gray, blur).
-    oob / weight_bits: the implementation-defined switches (orc_impl_t); y8: a one-byte-per-pixel frame."""
+    oob / weight_bits / contract: the implementation-defined switches (orc_impl_t); y8: a one-byte-per-pixel frame."""
     rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
     H, W = rgba.shape[:2]
     corners = np.zeros(max_features, dtype=CORNER_DTYPE)
@@ -195,7 +197,7 @@ def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=Fal
     _, ntex = level_dims(W, H, depth)
     gray = np.zeros(ntex, dtype=np.uint16) if planes else None
     blur = np.zeros(ntex, dtype=np.uint16) if planes else None
-    impl = _impl(oob, weight_bits)
+    impl = _impl(oob, weight_bits, contract)
     rc = lib().orc_extract_impl(_ptr(rgba), 1 if y8 else 0, W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
                                 ctypes.cast(impl, ctypes.c_void_p), _ptr(corners), _ptr(desc), ctypes.byref(total),
                                 _ptr(gray) if planes else None, _ptr(blur) if planes else None)
@@ -205,7 +207,7 @@ def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=Fal
     return dict(total=total.value, corners=corners[:n], descriptors=desc[:n], gray=gray, blur=blur)
 
 
-def brief(blur_pyr, W, H, depth, corners, oob="zero"):
+def brief(blur_pyr, W, H, depth, corners, oob="zero", contract=0):
     """Descriptors (n, 8) u32 of the given keypoints (CORNER_DTYPE: x, y, angle, octave) over a blur pyramid as `extract(...,
     planes=True)["blur"]` returns it (orc_brief_impl: brief.wgsl:20-68 under an out-of-level policy).  tools/pin_oracle.py uses
     it to ask what the restatement's descriptor is at an angle code somebody else computed."""
@@ -217,8 +219,8 @@ def brief(blur_pyr, W, H, depth, corners, oob="zero"):
     lib().orc_pyramid_layout(W, H, depth, ctypes.byref(p))
     out = np.zeros((len(corners), 8), dtype=np.uint32)
     if len(corners):
-        lib().orc_brief_impl(_ptr(blur_pyr), ctypes.byref(p), _ptr(corners), len(corners),
-                             OOB_POLICIES[oob] if isinstance(oob, str) else int(oob), _ptr(out))
+        lib().orc_brief_impl2(_ptr(blur_pyr), ctypes.byref(p), _ptr(corners), len(corners),
+                              OOB_POLICIES[oob] if isinstance(oob, str) else int(oob), int(contract), _ptr(out))
     return out
 
 

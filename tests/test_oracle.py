@@ -607,3 +607,70 @@ def test_pin_tool_tells_an_atan2_difference_from_a_real_one(oracle, tmp_path):
     _, results, _ = pin_oracle.check(str(tmp_path))
     assert not results[("zero", 0)]["exact_up_to_atan2"] and results[("zero", 0)]["descriptor_bits_where_angles_agree"] == 1
     assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 1
+
+
+def _rn32(fr):
+    """Fraction -> binary32, round to nearest even, exactly (float(Fraction) is correctly rounded to binary64; the candidates
+    around its binary32 rounding are compared as fractions)."""
+    from fractions import Fraction
+    x = np.float32(float(fr))
+    best = None
+    for c in (np.nextafter(x, np.float32(-np.inf)), x, np.nextafter(x, np.float32(np.inf))):
+        d = abs(Fraction(float(c)) - fr)
+        even = (np.frombuffer(np.float32(c).tobytes(), dtype=np.uint32)[0] & 1) == 0
+        if best is None or d < best[0] or (d == best[0] and even):
+            best = (d, c)
+    return np.float32(best[1])
+
+
+def test_contracted_luminance_is_an_exact_fma_chain(oracle):
+    """CRD-13, orc_impl_t::contract = 1: the luminance is r*wr, then fma(g, wg, .), then fma(b, wb, .), each fma rounded ONCE --
+    checked against exact rational arithmetic on 300 random colours; and it is a different function from the default
+    (every product and sum rounded) on some of them."""
+    from fractions import Fraction
+    rng = np.random.default_rng(11)
+    rgba = rng.integers(0, 256, size=(1, 300, 4), dtype=np.uint8)
+    out = np.zeros(300, dtype=np.uint16)
+    oracle.lib().orc_grayscale_impl(rgba.ctypes.data, 300, 1, out.ctypes.data, 1)
+    want = np.zeros(300, dtype=np.uint16)
+    wr, wg, wb = (Fraction(float(np.float32(w))) for w in (0.229, 0.587, 0.114))
+    for i, (r, g, b, _) in enumerate(rgba[0]):
+        fr, fg, fb = (Fraction(float(np.float32(np.float32(v) / np.float32(255)))) for v in (r, g, b))
+        t = _rn32(wr * fr)
+        t = _rn32(fg * wg + Fraction(float(t)))
+        t = _rn32(fb * wb + Fraction(float(t)))
+        want[i] = oracle.f32_to_f16(float(t))
+    assert np.array_equal(out, want)
+    # the two readings differ somewhere on a frame (a handful of texels in a million), and nowhere else than in the last place
+    frame = oracle.synth_frame(640, 480, 2, 15)
+    a = oracle.extract(frame, depth=2, threshold=THR, planes=True)
+    b = oracle.extract(frame, depth=2, threshold=THR, planes=True, contract=1)
+    diff = a["gray"].astype(np.int32) - b["gray"].astype(np.int32)
+    assert 0 < np.count_nonzero(diff) < 100 and np.abs(diff).max() == 1
+
+
+def test_pin_tool_names_a_contracting_compiler(oracle, tmp_path):
+    """A dump fabricated from the restatement with contract = 1 on a frame where that changes an angle code: the tool must
+    explain it by contraction (exit code 4) -- not by the adapter's atan2, which would fit too -- and a dump of the default
+    arithmetic on the same frame must say that the compiler does not contract."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pin_oracle
+    seed, flags = 1, 15
+    t, c, d = pin_oracle.oracle_result("zero", 0, seed, flags, contract=1)
+    t0, c0, d0 = pin_oracle.oracle_result("zero", 0, seed, flags)
+    assert t == t0 and (not np.array_equal(c, c0) or not np.array_equal(d, d0))  # the frame tells the two apart
+
+    def write(cc, dd):
+        np.save(tmp_path / "total.npy", np.uint32(t))
+        np.save(tmp_path / "corners.npy", cc)
+        np.save(tmp_path / "descriptors.npy", dd)
+        np.save(tmp_path / "params.npy", np.array([640, 480, 2, seed, flags, 8192], dtype=np.uint32))
+
+    write(c, d)
+    _, results, exact = pin_oracle.check(str(tmp_path))
+    assert not exact and results[("zero", 0)]["contracted"]["exact"] and not results[("clamp", 0)]["contracted"]["exact"]
+    assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 4
+    write(c0, d0)
+    _, results, exact = pin_oracle.check(str(tmp_path))
+    assert ("zero", 0) in exact and not results[("zero", 0)]["contracted"]["exact"]
+    assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 0

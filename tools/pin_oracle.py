@@ -12,7 +12,8 @@
                                                   reports which ones the adapter may follow, or how far the nearest one is and
                                                   where the differences sit.  Exit code 0: pinned; 3: pinned up to the adapter's
                                                   atan2 (angle codes off by one milliradian whose descriptors, recomputed at the
-                                                  dumped angle, are the dump's); 1: not pinned
+                                                  dumped angle, are the dump's); 4: pinned only by the restatement of a shader
+                                                  compiler that contracts products and sums into fmas (CRD-13); 1: not pinned
 
 TEST INFRASTRUCTURE (it imports oracle/): never part of the product.
 """
@@ -47,24 +48,25 @@ def load_dump(d):
     return total, corners[order], desc[order]
 
 
-def oracle_result(oob, wbits, seed=SEED, flags=FLAGS, planes=False):
+def oracle_result(oob, wbits, seed=SEED, flags=FLAGS, planes=False, contract=0):
     rgba = orb_oracle.synth_frame(W, H, seed, flags)
-    ref = orb_oracle.extract(rgba, depth=DEPTH, threshold=THR, max_features=CAP, oob=oob, weight_bits=wbits, planes=planes)
+    ref = orb_oracle.extract(rgba, depth=DEPTH, threshold=THR, max_features=CAP, oob=oob, weight_bits=wbits, planes=planes,
+                             contract=contract)
     c, d = orb_oracle.sort_keypoints(ref["corners"], ref["descriptors"])
     out = ref["total"], np.stack([c[k] for k in ("x", "y", "angle", "octave")], 1).astype(np.uint32), d.astype(np.uint32)
     return out + (ref["blur"],) if planes else out
 
 
-def descriptors_at(blur, corners_xyao, oob):
+def descriptors_at(blur, corners_xyao, oob, contract=0):
     """The restatement's descriptors of the given (x, y, angle, octave) rows over its own blur pyramid: what brief.wgsl:20-68
     yields at an angle code that somebody else's atan2 produced."""
     c = np.zeros(len(corners_xyao), dtype=orb_oracle.CORNER_DTYPE)
     for i, k in enumerate(("x", "y", "angle", "octave")):
         c[k] = corners_xyao[:, i]
-    return orb_oracle.brief(blur, W, H, DEPTH, c, oob=oob)
+    return orb_oracle.brief(blur, W, H, DEPTH, c, oob=oob, contract=contract)
 
 
-def compare(dump, ref, blur=None, oob="zero"):
+def compare(dump, ref, blur=None, oob="zero", contract=0):
     """Differences between a dump and one oracle setting, by kind.  With the setting's blur pyramid: the keypoints whose angle
     code differs by one milliradian are described again at the DUMP's angle -- if those descriptors are the dump's, the only
     thing the adapter does differently there is atan2 (CRD-9: a driver's atan2 may round the other way next to an integer
@@ -91,7 +93,7 @@ def compare(dump, ref, blur=None, oob="zero"):
             bits_same_angle += b
     bits_at_dump_angle = None
     if blur is not None and off1:
-        again = descriptors_at(blur, c0[off1], oob)
+        again = descriptors_at(blur, c0[off1], oob, contract)
         bits_at_dump_angle = int(np.unpackbits((again ^ d0[off1]).view(np.uint8)).sum())
     same_sets = t0 == t1 and not only_dump and not only_oracle
     return {"total_dump": t0, "total_oracle": t1, "only_in_dump": only_dump, "only_in_oracle": only_oracle,
@@ -111,6 +113,10 @@ def check(d):
     for s in SETTINGS:
         ref = oracle_result(s[0], s[1], seed, flags, planes=True)
         results[s] = compare(dump, ref, blur=ref[3], oob=s[0])
+        # the same setting under a shader compiler that contracts products and sums into fmas (CRD-13): a diagnosis -- the
+        # kernels follow contract = 0 only -- under "contracted"
+        refc = oracle_result(s[0], s[1], seed, flags, planes=True, contract=1)
+        results[s]["contracted"] = compare(dump, refc, blur=refc[3], oob=s[0], contract=1)
     exact = [s for s in SETTINGS if results[s]["exact"]]
     return dump, results, exact
 
@@ -136,10 +142,25 @@ def main(argv):
                   "in %s (OrbOptions / orc_impl_t)." % exact)
             if ("zero", 0) not in exact:
                 print("The defaults (zero, 0) are NOT among them: change the defaults or pass the switches.")
+            both = [s for s in exact if results[s]["contracted"]["exact"]]
+            print("Contraction (CRD-13): %s." % ("this frame does not tell a contracting shader compiler from one that rounds every product "
+                                                 "and sum (both reproduce the dump)" if both else
+                                                 "the adapter's compiler does NOT contract (the fma-chain restatement differs from the dump)"))
             if len(exact) > 1:
                 print("Several settings agree on this frame -- it does not tell them apart; dump the noisy frame as well "
                       "(`frame <out> 2 15`).")
             return 0
+        def contracted_note(fused, how):
+            print("\nPINNED ONLY WITH A CONTRACTING SHADER COMPILER (CRD-13) on this frame%s, (oob_policy, sampler_weight_bits) in %s: the "
+                  "adapter evaluates dot() (grayscale.wgsl:36), `result += sample * weight` (gaussian_blur_x.wgsl:58) and matrix * vector "
+                  "(brief.wgsl:53-54) as fma chains.  The restatement follows (orc_impl_t::contract = 1); the kernels round every product "
+                  "and sum on their own and would need the fused forms in luminance_pair_f16, the blur taps and the rotation -- under the "
+                  "kernels' arithmetic this frame differs in %d angle codes and %d descriptor bits."
+                  % (how, fused, results[fused[0]]["angle_off_by_1"] + results[fused[0]]["angle_off_by_more"], results[fused[0]]["descriptor_bits"]))
+            return 4
+        fused = [s for s in SETTINGS if results[s]["contracted"]["exact"]]
+        if fused:  # an exact explanation beats one that needs an atan2 excuse
+            return contracted_note(fused, "")
         near = [s for s in SETTINGS if results[s]["exact_up_to_atan2"]]
         if near:
             r = results[near[0]]
@@ -149,6 +170,9 @@ def main(argv):
                   "next to an integer milliradian there -- no switch can follow a driver's atan2; compare angles with a tolerance of "
                   "one code and descriptors at the reference's angle." % (near, r["angle_off_by_1"]))
             return 3
+        fused = [s for s in SETTINGS if results[s]["contracted"]["exact_up_to_atan2"]]
+        if fused:
+            return contracted_note(fused, " (and up to the adapter's atan2)")
         best = min(SETTINGS, key=lambda s: (len(results[s]["only_in_dump"]) + len(results[s]["only_in_oracle"]),
                                             results[s]["descriptor_bits"] + results[s]["angle_off_by_1"]))
         r = results[best]
