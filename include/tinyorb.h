@@ -311,7 +311,9 @@ int orb_node_read_collated(OrbNode *node, CornerData *corners, CornerDescriptor 
  * Brute-force Hamming matching between consecutive frames of the last batch: for every stored keypoint i of frame
  * f (query) the stored keypoint j of frame f+1 with the smallest popcount(desc_f[i] ^ desc_f+1[j]); ties go to the
  * smallest j.  `second` is the smallest distance over all other j (for a ratio test).  Without candidates:
- * index = ORB_MATCH_NONE, distance = second = 0xffff; with one candidate second = 0xffff. */
+ * index = ORB_MATCH_NONE, distance = second = 0xffff; with one candidate second = 0xffff.
+ * Runs on the matrix cores (descriptors as +-1 bytes, int8 MFMA: csrc/orb_kernels_match.h; the first call allocates
+ * 256 bytes per record of a batch for them) when max_features <= 2^22, else on the vector unit. */
 typedef struct {
     uint32_t index;
     uint16_t distance;

@@ -475,8 +475,11 @@ def test_intended_pathological_dense_tile(tinyorb, oracle):
 # ---------------------------------------------------------------------------------------------
 # Hamming matcher between consecutive frames (not in the reference): GPU vs NumPy brute force
 # ---------------------------------------------------------------------------------------------
-def test_match_consecutive_frames(tinyorb, oracle):
+@pytest.mark.parametrize("valu", [0, 1])
+def test_match_consecutive_frames(tinyorb, oracle, monkeypatch, valu):
+    """valu = 0: the matrix-core matcher (k_desc_expand + k_match_mfma), 1: the vector-unit one (k_match, TINYORB_MATCH_VALU=1)."""
     from oracle import orb_numpy
+    monkeypatch.setenv("TINYORB_MATCH_VALU", str(valu))
     W, H, cap = 320, 240, 600
     base = oracle.synth_frame(W + 8, H + 6, 300)
     frames = np.stack([np.ascontiguousarray(base[dy:dy + H, dx:dx + W]) for dx, dy in ((0, 0), (3, 2), (8, 6))]
@@ -497,6 +500,29 @@ def test_match_consecutive_frames(tinyorb, oracle):
         assert (prog.match_read(2, int(counts[2]))["index"] == tinyorb.ORB_MATCH_NONE).all()
         with pytest.raises(tinyorb.OrbError):
             prog.match_consecutive(5)
+
+
+@pytest.mark.parametrize("valu", [0, 1])
+def test_match_frames_of_different_sizes(tinyorb, oracle, monkeypatch, valu):
+    """Counts that are no multiple of a tile (16 candidates, 64 queries per wave, 256 per workgroup), more queries than one
+    workgroup takes, a frame with a single keypoint (no runner-up) and a capacity cut: every record against the NumPy brute force."""
+    from oracle import orb_numpy
+    monkeypatch.setenv("TINYORB_MATCH_VALU", str(valu))
+    W, H, cap = 640, 480, 1200
+    frames = np.stack([oracle.synth_frame(W, H, 41, 7), oracle.synth_frame(W, H, 41, 3), oracle.synth_frame(W, H, 41, 5),
+                       np.zeros((H, W, 4), np.uint8), oracle.synth_frame(W, H, 44)])
+    frames[3, 200:203, 300:303] = 255  # one 3x3 blob: a handful of keypoints at most
+    with _program(tinyorb, W, H, 2, max_features=cap, max_batch=5) as prog:
+        prog.extract_batch_host(frames)
+        counts = np.minimum(prog.batch_counts(5), cap)
+        assert counts[0] == cap and 256 < counts[1] < cap and counts[1] % 16 and 0 < counts[3] < 16, counts  # a cut frame, a ragged one, a tiny one
+        desc = [prog.batch_read(f, int(counts[f]))[1] for f in range(5)]
+        prog.match_consecutive(5)
+        for f in range(4):
+            got = prog.match_read(f, int(counts[f]))
+            idx, dist, second = orb_numpy.match(desc[f], desc[f + 1])
+            assert np.array_equal(got["index"], idx), f
+            assert np.array_equal(got["distance"], dist) and np.array_equal(got["second"], second), f
 
 
 def test_large_frames_take_the_fused_pipelines(tinyorb, oracle):

@@ -25,6 +25,9 @@ HIPCC_FLAGS = [
     # (half rate on gfx950) behind hundreds of v_mov that assemble their operands; the kernels that want packed
     # arithmetic ask for it themselves (float2 / half2 types)
     "-fno-slp-vectorize",
+    # MFMA results in VGPRs (the register file is unified on gfx950): the one kernel that uses the matrix cores, k_match_mfma, feeds
+    # every result to the vector unit at once, and from an AGPR that is one v_accvgpr_read per value on top of the three it costs
+    "-mllvm", "-amdgpu-mfma-vgpr-form",
 ]
 
 

@@ -22,6 +22,7 @@
 #include "orb_kernels_intended.h"
 #include "orb_kernels_staged.h"
 #include "orb_kernels_collate.h"
+#include "orb_kernels_match.h"
 
 using namespace orb;
 
@@ -98,6 +99,8 @@ struct OrbProgram {
     unsigned long long* d_thr_key = nullptr;
     uint32_t ibrief_lds = 0;
     MatchRecord* d_matches = nullptr;  // [max_batch][max_features], allocated by the first orb_match_consecutive
+    uint8_t* d_desc8 = nullptr;        // [max_batch][max_features][256]: the descriptors as +-1 bytes, k_match_mfma's operands
+    int match_valu = -1;               // TINYORB_MATCH_VALU=1: the vector-unit matcher (k_match) instead; read once
     uint32_t* d_prov2_counts = nullptr;
     CornerData* d_prov2 = nullptr;
     float* d_prov2_scores = nullptr;
@@ -1380,6 +1383,7 @@ void orb_program_destroy(OrbProgram* p) {
     (void)hipFree(p->d_sin);
     if (p->d_rot) (void)hipFree(p->d_rot);
     (void)hipFree(p->d_stamps);
+    (void)hipFree(p->d_desc8);
     if (p->h_count) (void)hipHostFree(p->h_count);
     if (p->d_single_done) (void)hipFree(p->d_single_done);
     if (p->h_corners) (void)hipHostFree(p->h_corners);
@@ -1965,7 +1969,25 @@ int orb_match_consecutive(OrbProgram* p, uint32_t n_frames, void* stream) {
     const size_t cap = p->cfg.max_features;
     if (!p->d_matches) HIP_TRY(p, hipMalloc(&p->d_matches, (size_t)p->max_batch * cap * sizeof(MatchRecord)));
     hipStream_t s = stream ? (hipStream_t)stream : (p->last_stream ? p->last_stream : p->stream);
-    {
+    if (p->match_valu < 0) {
+        const char* e = getenv("TINYORB_MATCH_VALU");
+        p->match_valu = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    // The matrix-core matcher (orb_kernels_match.h) needs the descriptors as bytes: 256 B per record of the batch.  A capacity
+    // beyond its key's 22 index bits, or no memory for the bytes, leaves the vector-unit kernel.
+    bool mfma = p->match_valu == 0 && cap <= (size_t)kMatchIdxMask;
+    if (mfma && !p->d_desc8 && hipMalloc(&p->d_desc8, (size_t)p->max_batch * cap * 256u) != hipSuccess) {
+        (void)hipGetLastError();
+        p->d_desc8 = nullptr;
+        mfma = false;
+    }
+    if (mfma) {
+        LaunchScope ls(p, s, KID_MATCH);
+        hipLaunchKernelGGL(k_desc_expand, dim3((unsigned)((cap + 31u) / 32u), n_frames), dim3(256), 0, s, p->d_counts, p->d_desc, (uint32_t)cap,
+                           p->d_desc8);
+        hipLaunchKernelGGL(k_match_mfma, dim3(n_frames - 1u, (unsigned)((cap + kMatchQueriesPerWg - 1u) / kMatchQueriesPerWg)),
+                           dim3(64 * kMatchWaves), 0, s, p->d_counts, p->d_desc8, (uint32_t)cap, p->d_matches);
+    } else {
         LaunchScope ls(p, s, KID_MATCH);
         hipLaunchKernelGGL(k_match, dim3(n_frames - 1u, (unsigned)((cap + 64u * kMatchQ - 1u) / (64u * kMatchQ))), dim3(64), 0, s, p->d_counts,
                            p->d_desc, (uint32_t)cap, p->d_matches);

@@ -1,0 +1,194 @@
+// orb_kernels_match.h -- the Hamming matcher of consecutive frames (not in the reference) on the matrix
+// cores.  All-pairs Hamming distance IS a matrix product: with a descriptor's 256 bits written as 256 signed bytes
+// s = +1 (bit set) / -1 (bit clear),  sum_k s_a[k] * s_b[k] = 256 - 2 * popcount(a ^ b)  -- exact in integers.
+//
+//   k_desc_expand   every stored descriptor of the batch as 256 bytes of +-1 (one 16-byte store per thread)
+//   k_match_mfma    a wave owns 64 queries of frame f (4 row tiles of 16: their A fragments stay in 64 VGPRs) and walks the
+//                   candidates of frame f + 1 in tiles of 16: four v_mfma_i32_16x16x64_i8 per row tile give 256 dot products
+//                   (accumulator preset to 256, so a value is 512 - 2 * distance >= 0), and a result costs the vector unit
+//                   THREE instructions -- key = value << 22 | (2^22 - 1 - candidate), then the median and the maximum of
+//                   (best, runner-up, key) for the two largest keys (= smallest distance, ties to the smallest candidate
+//                   index, and the runner-up) -- where k_match's loop spends 8 x (xor, popcount) + 4.  The 16 lanes that hold a row's columns merge their
+//                   pairs once, at the end.
+// A and B fragments are loaded by the same rule (lane l: descriptor row l & 15, bytes 64 t + 16 (l >> 4) ... + 15 of k tile t),
+// so whatever order the instruction gives the k index inside a lane group, both operands agree on it; only the row / column
+// maps matter, and those are the documented ones (A row = B column = l & 15; C column = l & 15, row = 4 (l >> 4) + register).
+#pragma once
+#include "orb_kernels_staged.h"
+
+namespace orb {
+
+constexpr int kMatchKeyShift = 22;                        // candidate index in the low 22 bits of a key (max_features <= 2^22)
+constexpr uint32_t kMatchIdxMask = (1u << kMatchKeyShift) - 1u;
+#ifndef TINYORB_MATCH_ROWTILES
+#define TINYORB_MATCH_ROWTILES 2
+#endif
+constexpr int kMatchRowTiles = TINYORB_MATCH_ROWTILES;    // row tiles of 16 queries per wave
+constexpr int kMatchWaves = 16 / kMatchRowTiles;          // waves per workgroup: 256 queries
+constexpr int kMatchQueriesPerWg = 16 * kMatchRowTiles * kMatchWaves;
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// grid (ceil(cap / 32), n_frames), block 256: thread -> (descriptor, word): 32 bits -> 32 bytes
+__global__ __launch_bounds__(256) void k_desc_expand(const uint32_t* __restrict__ counts, const CornerDescriptor* __restrict__ descriptors,
+                                                     uint32_t cap, uint8_t* __restrict__ desc8) {
+    const uint32_t frame = blockIdx.y, n = min(counts[frame], cap);
+    const uint32_t i = blockIdx.x * 32u + (threadIdx.x >> 3), wd = threadIdx.x & 7u;
+    if (i >= n) return;
+    const uint32_t bits = reinterpret_cast<const uint32_t*>(descriptors + (size_t)frame * cap + i)[wd];
+    uint32_t out[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {  // four bits -> four bytes: 0x01 where the bit is set, 0xff where it is clear
+        const uint32_t nib = (bits >> (4 * q)) & 15u;
+        const uint32_t y = (nib * 0x00204081u) & 0x01010101u;  // bit i of the nibble in the low bit of byte i (no two terms share a position)
+        out[q] = 0xffffffffu - ((y << 1) | (y << 2) | (y << 3) | (y << 4) | (y << 5) | (y << 6) | (y << 7));  // 0xff - 0xfe per set byte
+    }
+    uint4* dst = reinterpret_cast<uint4*>(desc8 + ((size_t)frame * cap + i) * 256u + wd * 32u);
+    dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+}
+
+// grid (n_pairs, ceil(cap / 256)), block 256 (the pair is the fast index, as in k_match: chunks past a frame's count exit at once).
+// Candidates come through LDS in chunks of 64 (16 KB, rows 272 bytes apart: the 64 lanes' 16-byte fragment reads then spread
+// evenly over the banks), loaded once per workgroup -- every wave loading its own fragments from the L1 asked the texture
+// path for 4 KB per wave and tile, four times the same bytes, and ran at a third of this form's rate -- and double-buffered:
+// the next chunk's loads are in flight while this one is multiplied, one barrier per chunk.
+constexpr int kMatchChunk = 64;            // candidates per LDS stage (4 column tiles)
+constexpr int kMatchRowBytes = 256 + 16;   // LDS row stride
+__global__ __launch_bounds__(64 * kMatchWaves) void k_match_mfma(const uint32_t* __restrict__ counts, const uint8_t* __restrict__ desc8,
+                                                                 uint32_t cap, MatchRecord* __restrict__ matches) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[2][kMatchChunk * kMatchRowBytes];
+    const uint32_t pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t na = min(counts[pair], cap), nb = min(counts[pair + 1u], cap);
+    const uint32_t qw = blockIdx.y * (uint32_t)kMatchQueriesPerWg;
+    if (qw >= na) return;  // uniform for the workgroup
+    const uint32_t q0 = qw + wave * (16u * kMatchRowTiles);
+    const bool wave_live = q0 < na;  // a wave without queries still stages candidates and meets the barriers
+    const uint32_t rc = lane & 15u, g = lane >> 4;  // row of A / column of B, and the lane group
+    const uint8_t* const qa = desc8 + (size_t)pair * cap * 256u + 16u * g;
+    const uint8_t* const qb = desc8 + (size_t)(pair + 1u) * cap * 256u;
+    v4i_t a[kMatchRowTiles][4];
+#pragma unroll
+    for (int m = 0; m < kMatchRowTiles; m++) {
+        const uint32_t row = min(q0 + 16u * (uint32_t)m + rc, na - 1u);  // rows past the frame's count repeat its last one; never stored
+#pragma unroll
+        for (int t = 0; t < 4; t++) a[m][t] = *reinterpret_cast<const v4i_t*>(qa + (size_t)row * 256u + 64u * (uint32_t)t);
+    }
+    uint32_t best[kMatchRowTiles][4], second[kMatchRowTiles][4];
+#pragma unroll
+    for (int m = 0; m < kMatchRowTiles; m++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) best[m][i] = second[m][i] = 0u;  // 0 = nothing: a real key is never 0 (its low bits are 2^22 - 1 - index > 0)
+
+    // staging: a chunk is 1024 pieces of 16 bytes, piece p = bytes 16 (p & 15) .. of candidate row p >> 4; a thread takes pieces
+    // tid + NT k.  (Written with explicit registers: an array captured by a lambda went through scratch memory.)
+    constexpr uint32_t NT = 64u * (uint32_t)kMatchWaves, NP = (uint32_t)(kMatchChunk * 16) / NT;  // threads, pieces per thread
+    static_assert(NP == 2u || NP == 4u, "staging is written for two or four pieces per thread");
+    const uint32_t prow = tid >> 4, pcol = 16u * (tid & 15u);   // piece k: row prow + (NT / 16) k
+    uint8_t* const put0 = &stage[0][prow * (uint32_t)kMatchRowBytes + pcol];
+    constexpr uint32_t kRowStep = NT / 16u, kPutStep = kRowStep * (uint32_t)kMatchRowBytes, kBufBytes = (uint32_t)(kMatchChunk * kMatchRowBytes);
+    uint4 p0 = make_uint4(0u, 0u, 0u, 0u), p1 = p0, p2 = p0, p3 = p0;
+#define MATCH_FETCH(J0)                                                                                                  \
+    do {                                                                                                                 \
+        const uint8_t* const fb_ = qb + pcol;                                                                            \
+        p0 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow, nb - 1u) * 256u);                            \
+        p1 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + kRowStep, nb - 1u) * 256u);                 \
+        if (NP == 4u) {                                                                                                  \
+            p2 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 2u * kRowStep, nb - 1u) * 256u);        \
+            p3 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 3u * kRowStep, nb - 1u) * 256u);        \
+        }                                                                                                                \
+    } while (0)
+#define MATCH_PUT(BUF)                                                                                                   \
+    do {                                                                                                                 \
+        uint8_t* const pb_ = put0 + (uint32_t)(BUF) * kBufBytes;                                                         \
+        *reinterpret_cast<uint4*>(pb_) = p0;                                                                             \
+        *reinterpret_cast<uint4*>(pb_ + kPutStep) = p1;                                                                  \
+        if (NP == 4u) {                                                                                                  \
+            *reinterpret_cast<uint4*>(pb_ + 2u * kPutStep) = p2;                                                         \
+            *reinterpret_cast<uint4*>(pb_ + 3u * kPutStep) = p3;                                                         \
+        }                                                                                                                \
+    } while (0)
+    // one column tile: 4 k steps x 4 row tiles with four independent accumulators (a dependent chain of MFMAs waits out each
+    // one's latency), then three vector instructions per result.  MASK: the frame's last, partial tile -- its missing columns get key 0.
+    auto tile = [&](auto mask_tag, const uint8_t* src, uint32_t jt) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        v4i_t b[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) b[t] = *reinterpret_cast<const v4i_t*>(src + 64 * t);
+        const uint32_t col = jt + rc;
+        uint32_t low = kMatchIdxMask - col;
+        asm volatile("" : "+v"(low));  // one value per tile: left to itself hipcc re-derives it inside every key (three operations instead of one)
+        v4i_t acc[kMatchRowTiles];
+#pragma unroll
+        for (int m = 0; m < kMatchRowTiles; m++) acc[m] = v4i_t{256, 256, 256, 256};
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int m = 0; m < kMatchRowTiles; m++) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m][t], b[t], acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < kMatchRowTiles; m++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                // (plain C: an asm statement that read an MFMA result would get no wait states in front of it)
+                uint32_t key = ((uint32_t)acc[m][i] << kMatchKeyShift) + low;
+                if (MASK) key = col < nb ? key : 0u;
+                // the two largest of {best >= second, key}: the runner-up is their median
+                asm("v_med3_u32 %0, %1, %2, %3" : "=v"(second[m][i]) : "v"(best[m][i]), "v"(second[m][i]), "v"(key));
+                best[m][i] = max(best[m][i], key);
+            }
+    };
+    if (nb) {
+        MATCH_FETCH(0u);
+        MATCH_PUT(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (uint32_t j0 = 0; j0 < nb; j0 += (uint32_t)kMatchChunk, buf ^= 1) {
+        const bool more = j0 + (uint32_t)kMatchChunk < nb;
+        if (more) MATCH_FETCH(j0 + (uint32_t)kMatchChunk);
+        if (wave_live) {
+            const uint8_t* const src0 = &stage[buf][rc * (uint32_t)kMatchRowBytes + 16u * g];
+            if (j0 + (uint32_t)kMatchChunk <= nb) {  // a whole chunk: four full tiles
+#pragma unroll
+                for (int tt = 0; tt < kMatchChunk / 16; tt++) tile(std::false_type{}, src0 + tt * 16 * kMatchRowBytes, j0 + 16u * (uint32_t)tt);
+            } else {
+                for (uint32_t tt = 0; j0 + 16u * tt < nb; tt++) {
+                    const uint32_t jt = j0 + 16u * tt;
+                    if (jt + 16u <= nb)
+                        tile(std::false_type{}, src0 + tt * (uint32_t)(16 * kMatchRowBytes), jt);
+                    else
+                        tile(std::true_type{}, src0 + tt * (uint32_t)(16 * kMatchRowBytes), jt);
+                }
+            }
+        }
+        if (more) MATCH_PUT(buf ^ 1);
+        __syncthreads();
+    }
+#undef MATCH_FETCH
+#undef MATCH_PUT
+    if (!wave_live) return;
+    // the sixteen lanes of a group hold one row's columns: merge their (best, second) pairs
+#pragma unroll
+    for (int m = 0; m < kMatchRowTiles; m++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t b1 = best[m][i], s1 = second[m][i];
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1) {
+                const uint32_t b2 = (uint32_t)__shfl_xor((int)b1, sh), s2 = (uint32_t)__shfl_xor((int)s1, sh);
+                s1 = max(min(b1, b2), max(s1, s2));
+                b1 = max(b1, b2);
+            }
+            const uint32_t q = q0 + 16u * (uint32_t)m + 4u * g + (uint32_t)i;
+            if (rc == 0u && q < na) {
+                MatchRecord r;
+                // value = 512 - 2 * distance
+                r.index = b1 ? kMatchIdxMask - (b1 & kMatchIdxMask) : 0xffffffffu;
+                const uint32_t d1 = b1 ? (512u - (b1 >> kMatchKeyShift)) >> 1 : 0xffffu;
+                const uint32_t d2 = s1 ? (512u - (s1 >> kMatchKeyShift)) >> 1 : 0xffffu;
+                r.dist = d1 | (d2 << 16);
+                matches[(size_t)pair * cap + q] = r;
+            }
+        }
+}
+
+}  // namespace orb
