@@ -313,7 +313,7 @@ int orb_node_read_collated(OrbNode *node, CornerData *corners, CornerDescriptor 
  * smallest j.  `second` is the smallest distance over all other j (for a ratio test).  Without candidates:
  * index = ORB_MATCH_NONE, distance = second = 0xffff; with one candidate second = 0xffff.
  * Runs on the matrix cores (descriptors as +-1 bytes, int8 MFMA: csrc/orb_kernels_match.h; the first call allocates
- * 256 bytes per record of a batch for them) when max_features <= 2^22, else on the vector unit. */
+ * 256 bytes per record of a batch for them) when max_features <= 16128, else on the vector unit. */
 typedef struct {
     uint32_t index;
     uint16_t distance;

@@ -1974,8 +1974,8 @@ int orb_match_consecutive(OrbProgram* p, uint32_t n_frames, void* stream) {
         p->match_valu = (e && atoi(e) != 0) ? 1 : 0;
     }
     // The matrix-core matcher (orb_kernels_match.h) needs the descriptors as bytes: 256 B per record of the batch.  A capacity
-    // beyond its key's 22 index bits, or no memory for the bytes, leaves the vector-unit kernel.
-    bool mfma = p->match_valu == 0 && cap <= (size_t)kMatchIdxMask;
+    // beyond its key's 16 128 indices, or no memory for the bytes, leaves the vector-unit kernel.
+    bool mfma = p->match_valu == 0 && cap <= (size_t)kMatchMaxCap;
     if (mfma && !p->d_desc8 && hipMalloc(&p->d_desc8, (size_t)p->max_batch * cap * 256u) != hipSuccess) {
         (void)hipGetLastError();
         p->d_desc8 = nullptr;

@@ -1,15 +1,17 @@
 // orb_kernels_match.h -- the Hamming matcher of consecutive frames (not in the reference) on the matrix
 // cores.  All-pairs Hamming distance IS a matrix product: with a descriptor's 256 bits written as 256 signed bytes
-// s = +1 (bit set) / -1 (bit clear),  sum_k s_a[k] * s_b[k] = 256 - 2 * popcount(a ^ b)  -- exact in integers.
+// s = +127 (bit set) / -127 (bit clear),  sum_k s_a[k] * s_b[k] = 127^2 * (256 - 2 * popcount(a ^ b))  -- exact in integers.
 //
-//   k_desc_expand   every stored descriptor of the batch as 256 bytes of +-1 (one 16-byte store per thread)
-//   k_match_mfma    a wave owns 64 queries of frame f (4 row tiles of 16: their A fragments stay in 64 VGPRs) and walks the
-//                   candidates of frame f + 1 in tiles of 16: four v_mfma_i32_16x16x64_i8 per row tile give 256 dot products
-//                   (accumulator preset to 256, so a value is 512 - 2 * distance >= 0), and a result costs the vector unit
-//                   THREE instructions -- key = value << 22 | (2^22 - 1 - candidate), then the median and the maximum of
-//                   (best, runner-up, key) for the two largest keys (= smallest distance, ties to the smallest candidate
-//                   index, and the runner-up) -- where k_match's loop spends 8 x (xor, popcount) + 4.  The 16 lanes that hold a row's columns merge their
-//                   pairs once, at the end.
+//   k_desc_expand   every stored descriptor of the batch as 256 bytes of +-127 (two 16-byte stores per thread)
+//   k_match_mfma    a wave owns 16 * kMatchRowTiles queries of frame f (their A fragments stay in registers) and walks the
+//                   candidates of frame f + 1 in tiles of 16: four v_mfma_i32_16x16x64_i8 per row tile give 256 dot products,
+//                   and the accumulator they start from is the REST OF THE KEY: with K = 127^2 it is preset to
+//                   256 K + (K - 1 - candidate), so the instruction's result is (512 - 2 * distance) * K + (K - 1 - candidate)
+//                   -- distance first, then the smaller candidate index -- and costs the vector unit TWO instructions, the
+//                   median and the maximum of (best, runner-up, key) for the two largest keys, where k_match's loop spends
+//                   8 x (xor, popcount) + 4.  (A power of two as the byte would make the key a shift, but 64 * 64 = 2^12 leaves
+//                   the index 12 bits; 127^2 = 16129 leaves it 16128 values.)  The 16 lanes that hold a row's columns merge
+//                   their pairs once, at the end.
 // A and B fragments are loaded by the same rule (lane l: descriptor row l & 15, bytes 64 t + 16 (l >> 4) ... + 15 of k tile t),
 // so whatever order the instruction gives the k index inside a lane group, both operands agree on it; only the row / column
 // maps matter, and those are the documented ones (A row = B column = l & 15; C column = l & 15, row = 4 (l >> 4) + register).
@@ -18,8 +20,8 @@
 
 namespace orb {
 
-constexpr int kMatchKeyShift = 22;                        // candidate index in the low 22 bits of a key (max_features <= 2^22)
-constexpr uint32_t kMatchIdxMask = (1u << kMatchKeyShift) - 1u;
+constexpr uint32_t kMatchK = 127u * 127u;                 // key = (512 - 2 * distance) * K + (K - 1 - candidate index)
+constexpr uint32_t kMatchMaxCap = kMatchK - 1u;           // candidate indices 0 .. K - 2: a real key is never 0
 #ifndef TINYORB_MATCH_ROWTILES
 #define TINYORB_MATCH_ROWTILES 2
 #endif
@@ -37,10 +39,10 @@ __global__ __launch_bounds__(256) void k_desc_expand(const uint32_t* __restrict_
     const uint32_t bits = reinterpret_cast<const uint32_t*>(descriptors + (size_t)frame * cap + i)[wd];
     uint32_t out[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) {  // four bits -> four bytes: 0x01 where the bit is set, 0xff where it is clear
+    for (int q = 0; q < 8; q++) {  // four bits -> four bytes: +127 (0x7f) where the bit is set, -127 (0x81) where it is clear
         const uint32_t nib = (bits >> (4 * q)) & 15u;
         const uint32_t y = (nib * 0x00204081u) & 0x01010101u;  // bit i of the nibble in the low bit of byte i (no two terms share a position)
-        out[q] = 0xffffffffu - ((y << 1) | (y << 2) | (y << 3) | (y << 4) | (y << 5) | (y << 6) | (y << 7));  // 0xff - 0xfe per set byte
+        out[q] = 0x81818181u - (y << 1);                         // 0x81 - 2 per set byte: no borrow between bytes
     }
     uint4* dst = reinterpret_cast<uint4*>(desc8 + ((size_t)frame * cap + i) * 256u + wd * 32u);
     dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_mfma(const uint32_t*
 #pragma unroll
     for (int m = 0; m < kMatchRowTiles; m++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) best[m][i] = second[m][i] = 0u;  // 0 = nothing: a real key is never 0 (its low bits are 2^22 - 1 - index > 0)
+        for (int i = 0; i < 4; i++) best[m][i] = second[m][i] = 0u;  // 0 = nothing: a real key is never 0 (its low part is K - 1 - index > 0)
 
     // staging: a chunk is 1024 pieces of 16 bytes, piece p = bytes 16 (p & 15) .. of candidate row p >> 4; a thread takes pieces
     // tid + NT k.  (Written with explicit registers: an array captured by a lambda went through scratch memory.)
@@ -115,11 +117,11 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_mfma(const uint32_t*
 #pragma unroll
         for (int t = 0; t < 4; t++) b[t] = *reinterpret_cast<const v4i_t*>(src + 64 * t);
         const uint32_t col = jt + rc;
-        uint32_t low = kMatchIdxMask - col;
-        asm volatile("" : "+v"(low));  // one value per tile: left to itself hipcc re-derives it inside every key (three operations instead of one)
+        const int c0 = (int)(256u * kMatchK + (kMatchK - 1u) - col);  // what the dot products are added to: the key's other two terms
+        const v4i_t cin = {c0, c0, c0, c0};
         v4i_t acc[kMatchRowTiles];
 #pragma unroll
-        for (int m = 0; m < kMatchRowTiles; m++) acc[m] = v4i_t{256, 256, 256, 256};
+        for (int m = 0; m < kMatchRowTiles; m++) acc[m] = cin;
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
@@ -128,12 +130,13 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_mfma(const uint32_t*
         for (int m = 0; m < kMatchRowTiles; m++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                // (plain C: an asm statement that read an MFMA result would get no wait states in front of it)
-                uint32_t key = ((uint32_t)acc[m][i] << kMatchKeyShift) + low;
+                uint32_t key = (uint32_t)acc[m][i];
                 if (MASK) key = col < nb ? key : 0u;
-                // the two largest of {best >= second, key}: the runner-up is their median
-                asm("v_med3_u32 %0, %1, %2, %3" : "=v"(second[m][i]) : "v"(best[m][i]), "v"(second[m][i]), "v"(key));
-                best[m][i] = max(best[m][i], key);
+                // the two largest of {best >= second, key}: the runner-up is their median.  (Plain C, not asm: an asm statement
+                // that reads an MFMA result gets no wait states in front of it -- a first version read stale registers.)
+                const uint32_t b0 = best[m][i], s0 = second[m][i];
+                second[m][i] = max(min(b0, key), min(max(b0, key), s0));  // = med3(b0, s0, key): hipcc emits v_med3_u32
+                best[m][i] = max(b0, key);
             }
     };
     if (nb) {
@@ -181,10 +184,10 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_mfma(const uint32_t*
             const uint32_t q = q0 + 16u * (uint32_t)m + 4u * g + (uint32_t)i;
             if (rc == 0u && q < na) {
                 MatchRecord r;
-                // value = 512 - 2 * distance
-                r.index = b1 ? kMatchIdxMask - (b1 & kMatchIdxMask) : 0xffffffffu;
-                const uint32_t d1 = b1 ? (512u - (b1 >> kMatchKeyShift)) >> 1 : 0xffffu;
-                const uint32_t d2 = s1 ? (512u - (s1 >> kMatchKeyShift)) >> 1 : 0xffffu;
+                const uint32_t v1 = b1 / kMatchK, v2 = s1 / kMatchK;  // 512 - 2 * distance
+                r.index = b1 ? kMatchK - 1u - (b1 - v1 * kMatchK) : 0xffffffffu;
+                const uint32_t d1 = b1 ? (512u - v1) >> 1 : 0xffffu;
+                const uint32_t d2 = s1 ? (512u - v2) >> 1 : 0xffffu;
                 r.dist = d1 | (d2 << 16);
                 matches[(size_t)pair * cap + q] = r;
             }
