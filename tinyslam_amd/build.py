@@ -73,6 +73,7 @@ def build_lib(force=False, verbose=False):
     flags = list(HIPCC_FLAGS)
     if os.environ.get("TINYORB_BUILD_STAMPS"):  # diagnostic build: in-kernel cycle stamps (tools/stamps.py)
         flags.append("-DTINYORB_STAMPS")
+    flags += os.environ.get("TINYORB_BUILD_EXTRA", "").split()  # experiments: extra compiler flags (e.g. -DTINYORB_B1_UNALIGNED)
     cmd = [_hipcc()] + flags + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
