@@ -312,8 +312,8 @@ int orb_node_read_collated(OrbNode *node, CornerData *corners, CornerDescriptor 
  * f (query) the stored keypoint j of frame f+1 with the smallest popcount(desc_f[i] ^ desc_f+1[j]); ties go to the
  * smallest j.  `second` is the smallest distance over all other j (for a ratio test).  Without candidates:
  * index = ORB_MATCH_NONE, distance = second = 0xffff; with one candidate second = 0xffff.
- * Runs on the matrix cores (descriptors as +-1 bytes, int8 MFMA: csrc/orb_kernels_match.h; the first call allocates
- * 256 bytes per record of a batch for them) when max_features <= 16128, else on the vector unit. */
+ * Runs on the matrix cores (descriptors as +-1 in fp4, block-scaled MFMA: csrc/orb_kernels_match.h; the first call
+ * allocates 128 bytes per record of a batch for them) when max_features <= 16383, else on the vector unit. */
 typedef struct {
     uint32_t index;
     uint16_t distance;

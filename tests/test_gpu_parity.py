@@ -475,11 +475,21 @@ def test_intended_pathological_dense_tile(tinyorb, oracle):
 # ---------------------------------------------------------------------------------------------
 # Hamming matcher between consecutive frames (not in the reference): GPU vs NumPy brute force
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("valu", [0, 1])
-def test_match_consecutive_frames(tinyorb, oracle, monkeypatch, valu):
-    """valu = 0: the matrix-core matcher (k_desc_expand + k_match_mfma), 1: the vector-unit one (k_match, TINYORB_MATCH_VALU=1)."""
+_MATCH_FORMS = {"fp4": {}, "i8": {"TINYORB_MATCH_I8": "1"}, "valu": {"TINYORB_MATCH_VALU": "1"}}
+
+
+def _match_form(monkeypatch, form):
+    """fp4: the default (k_desc_expand4 + k_match_fp4); i8: the int8 matrix-core form (k_desc_expand + k_match_mfma); valu: k_match."""
+    for k in ("TINYORB_MATCH_I8", "TINYORB_MATCH_VALU"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in _MATCH_FORMS[form].items():
+        monkeypatch.setenv(k, v)
+
+
+@pytest.mark.parametrize("form", list(_MATCH_FORMS))
+def test_match_consecutive_frames(tinyorb, oracle, monkeypatch, form):
     from oracle import orb_numpy
-    monkeypatch.setenv("TINYORB_MATCH_VALU", str(valu))
+    _match_form(monkeypatch, form)
     W, H, cap = 320, 240, 600
     base = oracle.synth_frame(W + 8, H + 6, 300)
     frames = np.stack([np.ascontiguousarray(base[dy:dy + H, dx:dx + W]) for dx, dy in ((0, 0), (3, 2), (8, 6))]
@@ -502,12 +512,12 @@ def test_match_consecutive_frames(tinyorb, oracle, monkeypatch, valu):
             prog.match_consecutive(5)
 
 
-@pytest.mark.parametrize("valu", [0, 1])
-def test_match_frames_of_different_sizes(tinyorb, oracle, monkeypatch, valu):
+@pytest.mark.parametrize("form", list(_MATCH_FORMS))
+def test_match_frames_of_different_sizes(tinyorb, oracle, monkeypatch, form):
     """Counts that are no multiple of a tile (16 candidates, 64 queries per wave, 256 per workgroup), more queries than one
     workgroup takes, a frame with a single keypoint (no runner-up) and a capacity cut: every record against the NumPy brute force."""
     from oracle import orb_numpy
-    monkeypatch.setenv("TINYORB_MATCH_VALU", str(valu))
+    _match_form(monkeypatch, form)
     W, H, cap = 640, 480, 1200
     frames = np.stack([oracle.synth_frame(W, H, 41, 7), oracle.synth_frame(W, H, 41, 3), oracle.synth_frame(W, H, 41, 5),
                        np.zeros((H, W, 4), np.uint8), oracle.synth_frame(W, H, 44)])

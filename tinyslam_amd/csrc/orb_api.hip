@@ -99,8 +99,8 @@ struct OrbProgram {
     unsigned long long* d_thr_key = nullptr;
     uint32_t ibrief_lds = 0;
     MatchRecord* d_matches = nullptr;  // [max_batch][max_features], allocated by the first orb_match_consecutive
-    uint8_t* d_desc8 = nullptr;        // [max_batch][max_features][256]: the descriptors as +-1 bytes, k_match_mfma's operands
-    int match_valu = -1;               // TINYORB_MATCH_VALU=1: the vector-unit matcher (k_match) instead; read once
+    uint8_t* d_desc8 = nullptr;        // [max_batch][max_features][128 or 256]: the descriptors as +-1 in fp4 (k_match_fp4) or +-127 in int8 (k_match_mfma)
+    int match_valu = -1;               // which matcher (0 fp4, 1 vector unit: TINYORB_MATCH_VALU=1, 2 int8: TINYORB_MATCH_I8=1); read once
     uint32_t* d_prov2_counts = nullptr;
     CornerData* d_prov2 = nullptr;
     float* d_prov2_scores = nullptr;
@@ -1969,24 +1969,29 @@ int orb_match_consecutive(OrbProgram* p, uint32_t n_frames, void* stream) {
     const size_t cap = p->cfg.max_features;
     if (!p->d_matches) HIP_TRY(p, hipMalloc(&p->d_matches, (size_t)p->max_batch * cap * sizeof(MatchRecord)));
     hipStream_t s = stream ? (hipStream_t)stream : (p->last_stream ? p->last_stream : p->stream);
-    if (p->match_valu < 0) {
+    if (p->match_valu < 0) {  // which matcher: 0 the block-scaled fp4 form on the matrix cores (default), 1 the vector unit, 2 the int8 form
         const char* e = getenv("TINYORB_MATCH_VALU");
-        p->match_valu = (e && atoi(e) != 0) ? 1 : 0;
+        const char* e8 = getenv("TINYORB_MATCH_I8");
+        p->match_valu = (e && atoi(e) != 0) ? 1 : ((e8 && atoi(e8) != 0) ? 2 : 0);
     }
-    // The matrix-core matcher (orb_kernels_match.h) needs the descriptors as bytes: 256 B per record of the batch.  A capacity
-    // beyond its key's 16 128 indices, or no memory for the bytes, leaves the vector-unit kernel.
-    bool mfma = p->match_valu == 0 && cap <= (size_t)kMatchMaxCap;
-    if (mfma && !p->d_desc8 && hipMalloc(&p->d_desc8, (size_t)p->max_batch * cap * 256u) != hipSuccess) {
+    // The matrix-core matchers (orb_kernels_match.h) need the descriptors as signed elements: 128 (fp4) or 256 (int8) bytes per
+    // record of the batch.  A capacity beyond their key's index range, or no memory for the bytes, leaves the vector-unit kernel.
+    const bool i8 = p->match_valu == 2;
+    bool mfma = p->match_valu != 1 && cap <= (size_t)(i8 ? kMatchMaxCap : kMatch4MaxCap);
+    if (mfma && !p->d_desc8 && hipMalloc(&p->d_desc8, (size_t)p->max_batch * cap * (i8 ? 256u : 128u)) != hipSuccess) {
         (void)hipGetLastError();
         p->d_desc8 = nullptr;
         mfma = false;
     }
-    if (mfma) {
+    const dim3 grid_e((unsigned)((cap + 31u) / 32u), n_frames), grid_m(n_frames - 1u, (unsigned)((cap + kMatchQueriesPerWg - 1u) / kMatchQueriesPerWg));
+    if (mfma && !i8) {
         LaunchScope ls(p, s, KID_MATCH);
-        hipLaunchKernelGGL(k_desc_expand, dim3((unsigned)((cap + 31u) / 32u), n_frames), dim3(256), 0, s, p->d_counts, p->d_desc, (uint32_t)cap,
-                           p->d_desc8);
-        hipLaunchKernelGGL(k_match_mfma, dim3(n_frames - 1u, (unsigned)((cap + kMatchQueriesPerWg - 1u) / kMatchQueriesPerWg)),
-                           dim3(64 * kMatchWaves), 0, s, p->d_counts, p->d_desc8, (uint32_t)cap, p->d_matches);
+        hipLaunchKernelGGL(k_desc_expand4, grid_e, dim3(256), 0, s, p->d_counts, p->d_desc, (uint32_t)cap, p->d_desc8);
+        hipLaunchKernelGGL(k_match_fp4, grid_m, dim3(64 * kMatchWaves), 0, s, p->d_counts, p->d_desc8, (uint32_t)cap, p->d_matches);
+    } else if (mfma) {
+        LaunchScope ls(p, s, KID_MATCH);
+        hipLaunchKernelGGL(k_desc_expand, grid_e, dim3(256), 0, s, p->d_counts, p->d_desc, (uint32_t)cap, p->d_desc8);
+        hipLaunchKernelGGL(k_match_mfma, grid_m, dim3(64 * kMatchWaves), 0, s, p->d_counts, p->d_desc8, (uint32_t)cap, p->d_matches);
     } else {
         LaunchScope ls(p, s, KID_MATCH);
         hipLaunchKernelGGL(k_match, dim3(n_frames - 1u, (unsigned)((cap + 64u * kMatchQ - 1u) / (64u * kMatchQ))), dim3(64), 0, s, p->d_counts,

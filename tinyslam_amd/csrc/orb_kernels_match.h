@@ -1,5 +1,5 @@
 // orb_kernels_match.h -- the Hamming matcher of consecutive frames (not in the reference) on the matrix
-// cores.  All-pairs Hamming distance IS a matrix product: with a descriptor's 256 bits written as 256 signed bytes
+// cores, in two forms: int8 (below, the first) and block-scaled fp4 (at the end of the file: the default, half the MFMAs and bytes).  All-pairs Hamming distance IS a matrix product: with a descriptor's 256 bits written as 256 signed bytes
 // s = +127 (bit set) / -127 (bit clear),  sum_k s_a[k] * s_b[k] = 127^2 * (256 - 2 * popcount(a ^ b))  -- exact in integers.
 //
 //   k_desc_expand   every stored descriptor of the batch as 256 bytes of +-127 (two 16-byte stores per thread)
@@ -188,6 +188,172 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_mfma(const uint32_t*
                 r.index = b1 ? kMatchK - 1u - (b1 - v1 * kMatchK) : 0xffffffffu;
                 const uint32_t d1 = b1 ? (512u - v1) >> 1 : 0xffffu;
                 const uint32_t d2 = s1 ? (512u - v2) >> 1 : 0xffffu;
+                r.dist = d1 | (d2 << 16);
+                matches[(size_t)pair * cap + q] = r;
+            }
+        }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The same matcher on the block-scaled fp4 form (v_mfma_scale_f32_16x16x128_f8f6f4, E2M1 operands: +-1 is exact, 0x2 / 0xa):
+// 128 bytes per descriptor instead of 256, two MFMAs per row tile and column tile instead of four, each at the int8 form's
+// cycles.  The block scales (E8M0, one per lane's 32 elements) are 2^7 on both sides, so a product is +-2^14 = +-K: the
+// accumulator is preset to 256 K + (K - 1 - candidate) as before, every value is an integer below 2^24 and exact in binary32,
+// and the two largest keys are kept with v_med3_f32 / v_max_f32.  A and B fragments are loaded by one rule (lane l: row l & 15,
+// bytes 64 t + 16 (l >> 4) .. + 15 of k step t), so the order of the 32 elements inside a lane's block cannot matter.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kMatch4K = 1u << 14;
+constexpr uint32_t kMatch4MaxCap = kMatch4K - 1u;
+constexpr int kMatch4RowBytes = 128 + 16;
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+// grid (ceil(cap / 32), n_frames), block 256: thread -> (descriptor, word): 32 bits -> 32 nibbles (16 bytes)
+__global__ __launch_bounds__(256) void k_desc_expand4(const uint32_t* __restrict__ counts, const CornerDescriptor* __restrict__ descriptors,
+                                                      uint32_t cap, uint8_t* __restrict__ desc4) {
+    const uint32_t frame = blockIdx.y, n = min(counts[frame], cap);
+    const uint32_t i = blockIdx.x * 32u + (threadIdx.x >> 3), wd = threadIdx.x & 7u;
+    if (i >= n) return;
+    const uint32_t bits = reinterpret_cast<const uint32_t*>(descriptors + (size_t)frame * cap + i)[wd];
+    uint32_t out[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {  // eight bits -> eight nibbles: 0x2 (+1) where the bit is set, 0xa (-1) where it is clear
+        const uint32_t b = (bits >> (8 * q)) & 255u;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v |= ((b >> k) & 1u) << (4 * k + 3);  // bit k at the top of nibble k
+        out[q] = 0xaaaaaaaau ^ v;
+    }
+    *reinterpret_cast<uint4*>(desc4 + ((size_t)frame * cap + i) * 128u + wd * 16u) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+__global__ __launch_bounds__(64 * kMatchWaves) void k_match_fp4(const uint32_t* __restrict__ counts, const uint8_t* __restrict__ desc4,
+                                                                uint32_t cap, MatchRecord* __restrict__ matches) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[2][kMatchChunk * kMatch4RowBytes];
+    const uint32_t pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t na = min(counts[pair], cap), nb = min(counts[pair + 1u], cap);
+    const uint32_t qw = blockIdx.y * (uint32_t)kMatchQueriesPerWg;
+    if (qw >= na) return;  // uniform for the workgroup
+    const uint32_t q0 = qw + wave * (16u * kMatchRowTiles);
+    const bool wave_live = q0 < na;
+    const uint32_t rc = lane & 15u, g = lane >> 4;
+    const uint8_t* const qa = desc4 + (size_t)pair * cap * 128u + 16u * g;
+    const uint8_t* const qb = desc4 + (size_t)(pair + 1u) * cap * 128u;
+    v4i_t a[kMatchRowTiles][2];
+#pragma unroll
+    for (int m = 0; m < kMatchRowTiles; m++) {
+        const uint32_t row = min(q0 + 16u * (uint32_t)m + rc, na - 1u);
+#pragma unroll
+        for (int t = 0; t < 2; t++) a[m][t] = *reinterpret_cast<const v4i_t*>(qa + (size_t)row * 128u + 64u * (uint32_t)t);
+    }
+    float best[kMatchRowTiles][4], second[kMatchRowTiles][4];
+#pragma unroll
+    for (int m = 0; m < kMatchRowTiles; m++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) best[m][i] = second[m][i] = 0.0f;  // 0 = nothing: a real key is >= 1
+
+    // staging: a chunk is 64 rows x 8 pieces of 16 bytes = 512 pieces, piece p = bytes 16 (p & 7) .. of candidate row p >> 3
+    constexpr uint32_t NT = 64u * (uint32_t)kMatchWaves, NP = (uint32_t)(kMatchChunk * 8) / NT;
+    static_assert(NP == 1u || NP == 2u, "staging is written for one or two pieces per thread");
+    const uint32_t prow = tid >> 3, pcol = 16u * (tid & 7u);
+    uint8_t* const put0 = &stage[0][prow * (uint32_t)kMatch4RowBytes + pcol];
+    constexpr uint32_t kRowStep = NT / 8u, kPutStep = kRowStep * (uint32_t)kMatch4RowBytes, kBufBytes = (uint32_t)(kMatchChunk * kMatch4RowBytes);
+    uint4 p0 = make_uint4(0u, 0u, 0u, 0u), p1 = p0;
+#define MATCH4_FETCH(J0)                                                                                                 \
+    do {                                                                                                                 \
+        const uint8_t* const fb_ = qb + pcol;                                                                            \
+        p0 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow, nb - 1u) * 128u);                            \
+        if (NP == 2u) p1 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + kRowStep, nb - 1u) * 128u);   \
+    } while (0)
+#define MATCH4_PUT(BUF)                                                                                                  \
+    do {                                                                                                                 \
+        uint8_t* const pb_ = put0 + (uint32_t)(BUF) * kBufBytes;                                                         \
+        *reinterpret_cast<uint4*>(pb_) = p0;                                                                             \
+        if (NP == 2u) *reinterpret_cast<uint4*>(pb_ + kPutStep) = p1;                                                    \
+    } while (0)
+    const int scale = 127 + 7;  // E8M0: 2^7 for every block of both operands
+    auto tile = [&](auto mask_tag, const uint8_t* src, uint32_t jt) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        v8i_t b[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const v4i_t q = *reinterpret_cast<const v4i_t*>(src + 64 * t);
+            b[t] = v8i_t{q[0], q[1], q[2], q[3], 0, 0, 0, 0};
+        }
+        const uint32_t col = jt + rc;
+        const float c0 = (float)(256u * kMatch4K + (kMatch4K - 1u) - col);
+        const v4f_t cin = {c0, c0, c0, c0};
+        v4f_t acc[kMatchRowTiles];
+#pragma unroll
+        for (int m = 0; m < kMatchRowTiles; m++) acc[m] = cin;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int m = 0; m < kMatchRowTiles; m++) {
+                const v8i_t am = {a[m][t][0], a[m][t][1], a[m][t][2], a[m][t][3], 0, 0, 0, 0};
+                acc[m] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(am, b[t], acc[m], 4, 4, 0, scale, 0, scale);
+            }
+#pragma unroll
+        for (int m = 0; m < kMatchRowTiles; m++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float key = acc[m][i];
+                if (MASK) key = col < nb ? key : 0.0f;
+                const float b0 = best[m][i];
+                second[m][i] = __builtin_amdgcn_fmed3f(b0, second[m][i], key);
+                best[m][i] = fmaxf(b0, key);
+            }
+    };
+    if (nb) {
+        MATCH4_FETCH(0u);
+        MATCH4_PUT(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (uint32_t j0 = 0; j0 < nb; j0 += (uint32_t)kMatchChunk, buf ^= 1) {
+        const bool more = j0 + (uint32_t)kMatchChunk < nb;
+        if (more) MATCH4_FETCH(j0 + (uint32_t)kMatchChunk);
+        if (wave_live) {
+            const uint8_t* const src0 = &stage[buf][rc * (uint32_t)kMatch4RowBytes + 16u * g];
+            if (j0 + (uint32_t)kMatchChunk <= nb) {
+#pragma unroll
+                for (int tt = 0; tt < kMatchChunk / 16; tt++) tile(std::false_type{}, src0 + tt * 16 * kMatch4RowBytes, j0 + 16u * (uint32_t)tt);
+            } else {
+                for (uint32_t tt = 0; j0 + 16u * tt < nb; tt++) {
+                    const uint32_t jt = j0 + 16u * tt;
+                    if (jt + 16u <= nb)
+                        tile(std::false_type{}, src0 + tt * (uint32_t)(16 * kMatch4RowBytes), jt);
+                    else
+                        tile(std::true_type{}, src0 + tt * (uint32_t)(16 * kMatch4RowBytes), jt);
+                }
+            }
+        }
+        if (more) MATCH4_PUT(buf ^ 1);
+        __syncthreads();
+    }
+#undef MATCH4_FETCH
+#undef MATCH4_PUT
+    if (!wave_live) return;
+#pragma unroll
+    for (int m = 0; m < kMatchRowTiles; m++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float b1 = best[m][i], s1 = second[m][i];
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1) {
+                const float b2 = __shfl_xor(b1, sh), s2 = __shfl_xor(s1, sh);
+                s1 = fmaxf(fminf(b1, b2), fmaxf(s1, s2));
+                b1 = fmaxf(b1, b2);
+            }
+            const uint32_t q = q0 + 16u * (uint32_t)m + 4u * g + (uint32_t)i;
+            if (rc == 0u && q < na) {
+                MatchRecord r;
+                const uint32_t k1 = (uint32_t)b1, k2 = (uint32_t)s1;  // exact: integers below 2^24
+                const uint32_t v1 = k1 >> 14, v2 = k2 >> 14;           // 512 - 2 * distance
+                r.index = k1 ? kMatch4K - 1u - (k1 & (kMatch4K - 1u)) : 0xffffffffu;
+                const uint32_t d1 = k1 ? (512u - v1) >> 1 : 0xffffu;
+                const uint32_t d2 = k2 ? (512u - v2) >> 1 : 0xffffu;
                 r.dist = d1 | (d2 << 16);
                 matches[(size_t)pair * cap + q] = r;
             }
