@@ -23,7 +23,7 @@ namespace orb {
 constexpr uint32_t kMatchK = 127u * 127u;                 // key = (512 - 2 * distance) * K + (K - 1 - candidate index)
 constexpr uint32_t kMatchMaxCap = kMatchK - 1u;           // candidate indices 0 .. K - 2: a real key is never 0
 #ifndef TINYORB_MATCH_ROWTILES
-#define TINYORB_MATCH_ROWTILES 2
+#define TINYORB_MATCH_ROWTILES 4
 #endif
 constexpr int kMatchRowTiles = TINYORB_MATCH_ROWTILES;    // row tiles of 16 queries per wave
 constexpr int kMatchWaves = 16 / kMatchRowTiles;          // waves per workgroup: 256 queries
