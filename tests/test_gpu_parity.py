@@ -594,3 +594,20 @@ def test_intended_full_size_batch(tinyorb, oracle):
         fused.batch_select_output(0)
         c0, d0 = _sorted(*fused.batch_read(37, int(counts[37])))
         assert np.array_equal(c0, c1) and np.array_equal(d0, d1)
+
+
+def test_match_capacity_beyond_the_matrix_core_key(tinyorb, oracle):
+    """max_features above 16 383 (the index range of the matrix-core matchers' key): orb_match_consecutive takes the vector-unit
+    kernel by itself; at 16 383 it is still the fp4 form.  Same records either way."""
+    from oracle import orb_numpy
+    W, H = 320, 240
+    frames = np.stack([oracle.synth_frame(W, H, 71), oracle.synth_frame(W, H, 72)])
+    for cap in (16383, 16500):
+        with _program(tinyorb, W, H, 2, max_features=cap, max_batch=2) as prog:
+            prog.extract_batch_host(frames)
+            counts = np.minimum(prog.batch_counts(2), cap)
+            desc = [prog.batch_read(f, int(counts[f]))[1] for f in range(2)]
+            prog.match_consecutive(2)
+            got = prog.match_read(0, int(counts[0]))
+            idx, dist, second = orb_numpy.match(desc[0], desc[1])
+            assert np.array_equal(got["index"], idx) and np.array_equal(got["distance"], dist) and np.array_equal(got["second"], second)
