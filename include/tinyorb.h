@@ -85,7 +85,13 @@ typedef struct OrbOptions {
     uint32_t sampler_weight_bits; /* 0: bilinear weights are the exact binary32 fractions; n = 1..23: a sampler that holds
                                    * them in n fractional bits, rounded to nearest, halves up (8 is common): the blur's
                                    * lerps (gaussian_blur_x.wgsl:53-58) and the blit of an odd-sized level (blit.wgsl:35) */
-    uint32_t reserved[2];
+    uint32_t fp_contract;         /* CRD-13: 0 = every binary32 product and sum of the shaders rounded on its own
+                                   * (the default); 1 = a shader compiler that contracts them into fused multiply-adds, in source
+                                   * order -- dot() (grayscale.wgsl:36), `result += sample * weight` (gaussian_blur_x.wgsl:58),
+                                   * matrix * vector (brief.wgsl:53-54).  Carried by the per-stage kernels only: such a program
+                                   * runs the staged pipeline (orb_pipeline_note says so).  RGBA input, the reference's detector.
+                                   * (Took the first of two reserved words: a zero-initialised OrbOptions means what it meant.) */
+    uint32_t reserved[1];
 } OrbOptions;
 
 #define ORB_OOB_ZERO 0u  /* 0.0 -- Vulkan robust image access; naga: image_load = Unchecked on such devices */

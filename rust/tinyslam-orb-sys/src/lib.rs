@@ -62,15 +62,19 @@ pub mod orb {
         fast_arc: u32, // 0 = FAST-12
         oob_policy: u32,          // ORB_OOB_ZERO / _CLAMP / _UMIN: textureLoad outside the level (0 = the default, CRD-6)
         sampler_weight_bits: u32, // 0 = exact bilinear weights (CRD-5); n = weights held in n fractional bits
-        reserved: [u32; 2],
+        fp_contract: u32,         // CRD-13: 1 = the adapter's shader compiler contracts products and sums into fmas (staged kernels only)
+        reserved: [u32; 1],
     }
 
-    /// The two points the reference's WGSL leaves to its adapter, as switches (`OrbOptions` of include/tinyorb.h).
+    /// The points the reference's WGSL leaves to its adapter, as switches (`OrbOptions` of include/tinyorb.h).
     /// `tools/pin_oracle.py check <dump>` says which setting a given adapter follows.
     #[derive(Clone, Copy, Default)]
     pub struct AdapterBehaviour {
         pub oob_policy: u32,
         pub sampler_weight_bits: u32,
+        /// CRD-13: 1 = the adapter's shader compiler contracts products and sums into fused multiply-adds (the program then runs
+        /// the per-stage kernels, which carry that arithmetic)
+        pub fp_contract: u32,
     }
     pub const ORB_OOB_ZERO: u32 = 0;
     pub const ORB_OOB_CLAMP: u32 = 1;
@@ -127,6 +131,7 @@ pub mod orb {
             let opt = OrbOptionsC {
                 oob_policy: self.adapter.oob_policy,
                 sampler_weight_bits: self.adapter.sampler_weight_bits,
+                fp_contract: self.adapter.fp_contract,
                 ..Default::default()
             };
             let rc = unsafe { orb_program_create(&c, &opt, &mut self.handle) };

@@ -275,7 +275,7 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
         else if (p->intended)
             hipLaunchKernelGGL(k_grayscale<true>, grid, dim3(256), 0, s, frames, p->frame_bytes, p->d_gray, pyr);
         else
-            hipLaunchKernelGGL(k_grayscale<false>, grid, dim3(256), 0, s, frames, p->frame_bytes, p->d_gray, pyr);
+            hipLaunchKernelGGL(k_grayscale<false>, grid, dim3(256), 0, s, frames, p->frame_bytes, p->d_gray, pyr, p->opt.fp_contract);
     }
     for (uint32_t m = 1; m < D; m++) {  // orb.rs:413-429
         LaunchScope ls(p, s, KID_MIP);
@@ -291,7 +291,7 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
         }
         dim3 grid(pyr.h[m], 1, n);
         size_t lds = (size_t)pyr.w[m] * 2u * sizeof(uint16_t);
-        hipLaunchKernelGGL(k_blur_rows, grid, dim3(256), lds, s, p->d_gray, p->d_blur, pyr, m, p->wq);
+        hipLaunchKernelGGL(k_blur_rows, grid, dim3(256), lds, s, p->d_gray, p->d_blur, pyr, m, p->wq, p->opt.fp_contract);
     }
     const bool nms = (p->opt.flags & ORB_FLAG_NMS) != 0u;
     const uint32_t im = p->intended ? 1u : 0u;
@@ -342,7 +342,7 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
         if (bx > 64u) bx = 64u;
         if (bx < 1u) bx = 1u;
         hipLaunchKernelGGL(k_brief, dim3(bx, 1, n), dim3(256), 0, s, p->d_blur, pyr, p->d_counts, p->d_corners, cap,
-                           p->d_desc, tab, im, p->oob);
+                           p->d_desc, tab, im, p->oob, p->opt.fp_contract);
     }
     HIP_TRY(p, hipGetLastError());
     p->planes_valid = true;
@@ -352,6 +352,7 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
 // Can the fused per-level kernels handle this configuration?  (Otherwise: staged pipeline.)
 bool fused_eligible(const OrbProgram* p) {
     if (p->opt.flags & (ORB_FLAG_STAGED | ORB_FLAG_NMS | ORB_FLAG_INTENDED)) return false;
+    if (p->opt.fp_contract) return false;  // CRD-13: only the per-stage kernels carry the contracted arithmetic
     if (p->arc != 12u) return false;  // the fused FAST phase is specialised for the reference's 12-run
     const Pyramid& pyr = p->pyr;
     // index arithmetic: v_mul_i32_i24 takes 24-bit operands (rows, widths < 2^14 here) and returns 32 bits; RGBA byte
@@ -912,6 +913,11 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         ((options->flags & (ORB_FLAG_INTENDED | ORB_FLAG_NMS)) || (options->fast_arc != 0 && options->fast_arc != 12)))
         return fail(nullptr, ORB_EINVAL, "oob_policy / sampler_weight_bits follow the reference's adapter: they are defined for the "
                                          "reference's detector only (no ORB_FLAG_INTENDED, ORB_FLAG_NMS or fast_arc other than 12)");
+    if (options && options->fp_contract > 1u) return fail(nullptr, ORB_EINVAL, "fp_contract must be 0 or 1");
+    if (options && options->fp_contract &&
+        ((options->flags & (ORB_FLAG_INTENDED | ORB_FLAG_NMS | ORB_FLAG_INPUT_Y8)) || (options->fast_arc != 0 && options->fast_arc != 12)))
+        return fail(nullptr, ORB_EINVAL, "fp_contract follows the reference's shader compiler: it is defined for the reference's detector on RGBA "
+                                         "input only (no ORB_FLAG_INTENDED, ORB_FLAG_NMS, ORB_FLAG_INPUT_Y8 or fast_arc other than 12)");
     if (options && (options->flags & ORB_FLAG_INTENDED) && (W > 16384u || H > 16384u))
         return fail(nullptr, ORB_EINVAL, "ORB_FLAG_INTENDED needs W, H <= 16384 (14-bit coordinates in the top-K key)");
 
@@ -1215,7 +1221,9 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         const Pyramid& py = p->pyr;
         char why[256];
         const bool plain = !p->intended && !(p->opt.flags & ORB_FLAG_NMS) && p->arc == 12u;  // the reference's own algorithm
-        if ((py.w[0] & 3u) != 0u && !plain)
+        if (p->opt.fp_contract)
+            snprintf(why, sizeof why, "OrbOptions::fp_contract: only the per-stage kernels carry the contracted arithmetic (CRD-13)");
+        else if ((py.w[0] & 3u) != 0u && !plain)
             snprintf(why, sizeof why, "width %u is not a multiple of 4 (the tile kernels read RGBA quads)", py.w[0]);
         else if (py.w[0] < 8u)
             snprintf(why, sizeof why, "width %u is below 8", py.w[0]);

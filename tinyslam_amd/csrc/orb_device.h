@@ -71,6 +71,16 @@ __device__ __forceinline__ float luminance(uint32_t rgba) {
     return (pr + pg) + pb;
 }
 
+// CRD-13, OrbOptions::fp_contract: a shader compiler that contracts -- dot() as one product and a chain of fmas, in source order.
+__device__ __forceinline__ float luminance_contracted(uint32_t rgba) {
+    float r = (float)(rgba & 255u) / 255.0f;
+    float g = (float)((rgba >> 8) & 255u) / 255.0f;
+    float b = (float)((rgba >> 16) & 255u) / 255.0f;
+    float t = 0.229f * r;
+    t = __builtin_fmaf(g, 0.587f, t);
+    return __builtin_fmaf(b, 0.114f, t);
+}
+
 // "intended" mode IM-1 (not in the reference): BT.601 weight for red.
 __device__ __forceinline__ float luminance_601(uint32_t rgba) {
     float r = (float)(rgba & 255u) / 255.0f;
