@@ -153,9 +153,10 @@ def main(argv):
         def contracted_note(fused, how):
             print("\nPINNED ONLY WITH A CONTRACTING SHADER COMPILER (CRD-13) on this frame%s, (oob_policy, sampler_weight_bits) in %s: the "
                   "adapter evaluates dot() (grayscale.wgsl:36), `result += sample * weight` (gaussian_blur_x.wgsl:58) and matrix * vector "
-                  "(brief.wgsl:53-54) as fma chains.  The restatement follows (orc_impl_t::contract = 1); the kernels round every product "
-                  "and sum on their own and would need the fused forms in luminance_pair_f16, the blur taps and the rotation -- under the "
-                  "kernels' arithmetic this frame differs in %d angle codes and %d descriptor bits."
+                  "(brief.wgsl:53-54) as fma chains.  The restatement follows (orc_impl_t::contract = 1) and so do the per-stage kernels: "
+                  "pass OrbOptions::fp_contract = 1 (the program then runs the staged pipeline; the fused kernels round every product and "
+                  "sum on their own and would need the fused forms in luminance_pair_f16, the blur taps and the rotation).  Under the "
+                  "default arithmetic this frame differs in %d angle codes and %d descriptor bits."
                   % (how, fused, results[fused[0]]["angle_off_by_1"] + results[fused[0]]["angle_off_by_more"], results[fused[0]]["descriptor_bits"]))
             return 4
         fused = [s for s in SETTINGS if results[s]["contracted"]["exact"]]
