@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_mfma(const uint32_t*
 // 128 bytes per descriptor instead of 256, two MFMAs per row tile and column tile instead of four, each at the int8 form's
 // cycles.  The block scales (E8M0, one per lane's 32 elements) are 2^7 on both sides, so a product is +-2^14 = +-K: the
 // accumulator is preset to 256 K + (K - 1 - candidate) as before, every value is an integer below 2^24 and exact in binary32,
-// and the two largest keys are kept with v_med3_f32 / v_max_f32.  A and B fragments are loaded by one rule (lane l: row l & 15,
+// and the two largest keys are kept with v_med3_u32 / v_max_u32 on their bit patterns.  A and B fragments are loaded by one rule (lane l: row l & 15,
 // bytes 64 t + 16 (l >> 4) .. + 15 of k step t), so the order of the 32 elements inside a lane's block cannot matter.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kMatch4K = 1u << 14;
@@ -247,11 +247,14 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_fp4(const uint32_t* 
 #pragma unroll
         for (int t = 0; t < 2; t++) a[m][t] = *reinterpret_cast<const v4i_t*>(qa + (size_t)row * 128u + 64u * (uint32_t)t);
     }
-    float best[kMatchRowTiles][4], second[kMatchRowTiles][4];
+    // The keys are kept as the BIT PATTERNS of the (non-negative) binary32 results, which order like the values: on floats every
+    // v_max_f32 / v_med3_f32 is preceded by a canonicalising v_max_f32 x, x, x of the MFMA result (hipcc cannot know it is no
+    // signalling NaN) -- 158 v_max_f32 per 64 results instead of 64.
+    uint32_t best[kMatchRowTiles][4], second[kMatchRowTiles][4];
 #pragma unroll
     for (int m = 0; m < kMatchRowTiles; m++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) best[m][i] = second[m][i] = 0.0f;  // 0 = nothing: a real key is >= 1
+        for (int i = 0; i < 4; i++) best[m][i] = second[m][i] = 0u;  // +0.0 = nothing: a real key is >= 1.0
 
     // staging: a chunk is 64 rows x 8 pieces of 16 bytes = 512 pieces, piece p = bytes 16 (p & 7) .. of candidate row p >> 3
     constexpr uint32_t NT = 64u * (uint32_t)kMatchWaves, NP = (uint32_t)(kMatchChunk * 8) / NT;
@@ -298,11 +301,11 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_fp4(const uint32_t* 
         for (int m = 0; m < kMatchRowTiles; m++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                float key = acc[m][i];
-                if (MASK) key = col < nb ? key : 0.0f;
-                const float b0 = best[m][i];
-                second[m][i] = __builtin_amdgcn_fmed3f(b0, second[m][i], key);
-                best[m][i] = fmaxf(b0, key);
+                uint32_t key = __float_as_uint(acc[m][i]);
+                if (MASK) key = col < nb ? key : 0u;
+                const uint32_t b0 = best[m][i], s0 = second[m][i];
+                second[m][i] = max(min(b0, key), min(max(b0, key), s0));  // = med3(b0, s0, key): hipcc emits v_med3_u32
+                best[m][i] = max(b0, key);
             }
     };
     if (nb) {
@@ -339,17 +342,17 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_fp4(const uint32_t* 
     for (int m = 0; m < kMatchRowTiles; m++)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            float b1 = best[m][i], s1 = second[m][i];
+            uint32_t b1 = best[m][i], s1 = second[m][i];
 #pragma unroll
             for (int sh = 1; sh < 16; sh <<= 1) {
-                const float b2 = __shfl_xor(b1, sh), s2 = __shfl_xor(s1, sh);
-                s1 = fmaxf(fminf(b1, b2), fmaxf(s1, s2));
-                b1 = fmaxf(b1, b2);
+                const uint32_t b2 = (uint32_t)__shfl_xor((int)b1, sh), s2 = (uint32_t)__shfl_xor((int)s1, sh);
+                s1 = max(min(b1, b2), max(s1, s2));
+                b1 = max(b1, b2);
             }
             const uint32_t q = q0 + 16u * (uint32_t)m + 4u * g + (uint32_t)i;
             if (rc == 0u && q < na) {
                 MatchRecord r;
-                const uint32_t k1 = (uint32_t)b1, k2 = (uint32_t)s1;  // exact: integers below 2^24
+                const uint32_t k1 = (uint32_t)__uint_as_float(b1), k2 = (uint32_t)__uint_as_float(s1);  // exact: integers below 2^24
                 const uint32_t v1 = k1 >> 14, v2 = k2 >> 14;           // 512 - 2 * distance
                 r.index = k1 ? kMatch4K - 1u - (k1 & (kMatch4K - 1u)) : 0xffffffffu;
                 const uint32_t d1 = k1 ? (512u - v1) >> 1 : 0xffffu;
