@@ -552,6 +552,9 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
                                    g.n_var, p->wq);
             }
             g.col_tab = p->d_col_tab[lvl];
+            // ... and the one tap the row constants need (IEEE division and floor: the host's equal the device's)
+            const BlurTap lt = blur_tap(pyr.w[lvl] - 1u, pyr.w[lvl], kBlurOffHost, p->wq);
+            g.far_i0 = (uint32_t)lt.i0, g.far_i1 = (uint32_t)lt.i1, g.lt_f = lt.f, g.lt_valid = 1u;
         }
         g.store_grey = (lvl == 0 && D > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) ? 1u : 0u;
         if (g.n_bands * (g.tiled ? g.n_ct : 1u) != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])

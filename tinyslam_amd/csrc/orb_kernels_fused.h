@@ -85,6 +85,8 @@ struct FrontGeom {
     uint32_t oob;         // OrbOptions::oob_policy (kOobZero / kOobClamp / kOobUmin); phase A of the levels >= 1 follows it through OOBK
     float wq;             // OrbOptions::sampler_weight_bits as 2^bits (0: exact lerp weights), for blur_tap()
     const struct BlurCol* col_tab;  // the level's n_var BlurCol entries, built once per program (k_blur_col_table); null: every band computes them
+    uint32_t lt_valid;    // 1: (far_i0, far_i1, lt_f) hold blur_tap(w - 1) -- the tap of pass 1 at the level's last column, which the band's
+    float lt_f;           //    row constants need: a division on the critical path between two barriers, the same for every band
 };
 
 // Tap positions of one column x >= blur_q of the literal blur (phase C): pass 2 at x lerps pass 1 at columns j0, j1
