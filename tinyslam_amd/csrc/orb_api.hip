@@ -556,6 +556,18 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
             const BlurTap lt = blur_tap(pyr.w[lvl] - 1u, pyr.w[lvl], kBlurOffHost, p->wq);
             g.far_i0 = (uint32_t)lt.i0, g.far_i1 = (uint32_t)lt.i1, g.lt_f = lt.f, g.lt_valid = 1u;
         }
+        if (p->col_tab_mode == 1 && !g.tiled) {
+            // ... and the reciprocals of the phases' item arithmetic (orb_front_body.inc: recip()); a phase checks the denominator
+            const bool general0 = lvl == 0 && ((pyr.w[0] & 3u) || g.store_grey);
+            const uint32_t iw = (lvl == 0 || p->ln_threads[lvl] == (uint32_t)kFrontThreadsLNBig) ? 16u : 8u;
+            const uint32_t wn = lvl + 1 < D ? pyr.w[lvl + 1] : 0u;
+            const uint32_t den[4] = {lvl == 0 ? ((general0 ? pyr.w[0] + 3u : pyr.w[0]) >> 2) : ((g.ls - (uint32_t)kLdsPad) >> 3),  // staging items per row
+                                     std::max((g.gw + iw - 1u) / iw, 1u),                                                          // pre-test items per row
+                                     std::max((wn + 3u) >> 2, 1u),                                                                 // mip items per row
+                                     (g.n_var + (lvl == 0 ? 1u : 0u)) / (lvl == 0 ? 2u : 1u)};                                     // blur column pairs per row
+            for (int k = 0; k < 4; k++)
+                if (den[k]) g.rcp_den[k] = den[k], g.rcp_inv[k] = 1.0f / (float)den[k];
+        }
         g.store_grey = (lvl == 0 && D > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) ? 1u : 0u;
         if (g.n_bands * (g.tiled ? g.n_ct : 1u) != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: band count mismatch at level %u", lvl);

@@ -85,6 +85,12 @@ struct FrontGeom {
     uint32_t oob;         // OrbOptions::oob_policy (kOobZero / kOobClamp / kOobUmin); phase A of the levels >= 1 follows it through OOBK
     float wq;             // OrbOptions::sampler_weight_bits as 2^bits (0: exact lerp weights), for blur_tap()
     const struct BlurCol* col_tab;  // the level's n_var BlurCol entries, built once per program (k_blur_col_table); null: every band computes them
+    // Reciprocals the phases divide their item indices with (rows of the staging, pre-test items, mip items, blur column pairs per
+    // row): level constants, yet every wave of every band ran the IEEE division sequence (about ten vector instructions) for each.
+    // rcp_den[k] != 0: rcp_inv[k] = 1.0f / (float)rcp_den[k] from the host (the same correctly rounded quotient); a phase uses it
+    // when its own denominator is that number and divides otherwise.
+    uint32_t rcp_den[4];
+    float rcp_inv[4];
     uint32_t lt_valid;    // 1: (far_i0, far_i1, lt_f) hold blur_tap(w - 1) -- the tap of pass 1 at the level's last column, which the band's
     float lt_f;           //    row constants need: a division on the critical path between two barriers, the same for every band
 };

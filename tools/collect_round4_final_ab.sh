@@ -1,5 +1,5 @@
 bash tools/collect_round4_final.sh 2>&1 | tail -1
-for i in 1 2; do
+for i in 1 2; do  # the three level-constant precomputes (TINYORB_NO_COLTAB switches them off together)
   python bench.py --cpu-sample 0 --no-single-frame --no-host-out > gpurun_out/r04f_ab_coltab_on_$i.json 2>/dev/null
   TINYORB_NO_COLTAB=1 python bench.py --cpu-sample 0 --no-single-frame --no-host-out > gpurun_out/r04f_ab_coltab_off_$i.json 2>/dev/null
 done
