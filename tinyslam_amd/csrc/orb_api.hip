@@ -99,8 +99,6 @@ struct OrbProgram {
     unsigned long long* d_thr_key = nullptr;
     uint32_t ibrief_lds = 0;
     MatchRecord* d_matches = nullptr;  // [max_batch][max_features], allocated by the first orb_match_consecutive
-    BlurCol* d_col_tab[kMaxLevels] = {nullptr};  // fused literal path: the blur column table of every level (k_blur_col_table), built by the first batch
-    int col_tab_mode = -1;                        // TINYORB_NO_COLTAB=1: every band computes its table (A/B); read once
     uint8_t* d_desc8 = nullptr;        // [max_batch][max_features][128 or 256]: the descriptors as +-1 in fp4 (k_match_fp4) or +-127 in int8 (k_match_mfma)
     int match_valu = -1;               // which matcher (0 fp4, 1 vector unit: TINYORB_MATCH_VALU=1, 2 int8: TINYORB_MATCH_I8=1); read once
     uint32_t* d_prov2_counts = nullptr;
@@ -541,33 +539,6 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         if (p->env.no_swizzle) g.xcd_swizzle = 0u;
         g.oob = p->oob;
         g.wq = p->wq;
-        if (p->col_tab_mode < 0) {
-            const char* e = getenv("TINYORB_NO_COLTAB");
-            p->col_tab_mode = (e && atoi(e) != 0) ? 0 : 1;
-        }
-        if (p->col_tab_mode == 1 && g.n_var > 0u && n >= 8u) {  // batches: the level's table from memory instead of from every band's arithmetic
-            if (!p->d_col_tab[lvl]) {
-                HIP_TRY(p, hipMalloc(&p->d_col_tab[lvl], (size_t)g.n_var * sizeof(BlurCol)));
-                hipLaunchKernelGGL(k_blur_col_table, dim3((g.n_var + 255u) / 256u), dim3(256), 0, s, p->d_col_tab[lvl], pyr.w[lvl], g.blur_p, g.blur_q,
-                                   g.n_var, p->wq);
-            }
-            g.col_tab = p->d_col_tab[lvl];
-            // ... and the one tap the row constants need (IEEE division and floor: the host's equal the device's)
-            const BlurTap lt = blur_tap(pyr.w[lvl] - 1u, pyr.w[lvl], kBlurOffHost, p->wq);
-            g.far_i0 = (uint32_t)lt.i0, g.far_i1 = (uint32_t)lt.i1, g.lt_f = lt.f, g.lt_valid = 1u;
-        }
-        if (p->col_tab_mode == 1 && !g.tiled) {
-            // ... and the reciprocals of the phases' item arithmetic (orb_front_body.inc: recip()); a phase checks the denominator
-            const bool general0 = lvl == 0 && ((pyr.w[0] & 3u) || g.store_grey);
-            const uint32_t iw = (lvl == 0 || p->ln_threads[lvl] == (uint32_t)kFrontThreadsLNBig) ? 16u : 8u;
-            const uint32_t wn = lvl + 1 < D ? pyr.w[lvl + 1] : 0u;
-            const uint32_t den[4] = {lvl == 0 ? ((general0 ? pyr.w[0] + 3u : pyr.w[0]) >> 2) : ((g.ls - (uint32_t)kLdsPad) >> 3),  // staging items per row
-                                     std::max((g.gw + iw - 1u) / iw, 1u),                                                          // pre-test items per row
-                                     std::max((wn + 3u) >> 2, 1u),                                                                 // mip items per row
-                                     (g.n_var + (lvl == 0 ? 1u : 0u)) / (lvl == 0 ? 2u : 1u)};                                     // blur column pairs per row
-            for (int k = 0; k < 4; k++)
-                if (den[k]) g.rcp_den[k] = den[k], g.rcp_inv[k] = 1.0f / (float)den[k];
-        }
         g.store_grey = (lvl == 0 && D > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) ? 1u : 0u;
         if (g.n_bands * (g.tiled ? g.n_ct : 1u) != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: band count mismatch at level %u", lvl);
@@ -1421,7 +1392,6 @@ void orb_program_destroy(OrbProgram* p) {
     if (p->d_rot) (void)hipFree(p->d_rot);
     (void)hipFree(p->d_stamps);
     (void)hipFree(p->d_desc8);
-    for (BlurCol* t : p->d_col_tab) (void)hipFree(t);
     if (p->h_count) (void)hipHostFree(p->h_count);
     if (p->d_single_done) (void)hipFree(p->d_single_done);
     if (p->h_corners) (void)hipHostFree(p->h_corners);

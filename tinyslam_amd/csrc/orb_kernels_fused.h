@@ -84,15 +84,6 @@ struct FrontGeom {
     uint32_t ovf_words;   // words of one bit set over the band's pre-test items (two sets in LDS: items whose survivors did not fit queue A)
     uint32_t oob;         // OrbOptions::oob_policy (kOobZero / kOobClamp / kOobUmin); phase A of the levels >= 1 follows it through OOBK
     float wq;             // OrbOptions::sampler_weight_bits as 2^bits (0: exact lerp weights), for blur_tap()
-    const struct BlurCol* col_tab;  // the level's n_var BlurCol entries, built once per program (k_blur_col_table); null: every band computes them
-    // Reciprocals the phases divide their item indices with (rows of the staging, pre-test items, mip items, blur column pairs per
-    // row): level constants, yet every wave of every band ran the IEEE division sequence (about ten vector instructions) for each.
-    // rcp_den[k] != 0: rcp_inv[k] = 1.0f / (float)rcp_den[k] from the host (the same correctly rounded quotient); a phase uses it
-    // when its own denominator is that number and divides otherwise.
-    uint32_t rcp_den[4];
-    float rcp_inv[4];
-    uint32_t lt_valid;    // 1: (far_i0, far_i1, lt_f) hold blur_tap(w - 1) -- the tap of pass 1 at the level's last column, which the band's
-    float lt_f;           //    row constants need: a division on the critical path between two barriers, the same for every band
 };
 
 // Tap positions of one column x >= blur_q of the literal blur (phase C): pass 2 at x lerps pass 1 at columns j0, j1
@@ -105,32 +96,6 @@ struct __attribute__((aligned(8))) BlurCol {
     uint32_t pad;
 };
 static_assert(sizeof(BlurCol) == 24, "BlurCol layout");
-
-// The BlurCol table of one level (FrontGeom::col_tab), once per program: entry c describes column blur_q + c -- the arithmetic a band
-// otherwise runs for itself (orb_front_body.inc, "blur column table"), on the same device function.
-__global__ __launch_bounds__(256) void k_blur_col_table(BlurCol* __restrict__ out, uint32_t w, uint32_t blur_p, uint32_t blur_q,
-                                                        uint32_t n_var, float wq) {
-    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
-    if (c >= n_var) return;
-    const int x = (int)(blur_q + c), P = (int)blur_p;
-    const BlurTap t2 = blur_tap((uint32_t)x, w, kBlurOff[1], wq);
-    BlurCol e;
-    e.f2 = t2.f;
-    e.pad = 0u;
-    if (t2.i0 < P) {
-        e.a0 = 0xffffu, e.a1 = 0u, e.fa = 0.0f;
-    } else {
-        const BlurTap t = blur_tap((uint32_t)t2.i0, w, kBlurOff[1], wq);
-        e.a0 = (uint16_t)t.i0, e.a1 = (uint16_t)t.i1, e.fa = t.f;
-    }
-    if (t2.i1 < P) {
-        e.b0 = 0xffffu, e.b1 = 0u, e.fb = 0.0f;
-    } else {
-        const BlurTap t = blur_tap((uint32_t)t2.i1, w, kBlurOff[1], wq);
-        e.b0 = (uint16_t)t.i0, e.b1 = (uint16_t)t.i1, e.fb = t.f;
-    }
-    out[c] = e;
-}
 
 __host__ __device__ inline uint32_t front_lds_bytes(const FrontGeom& g) {
     // grey rows + queues B/C (the blur column table lives there first: 24 B x n_var <= 8 B x ts, checked on the host)
