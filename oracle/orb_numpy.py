@@ -40,8 +40,31 @@ def _pattern():
 PATTERN = _pattern()
 
 
-def to_f16_bits(a):
-    return np.asarray(a, dtype=np.float32).astype(np.float16).view(np.uint16)
+def to_f16_bits(a, rtz=0):
+    """binary32 -> binary16 bit patterns, round to nearest even (CRD-3); rtz: toward zero (the `f16_round` switch: a store to an
+    R16Float target may round either way under Vulkan) -- the nearest-even result stepped back where it overshot."""
+    a = np.asarray(a, dtype=np.float32)
+    h = a.astype(np.float16)
+    if rtz:
+        over = np.abs(h.astype(np.float32)) > np.abs(a)  # finite values only on this path
+        h = np.where(over, np.nextafter(h, np.float16(0)), h).astype(np.float16)
+    return h.view(np.uint16)
+
+
+def fma32(a, b, c):
+    """fl32(a * b + c) with ONE rounding, for binary32 arrays -- NumPy has no fused multiply-add.  a * b is exact in binary64
+    (48 significant bits); the sum with c is formed there with its rounding error (TwoSum), rounded TO ODD (of the two
+    binary64 neighbours of the exact sum the one with an odd significand), and that is rounded to binary32: with 29 spare bits
+    the second rounding cannot see a tie that is not one.  Finite operands whose result is a normal binary32 (all this path has)."""
+    p = np.asarray(a, dtype=np.float32).astype(np.float64) * np.asarray(b, dtype=np.float32).astype(np.float64)
+    c = np.broadcast_to(np.asarray(c, dtype=np.float32).astype(np.float64), p.shape)
+    s = p + c
+    bb = s - p
+    err = (p - (s - bb)) + (c - bb)  # exact: p + c = s + err
+    even = (s.view(np.int64) & 1) == 0
+    toward = np.where(err > 0, np.inf, -np.inf)
+    s = np.where((err != 0) & even, np.nextafter(s, toward), s)
+    return s.astype(np.float32)
 
 
 def from_f16_bits(a):
@@ -53,18 +76,28 @@ def level_sizes(W, H, depth):
 
 
 # ------------------------------------------------------------------ stages
-def grayscale(rgba):
+def luminance(r, g, b, contract=0, dot_order=0):
+    """dot(color, vec4(0.229, 0.587, 0.114, 0.0)) (grayscale.wgsl:36) in the four forms a shader compiler can give it: products and
+    sums rounded one by one or as one product and a chain of fmas (`contract`), reduced from the first component up or from the
+    last one down (`dot_order`; the alpha term is +0 either way)."""
+    wr, wg, wb = F(0.229), F(0.587), F(0.114)
+    first, last = ((r, wr), (b, wb)) if not dot_order else ((b, wb), (r, wr))
+    if contract:
+        return fma32(last[0], last[1], fma32(g, wg, first[0] * first[1]))
+    return (first[0] * first[1] + g * wg) + last[0] * last[1]
+
+
+def grayscale(rgba, contract=0, dot_order=0, f16_round=0):
     """grayscale.wgsl: luminance of the vertically mirrored texel, stored as R16Float."""
     img = np.asarray(rgba, dtype=np.uint8)[::-1, :, :]
     chan = img.astype(np.float32) / F(255.0)
-    lum = (F(0.229) * chan[..., 0] + F(0.587) * chan[..., 1]) + F(0.114) * chan[..., 2]
-    return to_f16_bits(lum)
+    return to_f16_bits(luminance(chan[..., 0], chan[..., 1], chan[..., 2], contract, dot_order), f16_round)
 
 
-def grayscale_y8(y8):
+def grayscale_y8(y8, f16_round=0):
     """Y8 input variant (not in the reference's code): the Y sample of the vertically mirrored texel as R16Float."""
     img = np.asarray(y8, dtype=np.uint8)[::-1, :]
-    return to_f16_bits(img.astype(np.float32) / F(255.0))
+    return to_f16_bits(img.astype(np.float32) / F(255.0), f16_round)
 
 
 def _weight(frac, wbits):
@@ -85,7 +118,7 @@ def _lerp_axis_coords(n_dst, n_src, wbits=0):
     return i0, i1, frac
 
 
-def mip(src_bits, wbits=0):
+def mip(src_bits, wbits=0, f16_round=0):
     """blit.wgsl: bilinear sample of the previous level at each target texel centre."""
     src = from_f16_bits(src_bits)
     hs, ws = src.shape
@@ -93,17 +126,17 @@ def mip(src_bits, wbits=0):
     if ws == 2 * wd and hs == 2 * hd:
         top = src[0::2, 0::2] + src[0::2, 1::2]
         bot = src[1::2, 0::2] + src[1::2, 1::2]
-        return to_f16_bits((top + bot) * F(0.25))
+        return to_f16_bits((top + bot) * F(0.25), f16_round)
     x0, x1, fx = _lerp_axis_coords(wd, ws, wbits)
     y0, y1, fy = _lerp_axis_coords(hd, hs, wbits)
     a, b = src[np.ix_(y0, x0)], src[np.ix_(y0, x1)]
     c, d = src[np.ix_(y1, x0)], src[np.ix_(y1, x1)]
     top = a + fx[None, :] * (b - a)
     bot = c + fx[None, :] * (d - c)
-    return to_f16_bits(top + fy[:, None] * (bot - top))
+    return to_f16_bits(top + fy[:, None] * (bot - top), f16_round)
 
 
-def blur_pass(src_bits, wbits=0):
+def blur_pass(src_bits, wbits=0, contract=0, f16_round=0):
     """gaussian_blur_x.wgsl used for BOTH passes (orb.rs:399-402); offsets in UV units; flipped v."""
     src = from_f16_bits(src_bits)[::-1, :]
     h, w = src.shape
@@ -117,9 +150,9 @@ def blur_pass(src_bits, wbits=0):
         i0 = np.clip(c0.astype(np.int64), 0, w - 1)
         i1 = np.clip(c0.astype(np.int64) + 1, 0, w - 1)
         t0, t1 = src[:, i0], src[:, i1]
-        sample = t0 + frac[None, :] * (t1 - t0)
-        acc = acc + sample * wgt
-    return to_f16_bits(acc)
+        sample = t0 + frac[None, :] * (t1 - t0)  # the sampler's filter: not shader arithmetic, never contracted
+        acc = fma32(sample, wgt, acc) if contract else acc + sample * wgt  # `result += sample * weight` (gaussian_blur_x.wgsl:58)
+    return to_f16_bits(acc, f16_round)
 
 
 def _streak12(mask):
@@ -227,7 +260,17 @@ def fast(gray_levels_bits, threshold, oob="zero"):
     return np.array(rows, dtype=np.uint32).reshape(-1, 4)
 
 
-def brief(blur_levels_bits, corners, oob="zero"):
+def rotate(ct, st, x, y, contract=0, dot_order=0):
+    """mat2x2f(ct, -st, st, ct) * vec2(x, y) (brief.wgsl:38-54, column-major): x * column 0 + y * column 1.  Unfused, or with one of
+    the two products fused into the sum: the second term onto the first product (dot_order 0) or the first onto the second (1)."""
+    if not contract:
+        return ct * x + st * y, (-st) * x + ct * y
+    if not dot_order:
+        return fma32(st, y, ct * x), fma32(ct, y, (-st) * x)
+    return fma32(ct, x, st * y), fma32(-st, x, ct * y)
+
+
+def brief(blur_levels_bits, corners, oob="zero", contract=0, dot_order=0):
     """brief.wgsl: rotated BRIEF-256; returns uint32 (n, 8)."""
     corners = np.asarray(corners, dtype=np.uint32).reshape(-1, 4)
     n = corners.shape[0]
@@ -240,10 +283,8 @@ def brief(blur_levels_bits, corners, oob="zero"):
     py = corners[:, 1].astype(np.int64)
     for j in range(256):
         ax, ay, bx, by = (F(v) for v in PATTERN[j])
-        rax = ct * ax + st * ay
-        ray = (-st) * ax + ct * ay
-        rbx = ct * bx + st * by
-        rby = (-st) * bx + ct * by
+        rax, ray = rotate(ct, st, ax, ay, contract, dot_order)
+        rbx, rby = rotate(ct, st, bx, by, contract, dot_order)
         tax, tay = np.trunc(rax).astype(np.int64) + px, np.trunc(ray).astype(np.int64) + py
         tbx, tby = np.trunc(rbx).astype(np.int64) + px, np.trunc(rby).astype(np.int64) + py
         va = np.zeros(n, dtype=np.float32)
@@ -257,18 +298,23 @@ def brief(blur_levels_bits, corners, oob="zero"):
     return out
 
 
-def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, y8=False, oob="zero", weight_bits=0):
-    """orb.rs:469-557 stage order (y8: the frame is a one-byte-per-pixel Y plane).  oob / weight_bits: the two
-    implementation-defined switches (out-of-level loads, sampler weight precision); defaults = CRD-6 / CRD-5."""
-    gray = [grayscale_y8(rgba) if y8 else grayscale(rgba)]
+CONTRACT_LUM, CONTRACT_BLUR, CONTRACT_ROT = 1, 2, 4
+
+
+def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, y8=False, oob="zero", weight_bits=0, contract=0, dot_order=0,
+            f16_round=0):
+    """orb.rs:469-557 stage order (y8: the frame is a one-byte-per-pixel Y plane).  oob / weight_bits / contract (a bit per stage) /
+    dot_order / f16_round: the implementation-defined switches (out-of-level loads, sampler weight precision, fused multiply-adds,
+    reduction order, rounding of the R16Float stores); defaults = CRD-6 / CRD-5 / CRD-2, -5, -10 / CRD-3."""
+    gray = [grayscale_y8(rgba, f16_round) if y8 else grayscale(rgba, contract & CONTRACT_LUM, dot_order, f16_round)]
     for _ in range(1, depth):
-        gray.append(mip(gray[-1], weight_bits))
-    tmp = [blur_pass(g, weight_bits) for g in gray]
-    blur = [blur_pass(t, weight_bits) for t in tmp]
+        gray.append(mip(gray[-1], weight_bits, f16_round))
+    tmp = [blur_pass(g, weight_bits, contract & CONTRACT_BLUR, f16_round) for g in gray]
+    blur = [blur_pass(t, weight_bits, contract & CONTRACT_BLUR, f16_round) for t in tmp]
     kps = fast(gray, threshold, oob)
     total = kps.shape[0]
     kps = kps[:max_features]
-    desc = brief(blur, kps, oob)
+    desc = brief(blur, kps, oob, contract & CONTRACT_ROT, dot_order)
     return dict(total=total, corners=kps, descriptors=desc, gray=gray, blur=blur)
 
 

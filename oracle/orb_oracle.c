@@ -14,6 +14,8 @@
 
 #include "orb_pattern.h"
 
+static const orc_impl_t ORC_IMPL_DEFAULT = {ORC_OOB_ZERO, 0, 0, 0, 0};
+
 /* ------------------------------------------------------------------------------------------
  * scalar helpers
  * ---------------------------------------------------------------------------------------- */
@@ -31,18 +33,21 @@ static float bits_f32(uint32_t u) {
 }
 
 /* CRD-3: binary32 -> binary16, round to nearest even, subnormal results kept.  Render-target
- * stores of an R16Float attachment (orb.rs:151, 285, 393, 404). */
-uint16_t orc_f32_to_f16(float v) {
+ * stores of an R16Float attachment (orb.rs:151, 228, 296, 311).
+ * Implementation-defined point (orc_impl_t::f16_round): Vulkan leaves the rounding of a format conversion on a store to the
+ * implementation -- either neighbour is a legal result.  rtz != 0 is the other deterministic reading: round toward zero
+ * (truncation; a finite value beyond the largest binary16 stays at 65504). */
+uint16_t orc_f32_to_f16_mode(float v, uint32_t rtz) {
     uint32_t u = f32_bits(v);
     uint32_t sign = (u >> 16) & 0x8000u;
     uint32_t mag = u & 0x7fffffffu;
     if (mag >= 0x7f800000u) { /* inf / nan */
         return (uint16_t)(sign | 0x7c00u | ((mag > 0x7f800000u) ? 0x200u : 0u));
     }
-    if (mag >= 0x47800000u) { /* >= 65536 -> rounds to inf (65520 and up round to inf below) */
-        return (uint16_t)(sign | 0x7c00u);
+    if (mag >= 0x47800000u) { /* >= 65536 -> rounds to inf (65520 and up round to inf below); toward zero: the largest finite */
+        return (uint16_t)(sign | (rtz ? 0x7bffu : 0x7c00u));
     }
-    if (mag < 0x33000000u) { /* < 2^-25: rounds to zero (2^-25 itself ties to even = 0) */
+    if (mag < (rtz ? 0x33800000u : 0x33000000u)) { /* < 2^-25: rounds to zero (2^-25 itself ties to even = 0); toward zero: < 2^-24 */
         return (uint16_t)sign;
     }
     int32_t e = (int32_t)(mag >> 23) - 127; /* unbiased */
@@ -59,11 +64,12 @@ uint16_t orc_f32_to_f16(float v) {
     uint32_t q = m >> shift;
     uint32_t rem = m & ((1u << shift) - 1u);
     uint32_t halfway = 1u << (shift - 1);
-    if (rem > halfway || (rem == halfway && (q & 1u))) q++;
+    if (!rtz && (rem > halfway || (rem == halfway && (q & 1u)))) q++;
     /* normal: q carries the hidden bit (0x400); adding lets a mantissa overflow bump the exponent */
     uint32_t h = (half_exp == 0) ? q : (((half_exp - 1) << 10) + q);
     return (uint16_t)(sign | h);
 }
+uint16_t orc_f32_to_f16(float v) { return orc_f32_to_f16_mode(v, 0u); }
 
 float orc_f16_to_f32(uint16_t h) {
     uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
@@ -153,31 +159,59 @@ void orc_pyramid_layout(uint32_t W, uint32_t H, uint32_t depth, orc_pyramid_t *p
 void orc_grayscale(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray) { orc_grayscale_impl(rgba, W, H, gray, 0); }
 
 /* Implementation-defined point (CRD-13): WGSL lets a shader compiler contract a product and a sum into one fused
- * multiply-add, and `dot()` (grayscale.wgsl:36) has no evaluation order of its own -- GPU compilers commonly lower it to one
- * multiply and a chain of fmas.  contract == 0: every product and sum rounded on its own, left to right (CRD-2, the
- * default).  contract == 1: the contracting compiler, in source order -- r*wr, then fma(g, wg, .), then fma(b, wb, .); the
- * alpha term is a * 0.0 = +0 and changes nothing. */
-void orc_grayscale_impl(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray, uint32_t contract) {
+ * multiply-add, and `dot()` (grayscale.wgsl:36) has no evaluation order of its own.  Four forms a real compiler can produce,
+ * chosen by orc_impl_t::contract & ORC_CONTRACT_LUM and orc_impl_t::dot_order:
+ *   contract 0, order 0   ((r*wr + g*wg) + b*wb) [+ a*0]   every product and sum rounded on its own, first component first
+ *                         (CRD-2, the default);
+ *   contract 1, order 0   t = r*wr; t = fma(g, wg, t); t = fma(b, wb, t) [; fma(a, 0, t) = t]   one multiply and a chain of
+ *                         fmas, first component first (LLVM-based compilers);
+ *   contract 0, order 1   ((a*0 + b*wb) + g*wg) + r*wr = (b*wb + g*wg) + r*wr   the reduction from the LAST component down --
+ *                         Mesa's NIR lowers an inexact fdot that way (nir_lower_alu_to_scalar, reverse_order), also on
+ *                         hardware without an fma such as the reference's stated target, a Raspberry Pi 5 (README.md:20);
+ *   contract 1, order 1   t = a*0 = +0; t = fma(b, wb, t) = fl(b*wb); t = fma(g, wg, t); t = fma(r, wr, t)   the same
+ *                         lowering on hardware with an fma.
+ * The alpha term is +0 in every form (alpha is finite) and changes nothing. */
+static float luminance_form(float r, float g, float b, uint32_t contract, uint32_t last_first) {
+    const float wr = 0.229f, wg = 0.587f, wb = 0.114f; /* grayscale.wgsl:36: 0.229, not 0.299 */
+    if (!last_first) {
+        if (contract) {
+            float t = wr * r;
+            t = fmaf(g, wg, t);
+            return fmaf(b, wb, t);
+        }
+        float pr = wr * r;
+        float pg = wg * g;
+        float pb = wb * b;
+        return (pr + pg) + pb;
+    }
+    if (contract) {
+        float t = wb * b;
+        t = fmaf(g, wg, t);
+        return fmaf(r, wr, t);
+    }
+    float pb = wb * b;
+    float pg = wg * g;
+    float pr = wr * r;
+    return (pb + pg) + pr;
+}
+
+void orc_grayscale_fp(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray, const orc_impl_t *impl) {
+    const uint32_t ct = impl->contract & ORC_CONTRACT_LUM, lf = impl->dot_order, rtz = impl->f16_round;
     for (uint32_t y = 0; y < H; y++) {
         const uint8_t *src = rgba + (size_t)(H - 1 - y) * W * 4;
         for (uint32_t x = 0; x < W; x++) {
             float r = orc_unorm8(src[4 * x + 0]);
             float g = orc_unorm8(src[4 * x + 1]);
             float b = orc_unorm8(src[4 * x + 2]);
-            float lum;
-            if (contract) {
-                float t = 0.229f * r; /* grayscale.wgsl:36: 0.229, not 0.299 */
-                t = fmaf(g, 0.587f, t);
-                lum = fmaf(b, 0.114f, t);
-            } else {
-                float pr = 0.229f * r;
-                float pg = 0.587f * g;
-                float pb = 0.114f * b;
-                lum = (pr + pg) + pb;
-            }
-            gray[(size_t)y * W + x] = orc_f32_to_f16(lum);
+            gray[(size_t)y * W + x] = orc_f32_to_f16_mode(luminance_form(r, g, b, ct, lf), rtz);
         }
     }
+}
+
+/* contract != 0: the contracting compiler in source order (round 4's one form) */
+void orc_grayscale_impl(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray, uint32_t contract) {
+    orc_impl_t impl = {ORC_OOB_ZERO, 0, contract ? ORC_CONTRACT_ALL : 0u, 0, 0};
+    orc_grayscale_fp(rgba, W, H, gray, &impl);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -204,6 +238,14 @@ void orc_mip(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint3
 }
 
 void orc_mip_impl(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint32_t wd, uint32_t hd, uint32_t wbits) {
+    orc_impl_t impl = {ORC_OOB_ZERO, wbits, 0, 0, 0};
+    orc_mip_fp(src, ws, hs, dst, wd, hd, &impl);
+}
+
+/* The blit is one textureSample per target texel (blit.wgsl:35): sampler arithmetic, nothing a shader compiler contracts; the
+ * store to the R16Float level follows orc_impl_t::f16_round. */
+void orc_mip_fp(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint32_t wd, uint32_t hd, const orc_impl_t *impl) {
+    const uint32_t wbits = impl->sampler_weight_bits, rtz = impl->f16_round;
     if (ws == 2 * wd && hs == 2 * hd) { /* weights are exactly 1/2 at any precision */
         for (uint32_t y = 0; y < hd; y++)
             for (uint32_t x = 0; x < wd; x++) {
@@ -214,7 +256,7 @@ void orc_mip_impl(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, 
                 float top = a + b;
                 float bot = c + d;
                 float v = (top + bot) * 0.25f;
-                dst[(size_t)y * wd + x] = orc_f32_to_f16(v);
+                dst[(size_t)y * wd + x] = orc_f32_to_f16_mode(v, rtz);
             }
         return;
     }
@@ -240,7 +282,7 @@ void orc_mip_impl(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, 
             float bot = c + fx * dcd;
             float dtb = bot - top;
             float v = top + fy * dtb;
-            dst[(size_t)y * wd + x] = orc_f32_to_f16(v);
+            dst[(size_t)y * wd + x] = orc_f32_to_f16_mode(v, rtz);
         }
     }
 }
@@ -263,6 +305,14 @@ void orc_blur_pass_impl(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *d
 /* contract (CRD-13): `result += textureSample(..) * weight` (gaussian_blur_x.wgsl:58) as one fma per tap.  The bilinear
  * filter itself is the sampler's arithmetic, not the shader's: it keeps CRD-5 (and the weight precision switch). */
 void orc_blur_pass_impl2(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, uint32_t wbits, uint32_t contract) {
+    orc_impl_t impl = {ORC_OOB_ZERO, wbits, contract ? ORC_CONTRACT_ALL : 0u, 0, 0};
+    orc_blur_pass_fp(src, w, h, dst, &impl);
+}
+
+/* orc_impl_t::contract & ORC_CONTRACT_BLUR; the loop is sequential as written (no order for a compiler to choose), so
+ * dot_order does not apply; the store follows f16_round. */
+void orc_blur_pass_fp(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, const orc_impl_t *impl) {
+    const uint32_t wbits = impl->sampler_weight_bits, contract = impl->contract & ORC_CONTRACT_BLUR, rtz = impl->f16_round;
     float fw = (float)w;
     for (uint32_t y = 0; y < h; y++) {
         const uint16_t *row = src + (size_t)(h - 1 - y) * w; /* flipped v, sampled at the row centre */
@@ -286,7 +336,7 @@ void orc_blur_pass_impl2(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *
                     acc = acc + ws;
                 }
             }
-            dst[(size_t)y * w + x] = orc_f32_to_f16(acc);
+            dst[(size_t)y * w + x] = orc_f32_to_f16_mode(acc, rtz);
         }
     }
 }
@@ -397,30 +447,51 @@ void orc_brief_impl(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const or
     orc_brief_impl2(blur_pyr, lay, corners, n, oob, 0, out);
 }
 
-/* contract (CRD-13): `rotation_matrix * p` (brief.wgsl:53-54) is p.x * column 0 + p.y * column 1; contracted, the second
- * term is fused onto the first product: (fma(st, y, ct*x), fma(ct, y, -st*x)). */
+/* contract (CRD-13): `rotation_matrix * p` (brief.wgsl:53-54) is p.x * column 0 + p.y * column 1: (ct*x + st*y, -st*x + ct*y).
+ * Unfused the two-term sum has one value whatever the order.  Contracted (orc_impl_t::contract & ORC_CONTRACT_ROT), one of the
+ * two products is fused into the sum, and which one is the compiler's choice (orc_impl_t::dot_order):
+ *   order 0   the first term is the product, the second is fused onto it: (fma(st, y, ct*x), fma(ct, y, -st*x));
+ *   order 1   the last column first -- Mesa's spirv_to_nir builds matrix * vector from the last column down:
+ *             (fma(ct, x, st*y), fma(-st, x, ct*y)). */
+void orc_brief_rotate(uint32_t angle_code, int px, int py, uint32_t contract, uint32_t last_first, float *rx, float *ry) {
+    float theta = (float)angle_code / 1000.0f; /* brief.wgsl:35 */
+    float ct = (float)cos((double)theta);
+    float st = (float)sin((double)theta);
+    float nst = -st;
+    float x = (float)px, y = (float)py;
+    /* mat2x2f(ct,-st, st,ct) * p, column-major  brief.wgsl:38-54 */
+    float x0 = ct * x, x1 = st * y, y0 = nst * x, y1 = ct * y;
+    if (!contract) {
+        *rx = x0 + x1;
+        *ry = y0 + y1;
+    } else if (!last_first) {
+        *rx = fmaf(st, y, x0);
+        *ry = fmaf(ct, y, y0);
+    } else {
+        *rx = fmaf(ct, x, x1);
+        *ry = fmaf(nst, x, y1);
+    }
+}
+
 void orc_brief_impl2(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
                      uint32_t oob, uint32_t contract, orc_descriptor_t *out) {
+    orc_impl_t impl = {oob, 0, contract ? ORC_CONTRACT_ALL : 0u, 0, 0};
+    orc_brief_fp(blur_pyr, lay, corners, n, &impl, out);
+}
+
+void orc_brief_fp(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
+                  const orc_impl_t *impl, orc_descriptor_t *out) {
+    const uint32_t oob = impl->oob, contract = impl->contract & ORC_CONTRACT_ROT, lf = impl->dot_order;
     for (uint32_t fidx = 0; fidx < n; fidx++) {
         const orc_corner_t *k = &corners[fidx];
         uint32_t oct = k->octave;
-        float theta = (float)k->angle / 1000.0f; /* brief.wgsl:35 */
-        float ct = (float)cos((double)theta);
-        float st = (float)sin((double)theta);
-        float nst = -st;
         for (uint32_t word = 0; word < 8; word++) {
             uint32_t bits = 0;
             for (uint32_t i = 0; i < 32; i++) {
                 const int8_t *row = &ORC_BRIEF_PATTERN[4 * ((word << 5) | i)];
-                float ax = (float)row[0], ay = (float)row[1], bx = (float)row[2], by = (float)row[3];
-                /* mat2x2f(ct,-st, st,ct) * p, column-major: (ct*x + st*y, -st*x + ct*y)  brief.wgsl:38-54 */
-                float a0 = ct * ax, a1 = st * ay, a2 = nst * ax, a3 = ct * ay;
-                float b0 = ct * bx, b1 = st * by, b2 = nst * bx, b3 = ct * by;
-                float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
-                if (contract) {
-                    rax = fmaf(st, ay, a0), ray = fmaf(ct, ay, a2);
-                    rbx = fmaf(st, by, b0), rby = fmaf(ct, by, b2);
-                }
+                float rax, ray, rbx, rby;
+                orc_brief_rotate(k->angle, row[0], row[1], contract, lf, &rax, &ray);
+                orc_brief_rotate(k->angle, row[2], row[3], contract, lf, &rbx, &rby);
                 int64_t tax = (int64_t)(int32_t)rax + (int64_t)(int32_t)k->x; /* vec2i() truncates */
                 int64_t tay = (int64_t)(int32_t)ray + (int64_t)(int32_t)k->y;
                 int64_t tbx = (int64_t)(int32_t)rbx + (int64_t)(int32_t)k->x;
@@ -447,13 +518,15 @@ void orc_brief_impl2(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const o
  * and the vertical mirror of the full-screen pass (Q2, grayscale.wgsl:16-25) is kept, so that everything downstream --
  * mips, blur, detector, descriptors and every keypoint coordinate -- is the literal path's, unchanged. */
 void orc_grayscale_y8(const uint8_t *y8, uint32_t W, uint32_t H, uint16_t *gray) {
+    orc_grayscale_y8_fp(y8, W, H, gray, &ORC_IMPL_DEFAULT);
+}
+void orc_grayscale_y8_fp(const uint8_t *y8, uint32_t W, uint32_t H, uint16_t *gray, const orc_impl_t *impl) {
     for (uint32_t y = 0; y < H; y++) {
         const uint8_t *src = y8 + (size_t)(H - 1 - y) * W;
-        for (uint32_t x = 0; x < W; x++) gray[(size_t)y * W + x] = orc_f32_to_f16(orc_unorm8(src[x]));
+        for (uint32_t x = 0; x < W; x++) gray[(size_t)y * W + x] = orc_f32_to_f16_mode(orc_unorm8(src[x]), impl->f16_round);
     }
 }
 
-static const orc_impl_t ORC_IMPL_DEFAULT = {ORC_OOB_ZERO, 0, 0};
 
 static int extract_impl(const uint8_t *frame, int y8, uint32_t W, uint32_t H, uint32_t depth, float threshold,
                         uint32_t max_features, const orc_impl_t *impl, orc_corner_t *corners, orc_descriptor_t *descriptors,
@@ -462,7 +535,9 @@ static int extract_impl(const uint8_t *frame, int y8, uint32_t W, uint32_t H, ui
 int orc_extract_impl(const uint8_t *frame, int y8, uint32_t W, uint32_t H, uint32_t depth, float threshold,
                      uint32_t max_features, const orc_impl_t *impl, orc_corner_t *corners, orc_descriptor_t *descriptors,
                      uint32_t *total, uint16_t *gray_pyr, uint16_t *blur_pyr) {
-    if (impl && (impl->oob > ORC_OOB_UMIN || impl->sampler_weight_bits > 23 || impl->contract > 1)) return -1;
+    if (impl && (impl->oob > ORC_OOB_UMIN || impl->sampler_weight_bits > 23 || impl->contract > ORC_CONTRACT_ALL || impl->dot_order > 1 ||
+                 impl->f16_round > 1))
+        return -1;
     return extract_impl(frame, y8, W, H, depth, threshold, max_features, impl ? impl : &ORC_IMPL_DEFAULT, corners, descriptors,
                         total, gray_pyr, blur_pyr);
 }
@@ -484,7 +559,7 @@ int orc_extract_y8(const uint8_t *y8, uint32_t W, uint32_t H, uint32_t depth, fl
 static int extract_impl(const uint8_t *rgba, int y8, uint32_t W, uint32_t H, uint32_t depth, float threshold,
                         uint32_t max_features, const orc_impl_t *impl, orc_corner_t *corners, orc_descriptor_t *descriptors,
                         uint32_t *total, uint16_t *gray_pyr, uint16_t *blur_pyr) {
-    const uint32_t wbits = impl->sampler_weight_bits, oob = impl->oob, contract = impl->contract;
+    const uint32_t oob = impl->oob;
     if (!rgba || !W || !H || depth < 1 || depth > ORC_MAX_LEVELS || !total) return -1;
     orc_pyramid_t lay;
     orc_pyramid_layout(W, H, depth, &lay);
@@ -498,17 +573,17 @@ static int extract_impl(const uint8_t *rgba, int y8, uint32_t W, uint32_t H, uin
         return -1;
     }
     if (y8)
-        orc_grayscale_y8(rgba, W, H, gray);
+        orc_grayscale_y8_fp(rgba, W, H, gray, impl);
     else
-        orc_grayscale_impl(rgba, W, H, gray, contract);
+        orc_grayscale_fp(rgba, W, H, gray, impl);
     for (uint32_t m = 1; m < depth; m++)
-        orc_mip_impl(gray + lay.offset[m - 1], lay.w[m - 1], lay.h[m - 1], gray + lay.offset[m], lay.w[m], lay.h[m], wbits);
-    for (uint32_t m = 0; m < depth; m++) orc_blur_pass_impl2(gray + lay.offset[m], lay.w[m], lay.h[m], tmp + lay.offset[m], wbits, contract);
-    for (uint32_t m = 0; m < depth; m++) orc_blur_pass_impl2(tmp + lay.offset[m], lay.w[m], lay.h[m], blur + lay.offset[m], wbits, contract);
+        orc_mip_fp(gray + lay.offset[m - 1], lay.w[m - 1], lay.h[m - 1], gray + lay.offset[m], lay.w[m], lay.h[m], impl);
+    for (uint32_t m = 0; m < depth; m++) orc_blur_pass_fp(gray + lay.offset[m], lay.w[m], lay.h[m], tmp + lay.offset[m], impl);
+    for (uint32_t m = 0; m < depth; m++) orc_blur_pass_fp(tmp + lay.offset[m], lay.w[m], lay.h[m], blur + lay.offset[m], impl);
     uint32_t count = 0;
     orc_fast_impl(gray, &lay, threshold, oob, corners, max_features, &count);
     uint32_t stored = count < max_features ? count : max_features;
-    if (descriptors) orc_brief_impl2(blur, &lay, corners, stored, oob, contract, descriptors);
+    if (descriptors) orc_brief_fp(blur, &lay, corners, stored, impl, descriptors);
     *total = count;
     if (gray_pyr) memcpy(gray_pyr, gray, lay.total * sizeof(uint16_t));
     if (blur_pyr) memcpy(blur_pyr, blur, lay.total * sizeof(uint16_t));

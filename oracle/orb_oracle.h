@@ -89,20 +89,46 @@ int orc_extract(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, flo
  *   sampler_weight_bits   precision of a bilinear sampler's weights (gaussian_blur_x.wgsl:53-58; blit.wgsl:35 for odd
  *                         sizes): 0 = the exact binary32 fraction (CRD-5, the default), n = 1..23: the fraction rounded
  *                         to n fractional bits, halves up (8 is what GPUs commonly implement).
- *   contract              CRD-13: 0 = every binary32 product and sum of the shaders rounded on its own (CRD-2, -5, -10; the
- *                         default); 1 = a shader compiler that contracts a product and the sum that follows it into one fused
- *                         multiply-add, in source order -- WGSL permits it, and GPU compilers commonly lower `dot()`
- *                         (grayscale.wgsl:36), `result += sample * weight` (gaussian_blur_x.wgsl:58) and matrix * vector
- *                         (brief.wgsl:53-54) to fma chains.
+ *   contract              CRD-13, a bit per stage (ORC_CONTRACT_LUM | _BLUR | _ROT): 0 = every binary32 product and sum of that
+ *                         stage rounded on its own (CRD-2, -5, -10; the default); set = a shader compiler that contracts a
+ *                         product and the sum behind it into one fused multiply-add -- WGSL permits it, naga emits no
+ *                         NoContraction, and GPU compilers commonly lower `dot()` (grayscale.wgsl:36), `result += sample *
+ *                         weight` (gaussian_blur_x.wgsl:58) and matrix * vector (brief.wgsl:53-54) to fma chains.  Per stage
+ *                         because a compiler decides expression by expression.
+ *   dot_order             the order in which `dot()` and matrix * vector are reduced, which WGSL does not fix: 0 = first
+ *                         component / column first (as written; LLVM-based compilers), 1 = last first (Mesa: NIR's inexact
+ *                         fdot lowering and spirv_to_nir's matrix * vector start from the last component / column).  Changes the
+ *                         luminance with or without contraction ((r + g) + b against (b + g) + r) and the rotation only when
+ *                         contracted (which product is the fused one); the blur's accumulation is a sequential loop.
+ *   f16_round             the store to the R16Float targets (orb.rs:151, 228, 296, 311): 0 = round to nearest even (CRD-3, the
+ *                         default), 1 = toward zero -- Vulkan leaves the rounding of a format conversion to the implementation.
+ *                         Restatement and tools/pin_oracle.py only; the kernels round to nearest even.
  * The defaults are what every other entry of this header computes. */
 #define ORC_OOB_ZERO 0u
 #define ORC_OOB_CLAMP 1u
 #define ORC_OOB_UMIN 2u
+#define ORC_CONTRACT_LUM 1u
+#define ORC_CONTRACT_BLUR 2u
+#define ORC_CONTRACT_ROT 4u
+#define ORC_CONTRACT_ALL 7u
 typedef struct {
     uint32_t oob;
     uint32_t sampler_weight_bits;
     uint32_t contract;
+    uint32_t dot_order;
+    uint32_t f16_round;
 } orc_impl_t;
+uint16_t orc_f32_to_f16_mode(float v, uint32_t rtz);
+void orc_grayscale_fp(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray, const orc_impl_t *impl);
+void orc_grayscale_y8_fp(const uint8_t *y8, uint32_t W, uint32_t H, uint16_t *gray, const orc_impl_t *impl);
+void orc_mip_fp(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint32_t wd, uint32_t hd, const orc_impl_t *impl);
+void orc_blur_pass_fp(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, const orc_impl_t *impl);
+void orc_brief_fp(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
+                  const orc_impl_t *impl, orc_descriptor_t *out);
+/* One pattern point (px, py) under the rotation of brief.wgsl:35-54 at an angle code, BEFORE vec2i() truncates it (tools/pin_oracle.py
+ * asks how close a rotated coordinate lies to an integer, where an adapter's own cos / sin would flip the truncation). */
+void orc_brief_rotate(uint32_t angle_code, int px, int py, uint32_t contract, uint32_t last_first, float *rx, float *ry);
+/* round 4's forms: contract != 0 means every stage contracted, first term first */
 void orc_grayscale_impl(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray, uint32_t contract);
 void orc_blur_pass_impl2(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, uint32_t wbits, uint32_t contract);
 void orc_brief_impl2(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,

@@ -72,6 +72,15 @@ def lib():
         L.orc_brief.argtypes = [vp, ctypes.POINTER(_Pyramid), vp, u32, vp]
         L.orc_brief_impl2.argtypes = [vp, ctypes.POINTER(_Pyramid), vp, u32, u32, u32, vp]
         L.orc_brief_impl2.restype = None
+        L.orc_brief_fp.argtypes = [vp, ctypes.POINTER(_Pyramid), vp, u32, vp, vp]
+        L.orc_brief_fp.restype = None
+        L.orc_brief_rotate.argtypes = [u32, ctypes.c_int, ctypes.c_int, u32, u32, ctypes.POINTER(f32), ctypes.POINTER(f32)]
+        L.orc_brief_rotate.restype = None
+        L.orc_f32_to_f16_mode.argtypes = [f32, u32]
+        L.orc_f32_to_f16_mode.restype = ctypes.c_uint16
+        L.orc_grayscale_fp.argtypes = [vp, u32, u32, vp, vp]
+        L.orc_mip_fp.argtypes = [vp, u32, u32, vp, u32, u32, vp]
+        L.orc_blur_pass_fp.argtypes = [vp, u32, u32, vp, vp]
         L.orc_grayscale_impl.argtypes = [vp, u32, u32, vp, u32]
         L.orc_blur_pass_impl2.argtypes = [vp, u32, u32, vp, u32, u32]
         L.orc_extract.argtypes = [vp, u32, u32, u32, f32, u32, vp, vp, u32p, vp, vp]
@@ -114,8 +123,9 @@ def level_dims(W, H, depth):
     return [(int(p.w[m]), int(p.h[m]), int(p.offset[m])) for m in range(depth)], int(p.total)
 
 
-def f32_to_f16(v):
-    return int(lib().orc_f32_to_f16(float(np.float32(v))))
+def f32_to_f16(v, rtz=0):
+    """CRD-3 (round to nearest even); rtz = 1: toward zero (orc_impl_t::f16_round)."""
+    return int(lib().orc_f32_to_f16_mode(float(np.float32(v)), int(rtz)))
 
 
 def f16_to_f32(h):
@@ -177,18 +187,61 @@ def blur_pass(src, weight_bits=0):
     return out
 
 
-# The implementation-defined switches of orb_oracle.h (orc_impl_t): what a textureLoad outside the level returns, and the
-# precision of a bilinear sampler's weights.  The defaults are CRD-6 / CRD-5.
+# The implementation-defined switches of orb_oracle.h (orc_impl_t): what a textureLoad outside the level returns, the precision of a
+# bilinear sampler's weights, which stages' products and sums a shader compiler fuses (a bit per stage), the order in which it reduces
+# dot() / matrix * vector, and how a store to an R16Float target rounds.  The defaults are CRD-6 / CRD-5 / CRD-2, -5, -10 / CRD-3.
 OOB_POLICIES = {"zero": 0, "clamp": 1, "umin": 2}
+CONTRACT_LUM, CONTRACT_BLUR, CONTRACT_ROT, CONTRACT_ALL = 1, 2, 4, 7
 
 
-def _impl(oob, weight_bits, contract=0):
-    return (ctypes.c_uint32 * 3)(OOB_POLICIES[oob] if isinstance(oob, str) else int(oob), int(weight_bits), int(contract))
+def _impl(oob, weight_bits, contract=0, dot_order=0, f16_round=0):
+    return (ctypes.c_uint32 * 5)(OOB_POLICIES[oob] if isinstance(oob, str) else int(oob), int(weight_bits), int(contract), int(dot_order),
+                                 int(f16_round))
 
 
-def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=False, oob="zero", weight_bits=0, y8=False, contract=0):
+def grayscale_fp(rgba, contract=0, dot_order=0, f16_round=0):
+    """grayscale.wgsl:12-38 under the arithmetic switches (contract & CONTRACT_LUM, dot_order, f16_round)."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    H, W = rgba.shape[:2]
+    out = np.empty((H, W), dtype=np.uint16)
+    impl = _impl("zero", 0, contract, dot_order, f16_round)
+    lib().orc_grayscale_fp(_ptr(rgba), W, H, _ptr(out), ctypes.cast(impl, ctypes.c_void_p))
+    return out
+
+
+def blur_pass_fp(src, weight_bits=0, contract=0, f16_round=0):
+    src = np.ascontiguousarray(src, dtype=np.uint16)
+    h, w = src.shape
+    out = np.empty((h, w), dtype=np.uint16)
+    impl = _impl("zero", weight_bits, contract, 0, f16_round)
+    lib().orc_blur_pass_fp(_ptr(src), w, h, _ptr(out), ctypes.cast(impl, ctypes.c_void_p))
+    return out
+
+
+def mip_fp(src, wd=None, hd=None, weight_bits=0, f16_round=0):
+    src = np.ascontiguousarray(src, dtype=np.uint16)
+    hs, ws = src.shape
+    wd = max(1, ws >> 1) if wd is None else wd
+    hd = max(1, hs >> 1) if hd is None else hd
+    out = np.empty((hd, wd), dtype=np.uint16)
+    impl = _impl("zero", weight_bits, 0, 0, f16_round)
+    lib().orc_mip_fp(_ptr(src), ws, hs, _ptr(out), wd, hd, ctypes.cast(impl, ctypes.c_void_p))
+    return out
+
+
+def brief_rotate(code, px, py, contract=0, dot_order=0):
+    """One pattern point under brief.wgsl:35-54's rotation at an angle code, before vec2i() truncates it: (rx, ry) as binary32."""
+    rx, ry = ctypes.c_float(0), ctypes.c_float(0)
+    lib().orc_brief_rotate(int(code), int(px), int(py), 1 if (int(contract) & CONTRACT_ROT) else 0, int(dot_order), ctypes.byref(rx),
+                           ctypes.byref(ry))
+    return np.float32(rx.value), np.float32(ry.value)
+
+
+def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=False, oob="zero", weight_bits=0, y8=False, contract=0,
+            dot_order=0, f16_round=0):
     """Whole frame.  Returns dict(total, corners[structured], descriptors[u32 (n,8)], gray, blur).
-    oob / weight_bits / contract: the implementation-defined switches (orc_impl_t); y8: a one-byte-per-pixel frame."""
+    oob / weight_bits / contract (bits CONTRACT_*) / dot_order / f16_round: the implementation-defined switches (orc_impl_t);
+    y8: a one-byte-per-pixel frame."""
     rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
     H, W = rgba.shape[:2]
     corners = np.zeros(max_features, dtype=CORNER_DTYPE)
@@ -197,7 +250,7 @@ def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=Fal
     _, ntex = level_dims(W, H, depth)
     gray = np.zeros(ntex, dtype=np.uint16) if planes else None
     blur = np.zeros(ntex, dtype=np.uint16) if planes else None
-    impl = _impl(oob, weight_bits, contract)
+    impl = _impl(oob, weight_bits, contract, dot_order, f16_round)
     rc = lib().orc_extract_impl(_ptr(rgba), 1 if y8 else 0, W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
                                 ctypes.cast(impl, ctypes.c_void_p), _ptr(corners), _ptr(desc), ctypes.byref(total),
                                 _ptr(gray) if planes else None, _ptr(blur) if planes else None)
@@ -207,10 +260,10 @@ def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=Fal
     return dict(total=total.value, corners=corners[:n], descriptors=desc[:n], gray=gray, blur=blur)
 
 
-def brief(blur_pyr, W, H, depth, corners, oob="zero", contract=0):
+def brief(blur_pyr, W, H, depth, corners, oob="zero", contract=0, dot_order=0):
     """Descriptors (n, 8) u32 of the given keypoints (CORNER_DTYPE: x, y, angle, octave) over a blur pyramid as `extract(...,
-    planes=True)["blur"]` returns it (orc_brief_impl: brief.wgsl:20-68 under an out-of-level policy).  tools/pin_oracle.py uses
-    it to ask what the restatement's descriptor is at an angle code somebody else computed."""
+    planes=True)["blur"]` returns it (orc_brief_fp: brief.wgsl:20-68 under an out-of-level policy and a rotation arithmetic).
+    tools/pin_oracle.py uses it to ask what the restatement's descriptor is at an angle code somebody else computed."""
     corners = np.ascontiguousarray(corners, dtype=CORNER_DTYPE)
     blur_pyr = np.ascontiguousarray(blur_pyr, dtype=np.uint16)
     lay, ntex = level_dims(W, H, depth)
@@ -219,8 +272,8 @@ def brief(blur_pyr, W, H, depth, corners, oob="zero", contract=0):
     lib().orc_pyramid_layout(W, H, depth, ctypes.byref(p))
     out = np.zeros((len(corners), 8), dtype=np.uint32)
     if len(corners):
-        lib().orc_brief_impl2(_ptr(blur_pyr), ctypes.byref(p), _ptr(corners), len(corners),
-                              OOB_POLICIES[oob] if isinstance(oob, str) else int(oob), int(contract), _ptr(out))
+        impl = _impl(oob, 0, contract, dot_order, 0)
+        lib().orc_brief_fp(_ptr(blur_pyr), ctypes.byref(p), _ptr(corners), len(corners), ctypes.cast(impl, ctypes.c_void_p), _ptr(out))
     return out
 
 

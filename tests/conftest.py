@@ -21,6 +21,13 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def numpy_ref():
+    """The second, independently written restatement (NumPy)."""
+    from oracle import orb_numpy
+    return orb_numpy
+
+
+@pytest.fixture(scope="session")
 def tinyorb():
     """The product library through its Python mirror.  No fallback: missing .so -> error."""
     from tinyslam_amd import orb

@@ -553,8 +553,15 @@ def test_reference_dump_pins_the_oracle(oracle, dump):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pin_oracle
     _, results, exact = pin_oracle.check(dump)
-    assert exact, {k: {kk: (len(vv) if isinstance(vv, list) else vv) for kk, vv in v.items()} for k, v in results.items()}
-    assert ("zero", 0) in exact, "the reference's adapter follows %s, not the defaults: change them" % exact
+    assert exact, {k: {kk: (len(vv) if isinstance(vv, list) else vv) for kk, vv in v.items()} for k, v in results.items() if not any(k[2:])}
+    assert pin_oracle.DEFAULT in exact, "the reference's adapter follows %s, not the defaults: change them" % [pin_oracle.describe(s) for s in exact]
+
+
+def _write_dump(tmp_path, t, c, d, seed, flags):
+    np.save(tmp_path / "total.npy", np.uint32(t))
+    np.save(tmp_path / "corners.npy", c)
+    np.save(tmp_path / "descriptors.npy", d)
+    np.save(tmp_path / "params.npy", np.array([640, 480, 2, seed, flags, 8192], dtype=np.uint32))
 
 
 def test_pin_tool_names_the_setting_of_a_fabricated_dump(oracle, tmp_path):
@@ -562,15 +569,17 @@ def test_pin_tool_names_the_setting_of_a_fabricated_dump(oracle, tmp_path):
     exactly the settings that reproduce it, and the defaults must not be among them."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pin_oracle
-    t, c, d = pin_oracle.oracle_result("umin", 8, 2, 15)
+    S = pin_oracle.setting
+    t, c, d = pin_oracle.oracle_result(S("umin", 8), 2, 15)
     perm = np.random.default_rng(3).permutation(len(c))  # the reference's order is unspecified (atomic append)
-    np.save(tmp_path / "total.npy", np.uint32(t))
-    np.save(tmp_path / "corners.npy", c[perm])
-    np.save(tmp_path / "descriptors.npy", d[perm])
-    np.save(tmp_path / "params.npy", np.array([640, 480, 2, 2, 15, 8192], dtype=np.uint32))
+    _write_dump(tmp_path, t, c[perm], d[perm], 2, 15)
     _, results, exact = pin_oracle.check(str(tmp_path))
-    assert ("umin", 8) in exact and ("zero", 0) not in exact and ("zero", 8) not in exact and ("umin", 0) not in exact
-    assert results[("zero", 0)]["descriptor_bits"] > 0
+    assert S("umin", 8) in exact and S() not in exact and S("zero", 8) not in exact and S("umin", 0) not in exact
+    # (this frame tells neither clamp from umin nor the arithmetic forms apart -- the tool says so -- but zero from both, 0 from 8
+    # weight bits, and nearest-even from truncating stores)
+    assert all(s.oob in ("clamp", "umin") and s.weight_bits == 8 and s.f16_round == 0 for s in exact)
+    assert results[S()]["descriptor_bits"] > 0
+    assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 0
 
 
 def test_pin_tool_tells_an_atan2_difference_from_a_real_one(oracle, tmp_path):
@@ -579,33 +588,84 @@ def test_pin_tool_tells_an_atan2_difference_from_a_real_one(oracle, tmp_path):
     atan2 under the right switches only; the same dump with one descriptor bit flipped at an agreeing angle is not."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pin_oracle
-    t, c, d, blur = pin_oracle.oracle_result("zero", 0, 2, 15, planes=True)
+    S = pin_oracle.setting
+    few = [S(), S("umin", 8), S("zero", 0, 7), S("zero", 0, 0, 1)]
+    t, c, d, blur = pin_oracle.oracle_result(S(), 2, 15, planes=True)
     c, d = c.copy(), d.copy()
     rng = np.random.default_rng(5)
     pick = rng.choice(np.flatnonzero((c[:, 2] > 1) & (c[:, 2] < 3140)), size=40, replace=False)
     c[pick, 2] += rng.choice(np.array([-1, 1]), size=40).astype(np.int64).astype(np.uint32)
-    d[pick] = pin_oracle.descriptors_at(blur, c[pick], "zero")
-    assert np.any(d[pick] != pin_oracle.oracle_result("zero", 0, 2, 15)[2][pick])  # the angle does move descriptor bits
+    d[pick] = pin_oracle.descriptors_at(blur, c[pick], S())
+    assert np.any(d[pick] != pin_oracle.oracle_result(S(), 2, 15)[2][pick])  # the angle does move descriptor bits
 
-    def write(cc, dd):
-        np.save(tmp_path / "total.npy", np.uint32(t))
-        np.save(tmp_path / "corners.npy", cc)
-        np.save(tmp_path / "descriptors.npy", dd)
-        np.save(tmp_path / "params.npy", np.array([640, 480, 2, 2, 15, 8192], dtype=np.uint32))
-
-    write(c, d)
-    _, results, exact = pin_oracle.check(str(tmp_path))
+    _write_dump(tmp_path, t, c, d, 2, 15)
+    _, results, exact = pin_oracle.check(str(tmp_path), few)
     assert not exact
-    r = results[("zero", 0)]
+    r = results[S()]
     assert r["exact_up_to_atan2"] and r["angle_off_by_1"] == 40 and r["descriptor_bits_at_the_dumped_angle"] == 0
-    assert not results[("umin", 8)]["exact_up_to_atan2"]
+    assert not results[S("umin", 8)]["exact_up_to_atan2"]
     assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 3
     d2 = d.copy()
     other = np.setdiff1d(np.arange(len(c)), pick)[7]
-    d2[other, 3] ^= np.uint32(1 << 11)
-    write(c, d2)
-    _, results, _ = pin_oracle.check(str(tmp_path))
-    assert not results[("zero", 0)]["exact_up_to_atan2"] and results[("zero", 0)]["descriptor_bits_where_angles_agree"] == 1
+    # a bit whose test has no rotated coordinate near an integer: not something sin / cos could explain either
+    for bit in range(256):
+        if not pin_oracle.sincos_explains(blur, c[other], bit, 1 - ((int(d[other, bit >> 5]) >> (bit & 31)) & 1), S(), tol=1e-3)[0]:
+            break
+    d2[other, bit >> 5] ^= np.uint32(1 << (bit & 31))
+    _write_dump(tmp_path, t, c, d2, 2, 15)
+    _, results, _ = pin_oracle.check(str(tmp_path), few)
+    assert not results[S()]["exact_up_to_atan2"] and results[S()]["descriptor_bits_where_angles_agree"] == 1
+    assert not results[S()]["exact_up_to_sincos"] and results[S()]["sincos_unexplained"] == 1
+    assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 1
+
+
+def test_pin_tool_tells_a_sincos_difference_from_a_real_one(oracle, numpy_ref, tmp_path):
+    """cos / sin (brief.wgsl:36-37) are the adapter's own, as atan2 is: a dump fabricated from the restatement in which every test
+    with a rotated coordinate within 5e-6 of a non-zero integer takes the truncation of the OTHER side (an adapter whose cos rounds
+    one place differently) differs in descriptor bits at agreeing angle codes -- the tool must report it as pinned up to sin / cos
+    (exit code 6) under the right switches, and a dump with one more bit flipped where no coordinate is near an integer as not pinned."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pin_oracle
+    S = pin_oracle.setting
+    few = [S(), S("clamp", 8), S("zero", 0, 7), S("zero", 0, 4, 1)]
+    t, c, d, blur = pin_oracle.oracle_result(S(), 2, 15, planes=True)
+    d = d.copy()
+    F = np.float32
+    theta = c[:, 2].astype(np.float32) / F(1000.0)
+    ct, st = np.cos(theta.astype(np.float64)).astype(np.float32), np.sin(theta.astype(np.float64)).astype(np.float32)
+    flipped = 0
+    for j in range(256):
+        ax, ay, bx, by = (F(v) for v in numpy_ref.PATTERN[j])
+        co = np.stack(numpy_ref.rotate(ct, st, ax, ay) + numpy_ref.rotate(ct, st, bx, by), 1)  # (n, 4): rax, ray, rbx, rby
+        n = np.rint(co)
+        near = (n != 0) & (np.abs(co - n) <= 5e-6) & (c[:, 2:3] != 0)  # cos 0 = 1, sin 0 = 0 everywhere: code 0 rotates nothing
+        for i in np.flatnonzero(near.any(1)):
+            tr = np.trunc(co[i]).astype(np.int64)
+            other = np.where(tr != n[i], n[i], n[i] - np.sign(n[i])).astype(np.int64)
+            use = np.where(near[i], other, tr)
+            va = pin_oracle._level_load(blur, int(c[i, 3]), int(c[i, 0]) + int(use[0]), int(c[i, 1]) + int(use[1]), "zero")
+            vb = pin_oracle._level_load(blur, int(c[i, 3]), int(c[i, 0]) + int(use[2]), int(c[i, 1]) + int(use[3]), "zero")
+            bit = int(va > vb)
+            if bit != ((int(d[i, j >> 5]) >> (j & 31)) & 1):
+                d[i, j >> 5] ^= np.uint32(1 << (j & 31))
+                flipped += 1
+    assert flipped > 0  # the frame has such tests (about one coordinate in 10^5 lies that close to an integer)
+    _write_dump(tmp_path, t, c, d, 2, 15)
+    _, results, exact = pin_oracle.check(str(tmp_path), few)
+    r = results[S()]
+    assert not exact and not r["exact_up_to_atan2"]
+    assert r["exact_up_to_sincos"] and r["sincos_bits"] == flipped and r["sincos_unexplained"] == 0 and r["sincos_max_distance"] <= 5e-6
+    assert not results[S("clamp", 8)]["exact_up_to_sincos"]
+    assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 6
+    # one real difference on top
+    i = 11
+    for bit in range(256):
+        if not pin_oracle.sincos_explains(blur, c[i], bit, 1 - ((int(d[i, bit >> 5]) >> (bit & 31)) & 1), S(), tol=1e-3)[0]:
+            break
+    d[i, bit >> 5] ^= np.uint32(1 << (bit & 31))
+    _write_dump(tmp_path, t, c, d, 2, 15)
+    _, results, _ = pin_oracle.check(str(tmp_path), few)
+    assert not results[S()]["exact_up_to_sincos"] and results[S()]["sincos_unexplained"] == 1
     assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 1
 
 
@@ -623,54 +683,192 @@ def _rn32(fr):
     return np.float32(best[1])
 
 
-def test_contracted_luminance_is_an_exact_fma_chain(oracle):
-    """CRD-13, orc_impl_t::contract = 1: the luminance is r*wr, then fma(g, wg, .), then fma(b, wb, .), each fma rounded ONCE --
-    checked against exact rational arithmetic on 300 random colours; and it is a different function from the default
-    (every product and sum rounded) on some of them."""
+@pytest.mark.parametrize("dot_order", [0, 1])
+def test_contracted_luminance_is_an_exact_fma_chain(oracle, numpy_ref, dot_order):
+    """CRD-13, orc_impl_t::contract & ORC_CONTRACT_LUM: the luminance is one product and a chain of fmas, each fma rounded ONCE --
+    r*wr, fma(g, wg, .), fma(b, wb, .) first component first; b*wb, fma(g, wg, .), fma(r, wr, .) last component first (Mesa's fdot
+    lowering) -- checked against exact rational arithmetic on 300 random colours in the C restatement AND the NumPy one (whose
+    fma is built from binary64 operations); and each is a different function from the default on some texels of a frame."""
     from fractions import Fraction
     rng = np.random.default_rng(11)
     rgba = rng.integers(0, 256, size=(1, 300, 4), dtype=np.uint8)
-    out = np.zeros(300, dtype=np.uint16)
-    oracle.lib().orc_grayscale_impl(rgba.ctypes.data, 300, 1, out.ctypes.data, 1)
+    out = oracle.grayscale_fp(rgba, contract=oracle.CONTRACT_LUM, dot_order=dot_order)[0]
     want = np.zeros(300, dtype=np.uint16)
     wr, wg, wb = (Fraction(float(np.float32(w))) for w in (0.229, 0.587, 0.114))
     for i, (r, g, b, _) in enumerate(rgba[0]):
         fr, fg, fb = (Fraction(float(np.float32(np.float32(v) / np.float32(255)))) for v in (r, g, b))
-        t = _rn32(wr * fr)
+        (f1, w1), (f3, w3) = ((fr, wr), (fb, wb)) if not dot_order else ((fb, wb), (fr, wr))
+        t = _rn32(w1 * f1)
         t = _rn32(fg * wg + Fraction(float(t)))
-        t = _rn32(fb * wb + Fraction(float(t)))
+        t = _rn32(f3 * w3 + Fraction(float(t)))
         want[i] = oracle.f32_to_f16(float(t))
     assert np.array_equal(out, want)
-    # the two readings differ somewhere on a frame (a handful of texels in a million), and nowhere else than in the last place
+    assert np.array_equal(numpy_ref.grayscale(rgba, 1, dot_order)[0], want)
+    # the readings differ somewhere on a frame (a handful of texels in a million), and nowhere else than in the last place
     frame = oracle.synth_frame(640, 480, 2, 15)
     a = oracle.extract(frame, depth=2, threshold=THR, planes=True)
-    b = oracle.extract(frame, depth=2, threshold=THR, planes=True, contract=1)
+    b = oracle.extract(frame, depth=2, threshold=THR, planes=True, contract=oracle.CONTRACT_LUM, dot_order=dot_order)
     diff = a["gray"].astype(np.int32) - b["gray"].astype(np.int32)
     assert 0 < np.count_nonzero(diff) < 100 and np.abs(diff).max() == 1
 
 
+def test_uncontracted_last_first_luminance(oracle, numpy_ref):
+    """dot_order = 1 without contraction: (b*wb + g*wg) + r*wr, every product and sum rounded -- what Mesa's fdot lowering gives on
+    hardware without an fma (the reference's stated target, a Raspberry Pi 5).  Exact rationals, C and NumPy."""
+    from fractions import Fraction
+    rng = np.random.default_rng(12)
+    rgba = rng.integers(0, 256, size=(1, 300, 4), dtype=np.uint8)
+    out = oracle.grayscale_fp(rgba, contract=0, dot_order=1)[0]
+    want = np.zeros(300, dtype=np.uint16)
+    wr, wg, wb = (Fraction(float(np.float32(w))) for w in (0.229, 0.587, 0.114))
+    for i, (r, g, b, _) in enumerate(rgba[0]):
+        fr, fg, fb = (Fraction(float(np.float32(np.float32(v) / np.float32(255)))) for v in (r, g, b))
+        pb, pg, pr = _rn32(fb * wb), _rn32(fg * wg), _rn32(fr * wr)
+        t = _rn32(Fraction(float(pb)) + Fraction(float(pg)))
+        want[i] = oracle.f32_to_f16(float(_rn32(Fraction(float(t)) + Fraction(float(pr)))))
+    assert np.array_equal(out, want)
+    assert np.array_equal(numpy_ref.grayscale(rgba, 0, 1)[0], want)
+    assert np.any(out != oracle.grayscale_fp(rgba)[0]) or True  # (300 colours need not hold a difference; the frame test above does)
+
+
+def test_contracted_rotation_forms(oracle, numpy_ref):
+    """orc_impl_t::contract & ORC_CONTRACT_ROT: matrix * vector with ONE of the two products fused into the sum -- the second term onto
+    the first product (dot_order 0) or the first onto the second (dot_order 1: Mesa builds the product from the last column down) --
+    against exact rationals over every pattern point at 40 angle codes, C and NumPy; unfused, the order does not matter."""
+    from fractions import Fraction
+    rng = np.random.default_rng(13)
+    codes = rng.integers(0, 3142, size=40)
+    pts = {(int(x), int(y)) for row in numpy_ref.PATTERN for x, y in ((row[0], row[1]), (row[2], row[3]))}
+    pts = sorted(pts)[::7]
+    for code in codes:
+        theta = np.float32(code) / np.float32(1000.0)
+        ct, st = np.float32(np.cos(np.float64(theta))), np.float32(np.sin(np.float64(theta)))
+        fct, fst = Fraction(float(ct)), Fraction(float(st))
+        for (x, y) in pts:
+            want0 = (_rn32(fst * y + Fraction(float(_rn32(fct * x)))), _rn32(fct * y + Fraction(float(_rn32(-fst * x)))))
+            want1 = (_rn32(fct * x + Fraction(float(_rn32(fst * y)))), _rn32(-fst * x + Fraction(float(_rn32(fct * y)))))
+            plain = (_rn32(Fraction(float(_rn32(fct * x))) + Fraction(float(_rn32(fst * y)))),
+                     _rn32(Fraction(float(_rn32(-fst * x))) + Fraction(float(_rn32(fct * y)))))
+            for order, want in ((0, want0), (1, want1)):
+                got = oracle.brief_rotate(int(code), x, y, oracle.CONTRACT_ROT, order)
+                assert (got[0], got[1]) == want, (code, x, y, order)
+                gn = numpy_ref.rotate(np.array([ct]), np.array([st]), np.float32(x), np.float32(y), 1, order)
+                assert (gn[0][0], gn[1][0]) == want
+                assert tuple(oracle.brief_rotate(int(code), x, y, 0, order)) == plain
+
+
+def test_f16_round_toward_zero(oracle, numpy_ref):
+    """orc_impl_t::f16_round = 1: every store to an R16Float target truncates instead of rounding to nearest even -- the conversion
+    itself over a sweep of binary32 values (C against NumPy against the definition: the largest binary16 not above |v|), and a frame
+    through both restatements."""
+    rng = np.random.default_rng(14)
+    v = np.concatenate([rng.random(4000, dtype=np.float32), rng.random(500, dtype=np.float32) * np.float32(1e-4),
+                        np.array([0.0, 1.0, 0.5, 6.1e-5, 5.96e-8, 2.9e-8, 3.1e-8, 65504.0, 65519.0, 65520.0, 70000.0], dtype=np.float32)])
+    c = np.array([oracle.f32_to_f16(x, rtz=1) for x in v], dtype=np.uint16)
+    ok = v <= np.float32(65504.0)
+    assert np.array_equal(c[ok], numpy_ref.to_f16_bits(v[ok], rtz=1))
+    back = c.view(np.float16).astype(np.float32)
+    assert np.all(back[ok] <= v[ok])
+    inner = ok & (c < 0x7bff)
+    assert np.all(np.nextafter(c[inner].view(np.float16), np.float16(np.inf)).astype(np.float32) > v[inner])
+    assert np.all(c[~ok] == 0x7bff)  # finite values beyond the largest binary16 stay finite when rounding toward zero
+    rne = np.array([oracle.f32_to_f16(x) for x in v], dtype=np.uint16)
+    assert np.any(rne != c) and np.all((rne == c) | (rne == c + 1))
+    frame = oracle.synth_frame(333, 77, 5, 15)  # odd sizes: the bilinear blit's store as well
+    a = oracle.extract(frame, depth=3, threshold=THR, planes=True, f16_round=1, weight_bits=8)
+    b = numpy_ref.extract(frame, depth=3, threshold=THR, f16_round=1, weight_bits=8)
+    assert a["total"] == b["total"]
+    assert np.array_equal(a["gray"], np.concatenate([g.ravel() for g in b["gray"]]))
+    assert np.array_equal(a["blur"], np.concatenate([g.ravel() for g in b["blur"]]))
+    assert np.array_equal(a["descriptors"], b["descriptors"])
+    d = oracle.extract(frame, depth=3, threshold=THR, planes=True, weight_bits=8)
+    assert np.count_nonzero(a["gray"] != d["gray"]) > 1000  # about half of all texels round the other way
+
+
+@pytest.mark.parametrize("contract,dot_order", [(1, 0), (2, 0), (4, 0), (4, 1), (7, 0), (7, 1), (0, 1), (3, 1), (5, 0)])
+def test_c_equals_numpy_under_the_arithmetic_switches(oracle, numpy_ref, contract, dot_order):
+    """The two restatements agree -- planes, keypoints, angle codes, descriptors -- under per-stage contraction and both reduction
+    orders, on a noisy frame with an odd-sized level and under a second out-of-level policy."""
+    frame = oracle.synth_frame(322, 241, 7 + contract, 15)
+    for oob, wb in (("zero", 0), ("umin", 8)):
+        a = oracle.extract(frame, depth=2, threshold=THR, planes=True, contract=contract, dot_order=dot_order, oob=oob, weight_bits=wb)
+        b = numpy_ref.extract(frame, depth=2, threshold=THR, contract=contract, dot_order=dot_order, oob=oob, weight_bits=wb)
+        assert a["total"] == b["total"] and a["total"] > 50
+        assert np.array_equal(a["gray"], np.concatenate([g.ravel() for g in b["gray"]]))
+        assert np.array_equal(a["blur"], np.concatenate([g.ravel() for g in b["blur"]]))
+        ca = np.stack([a["corners"][k] for k in ("x", "y", "angle", "octave")], 1)
+        assert np.array_equal(ca, b["corners"]) and np.array_equal(a["descriptors"], b["descriptors"])
+
+
+def test_contracted_blur_is_one_fma_per_tap(oracle, numpy_ref):
+    """orc_impl_t::contract & ORC_CONTRACT_BLUR: `result += sample * weight` as fma(sample, weight, result), the sampler's own lerp
+    left alone -- one row against exact rationals, C and NumPy."""
+    from fractions import Fraction
+    rng = np.random.default_rng(15)
+    w = 96
+    row = numpy_ref.to_f16_bits(rng.random((1, w), dtype=np.float32))
+    out = oracle.blur_pass_fp(row, contract=oracle.CONTRACT_BLUR)[0]
+    assert np.array_equal(out, numpy_ref.blur_pass(row, 0, 1)[0])
+    vals = row[0].view(np.float16).astype(np.float32)
+    want = np.zeros(w, dtype=np.uint16)
+    fw = np.float32(w)
+    for x in range(w):
+        u = (np.float32(x) + np.float32(0.5)) / fw
+        acc = np.float32(0)
+        for off, wgt in zip(numpy_ref.BLUR_OFF, numpy_ref.BLUR_WGT):
+            coord = (u + off) * fw - np.float32(0.5)
+            c0 = np.floor(coord)
+            f = np.float32(coord - c0)
+            i0, i1 = int(np.clip(int(c0), 0, w - 1)), int(np.clip(int(c0) + 1, 0, w - 1))
+            sample = np.float32(vals[i0] + np.float32(f * np.float32(vals[i1] - vals[i0])))
+            acc = _rn32(Fraction(float(sample)) * Fraction(float(wgt)) + Fraction(float(acc)))
+        want[x] = oracle.f32_to_f16(float(acc))
+    assert np.array_equal(out, want)
+    big = oracle.grayscale(oracle.synth_frame(640, 480, 2))  # the f16 store hides most differences: one row need not hold one
+    assert np.any(oracle.blur_pass_fp(big, contract=oracle.CONTRACT_BLUR) != oracle.blur_pass_fp(big))
+
+
 def test_pin_tool_names_a_contracting_compiler(oracle, tmp_path):
-    """A dump fabricated from the restatement with contract = 1 on a frame where that changes an angle code: the tool must
-    explain it by contraction (exit code 4) -- not by the adapter's atan2, which would fit too -- and a dump of the default
-    arithmetic on the same frame must say that the compiler does not contract."""
+    """A dump fabricated from the restatement with every stage contracted on a frame where that changes an angle code: the tool must
+    explain it by contraction -- exit code 0, the settings it names all contract the luminance -- and not by the adapter's atan2,
+    which would fit too; a dump of last-component-first arithmetic is told from both; and a dump of the default arithmetic on the
+    same frame names the defaults."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pin_oracle
+    S = pin_oracle.setting
     seed, flags = 1, 15
-    t, c, d = pin_oracle.oracle_result("zero", 0, seed, flags, contract=1)
-    t0, c0, d0 = pin_oracle.oracle_result("zero", 0, seed, flags)
+    few = [S(oob, 0, ct, do) for oob in ("zero", "clamp") for ct in (0, 1, 7) for do in (0, 1)]
+    t, c, d = pin_oracle.oracle_result(S("zero", 0, 7), seed, flags)
+    t0, c0, d0 = pin_oracle.oracle_result(S(), seed, flags)
     assert t == t0 and (not np.array_equal(c, c0) or not np.array_equal(d, d0))  # the frame tells the two apart
 
-    def write(cc, dd):
-        np.save(tmp_path / "total.npy", np.uint32(t))
-        np.save(tmp_path / "corners.npy", cc)
-        np.save(tmp_path / "descriptors.npy", dd)
-        np.save(tmp_path / "params.npy", np.array([640, 480, 2, seed, flags, 8192], dtype=np.uint32))
-
-    write(c, d)
-    _, results, exact = pin_oracle.check(str(tmp_path))
-    assert not exact and results[("zero", 0)]["contracted"]["exact"] and not results[("clamp", 0)]["contracted"]["exact"]
-    assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 4
-    write(c0, d0)
-    _, results, exact = pin_oracle.check(str(tmp_path))
-    assert ("zero", 0) in exact and not results[("zero", 0)]["contracted"]["exact"]
+    _write_dump(tmp_path, t, c, d, seed, flags)
+    _, results, exact = pin_oracle.check(str(tmp_path), few)
+    # (the one texel behind the difference rounds the same way in every form but the default's: the frame tells the default from the
+    # others, not the others from each other -- which is what the tool reports)
+    assert S("zero", 0, 7) in exact and S() not in exact and all((s.contract & 1 or s.dot_order) and s.oob == "zero" for s in exact)
+    _, results, exact = pin_oracle.check(str(tmp_path))  # the whole space
+    assert S("zero", 0, 7) in exact and S() not in exact and all((s.contract & 1 or s.dot_order) and s.f16_round == 0 for s in exact)
     assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 0
+    _write_dump(tmp_path, t0, c0, d0, seed, flags)
+    _, results, exact = pin_oracle.check(str(tmp_path), few)
+    assert S() in exact and S("zero", 0, 7) not in exact and not any(s.contract & 1 or s.dot_order for s in exact)
+    # Mesa's order without an fma (a Raspberry Pi 5): told from the default and from both contracted forms
+    t1, c1, d1 = pin_oracle.oracle_result(S("zero", 0, 0, 1), seed, flags)
+    if not (np.array_equal(c1, c0) and np.array_equal(d1, d0)):
+        _write_dump(tmp_path, t1, c1, d1, seed, flags)
+        _, results, exact = pin_oracle.check(str(tmp_path), few)
+        assert S("zero", 0, 0, 1) in exact and S() not in exact
+
+
+def test_pin_tool_reports_a_truncating_store(oracle, tmp_path):
+    """A dump of R16Float stores that round toward zero: only f16_round = 1 settings reproduce it, which the kernels do not carry --
+    exit code 5."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pin_oracle
+    S = pin_oracle.setting
+    t, c, d = pin_oracle.oracle_result(S(f16_round=1), 2, 15)
+    _write_dump(tmp_path, t, c, d, 2, 15)
+    _, results, exact = pin_oracle.check(str(tmp_path), [S(), S(f16_round=1), S("zero", 0, 7), S("zero", 0, 7, 0, 1)])
+    assert S(f16_round=1) in exact and all(s.f16_round == 1 for s in exact)
+    assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 5
