@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TINYORB_ABI_VERSION 4
+#define TINYORB_ABI_VERSION 5
 
 /* status codes (the reference panics instead: orb.rs:553 unwrap, label look-ups) */
 #define ORB_OK 0
@@ -85,12 +85,15 @@ typedef struct OrbOptions {
     uint32_t sampler_weight_bits; /* 0: bilinear weights are the exact binary32 fractions; n = 1..23: a sampler that holds
                                    * them in n fractional bits, rounded to nearest, halves up (8 is common): the blur's
                                    * lerps (gaussian_blur_x.wgsl:53-58) and the blit of an odd-sized level (blit.wgsl:35) */
-    uint32_t fp_contract;         /* CRD-13: 0 = every binary32 product and sum of the shaders rounded on its own
-                                   * (the default); 1 = a shader compiler that contracts them into fused multiply-adds, in source
-                                   * order -- dot() (grayscale.wgsl:36), `result += sample * weight` (gaussian_blur_x.wgsl:58),
-                                   * matrix * vector (brief.wgsl:53-54).  Carried by the per-stage kernels only: such a program
-                                   * runs the staged pipeline (orb_pipeline_note says so).  RGBA input, the reference's detector.
-                                   * (Took the first of two reserved words: a zero-initialised OrbOptions means what it meant.) */
+    uint32_t fp_contract;         /* CRD-13: the arithmetic WGSL leaves to the adapter's shader compiler, a mask of
+                                   * ORB_FP_*.  0 = every binary32 product and sum of the shaders rounded on its own, dot() reduced from its
+                                   * first component (the default).  ORB_FP_CONTRACT_LUMINANCE / _BLUR / _ROTATION: that stage's
+                                   * product-and-sum pairs as fused multiply-adds -- dot() (grayscale.wgsl:36), `result += sample *
+                                   * weight` (gaussian_blur_x.wgsl:58), matrix * vector (brief.wgsl:53-54).  ORB_FP_LAST_TERM_FIRST: dot()
+                                   * and matrix * vector reduced from the last component / column down (Mesa's lowering) instead of the
+                                   * first up.  Carried by the fused AND the per-stage kernels at full speed (the luminance and rotation
+                                   * forms are template instances, the blur's is a set of scalar constants).  RGBA input, the reference's
+                                   * detector.  ABI 4 knew the values 0 and 1 (= every stage contracted, per-stage kernels only). */
     uint32_t reserved[1];
 } OrbOptions;
 
@@ -98,6 +101,12 @@ typedef struct OrbOptions {
 #define ORB_OOB_CLAMP 1u /* every coordinate clamped into [0, size - 1] */
 #define ORB_OOB_UMIN 2u  /* naga's `Restrict` policy as its SPIR-V writer emits it: min(coordinate AS UNSIGNED, size - 1) --
                           * a negative coordinate lands on the LAST column / row of the level */
+
+#define ORB_FP_CONTRACT_LUMINANCE 1u
+#define ORB_FP_CONTRACT_BLUR 2u
+#define ORB_FP_CONTRACT_ROTATION 4u
+#define ORB_FP_CONTRACT_ALL 7u
+#define ORB_FP_LAST_TERM_FIRST 8u
 
 #define ORB_FLAG_STAGED 1u        /* force the one-kernel-per-stage pipeline (cross-check of the fused path) */
 #define ORB_FLAG_DOUBLE_OUTPUT 2u /* two sets of output slabs: batch k+1 computes while batch k is collated */

@@ -756,6 +756,26 @@ int orc_extract_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t W, uint32
     return rc;
 }
 
+/* The same under a setting of the implementation-defined switches (bench.py --contract: the CPU leg follows the GPU's arithmetic). */
+int orc_extract_batch_impl(const uint8_t *frames, int y8, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth, float threshold,
+                           uint32_t max_features, const orc_impl_t *impl, orc_corner_t *corners, orc_descriptor_t *descriptors,
+                           uint32_t *totals, int n_threads) {
+    int rc = 0;
+    size_t frame_bytes = (size_t)W * H * (y8 ? 1 : 4);
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int64_t f = 0; f < (int64_t)n_frames; f++) {
+        int r = orc_extract_impl(frames + (size_t)f * frame_bytes, y8, W, H, depth, threshold, max_features, impl,
+                                 corners + (size_t)f * max_features, descriptors ? descriptors + (size_t)f * max_features : NULL,
+                                 &totals[f], NULL, NULL);
+        if (r) {
+#pragma omp critical
+            rc = r;
+        }
+    }
+    return rc;
+}
+
 /* The same over Y8 frames (one byte per pixel). */
 int orc_extract_batch_y8(const uint8_t *y8, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth, float threshold,
                          uint32_t max_features, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *totals,

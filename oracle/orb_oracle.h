@@ -207,6 +207,10 @@ int orc_extract_batch(const uint8_t *rgba, uint32_t n_frames, uint32_t W, uint32
                       uint32_t max_features, orc_corner_t *corners, orc_descriptor_t *descriptors, uint32_t *totals,
                       int n_threads);
 
+int orc_extract_batch_impl(const uint8_t *frames, int y8, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t depth, float threshold,
+                           uint32_t max_features, const orc_impl_t *impl, orc_corner_t *corners, orc_descriptor_t *descriptors,
+                           uint32_t *totals, int n_threads);
+
 /* Synthetic frames: counter-based, integer only. */
 #define ORC_SYN_GRADIENT 1u
 #define ORC_SYN_BLOBS 2u

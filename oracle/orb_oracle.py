@@ -103,6 +103,8 @@ def lib():
         L.orc_extract_batch.argtypes = [vp, u32, u32, u32, u32, f32, u32, vp, vp, vp, ctypes.c_int]
         L.orc_extract_batch_y8.argtypes = [vp, u32, u32, u32, u32, f32, u32, vp, vp, vp, ctypes.c_int]
         L.orc_extract_batch.restype = ctypes.c_int
+        L.orc_extract_batch_impl.argtypes = [vp, ctypes.c_int, u32, u32, u32, u32, f32, u32, vp, vp, vp, vp, ctypes.c_int]
+        L.orc_extract_batch_impl.restype = ctypes.c_int
         L.orc_synth_frame.argtypes = [vp, u32, u32, u32, u32]
         _lib = L
     return _lib
@@ -354,12 +356,20 @@ def angle_code_signed(cy, cx):
     return int(lib().orc_angle_code_signed(float(np.float32(cy)), float(np.float32(cx))))
 
 
-def extract_batch(frames, depth=2, threshold=20.0 / 255.0, max_features=8192, n_threads=1, y8=False):
+def extract_batch(frames, depth=2, threshold=20.0 / 255.0, max_features=8192, n_threads=1, y8=False, oob="zero", weight_bits=0, contract=0,
+                  dot_order=0, f16_round=0):
     frames = np.ascontiguousarray(frames, dtype=np.uint8)
     F, H, W = frames.shape[:3]
     corners = np.zeros((F, max_features), dtype=CORNER_DTYPE)
     desc = np.zeros((F, max_features, 8), dtype=np.uint32)
     totals = np.zeros(F, dtype=np.uint32)
+    if (oob, weight_bits, contract, dot_order, f16_round) != ("zero", 0, 0, 0, 0):
+        impl = _impl(oob, weight_bits, contract, dot_order, f16_round)
+        rc = lib().orc_extract_batch_impl(_ptr(frames), 1 if y8 else 0, F, W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
+                                          ctypes.cast(impl, ctypes.c_void_p), _ptr(corners), _ptr(desc), _ptr(totals), int(n_threads))
+        if rc != 0:
+            raise ValueError("orc_extract_batch_impl failed")
+        return totals, corners, desc
     fn = lib().orc_extract_batch_y8 if y8 else lib().orc_extract_batch
     rc = fn(_ptr(frames), F, W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
             _ptr(corners), _ptr(desc), _ptr(totals), int(n_threads))

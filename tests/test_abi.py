@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(tinyorb):
     for n in names:
         assert hasattr(L, n), "libtinyorb.so does not export %s" % n
     assert sorted(tinyorb.EXPORTS) == names
-    assert L.orb_abi_version() == 4
+    assert L.orb_abi_version() == 5
 
 
 def test_record_layouts_match_reference(tinyorb):

@@ -394,45 +394,4 @@ def test_programs_on_different_threads(tinyorb, oracle):
     assert not errors, errors
 
 
-# ---------------------------------------------------------------------------------------------
-# CRD-13, OrbOptions::fp_contract: the shaders' products and sums as fma chains (a contracting shader compiler)
-# ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("W,H,depth,seed,flags", [(640, 480, 2, 1, 15), (320, 240, 3, 7, 15), (333, 211, 2, 13, 15), (1280, 720, 2, 2, 15)])
-def test_fp_contract_matches_the_contracted_oracle(tinyorb, oracle, W, H, depth, seed, flags):
-    """A program with fp_contract = 1 (it runs the per-stage kernels and says so) equals the restatement with contract = 1 -- planes,
-    counter, keypoints, angle codes, descriptors --, through the six calls and through a batch; (640x480, seed 1) is a frame on
-    which the two readings differ in an angle code, so the test could not pass on the default arithmetic."""
-    frame = oracle.synth_frame(W, H, seed, flags)
-    ref = oracle.extract(frame, depth=depth, threshold=THR, planes=True, contract=1)
-    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), hierarchy_depth=depth, initial_threshold=THR, fp_contract=1, max_batch=2)
-    with tinyorb.OrbProgram(cfg).init() as prog:
-        assert "fp_contract" in prog.pipeline_note()
-        prog.write_input_image(frame)
-        total = prog.extract_corners()
-        n = min(total, 8192)
-        _assert_frame_equal(oracle, ref, total, prog.read_corners(np.zeros(n, dtype=tinyorb.CORNER_DTYPE)),
-                            prog.read_descriptors(np.zeros((n, 8), dtype=np.uint32)))
-        dims, _ = oracle.level_dims(W, H, depth)
-        for m, (w, h, off) in enumerate(dims):
-            assert np.array_equal(prog.read_plane(tinyorb.ORB_PLANE_GRAY, m).ravel(), ref["gray"][off:off + w * h]), "gray level %d" % m
-            assert np.array_equal(prog.read_plane(tinyorb.ORB_PLANE_BLUR, m).ravel(), ref["blur"][off:off + w * h]), "blur level %d" % m
-        prog.extract_batch_host(np.stack([frame, frame]))
-        counts = prog.batch_counts(2)
-        for i in range(2):
-            c, d = prog.batch_read(i, min(int(counts[i]), 8192))
-            _assert_frame_equal(oracle, ref, int(counts[i]), c, d)
-    if (W, H, seed) == (640, 480, 1):
-        plain = oracle.extract(frame, depth=depth, threshold=THR)
-        c0, _ = oracle.sort_keypoints(plain["corners"], plain["descriptors"])
-        c1, _ = oracle.sort_keypoints(ref["corners"], ref["descriptors"])
-        assert not np.array_equal(c0["angle"], c1["angle"])
-
-
-def test_fp_contract_is_refused_with_the_extensions(tinyorb):
-    """The switch follows the reference's shader compiler: it exists for the reference's detector on RGBA input only."""
-    for kw in (dict(flags=tinyorb.ORB_FLAG_INTENDED), dict(flags=tinyorb.ORB_FLAG_NMS), dict(fast_arc=9), dict(flags=tinyorb.ORB_FLAG_INPUT_Y8),
-               dict(fp_contract=2)):
-        kw.setdefault("fp_contract", 1)
-        with pytest.raises(tinyorb.OrbError) as e:
-            tinyorb.OrbProgram(tinyorb.OrbConfig(tinyorb.Extent3d(320, 240), **kw)).init()
-        assert e.value.code == tinyorb.ORB_EINVAL
+# (CRD-13, OrbOptions::fp_contract: tests/test_gpu_round5.py -- since round 5 the fused kernels carry every form of it)

@@ -1,0 +1,187 @@
+"""GPU parity, round 5: the arithmetic a shader compiler may choose (CRD-13, OrbOptions::fp_contract -- per-stage contraction
+into fused multiply-adds, reduction order of dot() and matrix * vector) carried by the FUSED kernels as well as the per-stage
+ones, against the restatement under the same setting.  Bit for bit, as everywhere."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+THR = 20.0 / 255.0
+
+
+def _sorted(corners, desc):
+    order = np.lexsort((corners["x"], corners["y"], corners["octave"]))
+    return corners[order], desc[order]
+
+
+def _assert_frame_equal(oracle, ref, total, corners, desc):
+    assert total == ref["total"]
+    c, d = _sorted(corners, desc)
+    rc, rd = oracle.sort_keypoints(ref["corners"], ref["descriptors"])
+    assert len(c) == len(rc)
+    for k in ("octave", "y", "x", "angle"):
+        assert np.array_equal(c[k], rc[k]), k
+    assert np.array_equal(d, rd), "descriptors differ"
+
+
+def _oracle_kw(fp):
+    return dict(contract=fp & 7, dot_order=(fp >> 3) & 1)
+
+
+# luminance / blur / rotation alone, all three, last-term-first alone (what Mesa gives hardware without an fma), and with them
+FP_FORMS = [1, 2, 4, 7, 8, 9, 12, 15]
+# 640x480 seed 1: a frame on which the default and the contracted arithmetic differ in an angle code; 333x211: the general level-0
+# variant (rows not quad-aligned, level 1 by the bilinear blit); 2304x40 / 2306x40: column tiles, aligned and general
+SHAPES = [(640, 480, 2, 1), (320, 240, 3, 7), (333, 211, 2, 13), (1280, 720, 2, 2), (2304, 40, 2, 5), (2306, 40, 2, 6)]
+
+
+@pytest.mark.parametrize("W,H,depth,seed", SHAPES)
+@pytest.mark.parametrize("fp", FP_FORMS)
+@pytest.mark.parametrize("flags", [0, 1])
+def test_fp_forms_match_the_oracle_fused_and_staged(tinyorb, oracle, W, H, depth, seed, fp, flags):
+    """Every form of OrbOptions::fp_contract on the fused kernels (flags 0) and on the per-stage ones (ORB_FLAG_STAGED) equals the
+    restatement under the same setting: planes, counter, keypoints, angle codes, descriptors -- through the six calls of a
+    one-frame program (k_front_pair / k_brief_one where the shape allows) and through a batch (k_front per level, k_brief_t,
+    k_brief_nf)."""
+    frame = oracle.synth_frame(W, H, seed, 15)
+    ref = oracle.extract(frame, depth=depth, threshold=THR, planes=True, **_oracle_kw(fp))
+    staged = bool(flags & tinyorb.ORB_FLAG_STAGED)
+    for max_batch in (1, 3):
+        cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), hierarchy_depth=depth, initial_threshold=THR, fp_contract=fp, max_batch=max_batch,
+                                flags=flags)
+        with tinyorb.OrbProgram(cfg).init() as prog:
+            assert prog.pipeline() == ("staged" if staged else "fused") and prog.pipeline_note() == ""
+            if max_batch == 1:
+                prog.write_input_image(frame)
+                total = prog.extract_corners()
+                n = min(total, 8192)
+                _assert_frame_equal(oracle, ref, total, prog.read_corners(np.zeros(n, dtype=tinyorb.CORNER_DTYPE)),
+                                    prog.read_descriptors(np.zeros((n, 8), dtype=np.uint32)))
+            else:
+                other = oracle.synth_frame(W, H, seed + 100, 15)
+                prog.extract_batch_host(np.stack([frame, other, frame]))
+                counts = prog.batch_counts(3)
+                ref2 = oracle.extract(other, depth=depth, threshold=THR, **_oracle_kw(fp))
+                for i, r in enumerate((ref, ref2, ref)):
+                    c, d = prog.batch_read(i, min(int(counts[i]), 8192))
+                    _assert_frame_equal(oracle, r, int(counts[i]), c, d)
+                prog.extract_batch_host(np.stack([frame]))  # planes of frame 0
+            dims, _ = oracle.level_dims(W, H, depth)
+            for m, (w, h, off) in enumerate(dims):
+                if m > 0 or staged:  # the fused path keeps the level-0 grey plane in LDS only
+                    assert np.array_equal(prog.read_plane(tinyorb.ORB_PLANE_GRAY, m).ravel(), ref["gray"][off:off + w * h]), "gray level %d" % m
+                assert np.array_equal(prog.read_plane(tinyorb.ORB_PLANE_BLUR, m).ravel(), ref["blur"][off:off + w * h]), "blur level %d" % m
+
+
+def test_the_forms_are_different_functions(oracle):
+    """The test above could not pass on the wrong form: on its frames the restatement's planes differ between the default and each
+    stage's contraction, and between the two reduction orders (the f16 store hides most, not all, of the binary32 differences); on
+    (640x480, seed 1) an angle code differs as well."""
+    frame = oracle.synth_frame(1280, 720, 2, 15)
+    base = oracle.extract(frame, depth=2, threshold=THR, planes=True)
+    for fp, plane in ((1, "gray"), (8, "gray"), (9, "gray"), (2, "blur")):
+        r = oracle.extract(frame, depth=2, threshold=THR, planes=True, **_oracle_kw(fp))
+        assert np.any(r[plane] != base[plane]), fp
+    a = oracle.extract(frame, depth=2, threshold=THR, planes=True, **_oracle_kw(1))
+    b = oracle.extract(frame, depth=2, threshold=THR, planes=True, **_oracle_kw(9))
+    assert np.any(a["gray"] != b["gray"])
+    f2 = oracle.synth_frame(640, 480, 1, 15)
+    c0, _ = oracle.sort_keypoints(*[oracle.extract(f2, depth=2, threshold=THR)[k] for k in ("corners", "descriptors")])
+    c1, _ = oracle.sort_keypoints(*[oracle.extract(f2, depth=2, threshold=THR, contract=7)[k] for k in ("corners", "descriptors")])
+    assert not np.array_equal(c0["angle"], c1["angle"])
+    # the rotation: some keypoint of some frame has a pattern point whose two forms truncate differently
+    diff = 0
+    for code in range(1, 3142, 7):
+        for (x, y) in ((8, -3), (9, 5), (-13, 12), (7, -11), (-1, -6), (0, -11), (12, -13), (-11, 7)):
+            r = [tuple(int(v) for v in oracle.brief_rotate(code, x, y, ct, do)) for ct, do in ((0, 0), (4, 0), (4, 1))]
+            diff += len(set(r)) > 1
+    assert diff > 0
+
+
+@pytest.mark.parametrize("oob,wbits,fp", [("clamp", 8, 15), ("umin", 0, 7), ("umin", 8, 12), ("zero", 8, 3)])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_fp_forms_with_the_other_switches(tinyorb, oracle, oob, wbits, fp, flags):
+    """fp_contract together with an out-of-level policy and a sampler weight precision (the OOBK instances of k_front, k_brief_nf<OOB>,
+    the rotated-pattern table): three levels of a frame with an odd level, fused and staged."""
+    W, H, depth = 322, 242, 3
+    frame = oracle.synth_frame(W, H, 21, 15)
+    ref = oracle.extract(frame, depth=depth, threshold=THR, planes=True, oob=oob, weight_bits=wbits, **_oracle_kw(fp))
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), hierarchy_depth=depth, initial_threshold=THR, fp_contract=fp, max_batch=2, flags=flags,
+                            oob_policy=tinyorb.OOB_POLICIES[oob], sampler_weight_bits=wbits)
+    with tinyorb.OrbProgram(cfg).init() as prog:
+        prog.extract_batch_host(np.stack([frame, frame]))
+        counts = prog.batch_counts(2)
+        for i in range(2):
+            c, d = prog.batch_read(i, min(int(counts[i]), 8192))
+            _assert_frame_equal(oracle, ref, int(counts[i]), c, d)
+        prog.write_input_image(frame)
+        total = prog.extract_corners()
+        n = min(total, 8192)
+        _assert_frame_equal(oracle, ref, total, prog.read_corners(np.zeros(n, dtype=tinyorb.CORNER_DTYPE)),
+                            prog.read_descriptors(np.zeros((n, 8), dtype=np.uint32)))
+
+
+@pytest.mark.parametrize("fp", [4, 12, 15])
+def test_fp_forms_on_the_brief_fallback_kernel(tinyorb, oracle, monkeypatch, fp):
+    """TINYORB_BRIEF_ROWS=1 sends every keypoint through k_brief_rows (the wave-per-keypoint kernel frames too large for k_brief_t's
+    staging take): it rotates at run time and must follow the rotation's form too."""
+    monkeypatch.setenv("TINYORB_BRIEF_ROWS", "1")
+    W, H = 640, 480
+    frame = oracle.synth_frame(W, H, 2, 15)
+    ref = oracle.extract(frame, depth=2, threshold=THR, **_oracle_kw(fp))
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), hierarchy_depth=2, initial_threshold=THR, fp_contract=fp, max_batch=2)
+    with tinyorb.OrbProgram(cfg).init() as prog:
+        prog.extract_batch_host(np.stack([frame, frame]))
+        counts = prog.batch_counts(2)
+        c, d = prog.batch_read(1, min(int(counts[1]), 8192))
+        _assert_frame_equal(oracle, ref, int(counts[1]), c, d)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("fp", [7, 15])
+def test_fp_contract_batch_of_256(tinyorb, oracle, fp):
+    """256 distinct frames through the fused kernels under a contracting compiler, EVERY frame against the restatement (320x240), and
+    BASELINE configs[3]'s shape -- 256 x 1280x720 generated on the device -- fused against the per-stage kernels frame by frame, with
+    the first four also against the restatement."""
+    W, H, B = 320, 240, 256
+    frames = np.stack([oracle.synth_frame(W, H, 9000 + i, 15) for i in range(B)])
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), hierarchy_depth=2, initial_threshold=THR, fp_contract=fp, max_batch=B, max_features=4096)
+    with tinyorb.OrbProgram(cfg).init() as prog:
+        assert prog.pipeline() == "fused"
+        prog.extract_batch_host(frames)
+        counts = prog.batch_counts(B)
+        for i in range(B):
+            ref = oracle.extract(frames[i], depth=2, threshold=THR, max_features=4096, **_oracle_kw(fp))
+            c, d = prog.batch_read(i, min(int(counts[i]), 4096))
+            _assert_frame_equal(oracle, ref, int(counts[i]), c, d)
+    W, H = 1280, 720
+    out = {}
+    for flags in (0, tinyorb.ORB_FLAG_STAGED):
+        cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), hierarchy_depth=2, initial_threshold=THR, fp_contract=fp, max_batch=B, flags=flags)
+        with tinyorb.OrbProgram(cfg).init() as prog:
+            dev = prog.synth_frames_device(B, 1000, 15)
+            prog.extract_batch_device(dev, B)
+            counts = prog.batch_counts(B)
+            out[flags] = [(int(counts[i]),) + _sorted(*prog.batch_read(i, min(int(counts[i]), 8192))) for i in range(B)]
+    for i in range(B):
+        a, b = out[0][i], out[tinyorb.ORB_FLAG_STAGED][i]
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), i
+    for i in range(4):
+        ref = oracle.extract(oracle.synth_frame(W, H, 1000 + i, 15), depth=2, threshold=THR, **_oracle_kw(fp))
+        _assert_frame_equal(oracle, ref, out[0][i][0], out[0][i][1], out[0][i][2])
+
+
+def test_fp_contract_is_refused_with_the_extensions(tinyorb):
+    """The switch follows the reference's shader compiler: it exists for the reference's detector on RGBA input only, and is a mask of
+    four bits."""
+    for kw in (dict(flags=tinyorb.ORB_FLAG_INTENDED), dict(flags=tinyorb.ORB_FLAG_NMS), dict(fast_arc=9), dict(flags=tinyorb.ORB_FLAG_INPUT_Y8),
+               dict(fp_contract=16)):
+        kw.setdefault("fp_contract", tinyorb.ORB_FP_CONTRACT_ALL)
+        with pytest.raises(tinyorb.OrbError) as e:
+            tinyorb.OrbProgram(tinyorb.OrbConfig(tinyorb.Extent3d(320, 240), **kw)).init()
+        assert e.value.code == tinyorb.ORB_EINVAL
+    with tinyorb.OrbProgram(tinyorb.OrbConfig(tinyorb.Extent3d(320, 240), fp_contract=tinyorb.ORB_FP_LAST_TERM_FIRST)).init() as prog:
+        assert prog.pipeline() == "fused"

@@ -352,7 +352,6 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
 // Can the fused per-level kernels handle this configuration?  (Otherwise: staged pipeline.)
 bool fused_eligible(const OrbProgram* p) {
     if (p->opt.flags & (ORB_FLAG_STAGED | ORB_FLAG_NMS | ORB_FLAG_INTENDED)) return false;
-    if (p->opt.fp_contract) return false;  // CRD-13: only the per-stage kernels carry the contracted arithmetic
     if (p->arc != 12u) return false;  // the fused FAST phase is specialised for the reference's 12-run
     const Pyramid& pyr = p->pyr;
     // index arithmetic: v_mul_i32_i24 takes 24-bit operands (rows, widths < 2^14 here) and returns 32 bits; RGBA byte
@@ -417,6 +416,7 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
     }
     g.n_classes = 1u;
     g.phase_mask = 15u;  // run_fused_range applies the program's experiment switches (TINYORB_PHASE_MASK, TINYORB_NO_SWIZZLE)
+    front_blur_constants(&g);  // fp = 0: every product and sum rounded; run_fused_range sets the program's
     return g;
 }
 
@@ -472,9 +472,15 @@ int launch_brief(OrbProgram* p, hipStream_t s, uint32_t n, const RowsGeom& rows_
         const dim3 grid(n, (cap + (uint32_t)kBriefNfChunk - 1u) / (uint32_t)kBriefNfChunk);  // k_brief_nf's
         {
             LaunchScope ls(p, s, KID_BRIEF_T);
-            hipLaunchKernelGGL(k_brief_t<kBriefTWaves>, dim3(n, (cap + kBriefTThreads - 1u) / kBriefTThreads), dim3(kBriefTThreads),
-                               brieft_lds_bytes(tg), s, d_blur_rowc, p->pyr, tg, seg_counts, seg_before, seg, d_corners, cap,
-                               d_desc, tab);
+#define BRIEF_T_LAUNCH(ROT_)                                                                                                         \
+    hipLaunchKernelGGL((k_brief_t<kBriefTWaves, ROT_>), dim3(n, (cap + kBriefTThreads - 1u) / kBriefTThreads), dim3(kBriefTThreads), \
+                       brieft_lds_bytes(tg), s, d_blur_rowc, p->pyr, tg, seg_counts, seg_before, seg, d_corners, cap, d_desc, tab)
+            switch (rot_form(p->opt.fp_contract)) {  // the rotation's form (OrbOptions::fp_contract): a template parameter of the straight-line tests
+                case 1: BRIEF_T_LAUNCH(1); break;
+                case 2: BRIEF_T_LAUNCH(2); break;
+                default: BRIEF_T_LAUNCH(0); break;
+            }
+#undef BRIEF_T_LAUNCH
         }
         LaunchScope ls(p, s, KID_BRIEF_NF);
         if (p->oob != kOobZero)
@@ -487,6 +493,7 @@ int launch_brief(OrbProgram* p, hipStream_t s, uint32_t n, const RowsGeom& rows_
         LaunchScope ls(p, s, KID_BRIEF_ROWS);
         RowsGeom rg = rows_geom;
         rg.oob = p->oob;
+        rg.fp = p->opt.fp_contract;
         rg.split = 1u;  // small batches: several workgroups per band slot so that the chip still sees ~2000 of them
         while (rg.split < 16u && rg.n_slots * n * rg.split < 2048u) rg.split *= 2u;
         hipLaunchKernelGGL(k_brief_rows, dim3(rg.n_slots * rg.split, n), dim3(256), 0, s, d_blur, d_blur_rowc, p->pyr, rg,
@@ -539,6 +546,8 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         if (p->env.no_swizzle) g.xcd_swizzle = 0u;
         g.oob = p->oob;
         g.wq = p->wq;
+        g.fp = p->opt.fp_contract;
+        front_blur_constants(&g);
         g.store_grey = (lvl == 0 && D > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) ? 1u : 0u;
         if (g.n_bands * (g.tiled ? g.n_ct : 1u) != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: band count mismatch at level %u", lvl);
@@ -552,6 +561,21 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
 #define FRONT_LAUNCH_TILED(L0, Y8, UA)                                                                             \
     if (p->band_rows_lvl[lvl] == 16u) hipLaunchKernelGGL((k_front<L0, Y8, 16, UA, true>), grid, block, lds, s_lvl, FRONT_ARGS); \
     else hipLaunchKernelGGL((k_front<L0, Y8, 8, UA, true>), grid, block, lds, s_lvl, FRONT_ARGS);
+// level 0 from RGBA: the luminance's form (OrbOptions::fp_contract, lum_form()) is a template parameter -- UA_, TILED_ as above
+#define FRONT_LAUNCH_RGBA(UA_, TILED_, LUM_)                                                                                                            \
+    switch (p->band_rows_lvl[lvl]) {                                                                                                                    \
+        case 64: if (!TILED_) { hipLaunchKernelGGL((k_front<true, false, TILED_ ? 16 : 64, UA_, TILED_, false, false, 0, LUM_>), grid, block, lds, s_lvl, FRONT_ARGS); } break; \
+        case 32: if (!TILED_) { hipLaunchKernelGGL((k_front<true, false, TILED_ ? 16 : 32, UA_, TILED_, false, false, 0, LUM_>), grid, block, lds, s_lvl, FRONT_ARGS); } break; \
+        case 16: hipLaunchKernelGGL((k_front<true, false, 16, UA_, TILED_, false, false, 0, LUM_>), grid, block, lds, s_lvl, FRONT_ARGS); break;        \
+        default: hipLaunchKernelGGL((k_front<true, false, 8, UA_, TILED_, false, false, 0, LUM_>), grid, block, lds, s_lvl, FRONT_ARGS); break;         \
+    }
+#define FRONT_LAUNCH_RGBA_LUM(UA_, TILED_)                          \
+    switch (lum_form(p->opt.fp_contract)) {                         \
+        case 1: FRONT_LAUNCH_RGBA(UA_, TILED_, 1) break;            \
+        case 2: FRONT_LAUNCH_RGBA(UA_, TILED_, 2) break;            \
+        case 3: FRONT_LAUNCH_RGBA(UA_, TILED_, 3) break;            \
+        default: FRONT_LAUNCH_RGBA(UA_, TILED_, 0) break;           \
+    }
 #define FRONT_LAUNCH(L0, Y8)                                                                                       \
     switch (p->band_rows_lvl[lvl]) {                                                                               \
         case 64: hipLaunchKernelGGL((k_front<L0, Y8, 64>), grid, block, lds, s_lvl, FRONT_ARGS); break;                \
@@ -574,16 +598,16 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
             if (g.tiled) {
                 if (p->input_y8 && general) { FRONT_LAUNCH_TILED(true, true, true) }
                 else if (p->input_y8) { FRONT_LAUNCH_TILED(true, true, false) }
-                else if (general) { FRONT_LAUNCH_TILED(true, false, true) }
-                else { FRONT_LAUNCH_TILED(true, false, false) }
+                else if (general) { FRONT_LAUNCH_RGBA_LUM(true, true) }
+                else { FRONT_LAUNCH_RGBA_LUM(false, true) }
             } else if (p->input_y8 && general) {
                 FRONT_LAUNCH_UA(true)
             } else if (p->input_y8) {
                 FRONT_LAUNCH(true, true)
             } else if (general) {
-                FRONT_LAUNCH_UA(false)
+                FRONT_LAUNCH_RGBA_LUM(true, false)
             } else {
-                FRONT_LAUNCH(true, false)
+                FRONT_LAUNCH_RGBA_LUM(false, false)
             }
 #undef FRONT_LAUNCH_UA
         } else if (p->ln_threads[lvl] == (uint32_t)kFrontThreadsLNBig) {  // a level whose bands are large enough for level 0's shape (chosen at create)
@@ -615,6 +639,8 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         }
 #undef FRONT_LAUNCH
 #undef FRONT_LAUNCH_TILED
+#undef FRONT_LAUNCH_RGBA
+#undef FRONT_LAUNCH_RGBA_LUM
 #undef FRONT_ARGS
     }
     // orb.rs:523-534, plus the compaction of the band segments into the final lists
@@ -913,7 +939,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         ((options->flags & (ORB_FLAG_INTENDED | ORB_FLAG_NMS)) || (options->fast_arc != 0 && options->fast_arc != 12)))
         return fail(nullptr, ORB_EINVAL, "oob_policy / sampler_weight_bits follow the reference's adapter: they are defined for the "
                                          "reference's detector only (no ORB_FLAG_INTENDED, ORB_FLAG_NMS or fast_arc other than 12)");
-    if (options && options->fp_contract > 1u) return fail(nullptr, ORB_EINVAL, "fp_contract must be 0 or 1");
+    if (options && options->fp_contract > (ORB_FP_CONTRACT_ALL | ORB_FP_LAST_TERM_FIRST))
+        return fail(nullptr, ORB_EINVAL, "fp_contract is a mask of ORB_FP_CONTRACT_LUMINANCE / _BLUR / _ROTATION and ORB_FP_LAST_TERM_FIRST");
     if (options && options->fp_contract &&
         ((options->flags & (ORB_FLAG_INTENDED | ORB_FLAG_NMS | ORB_FLAG_INPUT_Y8)) || (options->fast_arc != 0 && options->fast_arc != 12)))
         return fail(nullptr, ORB_EINVAL, "fp_contract follows the reference's shader compiler: it is defined for the reference's detector on RGBA "
@@ -1115,8 +1142,16 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                     FRONT_FN_BIG(64), FRONT_FN_BIG(32), FRONT_FN_BIG(16), FRONT_FN_BIG(8),
 #undef FRONT_FN_BIG
 #define FRONT_FN_OOB(R, T) reinterpret_cast<const void*>(&k_front<false, false, R, false, T, false, true>)
-                    FRONT_FN_OOB(64, false), FRONT_FN_OOB(32, false), FRONT_FN_OOB(16, false), FRONT_FN_OOB(8, false), FRONT_FN_OOB(16, true), FRONT_FN_OOB(8, true)
+                    FRONT_FN_OOB(64, false), FRONT_FN_OOB(32, false), FRONT_FN_OOB(16, false), FRONT_FN_OOB(8, false), FRONT_FN_OOB(16, true), FRONT_FN_OOB(8, true),
 #undef FRONT_FN_OOB
+// level 0 from RGBA in the luminance's other forms (lum_form(): 1, 2, 3), aligned / general, full-width / tiled
+#define FRONT_FN_LUM1(R, UA, T, L) reinterpret_cast<const void*>(&k_front<true, false, R, UA, T, false, false, 0, L>)
+#define FRONT_FN_LUM(L) FRONT_FN_LUM1(64, false, false, L), FRONT_FN_LUM1(32, false, false, L), FRONT_FN_LUM1(16, false, false, L), FRONT_FN_LUM1(8, false, false, L), \
+                        FRONT_FN_LUM1(64, true, false, L), FRONT_FN_LUM1(32, true, false, L), FRONT_FN_LUM1(16, true, false, L), FRONT_FN_LUM1(8, true, false, L),     \
+                        FRONT_FN_LUM1(16, false, true, L), FRONT_FN_LUM1(8, false, true, L), FRONT_FN_LUM1(16, true, true, L), FRONT_FN_LUM1(8, true, true, L)
+                    FRONT_FN_LUM(1), FRONT_FN_LUM(2), FRONT_FN_LUM(3)
+#undef FRONT_FN_LUM
+#undef FRONT_FN_LUM1
 #undef FRONT_FN
 #undef FRONT_FN_TILED
                 };
@@ -1124,6 +1159,9 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                     CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_pair<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
                 CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_pair<8, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
+                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_pair<8, 8, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
+                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_pair<8, 8, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
+                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_pair<8, 8, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
             }
         }
     }
@@ -1221,9 +1259,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         const Pyramid& py = p->pyr;
         char why[256];
         const bool plain = !p->intended && !(p->opt.flags & ORB_FLAG_NMS) && p->arc == 12u;  // the reference's own algorithm
-        if (p->opt.fp_contract)
-            snprintf(why, sizeof why, "OrbOptions::fp_contract: only the per-stage kernels carry the contracted arithmetic (CRD-13)");
-        else if ((py.w[0] & 3u) != 0u && !plain)
+        if ((py.w[0] & 3u) != 0u && !plain)
             snprintf(why, sizeof why, "width %u is not a multiple of 4 (the tile kernels read RGBA quads)", py.w[0]);
         else if (py.w[0] < 8u)
             snprintf(why, sizeof why, "width %u is below 8", py.w[0]);
@@ -1317,7 +1353,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         const uint32_t n_codes = p->fused_i ? (uint32_t)ORB_ANGLE_STEPS_FULL : (uint32_t)ORB_ANGLE_STEPS;
         const int pitch = p->fused_i ? (int)p->itiles.pitch : kNfPatchCols;
         CREATE_TRY(hipMalloc(&p->d_rot, (size_t)n_codes * 64u * sizeof(uint4)));
-        hipLaunchKernelGGL(k_rot_table, dim3(n_codes), dim3(64), 0, p->stream, p->d_pattern, p->d_cos, p->d_sin, pitch, p->fused_i ? 1 : 0, p->d_rot);
+        hipLaunchKernelGGL(k_rot_table, dim3(n_codes), dim3(64), 0, p->stream, p->d_pattern, p->d_cos, p->d_sin, pitch, p->fused_i ? 1 : 0, p->d_rot,
+                           p->opt.fp_contract);
         CREATE_TRY(hipGetLastError());
         CREATE_TRY(hipStreamSynchronize(p->stream));
     }
@@ -1531,6 +1568,8 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
                 g[lvl].n_classes = p->seg_classes;
                 g[lvl].xcd_swizzle = 0u;
                 g[lvl].wq = p->wq;
+                g[lvl].fp = p->opt.fp_contract;
+                front_blur_constants(&g[lvl]);
                 if (p->env.phase_mask >= 0) g[lvl].phase_mask = (uint32_t)p->env.phase_mask;
                 lds = std::max(lds, front_lds_bytes(g[lvl]));
             }
@@ -1542,9 +1581,18 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
                 if (p->input_y8)
                     hipLaunchKernelGGL((k_front_pair<8, 8, true>), dim3(g[0].n_bands + g[1].n_bands), dim3(kFrontThreadsL0), lds, s, d_in,
                                        p->frame_bytes, p->d_gray, p->d_blur, p->d_blur_rowc, py, g[0], g[1], p->threshold, p->d_seg_counts, p->d_seg);
-                else
-                    hipLaunchKernelGGL((k_front_pair<8, 8>), dim3(g[0].n_bands + g[1].n_bands), dim3(kFrontThreadsL0), lds, s, d_in,
-                                       p->frame_bytes, p->d_gray, p->d_blur, p->d_blur_rowc, py, g[0], g[1], p->threshold, p->d_seg_counts, p->d_seg);
+                else {
+#define FRONT_PAIR_LAUNCH(LUM_)                                                                                                          \
+    hipLaunchKernelGGL((k_front_pair<8, 8, false, LUM_>), dim3(g[0].n_bands + g[1].n_bands), dim3(kFrontThreadsL0), lds, s, d_in,       \
+                       p->frame_bytes, p->d_gray, p->d_blur, p->d_blur_rowc, py, g[0], g[1], p->threshold, p->d_seg_counts, p->d_seg)
+                    switch (lum_form(p->opt.fp_contract)) {  // the luminance's form (OrbOptions::fp_contract)
+                        case 1: FRONT_PAIR_LAUNCH(1); break;
+                        case 2: FRONT_PAIR_LAUNCH(2); break;
+                        case 3: FRONT_PAIR_LAUNCH(3); break;
+                        default: FRONT_PAIR_LAUNCH(0); break;
+                    }
+#undef FRONT_PAIR_LAUNCH
+                }
             }
             if (py.depth > 2u)
                 if (int rc = run_fused_range(p, d_in, 0, 1, s, false, 2u)) return rc;
@@ -1554,10 +1602,17 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
         const uint32_t seq = ++p->single_seq ? p->single_seq : ++p->single_seq;  // never 0
         {
             LaunchScope ls(p, s, KID_BRIEF_ONE);
-            hipLaunchKernelGGL(k_brief_one, dim3((unsigned)((cap + kBriefOneChunk - 1u) / kBriefOneChunk)), dim3(kBriefOneThreads), brieft_lds_bytes(p->brieft), s, p->d_blur,
-                               p->d_blur_rowc, p->pyr, p->brieft, p->d_seg_counts, p->d_seg_before, p->d_seg, p->d_counts, p->d_corners,
-                               (uint32_t)cap, p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin, p->d_rot}, static_cast<uint32_t*>(dc),
-                               static_cast<CornerData*>(dk), static_cast<CornerDescriptor*>(dd), p->d_single_done, seq);
+#define BRIEF_ONE_LAUNCH(ROT_)                                                                                                                                  \
+    hipLaunchKernelGGL(k_brief_one<ROT_>, dim3((unsigned)((cap + kBriefOneChunk - 1u) / kBriefOneChunk)), dim3(kBriefOneThreads), brieft_lds_bytes(p->brieft), s, \
+                       p->d_blur, p->d_blur_rowc, p->pyr, p->brieft, p->d_seg_counts, p->d_seg_before, p->d_seg, p->d_counts, p->d_corners, (uint32_t)cap,      \
+                       p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin, p->d_rot}, static_cast<uint32_t*>(dc), static_cast<CornerData*>(dk),            \
+                       static_cast<CornerDescriptor*>(dd), p->d_single_done, seq)
+            switch (rot_form(p->opt.fp_contract)) {  // the rotation's form (OrbOptions::fp_contract)
+                case 1: BRIEF_ONE_LAUNCH(1); break;
+                case 2: BRIEF_ONE_LAUNCH(2); break;
+                default: BRIEF_ONE_LAUNCH(0); break;
+            }
+#undef BRIEF_ONE_LAUNCH
         }
         HIP_TRY(p, hipGetLastError());
         p->planes_valid = true;

@@ -71,14 +71,45 @@ __device__ __forceinline__ float luminance(uint32_t rgba) {
     return (pr + pg) + pb;
 }
 
-// CRD-13, OrbOptions::fp_contract: a shader compiler that contracts -- dot() as one product and a chain of fmas, in source order.
-__device__ __forceinline__ float luminance_contracted(uint32_t rgba) {
-    float r = (float)(rgba & 255u) / 255.0f;
-    float g = (float)((rgba >> 8) & 255u) / 255.0f;
-    float b = (float)((rgba >> 16) & 255u) / 255.0f;
-    float t = 0.229f * r;
-    t = __builtin_fmaf(g, 0.587f, t);
-    return __builtin_fmaf(b, 0.114f, t);
+// CRD-13, OrbOptions::fp_contract: the arithmetic WGSL leaves to the adapter's shader compiler, as one word.  A bit per stage
+// whose product-and-sum pairs the compiler fuses into fmas -- dot() (grayscale.wgsl:36), `result += sample * weight`
+// (gaussian_blur_x.wgsl:58), matrix * vector (brief.wgsl:53-54) -- and one for the order in which dot() and matrix * vector are
+// reduced: first component / column first (as written; LLVM-based compilers) or last first (Mesa's NIR lowering).
+constexpr uint32_t kFpLum = 1u, kFpBlur = 2u, kFpRot = 4u, kFpLastFirst = 8u, kFpMask = 15u;
+// the four forms of the luminance: bit 0 = contracted, bit 1 = last component first
+__host__ __device__ constexpr int lum_form(uint32_t fp) { return ((fp & kFpLum) ? 1 : 0) | ((fp & kFpLastFirst) ? 2 : 0); }
+// the three forms of the rotation: 0 = every product and sum rounded (the two-term sum has no order), 1 = the second term fused
+// onto the first product, 2 = the first term fused onto the second product
+__host__ __device__ constexpr int rot_form(uint32_t fp) { return !(fp & kFpRot) ? 0 : ((fp & kFpLastFirst) ? 2 : 1); }
+
+// dot(color, vec4(0.229, 0.587, 0.114, 0.0)) in form `form` (lum_form); r, g, b = byte / 255 (CRD-1).  The alpha term is +0
+// in every form.
+__device__ __forceinline__ float luminance_dot(float r, float g, float b, int form) {
+    const float wr = 0.229f, wg = 0.587f, wb = 0.114f;  // grayscale.wgsl:36 (0.229, sic)
+    if (form == 1) return __builtin_fmaf(b, wb, __builtin_fmaf(g, wg, wr * r));
+    if (form == 3) return __builtin_fmaf(r, wr, __builtin_fmaf(g, wg, wb * b));
+    const float pr = wr * r, pg = wg * g, pb = wb * b;
+    if (form == 2) return (pb + pg) + pr;
+    return (pr + pg) + pb;
+}
+__device__ __forceinline__ float luminance_fp(uint32_t rgba, int form) {
+    const float r = (float)(rgba & 255u) / 255.0f;
+    const float g = (float)((rgba >> 8) & 255u) / 255.0f;
+    const float b = (float)((rgba >> 16) & 255u) / 255.0f;
+    return luminance_dot(r, g, b, form);
+}
+
+// mat2x2f(ct, s2, s1, ct) * (x, y), column-major (brief.wgsl:38-54: s1 = st, s2 = -st): (ct*x + s1*y, s2*x + ct*y) in form
+// `form` (rot_form).
+__device__ __forceinline__ void rotate_fp(float ct, float s1, float s2, float x, float y, int form, float* rx, float* ry) {
+    const float x0 = ct * x, x1 = s1 * y, y0 = s2 * x, y1 = ct * y;
+    if (form == 1) {
+        *rx = __builtin_fmaf(s1, y, x0), *ry = __builtin_fmaf(ct, y, y0);
+    } else if (form == 2) {
+        *rx = __builtin_fmaf(ct, x, x1), *ry = __builtin_fmaf(s2, x, y1);
+    } else {
+        *rx = x0 + x1, *ry = y0 + y1;
+    }
 }
 
 // "intended" mode IM-1 (not in the reference): BT.601 weight for red.

@@ -87,7 +87,9 @@ __device__ __forceinline__ void brief_t_stage_rows(uint16_t* rows, const uint16_
 
 // CHUNK: keypoints per workgroup (the first CHUNK threads take one each; all 256 stage).  STAGED: the caller has already
 // put the list prefix and the row constants into lds_raw (k_brief_one does, next to its own prefix scan).
-template <int CHUNK = kBriefTThreads, bool STAGED = false>
+// ROT: the form matrix * vector takes under the adapter's shader compiler (rot_form(), CRD-13): 0 = both products and the sum rounded
+// (CRD-10, the default); 1 = y' = fma(ct, y, -st*x); 2 = y' = fma(-st, x, ct*y) -- a product fewer per point either way.
+template <int CHUNK = kBriefTThreads, bool STAGED = false, int ROT = 0>
 __device__ __forceinline__ void brief_t_body(uint8_t* lds_raw, uint32_t frame, uint32_t chunk, const uint16_t* __restrict__ blur_rowc,
                                              const Pyramid& pyr, const BriefTGeom& bg, const uint32_t* __restrict__ seg_counts,
                                              const uint32_t* __restrict__ seg_before, const CornerData* __restrict__ segments,
@@ -184,9 +186,18 @@ __device__ __forceinline__ void brief_t_body(uint8_t* lds_raw, uint32_t frame, u
         for (int i = 31; i >= 0; i--) {
             const int j = wd * 32 + i;
             // mat2x2f(ct,-st, st,ct) * p (column-major): y' = -st*x + ct*y, every product and the sum rounded (CRD-10)
-            const float a2 = nstw * (float)pat_ax(j), a3 = ctw * (float)pat_ay(j);
-            const float b2 = nstw * (float)pat_bx(j), b3 = ctw * (float)pat_by(j);
-            const float ray = a2 + a3, rby = b2 + b3;
+            float ray, rby;
+            if constexpr (ROT == 1) {
+                const float a2 = nstw * (float)pat_ax(j), b2 = nstw * (float)pat_bx(j);
+                ray = __builtin_fmaf(ctw, (float)pat_ay(j), a2), rby = __builtin_fmaf(ctw, (float)pat_by(j), b2);
+            } else if constexpr (ROT == 2) {
+                const float a3 = ctw * (float)pat_ay(j), b3 = ctw * (float)pat_by(j);
+                ray = __builtin_fmaf(nstw, (float)pat_ax(j), a3), rby = __builtin_fmaf(nstw, (float)pat_bx(j), b3);
+            } else {
+                const float a2 = nstw * (float)pat_ax(j), a3 = ctw * (float)pat_ay(j);
+                const float b2 = nstw * (float)pat_bx(j), b3 = ctw * (float)pat_by(j);
+                ray = a2 + a3, rby = b2 + b3;
+            }
             acc = push_gt(acc, base[(int)ray], base[(int)rby]);  // vec2i() truncates
         }
         d[wd] = acc;
@@ -199,7 +210,7 @@ __device__ __forceinline__ void brief_t_body(uint8_t* lds_raw, uint32_t frame, u
     }
 }
 
-template <int kWavesPerSimd>
+template <int kWavesPerSimd, int ROT = 0>
 __global__ __launch_bounds__(kBriefTThreads, kWavesPerSimd) void k_brief_t(const uint16_t* __restrict__ blur_rowc, Pyramid pyr, BriefTGeom bg,
                                                                 const uint32_t* __restrict__ seg_counts,
                                                                 const uint32_t* __restrict__ seg_before,
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(kBriefTThreads, kWavesPerSimd) void k_brief_t(const
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     // The frame is the FAST grid index: chunks past a frame's keypoint count exit at once, and with the chunk as the fast
     // index their regular pattern (15 busy, 17 idle, ...) lands every busy workgroup on the same half of the CUs.
-    brief_t_body(lds_raw, blockIdx.x, blockIdx.y, blur_rowc, pyr, bg, seg_counts, seg_before, segments, corners, cap, descriptors, tab);
+    brief_t_body<kBriefTThreads, false, ROT>(lds_raw, blockIdx.x, blockIdx.y, blur_rowc, pyr, bg, seg_counts, seg_before, segments, corners, cap, descriptors, tab);
 }
 
 // The keypoints k_brief_t leaves (not flat, 12 %: a sample may come from the stored tail of the blur plane, or lie left
@@ -237,7 +248,8 @@ constexpr int kNfPatchHalfs = kNfPatchRows * kNfPatchCols;
 // into the consumer's window.  3142 (6284) codes x 1 KB.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_rot_table(const uint32_t* __restrict__ pattern, const float* __restrict__ cos_tab,
-                                                  const float* __restrict__ sin_tab, int pitch, int intended, uint4* __restrict__ out) {
+                                                  const float* __restrict__ sin_tab, int pitch, int intended, uint4* __restrict__ out,
+                                                  uint32_t fp = 0u) {
     const uint32_t code = blockIdx.x, lane = threadIdx.x;
     const float ct = cos_tab[code], st = sin_tab[code], nst = -st;
     uint32_t w[4];
@@ -251,10 +263,9 @@ __global__ __launch_bounds__(64) void k_rot_table(const uint32_t* __restrict__ p
             const float a0 = ct * pax, a1 = nst * pay, a2 = st * pax, a3 = ct * pay;
             const float b0 = ct * pbx, b1 = nst * pby, b2 = st * pbx, b3 = ct * pby;
             rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
-        } else {  // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y), brief.wgsl:38-54
-            const float a0 = ct * pax, a1 = st * pay, a2 = nst * pax, a3 = ct * pay;
-            const float b0 = ct * pbx, b1 = st * pby, b2 = nst * pbx, b3 = ct * pby;
-            rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+        } else {  // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y), brief.wgsl:38-54; CRD-13: rot_form(fp)
+            rotate_fp(ct, st, nst, pax, pay, rot_form(fp), &rax, &ray);
+            rotate_fp(ct, st, nst, pbx, pby, rot_form(fp), &rbx, &rby);
         }
         const int oa = 2 * ((int)ray * pitch + (int)rax), ob = 2 * ((int)rby * pitch + (int)rbx);  // vec2i() truncates
         w[e] = ((uint32_t)oa & 0xffffu) | ((uint32_t)ob << 16);
@@ -464,6 +475,7 @@ constexpr int kBriefOneChunk = 64;
 // sequence number, in a cache line of its own (words 1..10: k_brief_one's stamps in the diagnostic build)
 constexpr int kSingleCountWords = 32, kSingleDoneWord = 16;
 constexpr int kBriefOneThreads = 512;  // the flat keypoints take the first wave, the others one wave each: eight of those per turn
+template <int ROT = 0>  // brief_t_body's
 __global__ __launch_bounds__(kBriefOneThreads) void k_brief_one(const uint16_t* __restrict__ blur, const uint16_t* __restrict__ blur_rowc, Pyramid pyr,
                                                    BriefTGeom bg, const uint32_t* __restrict__ seg_counts,
                                                    uint32_t* __restrict__ seg_before, const CornerData* __restrict__ segments,
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(kBriefOneThreads) void k_brief_one(const uint16_t* 
     BRIEF_ONE_STAMP();
     // (brief_t_body's first barrier publishes the prefix)
     // both bodies write their records and descriptors to the device lists AND to host staging (orb.rs:537-547): no copy pass
-    brief_t_body<kBriefOneChunk, true>(lds_raw, 0u, chunk, blur_rowc, pyr, bg, seg_counts, seg_before, segments, corners, cap,
+    brief_t_body<kBriefOneChunk, true, ROT>(lds_raw, 0u, chunk, blur_rowc, pyr, bg, seg_counts, seg_before, segments, corners, cap,
                                        descriptors, tab, host_corners, host_descriptors);
     __syncthreads();  // the chunk's records are in the final list: brief_nf_body reads them
     BRIEF_ONE_STAMP();

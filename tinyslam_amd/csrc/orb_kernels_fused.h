@@ -84,7 +84,18 @@ struct FrontGeom {
     uint32_t ovf_words;   // words of one bit set over the band's pre-test items (two sets in LDS: items whose survivors did not fit queue A)
     uint32_t oob;         // OrbOptions::oob_policy (kOobZero / kOobClamp / kOobUmin); phase A of the levels >= 1 follows it through OOBK
     float wq;             // OrbOptions::sampler_weight_bits as 2^bits (0: exact lerp weights), for blur_tap()
+    uint32_t fp;          // OrbOptions::fp_contract (kFp*); the luminance's form is the template parameter LUM, the blur's (kFpBlur) these:
+    // `result += sample * weight` (gaussian_blur_x.wgsl:58) for taps 1, 2, 3 as  t = s1 * bm1; acc = fma(t, bn1, acc); acc = fma(k2, bm2, acc);
+    // acc = fma(k3, bm3, acc)  with (bm1, bn1, bm2, bm3) = (w1, 1, 1, 1) and k2 = fl(s2 * w2), k3 = fl(s3 * w3) when every product and sum is
+    // rounded on its own -- fma(x, 1, acc) IS the rounded sum -- and (1, w1, w2, w3) with k2 = s2, k3 = s3 when the compiler fuses them: one
+    // instruction sequence for both, the constants in scalar registers (front_blur_constants())
+    float bm1, bn1, bm2, bm3;
 };
+inline void front_blur_constants(FrontGeom* g) {
+    const bool c = (g->fp & kFpBlur) != 0u;
+    const float w1 = 0.5037756553768409f, w2 = 0.32748695702046415f, w3 = 0.031251155234634016f;  // kBlurWgt[1..3]
+    g->bm1 = c ? 1.0f : w1, g->bn1 = c ? w1 : 1.0f, g->bm2 = c ? w2 : 1.0f, g->bm3 = c ? w3 : 1.0f;
+}
 
 // Tap positions of one column x >= blur_q of the literal blur (phase C): pass 2 at x lerps pass 1 at columns j0, j1
 // with fraction f2; pass 1 at j0 (j1) lerps the grey texels a0, a1 (b0, b1) with fraction fa (fb).  a0 (b0) == 0xffff:
@@ -150,7 +161,10 @@ __device__ __forceinline__ uint32_t pack_half2(float lo, float hi) {
 // Luminance (CRD-1, CRD-2) of two neighbouring texels as f16 in one word.  Written on two-element vectors so that the
 // packed binary32 instructions (v_pk_mul/fma/add_f32) work on the pair that v_cvt_pk_f16_f32 then rounds into one
 // register: left to itself the vectoriser pairs texels 0/2 and 1/3 and spends four more instructions re-interleaving.
-template <bool BT601 = false>  // false: the reference's 0.229 red weight (Q1); true: 0.299 (the intended mode's IM-1)
+// LUM: the form dot() takes under the adapter's shader compiler (lum_form(), CRD-13): 0 = (pr + pg) + pb, every product and sum
+// rounded (CRD-2, the default); 1 = r*wr, fma(g, wg, .), fma(b, wb, .) -- two packed operations per pair fewer; 2 = (pb + pg) + pr;
+// 3 = b*wb, fma(g, wg, .), fma(r, wr, .).
+template <bool BT601 = false, int LUM = 0>  // BT601 false: the reference's 0.229 red weight (Q1); true: 0.299 (the intended mode's IM-1)
 __device__ __forceinline__ uint32_t luminance_pair_f16(uint32_t rgba0, uint32_t rgba1) {
     const float2_t rc_hi = {0x1.010102p-8f, 0x1.010102p-8f}, rc_lo = {-0x1.fdfdfep-33f, -0x1.fdfdfep-33f};
     const float2_t R = {(float)(rgba0 & 255u), (float)(rgba1 & 255u)};
@@ -160,9 +174,27 @@ __device__ __forceinline__ uint32_t luminance_pair_f16(uint32_t rgba0, uint32_t 
     const float2_t r = __builtin_elementwise_fma(R, rc_hi, tr);  // exact byte/255, see unorm8_exact
     const float2_t g = __builtin_elementwise_fma(G, rc_hi, tg);
     const float2_t b = __builtin_elementwise_fma(B, rc_hi, tb);
-    const float2_t pr = r * (BT601 ? 0.299f : 0.229f), pg = g * 0.587f, pb = b * 0.114f;
-    const float2_t s = pr + pg;
-    const float2_t l = s + pb;
+    constexpr float wr1 = BT601 ? 0.299f : 0.229f;
+    const float2_t wr = {wr1, wr1}, wg = {0.587f, 0.587f}, wb = {0.114f, 0.114f};
+    float2_t l;
+    if constexpr (LUM == 1) {
+        const float2_t t = r * wr;
+        const float2_t u = __builtin_elementwise_fma(g, wg, t);
+        l = __builtin_elementwise_fma(b, wb, u);
+    } else if constexpr (LUM == 3) {
+        const float2_t t = b * wb;
+        const float2_t u = __builtin_elementwise_fma(g, wg, t);
+        l = __builtin_elementwise_fma(r, wr, u);
+    } else {
+        const float2_t pr = r * wr1, pg = g * 0.587f, pb = b * 0.114f;
+        if constexpr (LUM == 2) {
+            const float2_t s = pb + pg;
+            l = s + pr;
+        } else {
+            const float2_t s = pr + pg;
+            l = s + pb;
+        }
+    }
     uint32_t d;  // the instruction hipcc itself uses for two (half) casts (RNE, CRD-3); as asm so that the pairing stays
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(l.x), "v"(l.y));
     return d;
@@ -330,7 +362,8 @@ __device__ __forceinline__ void segment_append(bool is_corner, uint32_t x, uint3
 // NTO: threads of the workgroup when they are not the level's usual number (k_front_pair runs level 1 on 1024).
 // The body lives in orb_front_body.inc and is emitted twice: front_body<...> (a device function, for k_front_pair) and
 // the kernel k_front<...> itself.
-template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false, bool TILED = false, bool SRC = false, int NTO = 0, bool OOBK = false>
+// LUM (level 0 from RGBA, and SRC): the luminance's form (luminance_pair_f16).
+template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false, bool TILED = false, bool SRC = false, int NTO = 0, bool OOBK = false, int LUM = 0>
 __device__ __forceinline__ void front_body(const uint32_t block_id, const uint8_t* __restrict__ frames, size_t frame_bytes,
                                            uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                            uint16_t* __restrict__ blur_rowc, const Pyramid pyr,
@@ -340,7 +373,7 @@ __device__ __forceinline__ void front_body(const uint32_t block_id, const uint8_
 }
 
 // NTK: threads of the workgroup when not the level's default (levels >= 1: kFrontThreadsLNBig)
-template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false, bool TILED = false, bool SRC = false, bool OOBK = false, int NTK = 0>
+template <bool L0, bool Y8 = false, int RB = kFrontRows, bool UA = false, bool TILED = false, bool SRC = false, bool OOBK = false, int NTK = 0, int LUM = 0>
 __global__ __launch_bounds__(NTK ? NTK : (L0 ? kFrontThreadsL0 : kFrontThreadsLN), (L0 || NTK == kFrontThreadsLNBig) ? 8 : 4) void k_front(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                          uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                                          uint16_t* __restrict__ blur_rowc, Pyramid pyr,
@@ -354,17 +387,17 @@ __global__ __launch_bounds__(NTK ? NTK : (L0 ? kFrontThreadsL0 : kFrontThreadsLN
 // Levels 0 and 1 of ONE frame in one launch (the reference's call shape, orb.rs:469-557: one blocking call per frame, where a
 // dependent launch costs more than the work it starts): blocks [0, n0) are level 0's bands, the rest level 1's, which build
 // their grey rows from the frame itself (SRC) and so wait for nothing.  1024 threads for both.
-template <int RB0, int RB1, bool Y8 = false>
+template <int RB0, int RB1, bool Y8 = false, int LUM = 0>
 __global__ __launch_bounds__(kFrontThreadsL0) void k_front_pair(const uint8_t* __restrict__ frames, size_t frame_bytes,
                                                               uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
                                                               uint16_t* __restrict__ blur_rowc, Pyramid pyr, FrontGeom geo0,
                                                               FrontGeom geo1, float thr, uint32_t* __restrict__ seg_counts,
                                                               CornerData* __restrict__ segments) {
     if (blockIdx.x < geo0.n_bands)
-        front_body<true, Y8, RB0, false, false, false>(blockIdx.x, frames, frame_bytes, gray, blur, blur_rowc, pyr, geo0, thr, seg_counts, segments);
+        front_body<true, Y8, RB0, false, false, false, 0, false, LUM>(blockIdx.x, frames, frame_bytes, gray, blur, blur_rowc, pyr, geo0, thr, seg_counts, segments);
     else
-        front_body<false, Y8, RB1, false, false, true, kFrontThreadsL0>(blockIdx.x - geo0.n_bands, frames, frame_bytes, gray, blur, blur_rowc,
-                                                                       pyr, geo1, thr, seg_counts, segments);
+        front_body<false, Y8, RB1, false, false, true, kFrontThreadsL0, false, LUM>(blockIdx.x - geo0.n_bands, frames, frame_bytes, gray, blur, blur_rowc,
+                                                                                   pyr, geo1, thr, seg_counts, segments);
 }
 
 // Band slots of a frame: one per kFrontRows-row band per level, in level order.
@@ -394,6 +427,7 @@ struct RowsGeom {
     uint32_t qa[kMaxLevels];        // columns [0, qa) of the level's blur are the row constants
     uint32_t split;                 // workgroups per band slot (> 1 for small batches: more waves in flight)
     uint32_t oob;                   // OrbOptions::oob_policy for samples that leave the level (brief.wgsl:59-60)
+    uint32_t fp;                    // OrbOptions::fp_contract: the rotation's form (rot_form())
 };
 
 // One sample of the fused pipeline's blur under an out-of-level policy != kOobZero: the coordinates are mapped into the level,
@@ -463,8 +497,9 @@ __global__ __launch_bounds__(256) void k_brief_rows(const uint16_t* __restrict__
                     const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
                     const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
                     // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y); rows only
-                    const float a2 = nst * pax, a3 = ct * pay, b2 = nst * pbx, b3 = ct * pby;
-                    const float ray = a2 + a3, rby = b2 + b3;
+                    float rax, ray, rbx, rby;
+                    rotate_fp(ct, st, nst, pax, pay, rot_form(rg.fp), &rax, &ray);
+                    rotate_fp(ct, st, nst, pbx, pby, rot_form(rg.fp), &rbx, &rby);
                     ra[e] = (int)ray;  // vec2i() truncates
                     rb[e] = (int)rby;
                 }
@@ -485,9 +520,9 @@ __global__ __launch_bounds__(256) void k_brief_rows(const uint16_t* __restrict__
             for (int e = 0; e < 4; e++) {
                 const float pax = (float)(int8_t)(pat[e] & 255u), pay = (float)(int8_t)((pat[e] >> 8) & 255u);
                 const float pbx = (float)(int8_t)((pat[e] >> 16) & 255u), pby = (float)(int8_t)(pat[e] >> 24);
-                const float a0 = ct * pax, a1 = st * pay, a2 = nst * pax, a3 = ct * pay;
-                const float b0 = ct * pbx, b1 = st * pby, b2 = nst * pbx, b3 = ct * pby;
-                const float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
+                float rax, ray, rbx, rby;
+                rotate_fp(ct, st, nst, pax, pay, rot_form(rg.fp), &rax, &ray);
+                rotate_fp(ct, st, nst, pbx, pby, rot_form(rg.fp), &rbx, &rby);
                 const int dya = (int)ray, dyb = (int)rby;
                 const int xa = (int)rec.x + (int)rax, ya = (int)rec.y + dya;
                 const int xb = (int)rec.x + (int)rbx, yb = (int)rec.y + dyb;

@@ -18,9 +18,10 @@ namespace orb {
 // INTENDED (IM-1, not in the reference): BT.601 red weight and no mirror.
 template <bool INTENDED>
 __global__ __launch_bounds__(256) void k_grayscale(const uint8_t* __restrict__ frames, size_t frame_bytes,
-                                                   uint16_t* __restrict__ gray, Pyramid pyr, uint32_t contract = 0u) {
-    // contract (OrbOptions::fp_contract, CRD-13; the reference's detector only): the dot product as an fma chain
-    auto lum = [contract](uint32_t v) { return INTENDED ? luminance_601(v) : (contract ? luminance_contracted(v) : luminance(v)); };
+                                                   uint16_t* __restrict__ gray, Pyramid pyr, uint32_t fp = 0u) {
+    // fp (OrbOptions::fp_contract, CRD-13; the reference's detector only): which of the four forms the dot product takes
+    const int form = lum_form(fp);
+    auto lum = [form](uint32_t v) { return INTENDED ? luminance_601(v) : (form ? luminance_fp(v, form) : luminance(v)); };
     const uint32_t W = pyr.w[0], H = pyr.h[0];
     const uint32_t y = blockIdx.y, f = blockIdx.z;
     const uint32_t x0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(256) void k_mip(uint16_t* __restrict__ gray, Pyrami
 // One block = one row of one level of one frame; row and the f16-rounded intermediate in LDS.
 // grid: (h_level, 1, frames), dynamic LDS = 2 * w * 2 bytes.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float blur_point(const half_t* row, uint32_t x, uint32_t w, float wq, uint32_t contract = 0u) {
+__device__ __forceinline__ float blur_point(const half_t* row, uint32_t x, uint32_t w, float wq, uint32_t fp = 0u) {
+    const bool contract = (fp & kFpBlur) != 0u;
     float acc = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -145,7 +147,7 @@ __device__ __forceinline__ float blur_point(const half_t* row, uint32_t x, uint3
 }
 
 __global__ __launch_bounds__(256) void k_blur_rows(const uint16_t* __restrict__ gray, uint16_t* __restrict__ blur,
-                                                   Pyramid pyr, uint32_t m, float wq, uint32_t contract = 0u) {
+                                                   Pyramid pyr, uint32_t m, float wq, uint32_t fp = 0u) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t w = pyr.w[m];
     half_t* row = reinterpret_cast<half_t*>(lds_raw);
@@ -154,9 +156,9 @@ __global__ __launch_bounds__(256) void k_blur_rows(const uint16_t* __restrict__ 
     const size_t base = (size_t)blockIdx.z * pyr.stride + pyr.off[m] + (size_t)y * w;
     for (uint32_t x = threadIdx.x; x < w; x += 256u) row[x] = bits_half(gray[base + x]);
     __syncthreads();
-    for (uint32_t x = threadIdx.x; x < w; x += 256u) tmp[x] = to_half(blur_point(row, x, w, wq, contract));
+    for (uint32_t x = threadIdx.x; x < w; x += 256u) tmp[x] = to_half(blur_point(row, x, w, wq, fp));
     __syncthreads();
-    for (uint32_t x = threadIdx.x; x < w; x += 256u) blur[base + x] = half_bits(to_half(blur_point(tmp, x, w, wq, contract)));
+    for (uint32_t x = threadIdx.x; x < w; x += 256u) blur[base + x] = half_bits(to_half(blur_point(tmp, x, w, wq, fp)));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -530,17 +532,13 @@ __device__ __forceinline__ float level_load(const uint16_t* lvl, uint32_t w, uin
 
 // (s1, s2) = (st, -st): the reference's R(-theta); (-st, st): "intended" mode IM-6, R(+theta).
 __device__ __forceinline__ bool brief_test(uint32_t packed, float ct, float s1, float s2, int px, int py,
-                                           const uint16_t* lvl, uint32_t w, uint32_t h, uint32_t oob = kOobZero, uint32_t contract = 0u) {
+                                           const uint16_t* lvl, uint32_t w, uint32_t h, uint32_t oob = kOobZero, uint32_t fp = 0u) {
     const float ax = (float)(int8_t)(packed & 255u), ay = (float)(int8_t)((packed >> 8) & 255u);
     const float bx = (float)(int8_t)((packed >> 16) & 255u), by = (float)(int8_t)(packed >> 24);
-    // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y)   brief.wgsl:38-54
-    float a0 = ct * ax, a1 = s1 * ay, a2 = s2 * ax, a3 = ct * ay;
-    float b0 = ct * bx, b1 = s1 * by, b2 = s2 * bx, b3 = ct * by;
-    float rax = a0 + a1, ray = a2 + a3, rbx = b0 + b1, rby = b2 + b3;
-    if (contract) {  // CRD-13: matrix * vector = p.x * column 0, then p.y * column 1 fused onto it
-        rax = __builtin_fmaf(s1, ay, a0), ray = __builtin_fmaf(ct, ay, a2);
-        rbx = __builtin_fmaf(s1, by, b0), rby = __builtin_fmaf(ct, by, b2);
-    }
+    // mat2x2f(ct,-st, st,ct) * p (column-major): (ct*x + st*y, -st*x + ct*y)   brief.wgsl:38-54; CRD-13: rot_form(fp)
+    float rax, ray, rbx, rby;
+    rotate_fp(ct, s1, s2, ax, ay, rot_form(fp), &rax, &ray);
+    rotate_fp(ct, s1, s2, bx, by, rot_form(fp), &rbx, &rby);
     const float va = level_load(lvl, w, h, (int)rax + px, (int)ray + py, oob);  // vec2i() truncates, brief.wgsl:56-57
     const float vb = level_load(lvl, w, h, (int)rbx + px, (int)rby + py, oob);
     return va > vb;  // brief.wgsl:62
@@ -550,7 +548,7 @@ __global__ __launch_bounds__(256) void k_brief(const uint16_t* __restrict__ blur
                                                const uint32_t* __restrict__ counts,
                                                const CornerData* __restrict__ corners, uint32_t cap,
                                                CornerDescriptor* __restrict__ descriptors, BriefTables tab,
-                                               uint32_t intended, uint32_t oob = kOobZero, uint32_t contract = 0u) {
+                                               uint32_t intended, uint32_t oob = kOobZero, uint32_t fp = 0u) {
     const uint32_t f = blockIdx.z;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -572,10 +570,10 @@ __global__ __launch_bounds__(256) void k_brief(const uint16_t* __restrict__ blur
             const uint32_t w = pyr.w[oct], h = pyr.h[oct];
             const uint16_t* lvl = blur + (size_t)f * pyr.stride + pyr.off[oct];
             const int px = (int)rec.x, py = (int)rec.y;
-            b0 = __ballot(brief_test(p0, ct, st, nst, px, py, lvl, w, h, oob, contract));
-            b1 = __ballot(brief_test(p1, ct, st, nst, px, py, lvl, w, h, oob, contract));
-            b2 = __ballot(brief_test(p2, ct, st, nst, px, py, lvl, w, h, oob, contract));
-            b3 = __ballot(brief_test(p3, ct, st, nst, px, py, lvl, w, h, oob, contract));
+            b0 = __ballot(brief_test(p0, ct, st, nst, px, py, lvl, w, h, oob, fp));
+            b1 = __ballot(brief_test(p1, ct, st, nst, px, py, lvl, w, h, oob, fp));
+            b2 = __ballot(brief_test(p2, ct, st, nst, px, py, lvl, w, h, oob, fp));
+            b3 = __ballot(brief_test(p3, ct, st, nst, px, py, lvl, w, h, oob, fp));
         }
         if (lane < 8u) {
             const uint64_t src = lane < 2u ? b0 : (lane < 4u ? b1 : (lane < 6u ? b2 : b3));

@@ -28,6 +28,8 @@ ORB_FLAG_INTENDED = 8
 ORB_FLAG_INPUT_Y8 = 16
 ORB_OOB_ZERO, ORB_OOB_CLAMP, ORB_OOB_UMIN = 0, 1, 2  # OrbOptions.oob_policy
 OOB_POLICIES = {"zero": ORB_OOB_ZERO, "clamp": ORB_OOB_CLAMP, "umin": ORB_OOB_UMIN}
+# OrbOptions.fp_contract (CRD-13): which stages' products and sums the adapter's shader compiler fuses, and its reduction order
+ORB_FP_CONTRACT_LUMINANCE, ORB_FP_CONTRACT_BLUR, ORB_FP_CONTRACT_ROTATION, ORB_FP_CONTRACT_ALL, ORB_FP_LAST_TERM_FIRST = 1, 2, 4, 7, 8
 TRANSPORT_RECORD_WORDS = 10  # ORB_TRANSPORT_RECORD_BYTES / 4
 SYN_GRADIENT, SYN_BLOBS, SYN_WEDGES, SYN_NOISE = 1, 2, 4, 8
 SYN_ALL = 15
@@ -195,7 +197,7 @@ def load_library(path=None):
     L.orb_node_rccl_pairs.restype = ctypes.c_uint64
     L.orb_extract_batch_pinned.argtypes = [vp, vp, u32]
     L.orb_upload_sync.argtypes = [vp]
-    if L.orb_abi_version() != 4:
+    if L.orb_abi_version() != 5 and not os.environ.get("TINYORB_ALLOW_ABI"):  # (tools/ab_old_new.sh alternates libraries of other commits)
         raise OrbError(ORB_EINVAL, "libtinyorb ABI version mismatch")
     if path == LIB_PATH:
         _lib = L
@@ -276,7 +278,7 @@ class OrbConfig:
     # the two implementation-defined points of the reference's WGSL as switches (include/tinyorb.h, OrbOptions)
     oob_policy: int = 0           # ORB_OOB_ZERO / ORB_OOB_CLAMP / ORB_OOB_UMIN: textureLoad outside the level
     sampler_weight_bits: int = 0  # 0: exact bilinear weights; n: weights held in n fractional bits
-    fp_contract: int = 0  # CRD-13: 1 = a shader compiler that contracts products and sums into fmas (staged kernels only)
+    fp_contract: int = 0  # CRD-13: mask of ORB_FP_CONTRACT_LUMINANCE / _BLUR / _ROTATION (that stage's products and sums as fmas) and ORB_FP_LAST_TERM_FIRST
 
 
 def _ptr(a):

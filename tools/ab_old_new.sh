@@ -2,6 +2,7 @@
 # other commits' sources), three rounds, alternating; the tree's own library is put back at the end.  An A/B through a run-time switch inside ONE
 # binary does not see what a change costs the binary as a whole (registers, code around the switch) -- round 4 learnt that the hard way.
 out=gpurun_out/abso; mkdir -p $out
+export TINYORB_ALLOW_ABI=1  # libraries of older commits report an older ABI version; the bench uses nothing that changed
 cp tinyslam_amd/libtinyorb.so $out/keep.so
 run() { python bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-host-out --no-single-frame > $out/$1.json 2> $out/$1.err || { echo fail $1; tail -3 $out/$1.err; cp $out/keep.so tinyslam_amd/libtinyorb.so; exit 1; }
 python - <<PY
