@@ -92,13 +92,42 @@ def test_the_forms_are_different_functions(oracle):
     c0, _ = oracle.sort_keypoints(*[oracle.extract(f2, depth=2, threshold=THR)[k] for k in ("corners", "descriptors")])
     c1, _ = oracle.sort_keypoints(*[oracle.extract(f2, depth=2, threshold=THR, contract=7)[k] for k in ("corners", "descriptors")])
     assert not np.array_equal(c0["angle"], c1["angle"])
-    # the rotation: some keypoint of some frame has a pattern point whose two forms truncate differently
-    diff = 0
-    for code in range(1, 3142, 7):
-        for (x, y) in ((8, -3), (9, 5), (-13, 12), (7, -11), (-1, -6), (0, -11), (12, -13), (-11, 7)):
-            r = [tuple(int(v) for v in oracle.brief_rotate(code, x, y, ct, do)) for ct, do in ((0, 0), (4, 0), (4, 1))]
-            diff += len(set(r)) > 1
-    assert diff > 0
+    # the rotation: over all 3142 codes and every pattern point the three forms truncate differently in ONE place -- code 2214, where
+    # (cos, sin) rounds to (-0.6, 0.8) and the points (-3, 4), (6, -8), (8, 6) rotate onto integers -- a 3-4-5 triangle
+    diff = set()
+    for (x, y) in ((-3, 4), (6, -8), (8, 6), (8, -3)):
+        r = [tuple(int(v) for v in oracle.brief_rotate(2214, x, y, ct, do)) for ct, do in ((0, 0), (4, 0), (4, 1))]
+        if len(set(r)) > 1:
+            diff.add((x, y))
+    assert diff == {(-3, 4), (6, -8), (8, 6)}
+
+
+@pytest.mark.parametrize("fp", [4, 12])
+def test_rotated_pattern_table_follows_the_rotation_form(tinyorb, fp):
+    """k_rot_table under OrbOptions::fp_contract (k_brief_nf's and the odd-width gathers' source of rotated points): every entry against
+    the NumPy restatement's rotate() in the same form -- all 3142 codes x 256 tests x 2 points, code 2214 (where the forms part)
+    among them."""
+    from oracle import orb_numpy as on
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(320, 240), max_features=1024, hierarchy_depth=2, initial_threshold=THR, fp_contract=fp)
+    with tinyorb.OrbProgram(cfg) as prog:
+        table, pitch = prog.rot_table()
+    with tinyorb.OrbProgram(tinyorb.OrbConfig(tinyorb.Extent3d(320, 240), max_features=1024, hierarchy_depth=2, initial_threshold=THR)) as prog:
+        plain, _ = prog.rot_table()
+    assert table.shape[0] == 3142 and pitch == 48
+    F = np.float32
+    theta = np.arange(3142, dtype=np.float32) / F(1000.0)
+    ct = np.cos(theta.astype(np.float64)).astype(np.float32)
+    st = np.sin(theta.astype(np.float64)).astype(np.float32)
+    for j in range(256):
+        ax, ay, bx, by = (F(v) for v in on.PATTERN[j])
+        rax, ray = on.rotate(ct, st, ax, ay, 1, (fp >> 3) & 1)
+        rbx, rby = on.rotate(ct, st, bx, by, 1, (fp >> 3) & 1)
+        oa = 2 * (np.trunc(ray).astype(np.int64) * pitch + np.trunc(rax).astype(np.int64))
+        ob = 2 * (np.trunc(rby).astype(np.int64) * pitch + np.trunc(rbx).astype(np.int64))
+        assert np.array_equal(table[:, j & 63, j >> 6, 0].astype(np.int64), oa), "test %d point a" % j
+        assert np.array_equal(table[:, j & 63, j >> 6, 1].astype(np.int64), ob), "test %d point b" % j
+    where = np.argwhere(table != plain)
+    assert len(where) > 0 and set(where[:, 0].tolist()) == {2214}  # the one code at which a fused product changes a truncation
 
 
 @pytest.mark.parametrize("oob,wbits,fp", [("clamp", 8, 15), ("umin", 0, 7), ("umin", 8, 12), ("zero", 8, 3)])

@@ -13,9 +13,14 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libtinyorb.so")
-SOURCES = ["orb_api.hip", "orb_node.hip"]
+# Translation units: (source, extra flags, object name).  k_front's ~160 instances are spread over eight units, one per arithmetic form
+# of the adapter's shader compiler (csrc/orb_front_launch.h), compiled in parallel: a kernel is launched from the unit that instantiated
+# it, so the objects link as plain host code (no relocatable device code).
+UNITS = [("orb_api.hip", [], "orb_api.o"), ("orb_node.hip", [], "orb_node.o")] + \
+        [("orb_front_inst.hip", ["-DTINYORB_FRONT_FP=%d" % f], "orb_front_fp%d.o" % f) for f in range(8)]
+OBJ_DIR = os.path.join(PKG_DIR, "_obj")
 HIPCC_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-Wall", "-Wno-unused-function",
     # wave-aggregate LDS/global atomic adds of lane-varying amounts with a DPP scan; the default
@@ -52,8 +57,8 @@ def source_hash():
     header hold no device code and are not part of it."""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")) or f == "orb_api.hip")
-    h.update(" ".join(HIPCC_FLAGS).encode())
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")) or f in ("orb_api.hip", "orb_front_inst.hip"))
+    h.update(" ".join(HIPCC_FLAGS + ["-shared"]).encode())
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
@@ -67,14 +72,29 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build_lib(force=False, verbose=False):
+def build_lib(force=False, verbose=False, jobs=None):
     if not force and not needs_build():
         return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
     flags = list(HIPCC_FLAGS)
     if os.environ.get("TINYORB_BUILD_STAMPS"):  # diagnostic build: in-kernel cycle stamps (tools/stamps.py)
         flags.append("-DTINYORB_STAMPS")
     flags += os.environ.get("TINYORB_BUILD_EXTRA", "").split()  # experiments: extra compiler flags (e.g. -DTINYORB_B1_UNALIGNED)
-    cmd = [_hipcc()] + flags + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_unit(unit):
+        src, extra, obj = unit
+        cmd = [hipcc] + flags + extra + ["-c", "-o", os.path.join(OBJ_DIR, obj), os.path.join(CSRC, src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return os.path.join(OBJ_DIR, obj)
+
+    jobs = jobs or int(os.environ.get("TINYORB_BUILD_JOBS", "0")) or min(len(UNITS), os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(compile_unit, UNITS))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

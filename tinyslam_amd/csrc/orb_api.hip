@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/tinyorb.h"
+#include "orb_front_launch.h"
 #include "orb_kernels_fused.h"
 #include "orb_kernels_brief.h"
 #include "orb_kernels_intended.h"
@@ -36,6 +37,14 @@ const char* const kKernelNames[ORB_KERNEL_COUNT] = {"k_grayscale", "k_mip",     
                                                     "k_brief_one", "k_front_i_ln"};
 
 thread_local std::string g_create_error;
+
+// k_front's instances by arithmetic form (orb_front_launch.h: front_form())
+hipError_t (*const kFrontLaunch[8])(const FrontLaunch&) = {front_launch_fp0, front_launch_fp1, front_launch_fp2, front_launch_fp3,
+                                                           front_launch_fp4, front_launch_fp5, front_launch_fp6, front_launch_fp7};
+hipError_t (*const kFrontPairLaunch[8])(const FrontPairLaunch&) = {front_pair_launch_fp0, front_pair_launch_fp1, front_pair_launch_fp2, front_pair_launch_fp3,
+                                                                   front_pair_launch_fp4, front_pair_launch_fp5, front_pair_launch_fp6, front_pair_launch_fp7};
+hipError_t (*const kFrontSetMaxLds[8])(int) = {front_set_max_lds_fp0, front_set_max_lds_fp1, front_set_max_lds_fp2, front_set_max_lds_fp3,
+                                               front_set_max_lds_fp4, front_set_max_lds_fp5, front_set_max_lds_fp6, front_set_max_lds_fp7};
 
 struct ProfSpan {
     int kid;
@@ -416,7 +425,6 @@ FrontGeom front_geometry(const Pyramid& pyr, uint32_t lvl, uint32_t gw, uint32_t
     }
     g.n_classes = 1u;
     g.phase_mask = 15u;  // run_fused_range applies the program's experiment switches (TINYORB_PHASE_MASK, TINYORB_NO_SWIZZLE)
-    front_blur_constants(&g);  // fp = 0: every product and sum rounded; run_fused_range sets the program's
     return g;
 }
 
@@ -547,7 +555,6 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         g.oob = p->oob;
         g.wq = p->wq;
         g.fp = p->opt.fp_contract;
-        front_blur_constants(&g);
         g.store_grey = (lvl == 0 && D > 1 && !(pyr.w[0] == 2u * pyr.w[1] && pyr.h[0] == 2u * pyr.h[1])) ? 1u : 0u;
         if (g.n_bands * (g.tiled ? g.n_ct : 1u) != p->bands.slot_base[lvl + 1] - p->bands.slot_base[lvl])
             return fail(p, ORB_EINVAL, "internal: band count mismatch at level %u", lvl);
@@ -557,91 +564,17 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         lds += (uint32_t)p->env.lds_pad;  // TINYORB_LDS_PAD: occupancy experiments only
         if (lds > p->max_lds) return fail(p, ORB_EINVAL, "level %u needs %u bytes of LDS", lvl, lds);
         const dim3 grid(g.n_bands * (g.tiled ? g.n_ct : 1u) * n);
-#define FRONT_ARGS frames, p->frame_bytes, d_gray, d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg
-#define FRONT_LAUNCH_TILED(L0, Y8, UA)                                                                             \
-    if (p->band_rows_lvl[lvl] == 16u) hipLaunchKernelGGL((k_front<L0, Y8, 16, UA, true>), grid, block, lds, s_lvl, FRONT_ARGS); \
-    else hipLaunchKernelGGL((k_front<L0, Y8, 8, UA, true>), grid, block, lds, s_lvl, FRONT_ARGS);
-// level 0 from RGBA: the luminance's form (OrbOptions::fp_contract, lum_form()) is a template parameter -- UA_, TILED_ as above
-#define FRONT_LAUNCH_RGBA(UA_, TILED_, LUM_)                                                                                                            \
-    switch (p->band_rows_lvl[lvl]) {                                                                                                                    \
-        case 64: if (!TILED_) { hipLaunchKernelGGL((k_front<true, false, TILED_ ? 16 : 64, UA_, TILED_, false, false, 0, LUM_>), grid, block, lds, s_lvl, FRONT_ARGS); } break; \
-        case 32: if (!TILED_) { hipLaunchKernelGGL((k_front<true, false, TILED_ ? 16 : 32, UA_, TILED_, false, false, 0, LUM_>), grid, block, lds, s_lvl, FRONT_ARGS); } break; \
-        case 16: hipLaunchKernelGGL((k_front<true, false, 16, UA_, TILED_, false, false, 0, LUM_>), grid, block, lds, s_lvl, FRONT_ARGS); break;        \
-        default: hipLaunchKernelGGL((k_front<true, false, 8, UA_, TILED_, false, false, 0, LUM_>), grid, block, lds, s_lvl, FRONT_ARGS); break;         \
-    }
-#define FRONT_LAUNCH_RGBA_LUM(UA_, TILED_)                          \
-    switch (lum_form(p->opt.fp_contract)) {                         \
-        case 1: FRONT_LAUNCH_RGBA(UA_, TILED_, 1) break;            \
-        case 2: FRONT_LAUNCH_RGBA(UA_, TILED_, 2) break;            \
-        case 3: FRONT_LAUNCH_RGBA(UA_, TILED_, 3) break;            \
-        default: FRONT_LAUNCH_RGBA(UA_, TILED_, 0) break;           \
-    }
-#define FRONT_LAUNCH(L0, Y8)                                                                                       \
-    switch (p->band_rows_lvl[lvl]) {                                                                               \
-        case 64: hipLaunchKernelGGL((k_front<L0, Y8, 64>), grid, block, lds, s_lvl, FRONT_ARGS); break;                \
-        case 32: hipLaunchKernelGGL((k_front<L0, Y8, 32>), grid, block, lds, s_lvl, FRONT_ARGS); break;                \
-        case 16: hipLaunchKernelGGL((k_front<L0, Y8, 16>), grid, block, lds, s_lvl, FRONT_ARGS); break;                \
-        default: hipLaunchKernelGGL((k_front<L0, Y8, 8>), grid, block, lds, s_lvl, FRONT_ARGS); break;                 \
-    }
-        if (lvl == 0) {
-            LaunchScope ls(p, s_lvl, KID_FUSED_L0);
-            const dim3 block(kFrontThreadsL0);
-#define FRONT_LAUNCH_UA(Y8)                                                                                        \
-    switch (p->band_rows_lvl[lvl]) {                                                                               \
-        case 64: hipLaunchKernelGGL((k_front<true, Y8, 64, true>), grid, block, lds, s_lvl, FRONT_ARGS); break;        \
-        case 32: hipLaunchKernelGGL((k_front<true, Y8, 32, true>), grid, block, lds, s_lvl, FRONT_ARGS); break;        \
-        case 16: hipLaunchKernelGGL((k_front<true, Y8, 16, true>), grid, block, lds, s_lvl, FRONT_ARGS); break;        \
-        default: hipLaunchKernelGGL((k_front<true, Y8, 8, true>), grid, block, lds, s_lvl, FRONT_ARGS); break;         \
-    }
-            // rows not aligned to a quad, or the level-0 plane is needed (level 1 not an exact half): the general variant
-            const bool general = (pyr.w[0] & 3u) || g.store_grey;
-            if (g.tiled) {
-                if (p->input_y8 && general) { FRONT_LAUNCH_TILED(true, true, true) }
-                else if (p->input_y8) { FRONT_LAUNCH_TILED(true, true, false) }
-                else if (general) { FRONT_LAUNCH_RGBA_LUM(true, true) }
-                else { FRONT_LAUNCH_RGBA_LUM(false, true) }
-            } else if (p->input_y8 && general) {
-                FRONT_LAUNCH_UA(true)
-            } else if (p->input_y8) {
-                FRONT_LAUNCH(true, true)
-            } else if (general) {
-                FRONT_LAUNCH_RGBA_LUM(true, false)
-            } else {
-                FRONT_LAUNCH_RGBA_LUM(false, false)
-            }
-#undef FRONT_LAUNCH_UA
-        } else if (p->ln_threads[lvl] == (uint32_t)kFrontThreadsLNBig) {  // a level whose bands are large enough for level 0's shape (chosen at create)
-            LaunchScope ls(p, s_lvl, KID_FUSED_LN);
-            const dim3 block(kFrontThreadsLNBig);
-            switch (p->band_rows_lvl[lvl]) {
-                case 64: hipLaunchKernelGGL((k_front<false, false, 64, false, false, false, false, kFrontThreadsLNBig>), grid, block, lds, s_lvl, FRONT_ARGS); break;
-                case 32: hipLaunchKernelGGL((k_front<false, false, 32, false, false, false, false, kFrontThreadsLNBig>), grid, block, lds, s_lvl, FRONT_ARGS); break;
-                case 16: hipLaunchKernelGGL((k_front<false, false, 16, false, false, false, false, kFrontThreadsLNBig>), grid, block, lds, s_lvl, FRONT_ARGS); break;
-                default: hipLaunchKernelGGL((k_front<false, false, 8, false, false, false, false, kFrontThreadsLNBig>), grid, block, lds, s_lvl, FRONT_ARGS); break;
-            }
-        } else {
-            LaunchScope ls(p, s_lvl, KID_FUSED_LN);
-            const dim3 block(kFrontThreadsLN);
-            if (p->oob != kOobZero) {  // texels outside the level follow OrbOptions::oob_policy: the OOBK instances
-#define FRONT_LAUNCH_OOB(TILED_)                                                                                              \
-    switch (p->band_rows_lvl[lvl]) {                                                                                          \
-        case 64: hipLaunchKernelGGL((k_front<false, false, 64, false, TILED_, false, true>), grid, block, lds, s_lvl, FRONT_ARGS); break; \
-        case 32: hipLaunchKernelGGL((k_front<false, false, 32, false, TILED_, false, true>), grid, block, lds, s_lvl, FRONT_ARGS); break; \
-        case 16: hipLaunchKernelGGL((k_front<false, false, 16, false, TILED_, false, true>), grid, block, lds, s_lvl, FRONT_ARGS); break; \
-        default: hipLaunchKernelGGL((k_front<false, false, 8, false, TILED_, false, true>), grid, block, lds, s_lvl, FRONT_ARGS); break;  \
-    }
-                if (g.tiled && p->band_rows_lvl[lvl] == 16u) hipLaunchKernelGGL((k_front<false, false, 16, false, true, false, true>), grid, block, lds, s_lvl, FRONT_ARGS);
-                else if (g.tiled) hipLaunchKernelGGL((k_front<false, false, 8, false, true, false, true>), grid, block, lds, s_lvl, FRONT_ARGS);
-                else { FRONT_LAUNCH_OOB(false) }
-#undef FRONT_LAUNCH_OOB
-            } else if (g.tiled) { FRONT_LAUNCH_TILED(false, false, false) }
-            else { FRONT_LAUNCH(false, false) }
+        // The kernel instances live in orb_front_inst.hip, one translation unit per arithmetic form (orb_front_launch.h); the form a
+        // launch takes carries the luminance bits only where a luminance is computed (level 0 from RGBA).
+        FrontLaunch L{frames, p->frame_bytes, d_gray, d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg, s_lvl, grid.x, lds,
+                      p->band_rows_lvl[lvl], p->ln_threads[lvl], p->input_y8,
+                      // rows not aligned to a quad, or the level-0 plane is needed (level 1 not an exact half): the general variant
+                      lvl == 0 && ((pyr.w[0] & 3u) || g.store_grey), p->oob != kOobZero};
+        {
+            LaunchScope ls(p, s_lvl, lvl == 0 ? KID_FUSED_L0 : KID_FUSED_LN);
+            const hipError_t e = kFrontLaunch[front_form(p->opt.fp_contract, lvl == 0 && !p->input_y8)](L);
+            if (e != hipSuccess) return fail(p, ORB_EHIP, "k_front (level %u) failed to launch: %s", lvl, hipGetErrorString(e));
         }
-#undef FRONT_LAUNCH
-#undef FRONT_LAUNCH_TILED
-#undef FRONT_LAUNCH_RGBA
-#undef FRONT_LAUNCH_RGBA_LUM
-#undef FRONT_ARGS
     }
     // orb.rs:523-534, plus the compaction of the band segments into the final lists
     if (with_brief) launch_brief(p, s, n, p->rows, d_blur, d_blur_rowc, d_seg_counts, d_seg_before, d_seg, d_counts, d_corners, d_desc);
@@ -1130,38 +1063,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
                 // device's limit, so that a later, smaller program never lowers it under a live, larger one.
                 p->use_brief_t = brieft_geometry(p, rg, 2u, &p->brieft);
                 p->seg_classes = p->use_brief_t ? 2u : 1u;
-                const void* fronts[] = {
-#define FRONT_FN(R) reinterpret_cast<const void*>(&k_front<true, false, R>), reinterpret_cast<const void*>(&k_front<false, false, R>), \
-                    reinterpret_cast<const void*>(&k_front<true, true, R>), reinterpret_cast<const void*>(&k_front<true, false, R, true>), \
-                    reinterpret_cast<const void*>(&k_front<true, true, R, true>)
-#define FRONT_FN_TILED(R) reinterpret_cast<const void*>(&k_front<true, false, R, false, true>), reinterpret_cast<const void*>(&k_front<false, false, R, false, true>), \
-                    reinterpret_cast<const void*>(&k_front<true, true, R, false, true>), reinterpret_cast<const void*>(&k_front<true, false, R, true, true>), \
-                    reinterpret_cast<const void*>(&k_front<true, true, R, true, true>)
-                    FRONT_FN(64), FRONT_FN(32), FRONT_FN(16), FRONT_FN(8), FRONT_FN_TILED(16), FRONT_FN_TILED(8),
-#define FRONT_FN_BIG(R) reinterpret_cast<const void*>(&k_front<false, false, R, false, false, false, false, kFrontThreadsLNBig>)
-                    FRONT_FN_BIG(64), FRONT_FN_BIG(32), FRONT_FN_BIG(16), FRONT_FN_BIG(8),
-#undef FRONT_FN_BIG
-#define FRONT_FN_OOB(R, T) reinterpret_cast<const void*>(&k_front<false, false, R, false, T, false, true>)
-                    FRONT_FN_OOB(64, false), FRONT_FN_OOB(32, false), FRONT_FN_OOB(16, false), FRONT_FN_OOB(8, false), FRONT_FN_OOB(16, true), FRONT_FN_OOB(8, true),
-#undef FRONT_FN_OOB
-// level 0 from RGBA in the luminance's other forms (lum_form(): 1, 2, 3), aligned / general, full-width / tiled
-#define FRONT_FN_LUM1(R, UA, T, L) reinterpret_cast<const void*>(&k_front<true, false, R, UA, T, false, false, 0, L>)
-#define FRONT_FN_LUM(L) FRONT_FN_LUM1(64, false, false, L), FRONT_FN_LUM1(32, false, false, L), FRONT_FN_LUM1(16, false, false, L), FRONT_FN_LUM1(8, false, false, L), \
-                        FRONT_FN_LUM1(64, true, false, L), FRONT_FN_LUM1(32, true, false, L), FRONT_FN_LUM1(16, true, false, L), FRONT_FN_LUM1(8, true, false, L),     \
-                        FRONT_FN_LUM1(16, false, true, L), FRONT_FN_LUM1(8, false, true, L), FRONT_FN_LUM1(16, true, true, L), FRONT_FN_LUM1(8, true, true, L)
-                    FRONT_FN_LUM(1), FRONT_FN_LUM(2), FRONT_FN_LUM(3)
-#undef FRONT_FN_LUM
-#undef FRONT_FN_LUM1
-#undef FRONT_FN
-#undef FRONT_FN_TILED
-                };
-                for (const void* f : fronts)
-                    CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
-                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_pair<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
-                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_pair<8, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
-                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_pair<8, 8, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
-                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_pair<8, 8, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
-                CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_pair<8, 8, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds));
+                for (auto set_max_lds : kFrontSetMaxLds) CREATE_TRY(set_max_lds((int)p->max_lds));  // every instance of k_front / k_front_pair
             }
         }
     }
@@ -1569,7 +1471,6 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
                 g[lvl].xcd_swizzle = 0u;
                 g[lvl].wq = p->wq;
                 g[lvl].fp = p->opt.fp_contract;
-                front_blur_constants(&g[lvl]);
                 if (p->env.phase_mask >= 0) g[lvl].phase_mask = (uint32_t)p->env.phase_mask;
                 lds = std::max(lds, front_lds_bytes(g[lvl]));
             }
@@ -1578,21 +1479,10 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
                 return fail(p, ORB_EINVAL, "internal: k_front_pair does not fit this frame (%u bytes of LDS, %u columns)", lds, py.w[0]);
             {
                 LaunchScope ls(p, s, KID_FUSED_L0);
-                if (p->input_y8)
-                    hipLaunchKernelGGL((k_front_pair<8, 8, true>), dim3(g[0].n_bands + g[1].n_bands), dim3(kFrontThreadsL0), lds, s, d_in,
-                                       p->frame_bytes, p->d_gray, p->d_blur, p->d_blur_rowc, py, g[0], g[1], p->threshold, p->d_seg_counts, p->d_seg);
-                else {
-#define FRONT_PAIR_LAUNCH(LUM_)                                                                                                          \
-    hipLaunchKernelGGL((k_front_pair<8, 8, false, LUM_>), dim3(g[0].n_bands + g[1].n_bands), dim3(kFrontThreadsL0), lds, s, d_in,       \
-                       p->frame_bytes, p->d_gray, p->d_blur, p->d_blur_rowc, py, g[0], g[1], p->threshold, p->d_seg_counts, p->d_seg)
-                    switch (lum_form(p->opt.fp_contract)) {  // the luminance's form (OrbOptions::fp_contract)
-                        case 1: FRONT_PAIR_LAUNCH(1); break;
-                        case 2: FRONT_PAIR_LAUNCH(2); break;
-                        case 3: FRONT_PAIR_LAUNCH(3); break;
-                        default: FRONT_PAIR_LAUNCH(0); break;
-                    }
-#undef FRONT_PAIR_LAUNCH
-                }
+                const FrontPairLaunch PL{d_in, p->frame_bytes, p->d_gray, p->d_blur, p->d_blur_rowc, py, g[0], g[1], p->threshold, p->d_seg_counts, p->d_seg, s, lds,
+                                         p->input_y8};
+                const hipError_t e = kFrontPairLaunch[front_form(p->opt.fp_contract, !p->input_y8)](PL);
+                if (e != hipSuccess) return fail(p, ORB_EHIP, "k_front_pair failed to launch: %s", hipGetErrorString(e));
             }
             if (py.depth > 2u)
                 if (int rc = run_fused_range(p, d_in, 0, 1, s, false, 2u)) return rc;

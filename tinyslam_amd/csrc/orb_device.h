@@ -29,6 +29,14 @@ typedef _Float16 half_t;
 // CRD-3: f32 -> f16 round-to-nearest-even, subnormals kept (v_cvt_f16_f32).
 __device__ __forceinline__ half_t to_half(float v) { return (half_t)v; }
 __device__ __forceinline__ float from_half(half_t h) { return (float)h; }
+// The same conversion of a value that a fused multiply-add produced.  hipcc folds (half_t)fma(a, b, c) into ONE v_fma_mixlo_f16, and
+// the hardware rounds that instruction's exact a * b + c once, to binary16 -- not to binary32 and then to binary16 as an fma in a
+// shader followed by the store to an R16Float target does (and as LLVM's own pattern assumes): one result in some 10^4 differs by a
+// place (found by the blur-plane comparison of tests/test_gpu_round5.py).  The empty asm hides the fma from the conversion.
+__device__ __forceinline__ half_t to_half_strict(float v) {
+    asm("" : "+v"(v));
+    return (half_t)v;
+}
 __device__ __forceinline__ uint16_t half_bits(half_t h) { return __builtin_bit_cast(uint16_t, h); }
 __device__ __forceinline__ half_t bits_half(uint16_t b) { return __builtin_bit_cast(half_t, b); }
 

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void k_grayscale(const uint8_t* __restrict__ f
                                                    uint16_t* __restrict__ gray, Pyramid pyr, uint32_t fp = 0u) {
     // fp (OrbOptions::fp_contract, CRD-13; the reference's detector only): which of the four forms the dot product takes
     const int form = lum_form(fp);
-    auto lum = [form](uint32_t v) { return INTENDED ? luminance_601(v) : (form ? luminance_fp(v, form) : luminance(v)); };
+    // (to_half_strict: the contracted forms end in an fma, which must not be folded into the conversion)
+    auto lum16 = [form](uint32_t v) { return to_half_strict(INTENDED ? luminance_601(v) : (form ? luminance_fp(v, form) : luminance(v))); };
     const uint32_t W = pyr.w[0], H = pyr.h[0];
     const uint32_t y = blockIdx.y, f = blockIdx.z;
     const uint32_t x0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
@@ -31,15 +32,15 @@ __global__ __launch_bounds__(256) void k_grayscale(const uint8_t* __restrict__ f
     if (x0 + 4u <= W && (W & 3u) == 0u) {
         const uint4 px = *reinterpret_cast<const uint4*>(src_row + (size_t)x0 * 4u);
         ushort4 out;
-        out.x = half_bits(to_half(lum(px.x)));
-        out.y = half_bits(to_half(lum(px.y)));
-        out.z = half_bits(to_half(lum(px.z)));
-        out.w = half_bits(to_half(lum(px.w)));
+        out.x = half_bits(lum16(px.x));
+        out.y = half_bits(lum16(px.y));
+        out.z = half_bits(lum16(px.z));
+        out.w = half_bits(lum16(px.w));
         *reinterpret_cast<ushort4*>(dst_row + x0) = out;
     } else {
         for (uint32_t x = x0; x < W && x < x0 + 4u; x++) {
             uint32_t v = *reinterpret_cast<const uint32_t*>(src_row + (size_t)x * 4u);
-            dst_row[x] = half_bits(to_half(lum(v)));
+            dst_row[x] = half_bits(lum16(v));
         }
     }
 }
@@ -156,9 +157,9 @@ __global__ __launch_bounds__(256) void k_blur_rows(const uint16_t* __restrict__ 
     const size_t base = (size_t)blockIdx.z * pyr.stride + pyr.off[m] + (size_t)y * w;
     for (uint32_t x = threadIdx.x; x < w; x += 256u) row[x] = bits_half(gray[base + x]);
     __syncthreads();
-    for (uint32_t x = threadIdx.x; x < w; x += 256u) tmp[x] = to_half(blur_point(row, x, w, wq, fp));
+    for (uint32_t x = threadIdx.x; x < w; x += 256u) tmp[x] = to_half_strict(blur_point(row, x, w, wq, fp));
     __syncthreads();
-    for (uint32_t x = threadIdx.x; x < w; x += 256u) blur[base + x] = half_bits(to_half(blur_point(tmp, x, w, wq, fp)));
+    for (uint32_t x = threadIdx.x; x < w; x += 256u) blur[base + x] = half_bits(to_half_strict(blur_point(tmp, x, w, wq, fp)));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@ timeout -k 10 900 python -m pytest tests/test_gpu_round5.py -m gpu -x -q > gpuru
 [ $rc -ne 0 ] && exit $rc
 timeout -k 10 900 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_round5.py > gpurun_out/r05_gputest_all.log 2>&1; rc=$?; tail -3 gpurun_out/r05_gputest_all.log
 [ $rc -ne 0 ] && exit $rc
-bash tools/ab_old_new.sh r4 r5a 2>&1 | tee gpurun_out/r05_ab_r4_r5a.txt
+bash tools/ab_old_new.sh r4 r5b 2>&1 | tee gpurun_out/r05_ab_r4_r5b.txt
 for c in 0 7 15 8; do
   python bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-host-out --no-single-frame --contract $c > gpurun_out/r05_bench_contract$c.json 2> gpurun_out/r05_bench_contract$c.err || { echo "bench contract $c failed"; tail -3 gpurun_out/r05_bench_contract$c.err; exit 1; }
   python - <<PY
