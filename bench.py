@@ -183,60 +183,75 @@ def workload_text(args, world, B, strong):
                "orientation + separable Gaussian + BRIEF-256"))
 
 
-def single_frame_latency(orb, cfg_kwargs, n=200):
+def single_frame_latency(orb, cfg_kwargs, n=200, n_loop=2000):
     """The reference's only call shape (orb.rs:469-557): one blocking extract_corners per frame, 1280x720.  Returns
     the keys of the bench line: mean microseconds of orb_extract_corners alone on a resident frame; frames/s of the reference's loop
     write_input_image -> extract_corners -> read_corners -> read_descriptors from a host frame; frames/s of the same loop with
-    orb_write_input_image_pinned uploading frame k + 1 under the kernels of frame k."""
+    orb_write_input_image_pinned uploading frame k + 1 under the kernels of frame k -- each under both ways the call can wait for the
+    device: "poll" (default: the host thread spins on a completion word) and "block" (ORB_FLAG_SINGLE_BLOCKING_WAIT: a bounded spin, then
+    the thread sleeps until the completion interrupt, as the reference's device.poll(Wait) does)."""
     import numpy as np
-    cfg = orb.OrbConfig(orb.Extent3d(W, H), max_batch=1, **cfg_kwargs)
-    with orb.OrbProgram(cfg).init() as p1:
-        dev = p1.synth_frames_device(1, SEED0)
-        for _ in range(20):
-            p1.extract_corners()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            p1.extract_corners()
-        extract_us = (time.perf_counter() - t0) / n * 1e6
-        frame = p1.copy_to_host(dev, W * H * 4)
-        corners = np.zeros(MAX_FEATURES, dtype=orb.CORNER_DTYPE)
-        desc = np.zeros((MAX_FEATURES, 8), dtype=np.uint32)
 
-        def six_calls(write):
-            """frames/s of n iterations of write -> extract -> read -> read: (from the median iteration, from the total time,
-            iterations that took more than ten times the median).  On a shared box the host thread now and then loses its CPU
-            for a scheduler slice (20 ms, two to four times in 200 iterations of 90 us): the median is what the path costs."""
-            its = []
-            for k in range(n + 10):
-                a = time.perf_counter()
-                write()
+    def measure(flags):
+        kw = dict(cfg_kwargs)
+        kw["flags"] = kw.get("flags", 0) | flags
+        cfg = orb.OrbConfig(orb.Extent3d(W, H), max_batch=1, **kw)
+        with orb.OrbProgram(cfg).init() as p1:
+            dev = p1.synth_frames_device(1, SEED0)
+            for _ in range(20):
                 p1.extract_corners()
-                p1.read_corners(corners)
-                p1.read_descriptors(desc)
-                if k >= 10:
-                    its.append(time.perf_counter() - a)
-            med = float(np.median(its))
-            return 1.0 / med, len(its) / float(np.sum(its)), int(np.sum(np.asarray(its) > 10.0 * med))
-        blocking = six_calls(lambda: p1.write_input_image(frame))
-        pins = [orb.PinnedArray((H, W, 4), np.uint8) for _ in range(2)]
-        for pn in pins:
-            pn.array[:] = frame.reshape(H, W, 4)
-        st = {"k": 0}
+            t0 = time.perf_counter()
+            for _ in range(n):
+                p1.extract_corners()
+            extract_us = (time.perf_counter() - t0) / n * 1e6
+            frame = p1.copy_to_host(dev, W * H * 4)
+            corners = np.zeros(MAX_FEATURES, dtype=orb.CORNER_DTYPE)
+            desc = np.zeros((MAX_FEATURES, 8), dtype=np.uint32)
 
-        def write_ahead():  # frame k + 1 goes up while frame k is extracted (one image ahead)
-            p1.write_input_image_pinned(pins[st["k"] & 1].array)
-            st["k"] += 1
-        write_ahead()
-        ahead = six_calls(write_ahead)
-        p1.upload_sync()
-        for pn in pins:
-            pn.close()
-        return {"single_frame_us": extract_us, "single_frame_loop_fps": blocking[0], "single_frame_loop_pinned_fps": ahead[0],
-                "single_frame_loop": {"blocking_write": {"fps_median_iteration": blocking[0], "fps_total_time": blocking[1], "stalled_iterations": blocking[2]},
-                                      "pinned_write_one_ahead": {"fps_median_iteration": ahead[0], "fps_total_time": ahead[1], "stalled_iterations": ahead[2]},
-                                      "iterations": n,
-                                      "what": "write_input_image -> extract_corners -> read_corners -> read_descriptors per 1280x720 frame from a host "
-                                              "frame; pinned: orb_write_input_image_pinned uploads frame k + 1 under the kernels of frame k"}}
+            def six_calls(write):
+                """frames/s of n_loop iterations of write -> extract -> read -> read: (from the median iteration, from the total time,
+                iterations that took more than ten times the median).  On a shared box a host thread that spins now and then loses its CPU
+                for a scheduler slice (20 ms): the median is what the path costs, the total what a camera loop gets."""
+                its = []
+                for k in range(n_loop + 10):
+                    a = time.perf_counter()
+                    write()
+                    p1.extract_corners()
+                    p1.read_corners(corners)
+                    p1.read_descriptors(desc)
+                    if k >= 10:
+                        its.append(time.perf_counter() - a)
+                med = float(np.median(its))
+                return 1.0 / med, len(its) / float(np.sum(its)), int(np.sum(np.asarray(its) > 10.0 * med))
+            blocking = six_calls(lambda: p1.write_input_image(frame))
+            pins = [orb.PinnedArray((H, W, 4), np.uint8) for _ in range(2)]
+            for pn in pins:
+                pn.array[:] = frame.reshape(H, W, 4)
+            st = {"k": 0}
+
+            def write_ahead():  # frame k + 1 goes up while frame k is extracted (one image ahead)
+                p1.write_input_image_pinned(pins[st["k"] & 1].array)
+                st["k"] += 1
+            write_ahead()
+            ahead = six_calls(write_ahead)
+            p1.upload_sync()
+            for pn in pins:
+                pn.close()
+        return extract_us, blocking, ahead
+
+    def keys(r):
+        return {"blocking_write": {"fps_median_iteration": r[1][0], "fps_total_time": r[1][1], "stalled_iterations": r[1][2]},
+                "pinned_write_one_ahead": {"fps_median_iteration": r[2][0], "fps_total_time": r[2][1], "stalled_iterations": r[2][2]},
+                "extract_us": r[0]}
+    poll = measure(0)
+    block = measure(orb.ORB_FLAG_SINGLE_BLOCKING_WAIT)
+    return {"single_frame_us": poll[0], "single_frame_loop_fps": poll[1][0], "single_frame_loop_pinned_fps": poll[2][0],
+            "single_frame_us_blocking_wait": block[0],
+            "single_frame_loop": dict(keys(poll), wait="poll (default): the host thread spins on the completion word", iterations=n_loop,
+                                      what="write_input_image -> extract_corners -> read_corners -> read_descriptors per 1280x720 frame from a host "
+                                           "frame; pinned: orb_write_input_image_pinned uploads frame k + 1 under the kernels of frame k"),
+            "single_frame_loop_blocking_wait": dict(keys(block), wait="block (ORB_FLAG_SINGLE_BLOCKING_WAIT / TINYORB_SINGLE_WAIT=block): 50 us of spinning, "
+                                                                      "then asleep until the completion interrupt", iterations=n_loop)}
 
 
 def run_node(args):
@@ -267,12 +282,21 @@ def run_node(args):
         ptrs = [progs[r].synth_frames_device(B, SEED0 + r * B, syn_flags) for r in range(world)]
         last = {}
 
+        host = {"extract": 0.0, "begin": 0.0, "end": 0.0, "jobs": 0}  # host seconds inside the three calls of a job's pipeline
+
         def steps(n):
             for _ in range(n):
+                t0 = time.perf_counter()
                 node.extract_batch(ptrs, F)
+                t1 = time.perf_counter()
+                host["extract"] += t1 - t0
+                host["jobs"] += 1
                 if node.pending() == 2:
                     node.collate_begin()
+                    t2 = time.perf_counter()
                     last["r"] = node.collate_end(F)
+                    host["begin"] += t2 - t1
+                    host["end"] += time.perf_counter() - t2
 
         def drain():
             while node.pending():
@@ -291,7 +315,19 @@ def run_node(args):
         while time.perf_counter() < t_end:
             steps(2)
         steps(args.warmup)
+        host.update(extract=0.0, begin=0.0, end=0.0, jobs=0)
         repeats = [timed(args.steps) for _ in range(max(1, args.repeats))]
+        host_ms = {k: host[k] / max(1, host["jobs"]) * 1e3 for k in ("extract", "begin", "end")}
+        # the same repeats with the results left sharded (orb_node_set_results): kernel scaling without the links into the first device
+        sharded = None
+        if args.collate != "none":
+            drain()
+            node.set_results(True)
+            rs = [timed(args.steps) for _ in range(max(1, args.repeats))]
+            drain()
+            node.set_results(False)
+            sharded = sorted(rs)[len(rs) // 2]
+            steps(2)  # the profiled pass below is of the collated form again
         progs[0].profile_enable(True)
         progs[0].profile_reset()
         profiled = timed(args.steps)
@@ -326,7 +362,17 @@ def run_node(args):
             "keypoints_per_frame": n_mean,
             "hbm_algorithmic_gbs": bytes_per_frame * fps / 1e9,
             "roofline": roofline_of(args, prof, B * args.steps, bytes_per_frame, profiled),
+            "collate": {"host_extract_ms_per_job": host_ms["extract"], "host_collate_begin_ms_per_job": host_ms["begin"],
+                        "host_collate_end_ms_per_job": host_ms["end"],
+                        "host_ms_what": "the host thread inside orb_node_extract_batch (enqueue of kernels and packs on every device), "
+                                        "orb_node_collate_begin (waits for the OLDEST job's pack events, enqueues its exchange) and "
+                                        "orb_node_collate_end (waits for that exchange) per job of the timed repeats; a step's budget is ms_per_step"},
         }
+        if sharded is not None:
+            out["value_sharded"] = F * args.steps / sharded
+            out["ms_per_step_sharded"] = sharded / args.steps * 1e3
+            out["sharded_what"] = ("the same K steps x %d repeats with orb_node_set_results(ORB_NODE_RESULTS_SHARDED): every rank packs its own "
+                                   "records, nothing crosses a link -- kernel scaling alone; `value` is the collated figure" % max(1, args.repeats))
         if world == 1:
             n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 128
             if n_cpu > 0:
@@ -443,7 +489,9 @@ def run_rank(args):
         counts_t, corners_t, desc_t = views[slot]
         t_host = time.perf_counter()
         with torch.cuda.stream(comm_stream):
-            if transport:
+            if state.get("sharded"):  # the second set of repeats: the results stay on the GPU that computed them (as --collate none)
+                comm_stream.wait_event(done)
+            elif transport:
                 exchange_ticket()  # the batch before: its counters are on the host, its records move now
                 comm_stream.wait_event(done)  # the kernels that wrote this output set
                 cs = comm_stream.cuda_stream
@@ -534,8 +582,24 @@ def run_rank(args):
     for _ in range(args.warmup):
         step()
     state["host_s"] = 0.0
+    if collator is not None:
+        collator.wait_s = 0.0
     repeats = [timed(args.steps) for _ in range(max(1, args.repeats))]
-    collate_host_ms = state["host_s"] / max(1, len(repeats) * args.steps * max(1, len(batches))) * 1e3
+    n_collates = max(1, len(repeats) * args.steps * max(1, len(batches)))
+    collate_host_ms = state["host_s"] / n_collates * 1e3
+    # of which: waiting for the lagged counters' copy (TransportCollator.exchange; normally an event that is long set) -- the rest is
+    # Python + enqueue cost (pack launch, all_gather, all_to_all_single, unpack launch)
+    collate_wait_ms = (collator.wait_s / n_collates * 1e3) if collator is not None else 0.0
+    # The same timed repeats with the results left sharded (nothing packed, gathered or exchanged; the stream ordering stays): what the
+    # kernels scale like, beside `value`, which at N > 1 also carries the links into rank 0 -- one line separates the two.
+    sharded = None
+    if collating and args.collate != "none":
+        fence()
+        state["sharded"] = True
+        rs = [timed(args.steps) for _ in range(max(1, args.repeats))]
+        fence()
+        state["sharded"] = False
+        sharded = sorted(rs)[len(rs) // 2]
     state["gathered_bytes"] = 0
     prog.profile_enable(True)
     prog.profile_reset()
@@ -601,6 +665,10 @@ def run_rank(args):
                         "gbs_per_link": from_peers / (dt / n_rep) / 1e9 / max(world - 1, 1),
                         "bytes_gathered_per_step_timed": gathered_per_step, "backend": backend,
                         "host_ms_per_batch": collate_host_ms,
+                        "host_wait_ms_per_batch": collate_wait_ms, "host_enqueue_ms_per_batch": collate_host_ms - collate_wait_ms,
+                        "host_ms_what": "rank 0's Python thread inside collate() per batch of the timed repeats: host_wait = blocked on the event behind "
+                                        "the lagged counters' copy (node.TransportCollator.exchange), host_enqueue = everything else (pack launch, "
+                                        "all_gather, all_to_all_single, unpack launch); a step's budget is ms_per_step",
                         "exact": bool(transport and state["gathered_bytes"] == state["expected_bytes"]),
                         "how": ("exact and lagged: batch k's counters are all_gathered and copied to pinned host memory when it "
                                 "is packed; one batch later every rank reads the same totals S_r and one all_to_all_single with "
@@ -697,6 +765,11 @@ def run_rank(args):
         }
         if collate_info:
             out["collate"] = collate_info
+        if sharded is not None:
+            out["value_sharded"] = total_frames / sharded
+            out["ms_per_step_sharded"] = sharded / args.steps * 1e3
+            out["sharded_what"] = ("the same K steps x %d repeats with the results left on the GPU that computed them (no pack, no all_gather, no "
+                                   "exchange): kernel scaling alone; `value` is the collated figure the metric asks for" % max(1, args.repeats))
         if host_out:
             out["host_out_frames_per_s"] = host_out["frames_per_s"]
             out["host_out"] = host_out

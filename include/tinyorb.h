@@ -129,6 +129,12 @@ typedef struct OrbOptions {
                                    * downstream is the literal path, unchanged.  Not combined with ORB_FLAG_INTENDED, ORB_FLAG_NMS
                                    * or a fast_arc other than 12 (those have no Y8 definition to check against). */
 
+#define ORB_FLAG_SINGLE_BLOCKING_WAIT 32u /* how orb_extract_corners waits for the device.  Default: the host thread polls a completion word
+                                   * in pinned memory (the shortest latency; a spinning thread on a shared box now and then loses its CPU
+                                   * for a scheduler slice).  With this flag (or TINYORB_SINGLE_WAIT=block in the environment) the spin is
+                                   * bounded to 50 us, after which the thread sleeps until the completion interrupt -- what the reference's
+                                   * device.poll(Wait) does (orb.rs:547). */
+
 typedef struct OrbProgram OrbProgram; /* opaque; replaces orb.rs:47-51 `OrbProgram` */
 
 /* ---- lifetime: replaces the struct literal + OrbProgram::init (orb.rs:107-219) ---- */
@@ -336,7 +342,9 @@ typedef struct {
 } OrbMatch;
 #define ORB_MATCH_NONE 0xffffffffu
 /* Matches frame f against f+1 for f in [0, n_frames - 1) of the last batch, asynchronously on `stream` (NULL: the
- * program's stream; it is ordered after the batch that produced the descriptors when that ran on the same stream). */
+ * program's stream; it is ordered after the batch that produced the descriptors when that ran on the same stream).  A program has ONE
+ * result buffer (and one buffer of expanded descriptors), whichever output set the batch went to: a call overwrites the matches of the
+ * call before -- read them first -- and a call on another stream than the last one is ordered behind it. */
 int orb_match_consecutive(OrbProgram *p, uint32_t n_frames, void *stream);
 /* Copy up to n matches of the queries of `frame` to the host (synchronises). */
 int orb_match_read(OrbProgram *p, uint32_t frame, OrbMatch *dst, size_t n);
@@ -364,7 +372,7 @@ int orb_debug_angle_code(OrbProgram *p, const float *cy, const float *cx, uint32
 int orb_debug_rot_table(OrbProgram *p, int16_t *dst, size_t n_entries, uint32_t *codes, uint32_t *pitch);
 
 /* ---- measurement ---- */
-#define ORB_KERNEL_COUNT 21
+#define ORB_KERNEL_COUNT 22
 /* When enabled every kernel launch is bracketed by hipEvents on its stream. */
 int orb_profile_enable(OrbProgram *p, int enable);
 int orb_profile_reset(OrbProgram *p);

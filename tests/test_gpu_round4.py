@@ -86,6 +86,11 @@ def test_bench_ranks_path_collates_through_nccl_world1():
     kp = rec["keypoints_per_frame"] * 32
     assert abs(col["bytes_gathered_per_batch"] - 40 * kp) < 1e-6 * 40 * kp + 1
     assert rec["n_gpus"] == 1 and rec["value"] > 0
+    # round 5: one line separates kernel scaling from the collate -- the same repeats with the results left sharded -- and the
+    # host's time inside a collate is split into waiting (the lagged counters' event) and enqueueing
+    assert rec["value_sharded"] >= 0.9 * rec["value"] and rec["ms_per_step_sharded"] > 0
+    assert abs(col["host_wait_ms_per_batch"] + col["host_enqueue_ms_per_batch"] - col["host_ms_per_batch"]) < 1e-9
+    assert 0 <= col["host_wait_ms_per_batch"] <= col["host_ms_per_batch"] and col["host_enqueue_ms_per_batch"] > 0
 
 
 # ---------------------------------------------------------------------------------------------

@@ -29,12 +29,12 @@ using namespace orb;
 
 namespace {
 
-enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I, KID_MATCH, KID_COMPACT, KID_BRIEF_T, KID_BRIEF_NF, KID_PACK_T, KID_UNPACK_T, KID_BRIEF_ONE, KID_FRONT_I_LN };
+enum KernelId { KID_GRAY = 0, KID_MIP, KID_BLUR, KID_FAST, KID_BRIEF, KID_FUSED_L0, KID_FUSED_LN, KID_SYNTH, KID_BRIEF_ROWS, KID_PREFIX, KID_FRONT_I, KID_SELECT_I, KID_BRIEF_I, KID_MATCH, KID_COMPACT, KID_BRIEF_T, KID_BRIEF_NF, KID_PACK_T, KID_UNPACK_T, KID_BRIEF_ONE, KID_FRONT_I_LN, KID_DESC_EXPAND };
 const char* const kKernelNames[ORB_KERNEL_COUNT] = {"k_grayscale", "k_mip",      "k_blur_rows", "k_fast",       "k_brief",
                                                     "k_front_l0",  "k_front_ln", "k_synth",     "k_brief_rows", "k_slot_prefix",
                                                     "k_front_i_l0", "k_select_i", "k_brief_i",   "k_match",      "k_compact",
                                                     "k_brief_t",   "k_brief_nf",  "k_compact_transport", "k_unpack_transport",
-                                                    "k_brief_one", "k_front_i_ln"};
+                                                    "k_brief_one", "k_front_i_ln", "k_desc_expand"};
 
 thread_local std::string g_create_error;
 
@@ -60,10 +60,6 @@ struct OrbProgram {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // chunked uploads of orb_extract_batch_host
     hipEvent_t order_event = nullptr;   // orders work on a caller's stream behind the last batch
-    // run_fused: a batch is cut into sub-ranges whose BRIEF kernels run on this side stream under the next sub-range's front kernels
-    hipStream_t brief_stream = nullptr;
-    std::vector<hipEvent_t> split_events;  // two per sub-range: front kernels done, BRIEF done
-    uint32_t batch_split = 0;              // sub-ranges per batch (0: not decided yet; 1: none)
     std::vector<hipEvent_t> upload_events;  // one per chunk of a chunked upload (reused)
     hipEvent_t upload_done = nullptr;       // behind the last host-to-device copy of the last host batch
     // orb_batch_pack / orb_batch_fetch: packed records of an output set on the device, its counters and offsets in pinned
@@ -110,6 +106,10 @@ struct OrbProgram {
     MatchRecord* d_matches = nullptr;  // [max_batch][max_features], allocated by the first orb_match_consecutive
     uint8_t* d_desc8 = nullptr;        // [max_batch][max_features][128 or 256]: the descriptors as +-1 in fp4 (k_match_fp4) or +-127 in int8 (k_match_mfma)
     int match_valu = -1;               // which matcher (0 fp4, 1 vector unit: TINYORB_MATCH_VALU=1, 2 int8: TINYORB_MATCH_I8=1); read once
+    // d_matches and d_desc8 are ONE buffer each per program, shared by both output sets and by whatever stream the caller passes: a match
+    // on another stream is ordered behind the one before (its expand kernel would overwrite rows the earlier match still reads)
+    hipEvent_t match_done = nullptr;
+    hipStream_t match_stream = nullptr;
     uint32_t* d_prov2_counts = nullptr;
     CornerData* d_prov2 = nullptr;
     float* d_prov2_scores = nullptr;
@@ -125,7 +125,7 @@ struct OrbProgram {
     bool in_async[2] = {false, false};    // the slab's image came through the copy stream: extract_corners orders its kernels behind in_uploaded
     // environment switches (experiments and cross-checks), read once when the program is created
     struct {
-        bool single_memcpy = false, single_split = false, single_serial = false, single_sync = false;
+        bool single_memcpy = false, single_split = false, single_serial = false, single_sync = false, single_block = false;
         bool no_swizzle = false, quiet = false;
         int phase_mask = -1, brief_i_mask = -1, lds_pad = 0;
     } env;
@@ -163,6 +163,7 @@ struct OrbProgram {
     // host staging of the single-frame API (orb.rs:216-218 staging buffers)
     uint32_t* h_count = nullptr;      // pinned: [0] the raw counter of the last single-frame extract, [kSingleDoneWord] its completion sequence number (own cache line)
     uint32_t* d_single_done = nullptr;  // workgroups of k_brief_one that have finished (the last one publishes the sequence number and clears it)
+    hipEvent_t single_done_ev = nullptr;  // blocking-sync event behind k_brief_one (TINYORB_SINGLE_WAIT=block / ORB_FLAG_SINGLE_BLOCKING_WAIT)
     uint32_t single_seq = 0;
     CornerData* h_corners = nullptr;
     CornerDescriptor* h_desc = nullptr;
@@ -583,59 +584,13 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
 }
 
 int run_fused(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) {
-    // One launch per kernel for the whole batch -- measured twice:
-    //  * round 1: the batch cut into chunks that run whole pipelines on two streams (front kernel against front kernel):
-    //    2 / 4 / 8 chunks + 5 %, + 4 %, + 6 % time;
-    //  * round 4 (TINYORB_BATCH_SPLIT=n, the code below; profiles/r04_split_ab.txt): the batch cut into n sub-ranges of
-    //    frames, the BRIEF kernels of sub-range i on a side stream under the front kernels of sub-range i + 1 on `s`,
-    //        s:      F0 ----- F1 ----- F2 ----- B2 -- (waits for B0, B1)
-    //        side:            B0 ----- B1 --
-    //    same kernels, buffers, results and output layout: 0.534 ms per 256 frames in one piece, 0.580 / 0.621 / 0.659 with
-    //    2 / 3 / 4 sub-ranges -- 45 us MORE per cut.  k_front's two workgroups per CU hold all of the CU's LDS and all eight
-    //    wave slots of its SIMDs, so a kernel from another queue gets a CU only when a band retires, and then competes with
-    //    the next band for it; k_brief_t is as bound by the vector units as k_front is (30.7 M wave instructions x 4 cycles /
-    //    1024 SIMDs = 0.057 ms against its 0.049), so it has nothing to give back while it runs beside it; and every
-    //    cross-queue dependency costs the two queues a signal round trip.  The default therefore stays one piece.
-    if (p->batch_split == 0u) {
-        const char* e = getenv("TINYORB_BATCH_SPLIT");
-        p->batch_split = e ? (uint32_t)std::max(1, atoi(e)) : 1u;
-    }
-    uint32_t parts = p->profiling ? 1u : p->batch_split;
-    while (parts > 1u && (n / parts) < 32u) parts--;  // a sub-range should still fill the chip several times over
-    if (parts <= 1u) {
-        if (int rc = run_fused_range(p, frames, 0, n, s)) return rc;
-        p->planes_valid = true;  // except the level-0 grey plane, which the fused path keeps in LDS only
-        return ORB_OK;
-    }
-    if (!p->brief_stream) HIP_TRY(p, hipStreamCreateWithFlags(&p->brief_stream, hipStreamNonBlocking));
-    while (p->split_events.size() < 2u * parts) {
-        hipEvent_t ev = nullptr;
-        HIP_TRY(p, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        p->split_events.push_back(ev);
-    }
-    // sub-ranges of (almost) equal size, multiples of 8 frames: a launch deals whole groups of 8 frames to the 8 XCDs
-    const uint32_t unit = 8u;
-    uint32_t f0 = 0;
-    for (uint32_t i = 0; i < parts; i++) {
-        uint32_t m = i + 1u == parts ? n - f0 : ((n * (i + 1u) / parts) / unit) * unit - f0;
-        const bool last = i + 1u == parts;
-        if (int rc = run_fused_range(p, frames, f0, m, s, last)) return rc;  // the last sub-range's BRIEF stays on s
-        if (!last) {
-            hipEvent_t front_done = p->split_events[2u * i], brief_done = p->split_events[2u * i + 1u];
-            HIP_TRY(p, hipEventRecord(front_done, s));
-            HIP_TRY(p, hipStreamWaitEvent(p->brief_stream, front_done, 0));
-            const size_t lists = (size_t)p->bands.n_slots * p->seg_classes;
-            launch_brief(p, p->brief_stream, m, p->rows, p->d_blur + (size_t)f0 * p->pyr.stride, p->d_blur_rowc + (size_t)f0 * p->pyr.row_stride,
-                         p->d_seg_counts + (size_t)f0 * lists, p->d_seg_before + (size_t)f0 * lists,
-                         p->d_seg + (size_t)f0 * lists * p->bands.seg_cap, p->d_counts + f0, p->d_corners + (size_t)f0 * p->cfg.max_features,
-                         p->d_desc + (size_t)f0 * p->cfg.max_features);
-            HIP_TRY(p, hipGetLastError());
-            HIP_TRY(p, hipEventRecord(brief_done, p->brief_stream));
-        }
-        f0 += m;
-    }
-    for (uint32_t i = 0; i + 1u < parts; i++) HIP_TRY(p, hipStreamWaitEvent(s, p->split_events[2u * i + 1u], 0));
-    p->planes_valid = true;
+    // One launch per kernel for the whole batch.  Cutting the batch was measured twice and lost both times (NOTEBOOK.md): round 1, whole
+    // pipelines of 2 / 4 / 8 chunks on two streams: + 5 %, + 4 %, + 6 % time; round 4 (TINYORB_BATCH_SPLIT, profiles/r04_split_ab.txt), the
+    // BRIEF kernels of sub-range i on a side stream under the front kernels of sub-range i + 1: 45 us MORE per cut -- k_front's two
+    // workgroups per CU hold all of the CU's LDS and wave slots, k_brief_t is as bound by the vector units as k_front is, and every
+    // cross-queue dependency costs a signal round trip.  The experiment's code left the tree in round 5.
+    if (int rc = run_fused_range(p, frames, 0, n, s)) return rc;
+    p->planes_valid = true;  // except the level-0 grey plane, which the fused path keeps in LDS only
     return ORB_OK;
 }
 
@@ -902,6 +857,12 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         p->env.single_split = on("TINYORB_SINGLE_SPLIT");
         p->env.single_serial = on("TINYORB_SINGLE_SERIAL");
         p->env.single_sync = on("TINYORB_SINGLE_SYNC");
+        {   // how orb_extract_corners waits: "poll" (default) spins on the completion word; "block" spins for kSingleSpinUs, then sleeps
+            // in hipEventSynchronize on a blocking-sync event (an interrupt instead of a spin -- the reference blocks in device.poll(Wait),
+            // orb.rs:547); ORB_FLAG_SINGLE_BLOCKING_WAIT asks for the same from code
+            const char* w = getenv("TINYORB_SINGLE_WAIT");
+            p->env.single_block = (w && !strcmp(w, "block")) || (p->opt.flags & ORB_FLAG_SINGLE_BLOCKING_WAIT) != 0u;
+        }
         p->env.no_swizzle = on("TINYORB_NO_SWIZZLE");
         p->env.quiet = getenv("TINYORB_QUIET") != nullptr;
         p->env.phase_mask = num("TINYORB_PHASE_MASK", -1);
@@ -1290,7 +1251,6 @@ void orb_program_destroy(OrbProgram* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    if (p->brief_stream) (void)hipStreamSynchronize(p->brief_stream);
     for (auto& sp : p->pending) {
         (void)hipEventDestroy(sp.start);
         (void)hipEventDestroy(sp.stop);
@@ -1331,14 +1291,14 @@ void orb_program_destroy(OrbProgram* p) {
     if (p->d_rot) (void)hipFree(p->d_rot);
     (void)hipFree(p->d_stamps);
     (void)hipFree(p->d_desc8);
+    if (p->match_done) (void)hipEventDestroy(p->match_done);
+    if (p->single_done_ev) (void)hipEventDestroy(p->single_done_ev);
     if (p->h_count) (void)hipHostFree(p->h_count);
     if (p->d_single_done) (void)hipFree(p->d_single_done);
     if (p->h_corners) (void)hipHostFree(p->h_corners);
     if (p->h_desc) (void)hipHostFree(p->h_desc);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
-    if (p->brief_stream) (void)hipStreamDestroy(p->brief_stream);
-    for (hipEvent_t ev : p->split_events) (void)hipEventDestroy(ev);
     if (p->order_event) (void)hipEventDestroy(p->order_event);
     for (hipEvent_t ev : p->upload_events) (void)hipEventDestroy(ev);
     if (p->upload_done) (void)hipEventDestroy(p->upload_done);
@@ -1356,22 +1316,34 @@ void orb_program_destroy(OrbProgram* p) {
 // one being extracted next and the one uploaded under it).  With nothing pending the slab of the last extract is reused.
 // ahead = false (the blocking write, the reference's): the last write wins -- an image that is still waiting is overwritten,
 // the queue never grows past one.  ahead = true (orb_write_input_image_pinned): the image is queued behind a waiting one.
-static int claim_input_slab(OrbProgram* p, bool ahead, uint32_t* slab_out, uint8_t** dst) {
+// Nothing is published here: the queue, the pending count and the slab's "came through the copy stream" mark change only once the image
+// is really on its way (publish_input_slab), so that a failed allocation, event creation or copy leaves the program as it was.
+static int pick_input_slab(OrbProgram* p, bool ahead, uint32_t* slab_out, uint8_t** dst, bool* appended) {
     if (ahead && p->in_pending >= 2u)
         return fail(p, ORB_ESTATE, "two images are already waiting for extract_corners");
     if (int rc = ensure_input(p)) return rc;
     uint32_t slab;
     if (p->in_pending == 0u || ahead) {
         slab = p->in_pending == 0u ? p->in_last : (p->in_queue[0] ^ 1u);
-        p->in_queue[p->in_pending++] = slab;
+        *appended = true;
     } else {
         slab = p->in_queue[p->in_pending - 1u];  // overwrite the newest waiting image
         if (p->in_async[slab]) HIP_TRY(p, hipEventSynchronize(p->in_uploaded[slab]));  // its upload must not land on top of this one
+        *appended = false;
     }
     if (slab == 1u && !p->d_input_alt) HIP_TRY(p, hipMalloc(&p->d_input_alt, p->frame_bytes));
     *slab_out = slab;
     *dst = slab ? p->d_input_alt : p->d_input;
     return ORB_OK;
+}
+static void publish_input_slab(OrbProgram* p, uint32_t slab, bool appended, bool async) {
+    if (appended) p->in_queue[p->in_pending++] = slab;
+    p->in_async[slab] = async;
+}
+// A copy into a slab that was already queued (the blocking write overwrites the newest waiting image) failed half-way: that image
+// is gone, the queue must not name it any more.
+static void drop_newest_input(OrbProgram* p, bool appended) {
+    if (!appended && p->in_pending) p->in_pending--;
 }
 
 int orb_write_input_image(OrbProgram* p, const uint8_t* bytes, size_t len) {
@@ -1381,10 +1353,15 @@ int orb_write_input_image(OrbProgram* p, const uint8_t* bytes, size_t len) {
     HIP_TRY(p, hipSetDevice(p->device));
     uint32_t slab = 0;
     uint8_t* dst = nullptr;
-    if (int rc = claim_input_slab(p, false, &slab, &dst)) return rc;
-    p->in_async[slab] = false;
-    HIP_TRY(p, hipMemcpyAsync(dst, bytes, len, hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(p, hipStreamSynchronize(p->stream));  // the caller's slice may be reused right away
+    bool appended = false;
+    if (int rc = pick_input_slab(p, false, &slab, &dst, &appended)) return rc;
+    hipError_t e = hipMemcpyAsync(dst, bytes, len, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);  // the caller's slice may be reused right away
+    if (e != hipSuccess) {
+        drop_newest_input(p, appended);
+        return fail(p, ORB_EHIP, "write_input_image: the upload failed: %s", hipGetErrorString(e));
+    }
+    publish_input_slab(p, slab, appended, false);
     return ORB_OK;
 }
 
@@ -1395,7 +1372,8 @@ int orb_write_input_image_pinned(OrbProgram* p, const uint8_t* bytes_pinned, siz
     HIP_TRY(p, hipSetDevice(p->device));
     uint32_t slab = 0;
     uint8_t* dst = nullptr;
-    if (int rc = claim_input_slab(p, true, &slab, &dst)) return rc;
+    bool appended = false;
+    if (int rc = pick_input_slab(p, true, &slab, &dst, &appended)) return rc;
     if (!p->copy_stream) HIP_TRY(p, hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
     if (!p->in_uploaded[slab]) HIP_TRY(p, hipEventCreateWithFlags(&p->in_uploaded[slab], hipEventDisableTiming));
     if (!p->upload_done) HIP_TRY(p, hipEventCreateWithFlags(&p->upload_done, hipEventDisableTiming));
@@ -1404,7 +1382,7 @@ int orb_write_input_image_pinned(OrbProgram* p, const uint8_t* bytes_pinned, siz
     HIP_TRY(p, hipMemcpyAsync(dst, bytes_pinned, len, hipMemcpyHostToDevice, p->copy_stream));
     HIP_TRY(p, hipEventRecord(p->in_uploaded[slab], p->copy_stream));
     HIP_TRY(p, hipEventRecord(p->upload_done, p->copy_stream));  // orb_upload_sync(): the host array may be reused
-    p->in_async[slab] = true;
+    publish_input_slab(p, slab, appended, true);  // only now: every call above succeeded, the image is on its way
     return ORB_OK;
 }
 
@@ -1505,17 +1483,32 @@ int orb_extract_corners(OrbProgram* p, uint32_t* corner_count) {
 #undef BRIEF_ONE_LAUNCH
         }
         HIP_TRY(p, hipGetLastError());
+        if (p->env.single_block) {
+            if (!p->single_done_ev) HIP_TRY(p, hipEventCreateWithFlags(&p->single_done_ev, hipEventBlockingSync | hipEventDisableTiming));
+            HIP_TRY(p, hipEventRecord(p->single_done_ev, s));
+        }
         p->planes_valid = true;
         // Block (orb.rs:549): the last workgroup of k_brief_one to finish publishes the call's sequence number in pinned memory
         // behind everything the launch wrote there, and the host polls that word -- hipStreamSynchronize costs 5 us more
         // than the poll (tools/ubench/launch_floor.hip: 11.6 against 6.5 us for an empty launch).  The poll gives up after
         // 20 ms (a faulted kernel never publishes) and a stream synchronisation reports what happened.
+        // A host thread that spins on a shared box now and then loses its CPU for a scheduler slice (two to four iterations of 200
+        // take 20 ms, NOTEBOOK.md): with TINYORB_SINGLE_WAIT=block / ORB_FLAG_SINGLE_BLOCKING_WAIT the spin is bounded (kSingleSpinUs: the call
+        // normally completes inside it) and the thread then SLEEPS in hipEventSynchronize on a blocking-sync event recorded behind the launch
+        // -- woken by the completion interrupt, as the reference's device.poll(Wait) is (orb.rs:547).
         bool seen = false;
+        constexpr int kSingleSpinUs = 50;
         if (!p->profiling && !p->env.single_sync) {
             const volatile uint32_t* const done = p->h_count + kSingleDoneWord;
             const auto t0 = std::chrono::steady_clock::now();
+            const auto limit = p->env.single_block ? std::chrono::microseconds(kSingleSpinUs) : std::chrono::microseconds(20000);
+            const uint32_t check = p->env.single_block ? 63u : 1023u;
             for (uint32_t spins = 0; !(seen = __atomic_load_n(done, __ATOMIC_ACQUIRE) == seq); spins++)
-                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+                if ((spins & check) == check && std::chrono::steady_clock::now() - t0 > limit) break;
+            if (!seen && p->env.single_block) {
+                HIP_TRY(p, hipEventSynchronize(p->single_done_ev));  // sleeps; the kernel is over when it returns, its stores are in host memory
+                seen = __atomic_load_n(done, __ATOMIC_ACQUIRE) == seq;
+            }
         }
         if (!seen) {
             HIP_TRY(p, hipStreamSynchronize(s));
@@ -1937,13 +1930,22 @@ int orb_match_consecutive(OrbProgram* p, uint32_t n_frames, void* stream) {
         mfma = false;
     }
     const dim3 grid_e((unsigned)((cap + 31u) / 32u), n_frames), grid_m(n_frames - 1u, (unsigned)((cap + kMatchQueriesPerWg - 1u) / kMatchQueriesPerWg));
+    // one result buffer and one expanded-descriptor buffer per program: a match on another stream than the last one waits for it
+    if (!p->match_done) HIP_TRY(p, hipEventCreateWithFlags(&p->match_done, hipEventDisableTiming));
+    if (p->match_stream && p->match_stream != s) HIP_TRY(p, hipStreamWaitEvent(s, p->match_done, 0));
     if (mfma && !i8) {
+        {
+            LaunchScope ls(p, s, KID_DESC_EXPAND);
+            hipLaunchKernelGGL(k_desc_expand4, grid_e, dim3(256), 0, s, p->d_counts, p->d_desc, (uint32_t)cap, p->d_desc8);
+        }
         LaunchScope ls(p, s, KID_MATCH);
-        hipLaunchKernelGGL(k_desc_expand4, grid_e, dim3(256), 0, s, p->d_counts, p->d_desc, (uint32_t)cap, p->d_desc8);
         hipLaunchKernelGGL(k_match_fp4, grid_m, dim3(64 * kMatchWaves), 0, s, p->d_counts, p->d_desc8, (uint32_t)cap, p->d_matches);
     } else if (mfma) {
+        {
+            LaunchScope ls(p, s, KID_DESC_EXPAND);
+            hipLaunchKernelGGL(k_desc_expand, grid_e, dim3(256), 0, s, p->d_counts, p->d_desc, (uint32_t)cap, p->d_desc8);
+        }
         LaunchScope ls(p, s, KID_MATCH);
-        hipLaunchKernelGGL(k_desc_expand, grid_e, dim3(256), 0, s, p->d_counts, p->d_desc, (uint32_t)cap, p->d_desc8);
         hipLaunchKernelGGL(k_match_mfma, grid_m, dim3(64 * kMatchWaves), 0, s, p->d_counts, p->d_desc8, (uint32_t)cap, p->d_matches);
     } else {
         LaunchScope ls(p, s, KID_MATCH);
@@ -1951,6 +1953,8 @@ int orb_match_consecutive(OrbProgram* p, uint32_t n_frames, void* stream) {
                            p->d_desc, (uint32_t)cap, p->d_matches);
     }
     HIP_TRY(p, hipGetLastError());
+    HIP_TRY(p, hipEventRecord(p->match_done, s));
+    p->match_stream = s;
     p->last_stream = s;
     return ORB_OK;
 }
@@ -2106,7 +2110,11 @@ int orb_synth_frames_device(OrbProgram* p, uint8_t* frames_dev, uint32_t n_frame
         if (n_frames > p->max_batch) return fail(p, ORB_EINVAL, "n_frames %u > max_batch %u", n_frames, p->max_batch);
         if (int rc = ensure_input(p)) return rc;
         frames_dev = p->d_input;
-        p->in_pending = 0u, p->in_last = 0u, p->in_async[0] = false;  // the program's own slab: what extract_corners works on next
+        // the program's own slab is what extract_corners works on next: an upload still in flight on the copy stream
+        // (orb_write_input_image_pinned) must not land on top of the synthesised frames -- wait for every slab's before the state is reset
+        for (uint32_t sl = 0; sl < 2u; sl++)
+            if (p->in_async[sl] && p->in_uploaded[sl]) HIP_TRY(p, hipEventSynchronize(p->in_uploaded[sl]));
+        p->in_pending = 0u, p->in_last = 0u, p->in_async[0] = p->in_async[1] = false;
     }
     const uint32_t W = p->pyr.w[0], H = p->pyr.h[0];
     if (p->input_y8) flags |= ORB_SYN_Y8;  // a Y8 program's frames are one byte per pixel

@@ -26,7 +26,13 @@ constexpr uint32_t kMatchMaxCap = kMatchK - 1u;           // candidate indices 0
 #define TINYORB_MATCH_ROWTILES 4
 #endif
 constexpr int kMatchRowTiles = TINYORB_MATCH_ROWTILES;    // row tiles of 16 queries per wave
-constexpr int kMatchWaves = 16 / kMatchRowTiles;          // waves per workgroup: 256 queries
+#ifndef TINYORB_MATCH_WAVES
+#define TINYORB_MATCH_WAVES (16 / TINYORB_MATCH_ROWTILES)
+#endif
+constexpr int kMatchWaves = TINYORB_MATCH_WAVES;          // waves per workgroup (default: 256 queries per workgroup)
+#ifndef TINYORB_MATCH_MINWAVES
+#define TINYORB_MATCH_MINWAVES 1
+#endif
 constexpr int kMatchQueriesPerWg = 16 * kMatchRowTiles * kMatchWaves;
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 
@@ -84,30 +90,34 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_mfma(const uint32_t*
     // staging: a chunk is 1024 pieces of 16 bytes, piece p = bytes 16 (p & 15) .. of candidate row p >> 4; a thread takes pieces
     // tid + NT k.  (Written with explicit registers: an array captured by a lambda went through scratch memory.)
     constexpr uint32_t NT = 64u * (uint32_t)kMatchWaves, NP = (uint32_t)(kMatchChunk * 16) / NT;  // threads, pieces per thread
-    static_assert(NP == 2u || NP == 4u, "staging is written for two or four pieces per thread");
+    static_assert(NP >= 1u && NP <= 8u && NP * NT == (uint32_t)(kMatchChunk * 16), "staging: whole pieces per thread");
     const uint32_t prow = tid >> 4, pcol = 16u * (tid & 15u);   // piece k: row prow + (NT / 16) k
     uint8_t* const put0 = &stage[0][prow * (uint32_t)kMatchRowBytes + pcol];
     constexpr uint32_t kRowStep = NT / 16u, kPutStep = kRowStep * (uint32_t)kMatchRowBytes, kBufBytes = (uint32_t)(kMatchChunk * kMatchRowBytes);
-    uint4 p0 = make_uint4(0u, 0u, 0u, 0u), p1 = p0, p2 = p0, p3 = p0;
-#define MATCH_FETCH(J0)                                                                                                  \
-    do {                                                                                                                 \
-        const uint8_t* const fb_ = qb + pcol;                                                                            \
-        p0 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow, nb - 1u) * 256u);                            \
-        p1 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + kRowStep, nb - 1u) * 256u);                 \
-        if (NP == 4u) {                                                                                                  \
-            p2 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 2u * kRowStep, nb - 1u) * 256u);        \
-            p3 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 3u * kRowStep, nb - 1u) * 256u);        \
-        }                                                                                                                \
+    uint4 p0 = make_uint4(0u, 0u, 0u, 0u), p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;  // (named registers: an array went through scratch memory)
+#define MATCH_FETCH(J0) \
+    do { \
+        const uint8_t* const fb_ = qb + pcol; \
+        if (NP > 0u) p0 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 0u * kRowStep, nb - 1u) * 256u); \
+        if (NP > 1u) p1 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 1u * kRowStep, nb - 1u) * 256u); \
+        if (NP > 2u) p2 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 2u * kRowStep, nb - 1u) * 256u); \
+        if (NP > 3u) p3 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 3u * kRowStep, nb - 1u) * 256u); \
+        if (NP > 4u) p4 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 4u * kRowStep, nb - 1u) * 256u); \
+        if (NP > 5u) p5 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 5u * kRowStep, nb - 1u) * 256u); \
+        if (NP > 6u) p6 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 6u * kRowStep, nb - 1u) * 256u); \
+        if (NP > 7u) p7 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 7u * kRowStep, nb - 1u) * 256u); \
     } while (0)
-#define MATCH_PUT(BUF)                                                                                                   \
-    do {                                                                                                                 \
-        uint8_t* const pb_ = put0 + (uint32_t)(BUF) * kBufBytes;                                                         \
-        *reinterpret_cast<uint4*>(pb_) = p0;                                                                             \
-        *reinterpret_cast<uint4*>(pb_ + kPutStep) = p1;                                                                  \
-        if (NP == 4u) {                                                                                                  \
-            *reinterpret_cast<uint4*>(pb_ + 2u * kPutStep) = p2;                                                         \
-            *reinterpret_cast<uint4*>(pb_ + 3u * kPutStep) = p3;                                                         \
-        }                                                                                                                \
+#define MATCH_PUT(BUF) \
+    do { \
+        uint8_t* const pb_ = put0 + (uint32_t)(BUF) * kBufBytes; \
+        if (NP > 0u) *reinterpret_cast<uint4*>(pb_ + 0u * kPutStep) = p0; \
+        if (NP > 1u) *reinterpret_cast<uint4*>(pb_ + 1u * kPutStep) = p1; \
+        if (NP > 2u) *reinterpret_cast<uint4*>(pb_ + 2u * kPutStep) = p2; \
+        if (NP > 3u) *reinterpret_cast<uint4*>(pb_ + 3u * kPutStep) = p3; \
+        if (NP > 4u) *reinterpret_cast<uint4*>(pb_ + 4u * kPutStep) = p4; \
+        if (NP > 5u) *reinterpret_cast<uint4*>(pb_ + 5u * kPutStep) = p5; \
+        if (NP > 6u) *reinterpret_cast<uint4*>(pb_ + 6u * kPutStep) = p6; \
+        if (NP > 7u) *reinterpret_cast<uint4*>(pb_ + 7u * kPutStep) = p7; \
     } while (0)
     // one column tile: 4 k steps x 4 row tiles with four independent accumulators (a dependent chain of MFMAs waits out each
     // one's latency), then three vector instructions per result.  MASK: the frame's last, partial tile -- its missing columns get key 0.
@@ -144,27 +154,30 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_mfma(const uint32_t*
         MATCH_PUT(0);
     }
     __syncthreads();
-    int buf = 0;
-    for (uint32_t j0 = 0; j0 < nb; j0 += (uint32_t)kMatchChunk, buf ^= 1) {
-        const bool more = j0 + (uint32_t)kMatchChunk < nb;
+    // whole chunks without a branch around the tiles, the partial chunk behind the loop (see k_match_fp4)
+    const uint8_t* const src_base = &stage[0][rc * (uint32_t)kMatchRowBytes + 16u * g];
+    const uint32_t n_whole = nb / (uint32_t)kMatchChunk, n_chunks = (nb + (uint32_t)kMatchChunk - 1u) / (uint32_t)kMatchChunk;
+    uint32_t c = 0;
+    for (; c < n_whole; c++) {
+        const uint32_t j0 = c * (uint32_t)kMatchChunk;
+        const bool more = c + 1u < n_chunks;
         if (more) MATCH_FETCH(j0 + (uint32_t)kMatchChunk);
-        if (wave_live) {
-            const uint8_t* const src0 = &stage[buf][rc * (uint32_t)kMatchRowBytes + 16u * g];
-            if (j0 + (uint32_t)kMatchChunk <= nb) {  // a whole chunk: four full tiles
+        const uint8_t* const src0 = src_base + (c & 1u) * kBufBytes;
 #pragma unroll
-                for (int tt = 0; tt < kMatchChunk / 16; tt++) tile(std::false_type{}, src0 + tt * 16 * kMatchRowBytes, j0 + 16u * (uint32_t)tt);
-            } else {
-                for (uint32_t tt = 0; j0 + 16u * tt < nb; tt++) {
-                    const uint32_t jt = j0 + 16u * tt;
-                    if (jt + 16u <= nb)
-                        tile(std::false_type{}, src0 + tt * (uint32_t)(16 * kMatchRowBytes), jt);
-                    else
-                        tile(std::true_type{}, src0 + tt * (uint32_t)(16 * kMatchRowBytes), jt);
-                }
-            }
-        }
-        if (more) MATCH_PUT(buf ^ 1);
+        for (int tt = 0; tt < kMatchChunk / 16; tt++) tile(std::false_type{}, src0 + tt * 16 * kMatchRowBytes, j0 + 16u * (uint32_t)tt);
+        if (more) MATCH_PUT((c & 1u) ^ 1u);
         __syncthreads();
+    }
+    if (c < n_chunks) {  // the partial chunk: whole tiles, then one masked tile
+        const uint32_t j0 = c * (uint32_t)kMatchChunk;
+        const uint8_t* const src0 = src_base + (c & 1u) * kBufBytes;
+        for (uint32_t tt = 0; j0 + 16u * tt < nb; tt++) {
+            const uint32_t jt = j0 + 16u * tt;
+            if (jt + 16u <= nb)
+                tile(std::false_type{}, src0 + tt * (uint32_t)(16 * kMatchRowBytes), jt);
+            else
+                tile(std::true_type{}, src0 + tt * (uint32_t)(16 * kMatchRowBytes), jt);
+        }
     }
 #undef MATCH_FETCH
 #undef MATCH_PUT
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(256) void k_desc_expand4(const uint32_t* __restrict
     *reinterpret_cast<uint4*>(desc4 + ((size_t)frame * cap + i) * 128u + wd * 16u) = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
-__global__ __launch_bounds__(64 * kMatchWaves) void k_match_fp4(const uint32_t* __restrict__ counts, const uint8_t* __restrict__ desc4,
+__global__ __launch_bounds__(64 * kMatchWaves, TINYORB_MATCH_MINWAVES) void k_match_fp4(const uint32_t* __restrict__ counts, const uint8_t* __restrict__ desc4,
                                                                 uint32_t cap, MatchRecord* __restrict__ matches) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[2][kMatchChunk * kMatch4RowBytes];
     const uint32_t pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -258,22 +271,34 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_fp4(const uint32_t* 
 
     // staging: a chunk is 64 rows x 8 pieces of 16 bytes = 512 pieces, piece p = bytes 16 (p & 7) .. of candidate row p >> 3
     constexpr uint32_t NT = 64u * (uint32_t)kMatchWaves, NP = (uint32_t)(kMatchChunk * 8) / NT;
-    static_assert(NP == 1u || NP == 2u, "staging is written for one or two pieces per thread");
+    static_assert(NP >= 1u && NP <= 8u && NP * NT == (uint32_t)(kMatchChunk * 8), "staging: whole pieces per thread");
     const uint32_t prow = tid >> 3, pcol = 16u * (tid & 7u);
     uint8_t* const put0 = &stage[0][prow * (uint32_t)kMatch4RowBytes + pcol];
     constexpr uint32_t kRowStep = NT / 8u, kPutStep = kRowStep * (uint32_t)kMatch4RowBytes, kBufBytes = (uint32_t)(kMatchChunk * kMatch4RowBytes);
-    uint4 p0 = make_uint4(0u, 0u, 0u, 0u), p1 = p0;
-#define MATCH4_FETCH(J0)                                                                                                 \
-    do {                                                                                                                 \
-        const uint8_t* const fb_ = qb + pcol;                                                                            \
-        p0 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow, nb - 1u) * 128u);                            \
-        if (NP == 2u) p1 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + kRowStep, nb - 1u) * 128u);   \
+    uint4 p0 = make_uint4(0u, 0u, 0u, 0u), p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;  // (named registers: an array went through scratch memory)
+#define MATCH4_FETCH(J0) \
+    do { \
+        const uint8_t* const fb_ = qb + pcol; \
+        if (NP > 0u) p0 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 0u * kRowStep, nb - 1u) * 128u); \
+        if (NP > 1u) p1 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 1u * kRowStep, nb - 1u) * 128u); \
+        if (NP > 2u) p2 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 2u * kRowStep, nb - 1u) * 128u); \
+        if (NP > 3u) p3 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 3u * kRowStep, nb - 1u) * 128u); \
+        if (NP > 4u) p4 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 4u * kRowStep, nb - 1u) * 128u); \
+        if (NP > 5u) p5 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 5u * kRowStep, nb - 1u) * 128u); \
+        if (NP > 6u) p6 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 6u * kRowStep, nb - 1u) * 128u); \
+        if (NP > 7u) p7 = *reinterpret_cast<const uint4*>(fb_ + (size_t)min((J0) + prow + 7u * kRowStep, nb - 1u) * 128u); \
     } while (0)
-#define MATCH4_PUT(BUF)                                                                                                  \
-    do {                                                                                                                 \
-        uint8_t* const pb_ = put0 + (uint32_t)(BUF) * kBufBytes;                                                         \
-        *reinterpret_cast<uint4*>(pb_) = p0;                                                                             \
-        if (NP == 2u) *reinterpret_cast<uint4*>(pb_ + kPutStep) = p1;                                                    \
+#define MATCH4_PUT(BUF) \
+    do { \
+        uint8_t* const pb_ = put0 + (uint32_t)(BUF) * kBufBytes; \
+        if (NP > 0u) *reinterpret_cast<uint4*>(pb_ + 0u * kPutStep) = p0; \
+        if (NP > 1u) *reinterpret_cast<uint4*>(pb_ + 1u * kPutStep) = p1; \
+        if (NP > 2u) *reinterpret_cast<uint4*>(pb_ + 2u * kPutStep) = p2; \
+        if (NP > 3u) *reinterpret_cast<uint4*>(pb_ + 3u * kPutStep) = p3; \
+        if (NP > 4u) *reinterpret_cast<uint4*>(pb_ + 4u * kPutStep) = p4; \
+        if (NP > 5u) *reinterpret_cast<uint4*>(pb_ + 5u * kPutStep) = p5; \
+        if (NP > 6u) *reinterpret_cast<uint4*>(pb_ + 6u * kPutStep) = p6; \
+        if (NP > 7u) *reinterpret_cast<uint4*>(pb_ + 7u * kPutStep) = p7; \
     } while (0)
     const int scale = 127 + 7;  // E8M0: 2^7 for every block of both operands
     auto tile = [&](auto mask_tag, const uint8_t* src, uint32_t jt) {
@@ -313,27 +338,34 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_fp4(const uint32_t* 
         MATCH4_PUT(0);
     }
     __syncthreads();
-    int buf = 0;
-    for (uint32_t j0 = 0; j0 < nb; j0 += (uint32_t)kMatchChunk, buf ^= 1) {
-        const bool more = j0 + (uint32_t)kMatchChunk < nb;
+    // The loop over whole chunks has NO branch around the tiles: a wave without queries (wave_live false: its rows repeat the frame's last
+    // one, nothing of it is stored) multiplies like the others, and the frame's last, partial chunk is handled behind the loop.  With the
+    // partial chunk and `if (wave_live)` inside the loop hipcc kept the 2 x 16 (best, runner-up) registers of the two paths in different
+    // places and copied them back every iteration: 32 v_mov per chunk next to its 128 useful vector instructions (6.4 vector instructions
+    // per MFMA in the counters where the tile's arithmetic needs 4; 5.3 without them, 0.623 -> 0.59 ms per 255 pairs).
+    const uint8_t* const src_base = &stage[0][rc * (uint32_t)kMatch4RowBytes + 16u * g];
+    const uint32_t n_whole = nb / (uint32_t)kMatchChunk, n_chunks = (nb + (uint32_t)kMatchChunk - 1u) / (uint32_t)kMatchChunk;
+    uint32_t c = 0;
+    for (; c < n_whole; c++) {
+        const uint32_t j0 = c * (uint32_t)kMatchChunk;
+        const bool more = c + 1u < n_chunks;
         if (more) MATCH4_FETCH(j0 + (uint32_t)kMatchChunk);
-        if (wave_live) {
-            const uint8_t* const src0 = &stage[buf][rc * (uint32_t)kMatch4RowBytes + 16u * g];
-            if (j0 + (uint32_t)kMatchChunk <= nb) {
+        const uint8_t* const src0 = src_base + (c & 1u) * kBufBytes;
 #pragma unroll
-                for (int tt = 0; tt < kMatchChunk / 16; tt++) tile(std::false_type{}, src0 + tt * 16 * kMatch4RowBytes, j0 + 16u * (uint32_t)tt);
-            } else {
-                for (uint32_t tt = 0; j0 + 16u * tt < nb; tt++) {
-                    const uint32_t jt = j0 + 16u * tt;
-                    if (jt + 16u <= nb)
-                        tile(std::false_type{}, src0 + tt * (uint32_t)(16 * kMatch4RowBytes), jt);
-                    else
-                        tile(std::true_type{}, src0 + tt * (uint32_t)(16 * kMatch4RowBytes), jt);
-                }
-            }
-        }
-        if (more) MATCH4_PUT(buf ^ 1);
+        for (int tt = 0; tt < kMatchChunk / 16; tt++) tile(std::false_type{}, src0 + tt * 16 * kMatch4RowBytes, j0 + 16u * (uint32_t)tt);
+        if (more) MATCH4_PUT((c & 1u) ^ 1u);
         __syncthreads();
+    }
+    if (c < n_chunks) {  // the partial chunk: whole tiles, then one masked tile
+        const uint32_t j0 = c * (uint32_t)kMatchChunk;
+        const uint8_t* const src0 = src_base + (c & 1u) * kBufBytes;
+        for (uint32_t tt = 0; j0 + 16u * tt < nb; tt++) {
+            const uint32_t jt = j0 + 16u * tt;
+            if (jt + 16u <= nb)
+                tile(std::false_type{}, src0 + tt * (uint32_t)(16 * kMatch4RowBytes), jt);
+            else
+                tile(std::true_type{}, src0 + tt * (uint32_t)(16 * kMatch4RowBytes), jt);
+        }
     }
 #undef MATCH4_FETCH
 #undef MATCH4_PUT

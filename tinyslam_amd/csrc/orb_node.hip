@@ -581,11 +581,15 @@ int orb_node_extract_batch_host(OrbNode* node, const uint8_t* frames_host, uint3
     const bool pinned = hipHostRegister(const_cast<uint8_t*>(frames_host), total, hipHostRegisterPortable) == hipSuccess;
     if (!pinned) (void)hipGetLastError();  // already pinned by the caller (orb_host_alloc), or not pinnable: the runtime stages the copies
     int rc = submit_job(node, nullptr, frames_host, n_frames);
+    const bool queued = rc == ORB_OK;
     for (int r = 0; r < node->n; r++) {
         const int rs = orb_upload_sync(node->progs[r]);
         if (rs != ORB_OK && rc == ORB_OK) rc = nfail(node, rs, "upload to device %d: %s", node->devices[r], orb_last_error(node->progs[r]));
     }
     if (pinned) (void)hipHostUnregister(const_cast<uint8_t*>(frames_host));
+    // an upload that failed behind a job that IS queued: the job's kernels read frames that never arrived -- the node goes out of
+    // service like after any other failure in the middle of an enqueue sequence (a retry must not collate that job)
+    if (queued && rc != ORB_OK) return poison(node, rc);
     return rc;
 }
 
@@ -604,17 +608,20 @@ int orb_node_collate_end(OrbNode* node, uint32_t* counts, uint64_t* offsets, voi
     NodeJob& job = node->jobs.front();
     const int slot = job.slot;
     const size_t cap = node->cfg.max_features;
+    // a wait that fails here leaves a job whose exchange is in an unknown state: out of service, as in begin_oldest / submit_job
+    hipError_t we = hipSuccess;
     if (node->sharded) {
-        for (int r = 0; r < node->n; r++) {
+        for (int r = 0; r < node->n && we == hipSuccess; r++) {
             if (job.shard_n[r] == 0) continue;
-            NODE_HIP(node, hipSetDevice(node->devices[r]));
-            NODE_HIP(node, hipEventSynchronize(node->ev_pack[slot][r]));  // rank r's records are packed on its device
+            we = hipSetDevice(node->devices[r]);
+            if (we == hipSuccess) we = hipEventSynchronize(node->ev_pack[slot][r]);  // rank r's records are packed on its device
         }
     } else {
-        NODE_HIP(node, hipSetDevice(node->devices[0]));
-        if (job.shard_n[0]) NODE_HIP(node, hipEventSynchronize(node->ev_pack[slot][0]));  // rank 0's own records are in place
-        NODE_HIP(node, hipEventSynchronize(node->ev_xchg[slot][0]));                       // and everybody else's
+        we = hipSetDevice(node->devices[0]);
+        if (we == hipSuccess && job.shard_n[0]) we = hipEventSynchronize(node->ev_pack[slot][0]);  // rank 0's own records are in place
+        if (we == hipSuccess) we = hipEventSynchronize(node->ev_xchg[slot][0]);                    // and everybody else's
     }
+    if (we != hipSuccess) return poison(node, nfail(node, ORB_EHIP, "collate_end: waiting for the job failed: %s", hipGetErrorString(we)));
     // frame-ordered counters and offsets for the caller
     uint64_t off = 0;
     uint32_t f_out = 0;
@@ -652,17 +659,34 @@ int orb_node_set_results(OrbNode* node, int where) {
     if (where != ORB_NODE_RESULTS_ROOT && where != ORB_NODE_RESULTS_SHARDED) return nfail(node, ORB_EINVAL, "results: ORB_NODE_RESULTS_ROOT or _SHARDED");
     if (!node->jobs.empty()) return nfail(node, ORB_ESTATE, "set_results with %zu jobs outstanding", node->jobs.size());
     if (where == ORB_NODE_RESULTS_SHARDED && node->d_shard_c[0].empty()) {
+        // Allocate into local vectors and commit them only when every hipMalloc succeeded: a failed call must not leave the node with
+        // half of its buffers (a retry would take "not empty" for "allocated" and pack through null pointers).
         const size_t pack = (size_t)node->max_batch * node->cfg.max_features;
-        for (int c = 0; c < kCollSlots; c++) {
-            node->d_shard_c[c].assign(node->n, nullptr);
-            node->d_shard_d[c].assign(node->n, nullptr);
-        }
-        for (int c = 0; c < kCollSlots; c++)
-            for (int r = 0; r < node->n; r++) {
-                NODE_HIP(node, hipSetDevice(node->devices[r]));
-                NODE_HIP(node, hipMalloc(&node->d_shard_c[c][r], pack * sizeof(CornerData)));
-                NODE_HIP(node, hipMalloc(&node->d_shard_d[c][r], pack * sizeof(CornerDescriptor)));
+        std::vector<CornerData*> sc[kCollSlots];
+        std::vector<CornerDescriptor*> sd[kCollSlots];
+        hipError_t bad = hipSuccess;
+        for (int c = 0; c < kCollSlots && bad == hipSuccess; c++) {
+            sc[c].assign(node->n, nullptr);
+            sd[c].assign(node->n, nullptr);
+            for (int r = 0; r < node->n && bad == hipSuccess; r++) {
+                bad = hipSetDevice(node->devices[r]);
+                if (bad == hipSuccess) bad = hipMalloc(&sc[c][r], pack * sizeof(CornerData));
+                if (bad == hipSuccess) bad = hipMalloc(&sd[c][r], pack * sizeof(CornerDescriptor));
             }
+        }
+        if (bad != hipSuccess) {
+            for (int c = 0; c < kCollSlots; c++)
+                for (size_t r = 0; r < sc[c].size(); r++) {
+                    (void)hipSetDevice(node->devices[r]);
+                    if (sc[c][r]) (void)hipFree(sc[c][r]);
+                    if (r < sd[c].size() && sd[c][r]) (void)hipFree(sd[c][r]);
+                }
+            return nfail(node, ORB_EHIP, "set_results: allocating the shard buffers failed: %s", hipGetErrorString(bad));
+        }
+        for (int c = 0; c < kCollSlots; c++) {
+            node->d_shard_c[c] = std::move(sc[c]);
+            node->d_shard_d[c] = std::move(sd[c]);
+        }
     }
     node->sharded = where == ORB_NODE_RESULTS_SHARDED;
     node->collated = false;

@@ -8,6 +8,7 @@ transport records packed back to back (`collate_transport_to_root`, what bench.p
 keypoint/descriptor slabs trimmed to the largest per-frame count (`collate_to_root`).  With backend
 "nccl" this is RCCL over xGMI; the CPU tests run the same code over gloo.
 """
+import time
 from typing import Optional, Tuple
 
 import torch
@@ -149,6 +150,7 @@ class TransportCollator:
         self.records = [None] * slots        # the rank's transport records of the batch in this slot
         self.merged = [None] * slots         # root: (world * s_cap, 10) landing area per slot, allocated on first use
         self.bytes_exchanged = 0
+        self.wait_s = 0.0                    # host time spent waiting for a batch's counters in exchange() (the rest of a collate's host time is enqueueing)
 
     def submit(self, slot: int, counts: torch.Tensor, records: torch.Tensor):
         """Enqueues the first half of batch `slot`'s collate on the current stream: all_gather of the counters and their
@@ -170,7 +172,9 @@ class TransportCollator:
         first[r]..first[r+1]; other ranks None)}."""
         slot = ticket
         if self.copied[slot] is not None:
-            self.copied[slot].synchronize()
+            t0 = time.perf_counter()
+            self.copied[slot].synchronize()  # one batch behind: normally set long ago -- wait_s says whether it was
+            self.wait_s += time.perf_counter() - t0
         counts_all = self.h_counts[slot].numpy().copy()
         totals = [int(t) for t in counts_all.clip(max=self.cap).reshape(self.world, -1).sum(axis=1)]
         first = [0]

@@ -20,12 +20,13 @@ LIB_PATH = os.environ.get("TINYORB_LIB") or os.path.join(os.path.dirname(os.path
 
 ORB_OK, ORB_EINVAL, ORB_EHIP, ORB_ECAPACITY, ORB_ESTATE = 0, 1, 2, 3, 4
 ORB_PLANE_GRAY, ORB_PLANE_BLUR = 0, 1
-ORB_KERNEL_COUNT = 21
+ORB_KERNEL_COUNT = 22
 ORB_FLAG_STAGED = 1
 ORB_FLAG_DOUBLE_OUTPUT = 2
 ORB_FLAG_NMS = 4
 ORB_FLAG_INTENDED = 8
 ORB_FLAG_INPUT_Y8 = 16
+ORB_FLAG_SINGLE_BLOCKING_WAIT = 32  # orb_extract_corners: bounded spin, then sleep until the completion interrupt
 ORB_OOB_ZERO, ORB_OOB_CLAMP, ORB_OOB_UMIN = 0, 1, 2  # OrbOptions.oob_policy
 OOB_POLICIES = {"zero": ORB_OOB_ZERO, "clamp": ORB_OOB_CLAMP, "umin": ORB_OOB_UMIN}
 # OrbOptions.fp_contract (CRD-13): which stages' products and sums the adapter's shader compiler fuses, and its reduction order

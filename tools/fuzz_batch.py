@@ -43,6 +43,7 @@ for case in range(n_cases):
     n = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 24, 33, 40]))
     seeds = [int(s) for s in rng.integers(0, 1 << 30, n)]
     y8 = mode == "y8"
+    fp = int(rng.integers(0, 16)) if mode == "literal" and rng.random() < 0.6 else 0  # OrbOptions::fp_contract (round 5)
     frames = [oo.synth_frame_y8(W, H, s) if y8 else oo.synth_frame(W, H, s) for s in seeds]
     flags = (orb.ORB_FLAG_INTENDED if mode == "intended" else 0) | (orb.ORB_FLAG_NMS if nms else 0) \
         | (orb.ORB_FLAG_STAGED if staged else 0) | (orb.ORB_FLAG_INPUT_Y8 if y8 else 0)
@@ -55,9 +56,9 @@ for case in range(n_cases):
         elif mode == "arc":
             refs.append(oo.extract_ex(f, depth=depth, threshold=thr, max_features=cap, arc=arc, nms=nms))
         else:
-            refs.append(oo.extract(f, depth=depth, threshold=thr, max_features=cap))
+            refs.append(oo.extract(f, depth=depth, threshold=thr, max_features=cap, contract=fp & 7, dot_order=fp >> 3))
     cfg = orb.OrbConfig(orb.Extent3d(W, H), max_features=cap, hierarchy_depth=depth, initial_threshold=thr, flags=flags,
-                        fast_arc=arc, max_batch=n)
+                        fast_arc=arc, max_batch=n, fp_contract=fp)
     ok = True
     why = ""
     with orb.OrbProgram(cfg) as prog:

@@ -43,6 +43,9 @@ for case in range(n_cases):
     plain = (not intended) and (not nms) and arc in (0, 12)
     oob = str(rng.choice(["zero", "zero", "clamp", "umin"])) if plain else "zero"
     wbits = int(rng.choice([0, 0, 8, 4, 12])) if plain else 0
+    # OrbOptions::fp_contract (round 5): which stages' products and sums are fused, and the reduction order -- RGBA, the reference's detector
+    fp = int(rng.integers(0, 16)) if plain and not y8 and rng.random() < 0.5 else 0
+    fpk = dict(contract=fp & 7, dot_order=fp >> 3)
     cap = int(rng.choice([8192, 8192, 300, 40, 5]))
     staged = bool(rng.random() < 0.25)
     syn = int(rng.choice([15, 15, 7, 14, 9]))
@@ -61,9 +64,9 @@ for case in range(n_cases):
     elif nms or (arc not in (0, 12)):
         ref = oo.extract_ex(rgba, depth=depth, threshold=thr, max_features=cap, arc=arc or 12, nms=nms)
     else:
-        ref = oo.extract(rgba, depth=depth, threshold=thr, max_features=cap, oob=oob, weight_bits=wbits)
+        ref = oo.extract(rgba, depth=depth, threshold=thr, max_features=cap, oob=oob, weight_bits=wbits, **fpk)
     cfg = orb.OrbConfig(orb.Extent3d(W, H), max_features=cap, hierarchy_depth=depth, initial_threshold=thr, flags=flags, fast_arc=arc,
-                        oob_policy=orb.OOB_POLICIES[oob], sampler_weight_bits=wbits)
+                        oob_policy=orb.OOB_POLICIES[oob], sampler_weight_bits=wbits, fp_contract=fp)
     with orb.OrbProgram(cfg) as prog:
         total, corners, desc = prog.extract(rgba)
         pipe = prog.pipeline()
@@ -75,14 +78,14 @@ for case in range(n_cases):
         ok = len(c) == len(rc) and all(np.array_equal(c[k], rc[k]) for k in ("x", "y", "angle", "octave")) and np.array_equal(d, rd)
     elif ok:
         full = oo.extract_y8(rgba, depth=depth, threshold=thr, max_features=1 << 20, oob=oob, weight_bits=wbits) if y8 else \
-            oo.extract(rgba, depth=depth, threshold=thr, max_features=1 << 20, oob=oob, weight_bits=wbits) if not (nms or arc not in (0, 12)) else \
+            oo.extract(rgba, depth=depth, threshold=thr, max_features=1 << 20, oob=oob, weight_bits=wbits, **fpk) if not (nms or arc not in (0, 12)) else \
             oo.extract_ex(rgba, depth=depth, threshold=thr, max_features=1 << 20, arc=arc or 12, nms=nms)
         table = {(int(k["octave"]), int(k["y"]), int(k["x"])): (int(k["angle"]), dd.tobytes()) for k, dd in zip(full["corners"], full["descriptors"])}
         ok = len(corners) == cap and all(table.get((int(k["octave"]), int(k["y"]), int(k["x"]))) == (int(k["angle"]), dd.tobytes())
                                          for k, dd in zip(corners, desc))
     if not ok:
         bad += 1
-        print("MISMATCH", dict(W=W, H=H, depth=depth, thr=thr, intended=intended, nms=nms, arc=arc, cap=cap, staged=staged, y8=y8, oob=oob, wbits=wbits,
+        print("MISMATCH", dict(W=W, H=H, depth=depth, thr=thr, intended=intended, nms=nms, arc=arc, cap=cap, staged=staged, y8=y8, oob=oob, wbits=wbits, fp=fp,
                                syn=syn, seed=seed, pipe=pipe, total=total, ref_total=ref["total"]), flush=True)
     if case % 20 == 19:
         print("case %d, %d mismatches, %.0f s" % (case + 1, bad, time.time() - t0), flush=True)

@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/fuzz_round4_final.sh [n_single n_batch seed0]  -- the fuzz sweeps at the round's final kernels; output under gpurun_out/fuzz/
+# usage (GPU box): bash tools/fuzz_round4_final.sh [n_single n_batch seed0]  -- the fuzz sweeps at a round's final kernels (round 5: half of the plain RGBA cases under a random fp_contract); output under gpurun_out/fuzz/
 N1=${1:-6000}; N2=${2:-800}; S=${3:-91}
 mkdir -p gpurun_out/fuzz
 ( echo "## fuzz_parity.py $N1 $S"; timeout -k 10 1000 python tools/fuzz_parity.py $N1 $S | tail -2 ) > gpurun_out/fuzz/f1.txt 2>&1 &&

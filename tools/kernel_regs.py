@@ -5,16 +5,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tinyslam_amd import build
 os.makedirs("/tmp/isa", exist_ok=True)
-flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + os.environ.get("TINYORB_BUILD_EXTRA", "").split()
 s = ""
+pat = sys.argv[1] if len(sys.argv) > 1 else ""
 for src, extra, obj in build.UNITS:  # every translation unit with device code (k_front's instances: one unit per arithmetic form)
-    if src == "orb_node.hip":
+    if src == "orb_node.hip" or (pat and ("k_front" in pat) != (src == "orb_front_inst.hip")):  # a filter names the units it needs
         continue
     out = "/tmp/isa/" + obj.replace(".o", ".s")
     subprocess.check_call([build._hipcc()] + flags + extra + ["--cuda-device-only", "-S", "-o", out, os.path.join(build.CSRC, src)],
                           stderr=subprocess.DEVNULL)
     s += open(out).read()
-pat = sys.argv[1] if len(sys.argv) > 1 else ""
 for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.vgpr_count:\s+(\d+)", s, re.S):
     name, body, vg = m.group(1), m.group(2), m.group(3)
     sg = re.search(r"\.sgpr_count:\s+(\d+)", body)
