@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_desc_expand(const uint32_t* __restrict_
 // path for 4 KB per wave and tile, four times the same bytes, and ran at a third of this form's rate -- and double-buffered:
 // the next chunk's loads are in flight while this one is multiplied, one barrier per chunk.
 constexpr int kMatchChunk = 64;            // candidates per LDS stage (4 column tiles)
-constexpr int kMatchRowBytes = 256 + 16;   // LDS row stride
+constexpr int kMatchRowBytes = 256 + 32;   // LDS row stride (dword offset 72 r + 4 g: conflict-free by the rule found for k_match_fp4, kMatch4RowBytes)
 __global__ __launch_bounds__(64 * kMatchWaves) void k_match_mfma(const uint32_t* __restrict__ counts, const uint8_t* __restrict__ desc8,
                                                                  uint32_t cap, MatchRecord* __restrict__ matches) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[2][kMatchChunk * kMatchRowBytes];
@@ -218,7 +218,14 @@ __global__ __launch_bounds__(64 * kMatchWaves) void k_match_mfma(const uint32_t*
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kMatch4K = 1u << 14;
 constexpr uint32_t kMatch4MaxCap = kMatch4K - 1u;
-constexpr int kMatch4RowBytes = 128 + 16;
+#ifndef TINYORB_MATCH4_ROWBYTES
+#define TINYORB_MATCH4_ROWBYTES (128 + 32)
+#endif
+// LDS row stride of a staged candidate.  Lane (r = l & 15, g = l >> 4) reads 16 bytes at r * stride + 16 g: with a stride of 128 + 16 bytes
+// SQ_LDS_BANK_CONFLICT read 36 % of SQ_LDS_IDX_ACTIVE (7.3 cycles per LDS instruction); with 128 + 32 it reads 0 (4.7 cycles) -- the dword
+// offset 40 r + 4 g covers the 32 banks once per 4 rows x 2 groups, where 36 r + 4 g puts (r, g + 1) on (r + 1, g)'s banks.  176, 192, 208
+// and 272 conflict like 144 (profiles/r05_match_experiments.txt).  The kernel's time does not move (it waits for issue slots, not for LDS).
+constexpr int kMatch4RowBytes = TINYORB_MATCH4_ROWBYTES;
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
