@@ -414,29 +414,91 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
             seg_sc[idx] = score;
         }
     };
-    // Direct evaluation of one pixel (used when a queue overflowed): corner?  NMS by re-scoring its neighbours.
-    auto direct_pixel = [&](int x, int gy) {
-        const half_t* ctr = grey + __mul24(gy - y0 + kIApron, LS) + kIPad + (x - cx0);
-        if (!ring_has_arc(ctr, LS, thr, arc)) return;
-        float s;
-        uint32_t ang;
-        ring_score_angle(ctr, LS, thr, arc, lit, &s, &ang);
-        if (geo.nms) {
-            for (int dy = -1; dy <= 1; dy++)
-                for (int dx = -1; dx <= 1; dx++) {
-                    if (dx == 0 && dy == 0) continue;
-                    const int nx = x + dx, ny = gy + dy;
-                    if (!(nx > 16 && nx < gx1 && ny > 16 && ny < gy1)) continue;
-                    const half_t* nc = ctr + dy * LS + dx;
-                    if (!ring_has_arc(nc, LS, thr, arc)) continue;
-                    float t;
-                    uint32_t na;
-                    ring_score_angle(nc, LS, thr, arc, lit, &t, &na);
-                    const bool later = dy > 0 || (dy == 0 && dx > 0);
-                    if (t > s || (t == s && !later)) return;
+    // The dense path (a queue overflowed: a tile of texture at a low threshold).  Round 4's form evaluated every pixel of the tile on its
+    // own and, with NMS, scored each corner's eight neighbours AGAIN -- 12 ms per 256 frames of noise at threshold 8 / 255, the mode's
+    // one cliff.  Now the tile is walked down its region rows with a few rows of (score, angle) resident in the drained queues' storage (the
+    // 3x3 NMS of a row needs its two neighbours and nothing else): every pixel is tested once, no corner is scored twice, and no capacity
+    // is involved -- results cannot depend on how dense the tile is.
+    auto dense_rows = [&]() {
+        // Two region rows per step, FOUR resident (the rows of this step and the two before): compass pre-test of the step's pixels ->
+        // survivors compacted into a list (densely packed lanes for what follows) -> segment test of the polarities that passed, score and
+        // angle of the corners into the rows' (score, angle) buffers -> 3x3 suppression of the two rows whose neighbours are now resident.
+        constexpr int NCMAX = kITileW + 2;
+        const int nc = tw + 2 * apron;                                    // region columns, x = cx0 - apron + c
+        const int nr = min(R, dh - y0) + 2 * apron;                       // region rows, gy = y0 - apron + r
+        float* const sc4 = reinterpret_cast<float*>(queue_a);             // [4][NCMAX] scores, 0 = no corner (a corner's score is positive)
+        uint16_t* const an4 = reinterpret_cast<uint16_t*>(sc4 + 4 * NCMAX);  // [4][NCMAX] angle codes
+        uint16_t* const plist = an4 + 4 * NCMAX;                          // [2 * NCMAX] pre-test survivors of the step: pixel | flags << 14
+        static_assert(4 * NCMAX * 6 + 2 * NCMAX * 2 <= (kIQueueA + kIQueueB + kIQueueC) * 2, "the dense path's rows and list do not fit the queues' storage");
+        static_assert(2 * NCMAX < (1 << 14), "a step's pixel index and two flags share 16 bits");
+        const uint32_t need = arc >= 12u ? 3u : 2u;                       // compass points a run of `arc` holds at least
+        auto slot_of_row = [](int r) { return (r + 4) & 3; };
+        for (int c = tid; c < NCMAX; c += NT) sc4[slot_of_row(-1) * NCMAX + c] = 0.0f, sc4[slot_of_row(-2) * NCMAX + c] = 0.0f;  // above the region
+        const int n_steps = (nr + 2) / 2;
+        for (int k = 0; k < n_steps; k++) {
+            const int r0 = 2 * k;
+            // ---- a: compass pre-test (fast.wgsl:85-95 with the arc's count) of rows r0, r0 + 1; their buffers start as "no corner"
+            if (tid == 0) *qa_count = 0u;
+            __syncthreads();
+            for (int p = tid; p < 2 * nc; p += NT) {
+                const int rr = p >= nc ? 1 : 0, c = p - rr * nc, r = r0 + rr;
+                const int x = cx0 - apron + c, gy = y0 - apron + r;
+                sc4[slot_of_row(r) * NCMAX + c] = 0.0f;
+                if (r < nr && gy > 16 && gy < gy1 && x > 16 && x < gx1) {
+                    const half_t* ctr = grey + __mul24(gy - y0 + kIApron, LS) + kIPad + (x - cx0);
+                    const float cv = from_half(ctr[0]);
+                    const float d4[4] = {from_half(ctr[3]) - cv, from_half(ctr[-3]) - cv, from_half(ctr[3 * LS]) - cv, from_half(ctr[-3 * LS]) - cv};
+                    uint32_t n_over = 0, n_under = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) n_over += d4[q] > thr ? 1u : 0u, n_under += d4[q] < -thr ? 1u : 0u;
+                    const uint32_t fl = (n_over >= need ? 1u : 0u) | (n_under >= need ? 2u : 0u);
+                    if (fl) plist[atomicAdd(qa_count, 1u)] = (uint16_t)((uint32_t)p | (fl << 14));
                 }
+            }
+            __syncthreads();
+            // ---- b: segment test, score, angle -- on the list
+            const uint32_t n_l = *qa_count;
+            for (uint32_t i = (uint32_t)tid; i < n_l; i += NT) {
+                const uint32_t e = plist[i], p = e & 0x3fffu;
+                const int rr = (int)p >= nc ? 1 : 0, c = (int)p - rr * nc, r = r0 + rr;
+                const int x = cx0 - apron + c, gy = y0 - apron + r;
+                const half_t* ctr = grey + __mul24(gy - y0 + kIApron, LS) + kIPad + (x - cx0);
+                if (ring_has_arc(ctr, LS, thr, arc, (e >> 14) & 1u, (e >> 15) & 1u)) {
+                    float sv;
+                    uint32_t ang;
+                    ring_score_angle(ctr, LS, thr, arc, lit, &sv, &ang);
+                    if (!geo.nms) {
+                        append((uint32_t)x, (uint32_t)gy, ang, sv);  // no apron without suppression: every region pixel is the tile's own
+                    } else {
+                        sc4[slot_of_row(r) * NCMAX + c] = sv;
+                        an4[slot_of_row(r) * NCMAX + c] = (uint16_t)ang;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- c: suppression of rows r0 - 1 and r0 (their three rows are resident)
+            if (geo.nms)
+                for (int p = tid; p < 2 * nc; p += NT) {
+                    const int rr = p >= nc ? 1 : 0, c = p - rr * nc, r = r0 - 1 + rr;
+                    const int x = cx0 - apron + c, gy = y0 - apron + r;
+                    if (c < 1 || c >= nc - 1 || !in_core(x, gy)) continue;  // the region's border belongs to the neighbouring tiles
+                    const int sm = slot_of_row(r), su = slot_of_row(r - 1), sd = slot_of_row(r + 1);
+                    const float sv = sc4[sm * NCMAX + c];
+                    if (!(sv > 0.0f)) continue;
+                    bool keep = true;
+#pragma unroll
+                    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; dx++) {
+                            if (dx == 0 && dy == 0) continue;
+                            const float t = sc4[(dy < 0 ? su : (dy > 0 ? sd : sm)) * NCMAX + c + dx];
+                            const bool later = dy > 0 || (dy == 0 && dx > 0);
+                            if (t > sv || (t == sv && !later)) keep = false;  // t == 0: no corner there (sv > 0)
+                        }
+                    if (keep) append((uint32_t)x, (uint32_t)gy, (uint32_t)an4[sm * NCMAX + c], sv);
+                }
+            // (the next step's barrier in front of its pre-test orders its writes behind these reads)
         }
-        append((uint32_t)x, (uint32_t)gy, ang, s);
     };
 
     // =========================== B1: compass pre-test, 16 px per item ===========================
@@ -549,7 +611,9 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     // entry: one exact v_fma_mix_f32 difference and one compare per point.  The packed 16-bit form of the literal kernel's
     // 16-point test -- even_ring_mask_polar -- was measured here and is slower on eight points: finding the exact f16 threshold
     // of the pixel costs as much as half of them: 0.144 against 0.120 ms per batch)
-    if (geo.phase_mask & 2u) {
+    // (a tile whose pre-test already overflowed queue A takes the dense path: the stages in between would work on a truncated queue for nothing)
+    const bool early_overflow = *overflow != 0u;  // uniform: read behind the barrier that ends B1
+    if ((geo.phase_mask & 2u) && !early_overflow) {
         const uint32_t need_even = arc >> 1;
         const uint32_t n_a = min(*qa_count, (uint32_t)kIQueueA);
         for (uint32_t i = (uint32_t)tid; i < n_a; i += NT) {
@@ -567,7 +631,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     }
     __syncthreads();
     // =========================== S2: full segment test, B -> C ===========================
-    if (geo.phase_mask & 4u) {
+    if ((geo.phase_mask & 4u) && !early_overflow) {
         const uint32_t n_b = min(*qb_count, (uint32_t)kIQueueB);
         for (uint32_t i = (uint32_t)tid; i < n_b; i += NT) {
             const uint32_t e = queue_b[i];
@@ -584,7 +648,7 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
     }
     __syncthreads();
     // =========================== S3: score and angle of the corners -> list (A's storage) ===========================
-    if (geo.phase_mask & 8u) {
+    if ((geo.phase_mask & 8u) && !early_overflow) {
         const uint32_t n_c = min(*qc_count, (uint32_t)kIQueueC);
         for (uint32_t i = (uint32_t)tid; i < n_c; i += NT) {
             const uint32_t e = queue_c[i];
@@ -659,12 +723,9 @@ __global__ __launch_bounds__(kIThreads, 6) void k_front_i(const uint8_t* __restr
             }
         }
     } else {
-        // some queue was full (a pathologically dense tile): evaluate every pixel of the tile directly
-        const int n_px = R * tw;
-        for (int i = tid; i < n_px; i += NT) {
-            const int r = i / tw, x = cx0 + (i - r * tw), gy = y0 + r;
-            if (gy < dh && x > 16 && x < gx1 && gy > 16 && gy < gy1) direct_pixel(x, gy);
-        }
+        // some queue was full (a dense tile): the queues are drained and useless -- three resident rows at a time
+        __syncthreads();  // every wave has read the flag and is done with the queues' storage
+        dense_rows();
     }
 
     __syncthreads();

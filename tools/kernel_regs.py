@@ -9,7 +9,7 @@ flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + os.env
 s = ""
 pat = sys.argv[1] if len(sys.argv) > 1 else ""
 for src, extra, obj in build.UNITS:  # every translation unit with device code (k_front's instances: one unit per arithmetic form)
-    if src == "orb_node.hip" or (pat and ("k_front" in pat) != (src == "orb_front_inst.hip")):  # a filter names the units it needs
+    if src == "orb_node.hip" or (pat and (pat.startswith("k_front<") or pat.startswith("k_front_pair")) != (src == "orb_front_inst.hip")):  # a filter names the units it needs
         continue
     out = "/tmp/isa/" + obj.replace(".o", ".s")
     subprocess.check_call([build._hipcc()] + flags + extra + ["--cuda-device-only", "-S", "-o", out, os.path.join(build.CSRC, src)],
