@@ -91,6 +91,9 @@ def parse_args(argv=None):
                          "taps, 4 BRIEF rotation as fused multiply-adds, 8 dot() / matrix * vector reduced from the last term; 7 = an "
                          "LLVM-style contracting compiler, 15 = Mesa with an fma, 8 = Mesa without one.  0 (default) = every product and "
                          "sum rounded: the headline")
+    ap.add_argument("--angle-bins", type=int, default=0,
+                    help="--mode intended only (IM-6b, OrbOptions::angle_bins): descriptors rotated by the centre of their keypoint's angle bin "
+                         "instead of its milliradian code; 1024 bins = a 1 MB rotated-pattern table that stays in every XCD's L2")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the single-frame latency figure (profiling runs)")
     ap.add_argument("--preheat-ms", type=float, default=300.0,
                     help="untimed steps run for this long before the W warm-up steps, so that the clocks are up (the "
@@ -98,7 +101,7 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def cpu_baseline(n_sample, gpu_counts, intended=False, y8=False, syn_flags=15, threshold=THRESHOLD, fp=0):
+def cpu_baseline(n_sample, gpu_counts, intended=False, y8=False, syn_flags=15, threshold=THRESHOLD, fp=0, angle_bins=0):
     """Times oracle/ (the CPU restatement) on the first n_sample frames of the workload and checks that its per-frame
     counters equal the GPU's on those frames."""
     import numpy as np
@@ -116,7 +119,7 @@ def cpu_baseline(n_sample, gpu_counts, intended=False, y8=False, syn_flags=15, t
     t0 = time.perf_counter()
     if intended:
         totals, _, _ = orb_oracle.extract_intended_batch(frames, depth=DEPTH, threshold=threshold, max_features=MAX_FEATURES,
-                                                         arc=9, nms=True, n_threads=cores)
+                                                         arc=9, nms=True, n_threads=cores, angle_bins=angle_bins)
     else:
         totals, _, _ = orb_oracle.extract_batch(frames, depth=DEPTH, threshold=threshold, max_features=MAX_FEATURES,
                                                 n_threads=cores, y8=y8, contract=fp & 7, dot_order=(fp >> 3) & 1)
@@ -148,8 +151,9 @@ def roofline_of(args, prof, launches_frames, bytes_per_frame, profiled_s):
                             "right after the timed repeats (%.4f ms per step with the events in)"
                             % (args.steps, profiled_s / args.steps * 1e3),
                 "all_kernels_ms_per_step": {k_: v[0] / args.steps for k_, v in prof.items()}}
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s%s.json" % (args.mode, args.input, "_fp%d" % args.contract if args.contract else ""))
-    if not os.path.exists(tpath) and not args.contract:
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s%s%s.json" % (args.mode, args.input, "_fp%d" % args.contract if args.contract else "",
+                                                                        "_bins%d" % args.angle_bins if args.angle_bins else ""))
+    if not os.path.exists(tpath) and not args.contract and not args.angle_bins:
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # the headline: literal mode, RGBA input
     # `traffic` is a committed measurement (rocprofv3 counter passes cannot run inside this process): it is only quoted when it
     # was taken on exactly these kernels -- the stamp is a hash of csrc/ -- and on this workload; otherwise null, with the reason
@@ -271,7 +275,7 @@ def run_node(args):
                       flags=(orb.ORB_FLAG_STAGED if args.staged else 0)
                       | ((orb.ORB_FLAG_INTENDED | orb.ORB_FLAG_NMS) if args.mode == "intended" else 0)
                       | (orb.ORB_FLAG_INPUT_Y8 if args.input == "y8" else 0),
-                      fast_arc=9 if args.mode == "intended" else 0, fp_contract=args.contract)
+                      fast_arc=9 if args.mode == "intended" else 0, fp_contract=args.contract, angle_bins=args.angle_bins)
     cfg = orb.OrbConfig(orb.Extent3d(W, H), max_batch=B, **cfg_kwargs)
     frame_bytes = W * H * (1 if args.input == "y8" else 4)
     F = B * world
@@ -349,7 +353,7 @@ def run_node(args):
             "config": {"workload": workload_text(args, world, B, False),
                        "frames_per_gpu_per_batch": B, "frames_per_step": F, "width": W, "height": H,
                        "hierarchy_depth": DEPTH, "max_features": MAX_FEATURES, "threshold": threshold, "content": args.content, "mode": args.mode,
-                       "input": args.input, "pipeline": "staged" if args.staged else "default", "fp_contract": args.contract,
+                       "input": args.input, "pipeline": "staged" if args.staged else "default", "fp_contract": args.contract, "angle_bins": args.angle_bins,
                        "host": "node: one process, orb_node_* C ABI, no torch.distributed"
                                + (" (TINYORB_NODE_LOOPBACK: %d ranks on device 0, device copies instead of RCCL)" % world if loop else ""),
                        "collate": ("none: every job's records packed on the device that computed them (orb_node_set_results)"
@@ -377,7 +381,7 @@ def run_node(args):
             n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 128
             if n_cpu > 0:
                 out["cpu_baseline"] = cpu_baseline(n_cpu, counts[:B], intended=args.mode == "intended", y8=args.input == "y8",
-                                                   syn_flags=syn_flags, threshold=threshold, fp=args.contract)
+                                                   syn_flags=syn_flags, threshold=threshold, fp=args.contract, angle_bins=args.angle_bins)
     if args.mode == "literal" and args.content == "default" and not args.staged and not args.no_single_frame:
         out.update(single_frame_latency(orb, cfg_kwargs))
     emit(out)
@@ -433,7 +437,7 @@ def run_rank(args):
                         flags=(orb.ORB_FLAG_STAGED if args.staged else 0) | orb.ORB_FLAG_DOUBLE_OUTPUT
                         | ((orb.ORB_FLAG_INTENDED | orb.ORB_FLAG_NMS) if args.mode == "intended" else 0)
                         | (orb.ORB_FLAG_INPUT_Y8 if args.input == "y8" else 0),
-                        fast_arc=9 if args.mode == "intended" else 0, fp_contract=args.contract)
+                        fast_arc=9 if args.mode == "intended" else 0, fp_contract=args.contract, angle_bins=args.angle_bins)
     prog = orb.OrbProgram(cfg).init()
     frame_bytes = W * H * (1 if args.input == "y8" else 4)
     frames_t = torch.empty(max(n_local, 1) * frame_bytes, dtype=torch.uint8, device=dev)  # this rank's shard, in HBM
@@ -751,7 +755,7 @@ def run_rank(args):
                        "frames_per_gpu_per_batch": B, "frames_per_step": job_frames, "width": W, "height": H,
                        "hierarchy_depth": DEPTH, "max_features": MAX_FEATURES, "threshold": threshold, "content": args.content, "mode": args.mode,
                        "input": args.input,
-                       "pipeline": "staged" if args.staged else "default", "fp_contract": args.contract,
+                       "pipeline": "staged" if args.staged else "default", "fp_contract": args.contract, "angle_bins": args.angle_bins,
                        "batches_in_flight": fly,
                        "collate": ("none: results stay sharded on their GPUs" if args.collate == "none" else
                                    "RCCL exchange of every batch to rank 0 (exact sizes), overlapped with the next batch's kernels")
@@ -777,7 +781,7 @@ def run_rank(args):
             n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 128
             if n_cpu > 0:
                 out["cpu_baseline"] = cpu_baseline(n_cpu, counts_first, intended=args.mode == "intended", y8=args.input == "y8",
-                                                   syn_flags=syn_flags, threshold=threshold, fp=args.contract)
+                                                   syn_flags=syn_flags, threshold=threshold, fp=args.contract, angle_bins=args.angle_bins)
             if args.mode == "literal" and args.input == "rgba" and args.content == "default" and not args.staged and not args.no_single_frame:
                 # the reference's only call shape (orb.rs:469-557): one blocking extract per frame, microseconds per call
                 out.update(single_frame_latency(orb, dict(max_features=MAX_FEATURES, hierarchy_depth=DEPTH, initial_threshold=THRESHOLD,

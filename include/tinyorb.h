@@ -94,7 +94,11 @@ typedef struct OrbOptions {
                                    * first up.  Carried by the fused AND the per-stage kernels at full speed (the luminance and rotation
                                    * forms are template instances, the blur's is a set of scalar constants).  RGBA input, the reference's
                                    * detector.  ABI 4 knew the values 0 and 1 (= every stage contracted, per-stage kernels only). */
-    uint32_t reserved[1];
+    uint32_t angle_bins;          /* ORB_FLAG_INTENDED only (IM-6b): 0 = a descriptor is rotated by its keypoint's milliradian
+                                   * code (6284 rotated patterns: a 6.4 MB table that misses the 4 MB L2 of an XCD); N = 8..6284 = by the
+                                   * centre of its angle bin, bin = code * N / 6284, centre code = (bin * 6284 + 3142) / N -- 1024 bins are a
+                                   * 1 MB table (OpenCV's ORB uses 30).  The keypoint's reported angle stays the milliradian code.
+                                   * (Took the last reserved word.) */
 } OrbOptions;
 
 #define ORB_OOB_ZERO 0u  /* 0.0 -- Vulkan robust image access; naga: image_load = Unchecked on such devices */

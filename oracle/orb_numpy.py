@@ -556,13 +556,21 @@ def fast_intended(gray_levels_bits, threshold, arc=9):
     return np.array(rows, dtype=np.uint32).reshape(-1, 4), np.array(scores, dtype=np.float32)
 
 
-def brief_intended(blur_levels_bits, corners):
-    """IM-6: pattern rotated by +theta."""
+def binned_angle_code(codes, bins):
+    """IM-6b: angle codes quantised into `bins` bins of the full circle -- the code of the bin's centre (0: unchanged)."""
+    codes = np.minimum(np.asarray(codes, dtype=np.int64), 6283)
+    if not bins:
+        return codes
+    return ((codes * bins // 6284) * 6284 + 3142) // bins
+
+
+def brief_intended(blur_levels_bits, corners, angle_bins=0):
+    """IM-6: pattern rotated by +theta (IM-6b: theta of the keypoint's angle bin)."""
     corners = np.asarray(corners, dtype=np.uint32).reshape(-1, 4)
     n = corners.shape[0]
     out = np.zeros((n, 8), dtype=np.uint32)
     levels = [from_f16_bits(b) for b in blur_levels_bits]
-    theta = corners[:, 2].astype(np.float32) / F(1000.0)
+    theta = binned_angle_code(corners[:, 2], angle_bins).astype(np.float32) / F(1000.0)
     ct = np.cos(theta.astype(np.float64)).astype(np.float32)
     st = np.sin(theta.astype(np.float64)).astype(np.float32)
     px = corners[:, 0].astype(np.int64)
@@ -610,7 +618,7 @@ def topk(corners, scores, k):
     return corners[order[:k]]
 
 
-def extract_intended(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=9, use_nms=False):
+def extract_intended(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=9, use_nms=False, angle_bins=0):
     gray = [grayscale_intended(rgba)]
     for _ in range(1, depth):
         gray.append(mip(gray[-1]))
@@ -621,7 +629,7 @@ def extract_intended(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, a
         kps, scores = kps[keep], scores[keep]
     total = kps.shape[0]
     kps = topk(kps, scores, max_features)
-    return dict(total=total, corners=kps, descriptors=brief_intended(blur, kps), gray=gray, blur=blur)
+    return dict(total=total, corners=kps, descriptors=brief_intended(blur, kps, angle_bins), gray=gray, blur=blur)
 
 
 # ------------------------------------------------------------------ descriptor matching (definition: include/tinyorb.h)

@@ -894,12 +894,27 @@ void orc_fast_intended(const uint16_t *pyr, const orc_pyramid_t *lay, float thre
     *total = count;
 }
 
+/* IM-6b: the angle code the descriptor is rotated by when angles are quantised into `bins` bins of the full circle (0: the
+ * keypoint's own milliradian code): bin = code * bins / 6284 (integers), rotation by the bin's centre code
+ * (bin * 6284 + 3142) / bins.  The keypoint's reported angle is not changed. */
+uint32_t orc_binned_angle_code(uint32_t code, uint32_t bins) {
+    if (!bins) return code;
+    if (code > 6283u) code = 6283u;
+    uint32_t bin = (uint32_t)(((uint64_t)code * bins) / 6284u);
+    return (uint32_t)(((uint64_t)bin * 6284u + 3142u) / bins);
+}
+
 void orc_brief_intended(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
                         orc_descriptor_t *out) { /* IM-6 */
+    orc_brief_intended_bins(blur_pyr, lay, corners, n, 0, out);
+}
+
+void orc_brief_intended_bins(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
+                             uint32_t angle_bins, orc_descriptor_t *out) { /* IM-6, IM-6b */
     for (uint32_t fidx = 0; fidx < n; fidx++) {
         const orc_corner_t *k = &corners[fidx];
         uint32_t oct = k->octave;
-        float theta = (float)k->angle / 1000.0f;
+        float theta = (float)orc_binned_angle_code(k->angle, angle_bins) / 1000.0f;
         float ct = (float)cos((double)theta);
         float st = (float)sin((double)theta);
         float nst = -st;
@@ -991,7 +1006,8 @@ int orc_extract_intended(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t d
     }
     uint32_t stored = orc_topk(all, scores, n, max_features, kept);
     memcpy(corners, kept, (size_t)stored * sizeof(orc_corner_t));
-    if (descriptors) orc_brief_intended(blur, &lay, corners, stored, descriptors);
+    if (opt && opt->angle_bins && (opt->angle_bins < 8 || opt->angle_bins > 6284)) return -1; /* (checked up front in the wrappers too) */
+    if (descriptors) orc_brief_intended_bins(blur, &lay, corners, stored, opt ? opt->angle_bins : 0, descriptors);
     *total = n;
     if (gray_pyr) memcpy(gray_pyr, gray, lay.total * sizeof(uint16_t));
     if (blur_pyr) memcpy(blur_pyr, blur, lay.total * sizeof(uint16_t));

@@ -156,6 +156,8 @@ int orc_extract_impl(const uint8_t *frame, int y8, uint32_t W, uint32_t H, uint3
 typedef struct {
     uint32_t arc; /* 0 -> 12 */
     uint32_t nms; /* 0 / 1 */
+    uint32_t angle_bins; /* intended mode only, IM-6b: 0 = descriptors rotated by the keypoint's milliradian code; 8..6284 = by the centre of
+                          * its bin of the full circle */
 } orc_options_t;
 void orc_fast_ex(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, uint32_t arc, orc_corner_t *out,
                  float *scores, uint32_t cap, uint32_t *total);
@@ -178,6 +180,9 @@ int orc_extract_ex(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, 
  *      negative: 0..6283 milliradians, the full circle.
  * IM-6 BRIEF samples the IM-3 blur at p + trunc(R(+theta) q): (ct*x - st*y, st*x + ct*y), products and sums
  *      rounded on their own, ct/st the correctly rounded cos/sin of fl32(code/1000.0f).
+ * IM-6b optional (orc_options_t::angle_bins = N, 8..6284): the rotation of IM-6 uses the centre of the keypoint's angle bin instead of
+ *      its own code: bin = code * N / 6284, centre code = (bin * 6284 + 3142) / N (integer arithmetic); the reported angle stays the
+ *      milliradian code.  (OpenCV's ORB quantises to 30 bins; a table of 1024 rotated patterns is 1 MB and stays in every XCD's L2.)
  * IM-7 optional 3x3 NMS exactly as orc_nms.
  * IM-8 when more than max_features keypoints remain, the max_features best are kept: larger score first, ties by
  *      smaller (octave, y, x).  The returned counter is still the number before this cut. */
@@ -186,6 +191,9 @@ void orc_gauss_pass(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, 
 uint32_t orc_angle_code_signed(float cy, float cx);
 void orc_fast_intended(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, uint32_t arc, orc_corner_t *out,
                        float *scores, uint32_t cap, uint32_t *total);
+uint32_t orc_binned_angle_code(uint32_t code, uint32_t bins);
+void orc_brief_intended_bins(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
+                             uint32_t angle_bins, orc_descriptor_t *out);
 void orc_brief_intended(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
                         orc_descriptor_t *out);
 uint32_t orc_topk(const orc_corner_t *in, const float *scores, uint32_t n, uint32_t k, orc_corner_t *out);

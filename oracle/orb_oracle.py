@@ -315,7 +315,7 @@ def extract_ex(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=12,
     corners = np.zeros(max_features, dtype=CORNER_DTYPE)
     desc = np.zeros((max_features, 8), dtype=np.uint32)
     total = ctypes.c_uint32(0)
-    opt = (ctypes.c_uint32 * 2)(int(arc), 1 if nms else 0)
+    opt = (ctypes.c_uint32 * 3)(int(arc), 1 if nms else 0, 0)
     rc = lib().orc_extract_ex(_ptr(rgba), W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
                               ctypes.cast(opt, ctypes.c_void_p), _ptr(corners), _ptr(desc), ctypes.byref(total))
     if rc != 0:
@@ -324,8 +324,14 @@ def extract_ex(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=12,
     return dict(total=total.value, corners=corners[:n], descriptors=desc[:n])
 
 
-def extract_intended(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=9, nms=False, planes=False):
-    """"intended" mode (IM-1..IM-8 in orb_oracle.h).  Not in the reference."""
+def binned_angle_code(code, bins):
+    """IM-6b: the code a descriptor is rotated by when angles are quantised into `bins` bins (0: the code itself)."""
+    lib().orc_binned_angle_code.restype = ctypes.c_uint32
+    return int(lib().orc_binned_angle_code(ctypes.c_uint32(int(code)), ctypes.c_uint32(int(bins))))
+
+
+def extract_intended(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=9, nms=False, planes=False, angle_bins=0):
+    """"intended" mode (IM-1..IM-8 in orb_oracle.h; angle_bins: IM-6b).  Not in the reference."""
     rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
     H, W = rgba.shape[:2]
     corners = np.zeros(max_features, dtype=CORNER_DTYPE)
@@ -334,7 +340,7 @@ def extract_intended(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, a
     _, ntex = level_dims(W, H, depth)
     gray = np.zeros(ntex, dtype=np.uint16) if planes else None
     blur = np.zeros(ntex, dtype=np.uint16) if planes else None
-    opt = (ctypes.c_uint32 * 2)(int(arc), 1 if nms else 0)
+    opt = (ctypes.c_uint32 * 3)(int(arc), 1 if nms else 0, int(angle_bins))
     rc = lib().orc_extract_intended(_ptr(rgba), W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
                                     ctypes.cast(opt, ctypes.c_void_p), _ptr(corners), _ptr(desc), ctypes.byref(total),
                                     _ptr(gray) if planes else None, _ptr(blur) if planes else None)
@@ -378,13 +384,13 @@ def extract_batch(frames, depth=2, threshold=20.0 / 255.0, max_features=8192, n_
     return totals, corners, desc
 
 
-def extract_intended_batch(frames, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=9, nms=False, n_threads=1):
+def extract_intended_batch(frames, depth=2, threshold=20.0 / 255.0, max_features=8192, arc=9, nms=False, n_threads=1, angle_bins=0):
     frames = np.ascontiguousarray(frames, dtype=np.uint8)
     F, H, W = frames.shape[:3]
     corners = np.zeros((F, max_features), dtype=CORNER_DTYPE)
     desc = np.zeros((F, max_features, 8), dtype=np.uint32)
     totals = np.zeros(F, dtype=np.uint32)
-    opt = (ctypes.c_uint32 * 2)(int(arc), 1 if nms else 0)
+    opt = (ctypes.c_uint32 * 3)(int(arc), 1 if nms else 0, int(angle_bins))
     rc = lib().orc_extract_intended_batch(_ptr(frames), F, W, H, depth, ctypes.c_float(np.float32(threshold)),
                                           max_features, ctypes.cast(opt, ctypes.c_void_p), _ptr(corners), _ptr(desc),
                                           _ptr(totals), int(n_threads))

@@ -38,10 +38,10 @@ def test_record_layouts_match_reference(tinyorb):
     assert tinyorb._Config.max_features.offset == 12 and tinyorb._Config.initial_threshold.offset == 20
     assert ctypes.sizeof(tinyorb._Options) == 32
     # the switches took reserved words one after the other: a zero-initialised OrbOptions has always meant the defaults
-    assert [getattr(tinyorb._Options, k).offset for k in ("oob_policy", "sampler_weight_bits", "fp_contract", "reserved")] == [16, 20, 24, 28]
+    assert [getattr(tinyorb._Options, k).offset for k in ("oob_policy", "sampler_weight_bits", "fp_contract", "angle_bins")] == [16, 20, 24, 28]
     fields = re.search(r"typedef struct OrbOptions \{(.*?)\} OrbOptions;", open(HEADER).read(), re.S).group(1)
     order = re.findall(r"^\s*u?int32_t\s+(\w+)", fields, re.M)
-    assert order == ["device", "max_batch", "flags", "fast_arc", "oob_policy", "sampler_weight_bits", "fp_contract", "reserved"]
+    assert order == ["device", "max_batch", "flags", "fast_arc", "oob_policy", "sampler_weight_bits", "fp_contract", "angle_bins"]
 
 
 def test_header_constants_match_python_mirror(tinyorb):

@@ -214,3 +214,47 @@ def test_fp_contract_is_refused_with_the_extensions(tinyorb):
         assert e.value.code == tinyorb.ORB_EINVAL
     with tinyorb.OrbProgram(tinyorb.OrbConfig(tinyorb.Extent3d(320, 240), fp_contract=tinyorb.ORB_FP_LAST_TERM_FIRST)).init() as prog:
         assert prog.pipeline() == "fused"
+
+
+# ---------------------------------------------------------------------------------------------
+# intended mode, IM-6b (OrbOptions::angle_bins): descriptors rotated by the centre of the keypoint's angle bin
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bins", [30, 1024, 6284, 8])
+@pytest.mark.parametrize("flags_extra", [0, 1])
+def test_intended_angle_bins_match_the_oracle(tinyorb, oracle, bins, flags_extra):
+    """ORB_FLAG_INTENDED with angle_bins on the fused kernels (k_brief_i reads a table of one rotated pattern per BIN) and on the
+    per-stage ones (k_brief rotates by the bin's centre code): keypoints, angles (still milliradian codes) and descriptors equal the
+    restatement's under the same option -- a batch of three 640x480 frames and the six calls; 6284 bins reproduce the unbinned
+    descriptors, 30 bins change nearly all of them."""
+    W, H, depth = 640, 480, 2
+    frames = np.stack([oracle.synth_frame(W, H, 40 + i, 15) for i in range(3)])
+    flags = tinyorb.ORB_FLAG_INTENDED | tinyorb.ORB_FLAG_NMS | (tinyorb.ORB_FLAG_STAGED if flags_extra else 0)
+    cfg = tinyorb.OrbConfig(tinyorb.Extent3d(W, H), hierarchy_depth=depth, initial_threshold=THR, flags=flags, fast_arc=9, max_batch=3,
+                            angle_bins=bins)
+    refs = [oracle.extract_intended(f, depth=depth, threshold=THR, arc=9, nms=True, angle_bins=bins) for f in frames]
+    with tinyorb.OrbProgram(cfg).init() as prog:
+        assert prog.pipeline() == ("staged" if flags_extra else "fused")
+        prog.extract_batch_host(frames)
+        counts = prog.batch_counts(3)
+        for i in range(3):
+            c, d = prog.batch_read(i, min(int(counts[i]), 8192))
+            _assert_frame_equal(oracle, refs[i], int(counts[i]), c, d)
+        prog.write_input_image(frames[1])
+        total = prog.extract_corners()
+        n = min(total, 8192)
+        _assert_frame_equal(oracle, refs[1], total, prog.read_corners(np.zeros(n, dtype=tinyorb.CORNER_DTYPE)),
+                            prog.read_descriptors(np.zeros((n, 8), dtype=np.uint32)))
+    plain = oracle.extract_intended(frames[0], depth=depth, threshold=THR, arc=9, nms=True)
+    changed = int((refs[0]["descriptors"] != plain["descriptors"]).any(1).sum())
+    assert np.array_equal(refs[0]["corners"], plain["corners"])  # positions and reported angles do not depend on the bins
+    assert (changed == 0) if bins == 6284 else (changed > len(plain["descriptors"]) // (3 if bins == 1024 else 2))
+
+
+def test_angle_bins_is_an_option_of_the_intended_mode(tinyorb):
+    for kw in (dict(angle_bins=1024), dict(angle_bins=4, flags=tinyorb.ORB_FLAG_INTENDED), dict(angle_bins=7000, flags=tinyorb.ORB_FLAG_INTENDED)):
+        with pytest.raises(tinyorb.OrbError) as e:
+            tinyorb.OrbProgram(tinyorb.OrbConfig(tinyorb.Extent3d(320, 240), **kw)).init()
+        assert e.value.code == tinyorb.ORB_EINVAL
+    with tinyorb.OrbProgram(tinyorb.OrbConfig(tinyorb.Extent3d(320, 240), flags=tinyorb.ORB_FLAG_INTENDED, fast_arc=9, angle_bins=1024)).init() as prog:
+        table, pitch = prog.rot_table()
+        assert table.shape[0] == 1024

@@ -872,3 +872,24 @@ def test_pin_tool_reports_a_truncating_store(oracle, tmp_path):
     _, results, exact = pin_oracle.check(str(tmp_path), [S(), S(f16_round=1), S("zero", 0, 7), S("zero", 0, 7, 0, 1)])
     assert S(f16_round=1) in exact and all(s.f16_round == 1 for s in exact)
     assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 5
+
+
+@pytest.mark.parametrize("bins", [8, 30, 1024, 6284])
+def test_intended_angle_bins(oracle, numpy_ref, bins):
+    """IM-6b: bin = code * N / 6284, rotation by the bin's centre code (bin * 6284 + 3142) / N -- every code against the definition in
+    Python integers, C against NumPy on a frame; the centre lies inside its bin, 6284 bins are the identity, and binning never moves a
+    keypoint or its reported angle."""
+    codes = np.arange(6284)
+    want = np.array([((c * bins // 6284) * 6284 + 3142) // bins for c in codes])
+    assert np.array_equal(numpy_ref.binned_angle_code(codes, bins), want)
+    assert [oracle.binned_angle_code(int(c), bins) for c in codes[::37]] == want[::37].tolist()
+    assert np.all(want * bins // 6284 == codes * bins // 6284) and want.max() <= 6283
+    if bins == 6284:
+        assert np.array_equal(want, codes)
+    frame = oracle.synth_frame(320, 240, 5, 15)
+    a = oracle.extract_intended(frame, depth=2, threshold=THR, arc=9, nms=True, angle_bins=bins)
+    b = numpy_ref.extract_intended(frame, depth=2, threshold=THR, arc=9, use_nms=True, angle_bins=bins)
+    ca = np.stack([a["corners"][k] for k in ("x", "y", "angle", "octave")], 1)
+    assert a["total"] == b["total"] and np.array_equal(ca, b["corners"]) and np.array_equal(a["descriptors"], b["descriptors"])
+    plain = oracle.extract_intended(frame, depth=2, threshold=THR, arc=9, nms=True)
+    assert np.array_equal(plain["corners"], a["corners"])

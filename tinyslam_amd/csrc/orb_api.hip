@@ -352,7 +352,7 @@ int run_staged(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s) 
         if (bx > 64u) bx = 64u;
         if (bx < 1u) bx = 1u;
         hipLaunchKernelGGL(k_brief, dim3(bx, 1, n), dim3(256), 0, s, p->d_blur, pyr, p->d_counts, p->d_corners, cap,
-                           p->d_desc, tab, im, p->oob, p->opt.fp_contract);
+                           p->d_desc, tab, im, p->oob, p->opt.fp_contract, p->opt.angle_bins);
     }
     HIP_TRY(p, hipGetLastError());
     p->planes_valid = true;
@@ -668,6 +668,7 @@ int run_fused_i(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
         IBriefGeom bgl = bg;
         bgl.xcd_swizzle = (n % 8u == 0u) ? 1u : 0u;
         bgl.phase_mask = p->env.brief_i_mask >= 0 ? (uint32_t)p->env.brief_i_mask : 3u;
+        bgl.angle_bins = p->opt.angle_bins;
         hipLaunchKernelGGL(k_brief_i, dim3(bg.group_base[D] * n), dim3(kIBriefThreads), p->ibrief_lds, s, p->d_blur, pyr, bgl,
                            p->d_iseg_counts, p->d_iseg_before, p->d_thr_key, p->d_iseg, p->d_iseg_scores, p->d_corners, cap,
                            p->d_desc, BriefTables{p->d_pattern, p->d_cos, p->d_sin, p->d_rot});
@@ -833,6 +834,8 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
         ((options->flags & (ORB_FLAG_INTENDED | ORB_FLAG_NMS | ORB_FLAG_INPUT_Y8)) || (options->fast_arc != 0 && options->fast_arc != 12)))
         return fail(nullptr, ORB_EINVAL, "fp_contract follows the reference's shader compiler: it is defined for the reference's detector on RGBA "
                                          "input only (no ORB_FLAG_INTENDED, ORB_FLAG_NMS, ORB_FLAG_INPUT_Y8 or fast_arc other than 12)");
+    if (options && options->angle_bins && (!(options->flags & ORB_FLAG_INTENDED) || options->angle_bins < 8u || options->angle_bins > 6284u))
+        return fail(nullptr, ORB_EINVAL, "angle_bins is an option of ORB_FLAG_INTENDED (IM-6b): 0, or 8..6284 bins of the full circle");
     if (options && (options->flags & ORB_FLAG_INTENDED) && (W > 16384u || H > 16384u))
         return fail(nullptr, ORB_EINVAL, "ORB_FLAG_INTENDED needs W, H <= 16384 (14-bit coordinates in the top-K key)");
 
@@ -1213,11 +1216,12 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
     CREATE_TRY(hipMemcpy(p->d_sin, ORB_SIN_BITS, ORB_ANGLE_STEPS_FULL * 4, hipMemcpyHostToDevice));
     {   // the pattern rotated by every angle code, for the consumer this program has: k_brief_i's window (intended, full circle) or
         // k_brief_nf's patch (the reference's codes 0..3141)
-        const uint32_t n_codes = p->fused_i ? (uint32_t)ORB_ANGLE_STEPS_FULL : (uint32_t)ORB_ANGLE_STEPS;
+        // (IM-6b, OrbOptions::angle_bins: one entry per angle bin instead of one per milliradian code)
+        const uint32_t n_codes = p->fused_i ? (p->opt.angle_bins ? p->opt.angle_bins : (uint32_t)ORB_ANGLE_STEPS_FULL) : (uint32_t)ORB_ANGLE_STEPS;
         const int pitch = p->fused_i ? (int)p->itiles.pitch : kNfPatchCols;
         CREATE_TRY(hipMalloc(&p->d_rot, (size_t)n_codes * 64u * sizeof(uint4)));
         hipLaunchKernelGGL(k_rot_table, dim3(n_codes), dim3(64), 0, p->stream, p->d_pattern, p->d_cos, p->d_sin, pitch, p->fused_i ? 1 : 0, p->d_rot,
-                           p->opt.fp_contract);
+                           p->opt.fp_contract, p->fused_i ? p->opt.angle_bins : 0u);
         CREATE_TRY(hipGetLastError());
         CREATE_TRY(hipStreamSynchronize(p->stream));
     }
@@ -2065,7 +2069,7 @@ int orb_debug_angle_code(OrbProgram* p, const float* cy, const float* cx, uint32
 int orb_debug_rot_table(OrbProgram* p, int16_t* dst, size_t n_entries, uint32_t* codes, uint32_t* pitch) {
     if (!p) return ORB_EINVAL;
     if (!p->d_rot) return fail(p, ORB_ESTATE, "this program has no rotated-pattern table");
-    const uint32_t n_codes = p->fused_i ? (uint32_t)ORB_ANGLE_STEPS_FULL : (uint32_t)ORB_ANGLE_STEPS;
+    const uint32_t n_codes = p->fused_i ? (p->opt.angle_bins ? p->opt.angle_bins : (uint32_t)ORB_ANGLE_STEPS_FULL) : (uint32_t)ORB_ANGLE_STEPS;
     if (codes) *codes = n_codes;
     if (pitch) *pitch = p->fused_i ? p->itiles.pitch : (uint32_t)kNfPatchCols;
     const size_t n = std::min(n_entries, (size_t)n_codes * 512u);

@@ -181,6 +181,14 @@ __device__ __forceinline__ uint32_t angle_code_signed(float cy, float cx) {
     return code > 6283u ? 6283u : code;
 }
 
+// "intended" mode IM-6b (OrbOptions::angle_bins): the code a descriptor is rotated by when angles are quantised into `bins` bins of the
+// full circle -- the centre of the code's bin, in integers (0: the code itself).  code <= 6283.
+__host__ __device__ __forceinline__ uint32_t binned_angle_code(uint32_t code, uint32_t bins) {
+    if (!bins) return code;
+    const uint32_t bin = (code * bins) / 6284u;  // < 2^26
+    return (bin * 6284u + 3142u) / bins;
+}
+
 // FAST ring, fast.wgsl:32-49 (index order matters for the centroid sum, CRD-8).
 __device__ constexpr int kRingDx[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
 __device__ constexpr int kRingDy[16] = {0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1};

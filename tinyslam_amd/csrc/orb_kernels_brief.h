@@ -249,8 +249,9 @@ constexpr int kNfPatchHalfs = kNfPatchRows * kNfPatchCols;
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_rot_table(const uint32_t* __restrict__ pattern, const float* __restrict__ cos_tab,
                                                   const float* __restrict__ sin_tab, int pitch, int intended, uint4* __restrict__ out,
-                                                  uint32_t fp = 0u) {
-    const uint32_t code = blockIdx.x, lane = threadIdx.x;
+                                                  uint32_t fp = 0u, uint32_t angle_bins = 0u) {
+    // angle_bins (IM-6b, intended mode): entry b is the pattern rotated by the centre code of angle bin b, (b * 6284 + 3142) / bins
+    const uint32_t code = angle_bins ? (blockIdx.x * 6284u + 3142u) / angle_bins : blockIdx.x, lane = threadIdx.x;
     const float ct = cos_tab[code], st = sin_tab[code], nst = -st;
     uint32_t w[4];
 #pragma unroll
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(64) void k_rot_table(const uint32_t* __restrict__ p
         const int oa = 2 * ((int)ray * pitch + (int)rax), ob = 2 * ((int)rby * pitch + (int)rbx);  // vec2i() truncates
         w[e] = ((uint32_t)oa & 0xffffu) | ((uint32_t)ob << 16);
     }
-    out[(size_t)code * 64u + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+    out[(size_t)blockIdx.x * 64u + lane] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 __device__ __forceinline__ int rot_a(uint32_t w) { return (int)(int16_t)(w & 0xffffu); }  // byte offset of point a
 __device__ __forceinline__ int rot_b(uint32_t w) { return (int)w >> 16; }                  // ... of point b

@@ -869,6 +869,7 @@ struct IBriefGeom {
     uint32_t pitch;        // LDS row pitch in halfs: kITileW + 2 * kIBriefApronX
     uint32_t xcd_swizzle;  // all stacks of a frame on one XCD: its blur planes stay in that L2
     uint32_t phase_mask;   // timing experiments only: bit0 the window is staged, bit1 the keypoints are described
+    uint32_t angle_bins;   // OrbOptions::angle_bins (IM-6b): 0 = the table has one entry per milliradian code, N = one per angle bin
 };
 
 __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __restrict__ blur, Pyramid pyr,
@@ -1040,10 +1041,14 @@ __global__ __launch_bounds__(kIBriefThreads) void k_brief_i(const uint16_t* __re
             __syncthreads();
             if (mine && (c + 1u == ot + nt || tid == 255u)) tile_run[t] += pfx + (kept ? 1u : 0u) - tile_first[t];  // the tile's last entry in this chunk
             auto rot_of = [&](uint32_t r) {
-                const uint32_t code = min((uint32_t)__builtin_amdgcn_readfirstlane(kept_rec[r].z), (uint32_t)(ORB_ANGLE_STEPS_FULL - 1));
+                uint32_t code = min((uint32_t)__builtin_amdgcn_readfirstlane(kept_rec[r].z), (uint32_t)(ORB_ANGLE_STEPS_FULL - 1));
                 if constexpr (kIBriefTable) {
-                    return tab.rot[(size_t)code * 64u + lane];
-                } else {  // the rotation on the spot (k_rot_table's arithmetic): no table traffic, 24 more vector instructions per test
+                    // IM-6b: the table holds one entry per angle BIN (1024 bins: 1 MB, resident in every XCD's L2 where the 6284 codes'
+                    // 6.4 MB are not); the bin of a code is code * bins / 6284 in integers (scalar arithmetic: the code is wave-uniform)
+                    const uint32_t entry = bg.angle_bins ? (code * bg.angle_bins) / (uint32_t)ORB_ANGLE_STEPS_FULL : code;
+                    return tab.rot[(size_t)entry * 64u + lane];
+                } else {
+                    code = binned_angle_code(code, bg.angle_bins);  // the rotation on the spot (k_rot_table's arithmetic): no table traffic, 24 more vector instructions per test
                     const float ct = tab.cos_tab[code], st = tab.sin_tab[code], nst = -st;
                     uint32_t w[4];
 #pragma unroll

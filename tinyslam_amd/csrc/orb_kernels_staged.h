@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void k_brief(const uint16_t* __restrict__ blur
                                                const uint32_t* __restrict__ counts,
                                                const CornerData* __restrict__ corners, uint32_t cap,
                                                CornerDescriptor* __restrict__ descriptors, BriefTables tab,
-                                               uint32_t intended, uint32_t oob = kOobZero, uint32_t fp = 0u) {
+                                               uint32_t intended, uint32_t oob = kOobZero, uint32_t fp = 0u, uint32_t angle_bins = 0u) {
     const uint32_t f = blockIdx.z;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void k_brief(const uint16_t* __restrict__ blur
         const uint32_t oct = rec.w;
         uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
         if (oct < pyr.depth) {
-            const uint32_t code = min(rec.z, steps - 1u);
+            const uint32_t code = binned_angle_code(min(rec.z, steps - 1u), intended ? angle_bins : 0u);  // IM-6b: the bin's centre code
             const float ct = tab.cos_tab[code], sn = tab.sin_tab[code];
             const float st = intended ? -sn : sn, nst = -st;
             const uint32_t w = pyr.w[oct], h = pyr.h[oct];

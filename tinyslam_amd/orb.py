@@ -86,7 +86,7 @@ class _Config(ctypes.Structure):
 class _Options(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("max_batch", ctypes.c_uint32), ("flags", ctypes.c_uint32),
                 ("fast_arc", ctypes.c_uint32), ("oob_policy", ctypes.c_uint32), ("sampler_weight_bits", ctypes.c_uint32),
-                ("fp_contract", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 1)]
+                ("fp_contract", ctypes.c_uint32), ("angle_bins", ctypes.c_uint32)]
 
 
 _lib = None
@@ -279,6 +279,7 @@ class OrbConfig:
     # the two implementation-defined points of the reference's WGSL as switches (include/tinyorb.h, OrbOptions)
     oob_policy: int = 0           # ORB_OOB_ZERO / ORB_OOB_CLAMP / ORB_OOB_UMIN: textureLoad outside the level
     sampler_weight_bits: int = 0  # 0: exact bilinear weights; n: weights held in n fractional bits
+    angle_bins: int = 0   # ORB_FLAG_INTENDED, IM-6b: 0 = rotate by the milliradian code; 8..6284 = by the centre of the angle bin
     fp_contract: int = 0  # CRD-13: mask of ORB_FP_CONTRACT_LUMINANCE / _BLUR / _ROTATION (that stage's products and sums as fmas) and ORB_FP_LAST_TERM_FIRST
 
 
@@ -307,7 +308,7 @@ class OrbProgram:
         c = self.config
         cfg = _Config(_Extent3d(c.image_size.width, c.image_size.height, c.image_size.depth_or_array_layers),
                       c.max_features, c.hierarchy_depth, float(np.float32(c.initial_threshold)))
-        opt = _Options(c.device, c.max_batch, c.flags, c.fast_arc, c.oob_policy, c.sampler_weight_bits, c.fp_contract)
+        opt = _Options(c.device, c.max_batch, c.flags, c.fast_arc, c.oob_policy, c.sampler_weight_bits, c.fp_contract, c.angle_bins)
         h = ctypes.c_void_p()
         rc = L.orb_program_create(ctypes.byref(cfg), ctypes.byref(opt), ctypes.byref(h))
         if rc != ORB_OK:
@@ -574,7 +575,7 @@ class OrbNode:
         c = self.config
         cfg = _Config(_Extent3d(c.image_size.width, c.image_size.height, c.image_size.depth_or_array_layers),
                       c.max_features, c.hierarchy_depth, float(np.float32(c.initial_threshold)))
-        opt = _Options(0, c.max_batch, c.flags, c.fast_arc, c.oob_policy, c.sampler_weight_bits, c.fp_contract)
+        opt = _Options(0, c.max_batch, c.flags, c.fast_arc, c.oob_policy, c.sampler_weight_bits, c.fp_contract, c.angle_bins)
         devs = (ctypes.c_int * len(self.devices))(*self.devices)
         h = ctypes.c_void_p()
         rc = L.orb_node_create(devs, len(self.devices), ctypes.byref(cfg), ctypes.byref(opt), ctypes.byref(h))
