@@ -62,8 +62,8 @@ pub mod orb {
         fast_arc: u32, // 0 = FAST-12
         oob_policy: u32,          // ORB_OOB_ZERO / _CLAMP / _UMIN: textureLoad outside the level (0 = the default, CRD-6)
         sampler_weight_bits: u32, // 0 = exact bilinear weights (CRD-5); n = weights held in n fractional bits
-        fp_contract: u32,         // CRD-13: 1 = the adapter's shader compiler contracts products and sums into fmas (staged kernels only)
-        reserved: [u32; 1],
+        fp_contract: u32,         // CRD-13: mask of ORB_FP_* -- which stages' products and sums the adapter's shader compiler fuses, and its reduction order
+        angle_bins: u32,          // ORB_FLAG_INTENDED only (IM-6b); 0 for the reference's algorithm
     }
 
     /// The points the reference's WGSL leaves to its adapter, as switches (`OrbOptions` of include/tinyorb.h).
@@ -72,13 +72,21 @@ pub mod orb {
     pub struct AdapterBehaviour {
         pub oob_policy: u32,
         pub sampler_weight_bits: u32,
-        /// CRD-13: 1 = the adapter's shader compiler contracts products and sums into fused multiply-adds (the program then runs
-        /// the per-stage kernels, which carry that arithmetic)
+        /// CRD-13: a mask of `ORB_FP_CONTRACT_LUMINANCE | _BLUR | _ROTATION` (that stage's product-and-sum pairs as fused multiply-adds)
+        /// and `ORB_FP_LAST_TERM_FIRST` (dot() and matrix * vector reduced from the last term, as Mesa lowers them); carried by the
+        /// fused kernels at full speed since ABI 5
         pub fp_contract: u32,
     }
     pub const ORB_OOB_ZERO: u32 = 0;
     pub const ORB_OOB_CLAMP: u32 = 1;
     pub const ORB_OOB_UMIN: u32 = 2;
+    pub const ORB_FP_CONTRACT_LUMINANCE: u32 = 1;
+    pub const ORB_FP_CONTRACT_BLUR: u32 = 2;
+    pub const ORB_FP_CONTRACT_ROTATION: u32 = 4;
+    pub const ORB_FP_CONTRACT_ALL: u32 = 7;
+    pub const ORB_FP_LAST_TERM_FIRST: u32 = 8;
+    /// `OrbOptions::flags`: extract_corners spins for 50 us, then sleeps until the completion interrupt (the reference's `device.poll(Wait)`)
+    pub const ORB_FLAG_SINGLE_BLOCKING_WAIT: u32 = 32;
 
     extern "C" {
         fn orb_program_create(cfg: *const OrbConfigC, opt: *const OrbOptionsC, out: *mut *mut c_void) -> c_int;
