@@ -5,6 +5,8 @@ Integer/index work (keypoint x, y, angle code, octave) and descriptor bits must 
 is unspecified in the reference (atomic append), so lists are compared after
 sorting by (octave, y, x) (CRD-11).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -204,12 +206,19 @@ def test_full_size_batch_properties(tinyorb, oracle):
         # a second run over the same input reproduces every count (no state leaks between batches)
         fused.extract_batch_device(dev, B)
         assert np.array_equal(fused.batch_counts(B), counts)
-        # spot check against the oracle at full size
-        for i in (5, 200):
-            frame = fused.copy_to_host(dev + i * W * H * 4, W * H * 4).reshape(H, W, 4)
-            ref = oracle.extract(frame, depth=2, threshold=THR, max_features=cap)
-            corners, desc = fused.batch_read(i, int(counts[i]))
-            _assert_frame_equal(oracle, ref, int(counts[i]), corners, desc)
+        # EVERY distinct frame of the batch against the oracle, record by record (round 5; two spot frames before): the restatement runs
+        # frame-parallel over the host's threads on the frames copied back from the device
+        half = B // 2
+        frames = fused.copy_to_host(dev, half * W * H * 4).reshape(half, H, W, 4)
+        totals, rc, rd = oracle.extract_batch(frames, depth=2, threshold=THR, max_features=cap, n_threads=min(16, os.cpu_count() or 1))
+        assert np.array_equal(totals, counts[:half])
+        hb = fused.batch_read_all(B)
+        off = np.concatenate([[0], np.cumsum(np.minimum(counts, cap).astype(np.int64))])
+        for i in range(half):
+            ref = dict(total=int(totals[i]), corners=rc[i, :min(int(totals[i]), cap)], descriptors=rd[i, :min(int(totals[i]), cap)])
+            lo, hi = int(off[i]), int(off[i + 1])
+            _assert_frame_equal(oracle, ref, int(counts[i]), hb.corners[lo:hi], hb.descriptors[lo:hi].reshape(-1, 8))
+        hb.close()
 
 
 def test_threshold_and_reuse(tinyorb, oracle):

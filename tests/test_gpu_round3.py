@@ -1,6 +1,8 @@
 """GPU parity, round 3: BASELINE.json configs[4] at its own size through the eight-rank code path, the pipelined
 node-level collate (orb_node_collate_begin / _end), a Y8 node, the non-blocking pinned ingest.  Everything is compared
 with the CPU oracle or with the plain batched call, bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -168,12 +170,15 @@ def test_configs4_full_size_eight_ranks(tinyorb, oracle, monkeypatch):
         assert kp["octave"].max() <= 1
         key = ((frame_of * 2 + kp["octave"].astype(np.int64)) * 1024 + kp["y"].astype(np.int64)) * 2048 + kp["x"].astype(np.int64)
         assert len(np.unique(key)) == total
-        # spot frames: first, last, and both sides of two rank boundaries, against the oracle (CPU-generated frames)
-        for f in (0, 255, 256, 1791, 1792, 2047):
-            rgba = oracle.synth_frame(W, H, 1000 + f)
-            ref = oracle.extract(rgba, depth=2, threshold=THR)
+        # against the oracle (CPU-generated frames, the restatement frame-parallel over the host's threads): both sides of every rank
+        # boundary and every eighth frame in between -- 270 of the 2048 (round 5; six spot frames before)
+        pick = sorted(set(range(0, F, 8)) | {r * B + d for r in range(RANKS) for d in (0, B - 1)})
+        frames = np.stack([oracle.synth_frame(W, H, 1000 + f) for f in pick])
+        totals, rc, rd = oracle.extract_batch(frames, depth=2, threshold=THR, max_features=CAP, n_threads=min(16, os.cpu_count() or 1))
+        for k, f in enumerate(pick):
+            n = min(int(totals[k]), CAP)
             lo, hi = int(offsets[f]), int(offsets[f + 1])
-            _assert_frame_equal(oracle, ref, int(counts[f]), kp[lo:hi], desc[lo:hi])
+            _assert_frame_equal(oracle, dict(total=int(totals[k]), corners=rc[k, :n], descriptors=rd[k, :n]), int(counts[f]), kp[lo:hi], desc[lo:hi])
 
 
 @pytest.mark.parametrize("intended", [False, True])
