@@ -786,10 +786,30 @@ __global__ __launch_bounds__(1024) void k_select_i(const uint32_t* __restrict__ 
             for (uint32_t s = wv; s < n_slots; s += 16u) {  // one wave per slot
                 const uint32_t n = min(sc[s], seg_cap);
                 const size_t base = ((size_t)f * n_slots + s) * seg_cap;
-                for (uint32_t j = lane; j < n; j += 64u) {
-                    const unsigned long long k =
-                        select_key(*reinterpret_cast<const uint4*>(&segments[base + j]), seg_scores[base + j]);
-                    if ((k & known) == prefix) atomicAdd(&hist[(uint32_t)(k >> (8 * pass)) & 255u], 1u);
+                // The key's high word is the score's bit pattern: the four passes over it read 4 bytes per candidate, not the 20 of record +
+                // score, and the four passes over the low word (the position: ties in the score) read a record only where the score IS the
+                // selected one -- 32 instead of 160 bytes per candidate over the eight passes (k_select_i 0.78 ms per 256 overflowing frames before).
+                // (four loads in flight per lane: the pass is a chain of memory round trips otherwise -- one wave walks a slot, and the
+                // LDS atomics between the loads keep hipcc from overlapping the iterations)
+                for (uint32_t j0 = 0; j0 < n; j0 += 256u) {
+                    uint32_t sb4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t j = j0 + 64u * (uint32_t)u + lane;
+                        sb4[u] = j < n ? __float_as_uint(seg_scores[base + j]) : 0u;  // 0: no candidate (a corner's score is positive)
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t j = j0 + 64u * (uint32_t)u + lane, sbits = sb4[u];
+                        if (j >= n) continue;
+                        if (pass >= 4) {
+                            const unsigned long long k = (unsigned long long)sbits << 32;
+                            if ((k & known) == prefix) atomicAdd(&hist[(sbits >> (8 * (pass - 4))) & 255u], 1u);
+                        } else if (sbits == (uint32_t)(prefix >> 32)) {
+                            const unsigned long long k = select_key(*reinterpret_cast<const uint4*>(&segments[base + j]), seg_scores[base + j]);
+                            if ((k & known) == prefix) atomicAdd(&hist[(uint32_t)(k >> (8 * pass)) & 255u], 1u);
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -815,19 +835,41 @@ __global__ __launch_bounds__(1024) void k_select_i(const uint32_t* __restrict__ 
     __shared__ uint32_t carry;
     if (tid == 0u) carry = 0u;
     __syncthreads();
+    if (kth != 0ull) {
+        // kept keypoints of every slot, a wave per slot (lanes over the candidates, four loads in flight each; the score decides, the
+        // record is read only on a tie with the threshold's score), parked in the slot's place of the prefix array
+        const uint32_t kth_score = (uint32_t)(kth >> 32);
+        for (uint32_t s = wv; s < n_slots; s += 16u) {
+            const uint32_t n = min(sc[s], seg_cap);
+            const size_t base = ((size_t)f * n_slots + s) * seg_cap;
+            uint32_t kept = 0;
+            for (uint32_t j0 = 0; j0 < n; j0 += 256u) {
+                uint32_t sb4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t j = j0 + 64u * (uint32_t)u + lane;
+                    sb4[u] = j < n ? __float_as_uint(seg_scores[base + j]) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t j = j0 + 64u * (uint32_t)u + lane;
+                    if (j >= n) continue;
+                    if (sb4[u] != kth_score)
+                        kept += sb4[u] > kth_score ? 1u : 0u;
+                    else
+                        kept += select_key(*reinterpret_cast<const uint4*>(&segments[base + j]), seg_scores[base + j]) >= kth ? 1u : 0u;
+                }
+            }
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) kept += __shfl_xor(kept, sh);
+            if (lane == 0u) sb[s] = kept;
+        }
+        __syncthreads();  // (workgroup-scope: the counts are read back below by other threads of this workgroup)
+    }
     for (uint32_t s0 = 0; s0 < n_slots; s0 += 1024u) {
         const uint32_t s = s0 + tid;
         uint32_t kept = 0;
-        if (s < n_slots) {
-            const uint32_t n = min(sc[s], seg_cap);
-            if (kth == 0ull) {
-                kept = n;
-            } else {
-                const size_t base = ((size_t)f * n_slots + s) * seg_cap;
-                for (uint32_t j = 0; j < n; j++)
-                    kept += select_key(*reinterpret_cast<const uint4*>(&segments[base + j]), seg_scores[base + j]) >= kth ? 1u : 0u;
-            }
-        }
+        if (s < n_slots) kept = kth == 0ull ? min(sc[s], seg_cap) : sb[s];
         // block-wide exclusive scan of `kept`
         uint32_t incl = kept;
 #pragma unroll
