@@ -570,7 +570,7 @@ int run_fused_range(OrbProgram* p, const uint8_t* frames_all, uint32_t f0, uint3
         FrontLaunch L{frames, p->frame_bytes, d_gray, d_blur, d_blur_rowc, pyr, g, p->threshold, d_seg_counts, d_seg, s_lvl, grid.x, lds,
                       p->band_rows_lvl[lvl], p->ln_threads[lvl], p->input_y8,
                       // rows not aligned to a quad, or the level-0 plane is needed (level 1 not an exact half): the general variant
-                      lvl == 0 && ((pyr.w[0] & 3u) || g.store_grey), p->oob != kOobZero};
+                      lvl == 0 && ((pyr.w[0] & 3u) || g.store_grey), p->oob != kOobZero, false};
         {
             LaunchScope ls(p, s_lvl, lvl == 0 ? KID_FUSED_L0 : KID_FUSED_LN);
             const hipError_t e = kFrontLaunch[front_form(p->opt.fp_contract, lvl == 0 && !p->input_y8)](L);
@@ -764,8 +764,10 @@ int run_fused_x(OrbProgram* p, const uint8_t* frames, uint32_t n, hipStream_t s)
             const uint32_t lds = front_lds_bytes(fg);
             if (lds > p->max_lds) return fail(p, ORB_EINVAL, "level %u needs %u bytes of LDS", lvl, lds);
             LaunchScope ls(p, s, KID_FUSED_LN);
-            hipLaunchKernelGGL(k_front<false>, dim3(fg.n_bands * n), dim3(kFrontThreadsLN), lds, s, frames, p->frame_bytes,
-                               p->d_gray, p->d_blur, p->d_blur_rowc, pyr, fg, p->threshold, p->d_xband_counts, p->d_iseg);
+            const FrontLaunch L{frames, p->frame_bytes, p->d_gray, p->d_blur, p->d_blur_rowc, pyr, fg, p->threshold, p->d_xband_counts, p->d_iseg, s,
+                                fg.n_bands * n, lds, (uint32_t)kFrontRows, (uint32_t)kFrontThreadsLN, false, false, false, true};
+            const hipError_t e = kFrontLaunch[0](L);  // k_front<false> (16 rows, 512 threads), from the unit that instantiates it
+            if (e != hipSuccess) return fail(p, ORB_EHIP, "k_front (blur of level %u) failed to launch: %s", lvl, hipGetErrorString(e));
         }
     }
     launch_brief(p, s, n, p->xrows, p->d_blur, p->d_blur_rowc, p->d_iseg_counts, p->d_iseg_before, p->d_iseg, p->d_counts,
@@ -1112,8 +1114,7 @@ int orb_program_create(const OrbConfig* config, const OrbOptions* options, OrbPr
             p->fused_x = false;
         } else {
             p->use_brief_t = brieft_geometry(p, rg, 1u, &p->brieft);  // the tile kernels keep one list per tile
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->max_lds);
+            hipError_t ea = kFrontSetMaxLds[0]((int)p->max_lds);  // (the unit that holds k_front<false>)
             if (ea != hipSuccess) {
                 fail(p, ORB_EHIP, "hipFuncSetAttribute(k_front): %s", hipGetErrorString(ea));
                 return bail(ORB_EHIP);

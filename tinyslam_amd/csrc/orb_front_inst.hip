@@ -36,7 +36,7 @@ constexpr bool kRest = (FP & 3) == 0;    // this unit also holds the kernels tha
 hipError_t ORB_CAT(front_launch_fp, TINYORB_FRONT_FP)(const FrontLaunch& L) {
     const dim3 grid(L.grid);
     const bool tiled = L.g.tiled != 0u;
-    if (L.g.lvl == 0u && !L.input_y8) {  // level 0 from RGBA: the luminance's form is this unit's
+    if (L.g.lvl == 0u && !L.input_y8 && !L.from_plane) {  // level 0 from RGBA: the luminance's form is this unit's
         const dim3 block(kFrontThreadsL0);
         if (tiled && L.general) { FRONT_BY_ROWS_TILED(true COMMA false, true COMMA true COMMA false COMMA false COMMA 0 COMMA FP) }
         else if (tiled) { FRONT_BY_ROWS_TILED(true COMMA false, false COMMA true COMMA false COMMA false COMMA 0 COMMA FP) }
@@ -45,7 +45,7 @@ hipError_t ORB_CAT(front_launch_fp, TINYORB_FRONT_FP)(const FrontLaunch& L) {
         return hipGetLastError();
     }
     if constexpr (kRest) {
-        if (L.g.lvl == 0u) {  // Y8
+        if (L.g.lvl == 0u && !L.from_plane) {  // Y8
             const dim3 block(kFrontThreadsL0);
             if (tiled && L.general) { FRONT_BY_ROWS_TILED(true COMMA true, true COMMA true COMMA false COMMA false COMMA 0 COMMA FPB) }
             else if (tiled) { FRONT_BY_ROWS_TILED(true COMMA true, false COMMA true COMMA false COMMA false COMMA 0 COMMA FPB) }

@@ -29,6 +29,8 @@ struct FrontLaunch {
     bool input_y8;
     bool general;         // level 0: rows not quad-aligned, or the level-0 plane must be stored (UA)
     bool oob;             // an out-of-level policy other than "zero" (levels >= 1: the OOBK instances)
+    bool from_plane;      // take the level >= 1 kernel (rows from the stored grey plane) whatever g.lvl says: the arc / NMS extension's blur-only
+                          // launches read level 0's plane, which k_front_i has written (512 threads, 16-row bands)
 };
 
 struct FrontPairLaunch {  // k_front_pair: levels 0 and 1 of one frame in one launch (8-row bands)

@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256) void k_desc_expand(const uint32_t* __restrict_
 // evenly over the banks), loaded once per workgroup -- every wave loading its own fragments from the L1 asked the texture
 // path for 4 KB per wave and tile, four times the same bytes, and ran at a third of this form's rate -- and double-buffered:
 // the next chunk's loads are in flight while this one is multiplied, one barrier per chunk.
-constexpr int kMatchChunk = 64;            // candidates per LDS stage (4 column tiles)
+#ifndef TINYORB_MATCH_CHUNK
+#define TINYORB_MATCH_CHUNK 64
+#endif
+constexpr int kMatchChunk = TINYORB_MATCH_CHUNK;  // candidates per LDS stage (4 column tiles)
 constexpr int kMatchRowBytes = 256 + 32;   // LDS row stride (dword offset 72 r + 4 g: conflict-free by the rule found for k_match_fp4, kMatch4RowBytes)
 __global__ __launch_bounds__(64 * kMatchWaves) void k_match_mfma(const uint32_t* __restrict__ counts, const uint8_t* __restrict__ desc8,
                                                                  uint32_t cap, MatchRecord* __restrict__ matches) {
