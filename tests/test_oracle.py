@@ -893,3 +893,49 @@ def test_intended_angle_bins(oracle, numpy_ref, bins):
     assert a["total"] == b["total"] and np.array_equal(ca, b["corners"]) and np.array_equal(a["descriptors"], b["descriptors"])
     plain = oracle.extract_intended(frame, depth=2, threshold=THR, arc=9, nms=True)
     assert np.array_equal(plain["corners"], a["corners"])
+
+
+# ---------------------------------------------------------------------------------------------
+# The restatement's constants against the reference's TEXT, where the reference is at hand (this container; never on the GPU box, where
+# /root/reference does not exist -- and never in a -m gpu test).  Reading the shaders as text is study: numbers are parsed out of them and
+# compared with the constants the two restatements and the kernels' generated tables hold; nothing of the text is kept.
+# ---------------------------------------------------------------------------------------------
+_REF_SHADERS = "/root/reference/src/shaders"
+
+
+@pytest.mark.skipif(not os.path.isdir(_REF_SHADERS), reason="the reference's sources are not on this machine")
+def test_constants_match_the_reference_text(oracle, numpy_ref):
+    """Every numeric constant the restatements hold, parsed from the shader text itself: the luminance weights (grayscale.wgsl:36), the
+    blur's offsets and weights (gaussian_blur_x.wgsl:14-26), the 4-point and 16-point rings in order (fast.wgsl:25-49), the streak
+    shifts (fast.wgsl:56-60), the guard (fast.wgsl:77), the milliradian factors (fast.wgsl:153, brief.wgsl:35), the workgroup shapes, and
+    the BRIEF pattern row by row (brief.wgsl:70-327)."""
+    import re
+    rd = lambda n: open(os.path.join(_REF_SHADERS, n)).read()
+    num = r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?"
+    g = rd("grayscale.wgsl")
+    coefs = [float(v) for v in re.search(r"rgba_coefs\s*=\s*vec4f\(([^)]*)\)", g).group(1).split(",")]
+    assert coefs == [0.229, 0.587, 0.114, 0.0]  # 0.229, sic (Q1)
+    # ... and the restatement uses exactly their binary32 roundings: one white-red, white-green, white-blue texel each
+    for ch, wgt in enumerate(coefs[:3]):
+        px = np.zeros((1, 1, 4), dtype=np.uint8)
+        px[0, 0, ch] = 255
+        assert oracle.grayscale(px)[0, 0] == oracle.f32_to_f16(np.float32(wgt)) == numpy_ref.grayscale(px)[0, 0]
+    b = rd("gaussian_blur_x.wgsl")
+    offs = [float(v) for v in re.findall(num, re.search(r"offsets[^=]*=\s*array\(([^;]*)\);", b, re.S).group(1))]
+    wgts = [float(v) for v in re.findall(num, re.search(r"weights[^=]*=\s*array\(([^;]*)\);", b, re.S).group(1))]
+    assert [np.float32(v) for v in offs] == list(numpy_ref.BLUR_OFF) and [np.float32(v) for v in wgts] == list(numpy_ref.BLUR_WGT)
+    assert len(offs) == 4 and int(re.search(r"SAMPLE_COUNT\s*:\s*u32\s*=\s*(\d+)u", b).group(1)) == 4
+    f = rd("fast.wgsl")
+    ring = lambda name: [(int(x), int(y)) for x, y in re.findall(r"vec2i\((-?\d+),\s*(-?\d+)\)", re.search(name + r"[^=]*=\s*array\((.*?)\);", f, re.S).group(1))]
+    assert ring("CORNERS_4") == numpy_ref.RING4 and ring("CORNERS_16") == numpy_ref.RING16
+    body = re.search(r"fn detect_streak_16.*?\n}", f, re.S).group(0)
+    assert [int(v) for v in re.findall(r"rotate_bits_16\(\w+,\s*(\d+)u\)", body)] == [6, 3, 2, 1]
+    guard = re.search(r"global_id\.xy\s*>\s*vec2u\((\d+),\s*(\d+)\).*?-\s*vec2u\((\d+),\s*(\d+)\)", f)  # fast.wgsl:77
+    assert guard and [int(v) for v in guard.groups()] == [16, 16, 16, 16]
+    assert re.search(r"angle\s*\*\s*1000(\.0)?", f), "fast.wgsl: milliradians"
+    bt = rd("brief.wgsl")
+    assert re.search(r"/\s*1000(\.0)?", bt), "brief.wgsl: milliradians back to radians"
+    rows = re.findall(r"vec4i\(\s*(-?\d+)\s*,\s*(-?\d+)\s*,\s*(-?\d+)\s*,\s*(-?\d+)\s*\)", bt[bt.index("brief_descriptors"):])
+    assert len(rows) == 256 and np.array_equal(np.array(rows, dtype=np.int32), numpy_ref.PATTERN)
+    # the workgroup shapes the dispatch arithmetic of the restatement assumes (orb.rs:511-515 rounds to 8 x 8 groups; brief: 8 words per feature)
+    assert re.search(r"@workgroup_size\(8,\s*8(,\s*1)?\)", f) and re.search(r"@workgroup_size\(8", bt)
