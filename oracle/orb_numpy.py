@@ -209,7 +209,20 @@ def _load(level, xs, ys, oob="zero"):
     return level[uy, ux].astype(np.float32)
 
 
-def fast(gray_levels_bits, threshold, oob="zero"):
+def angle_code(cy, ang, neg_angle=0):
+    """fast.wgsl:153 `u32(angle * 1000.0)`.  A negative angle: 0 (Q7: GPUs saturate; the default), or -- the conversion is undefined in
+    SPIR-V -- the low 32 bits of the truncated value ("wrap", 1: x86-64 without AVX-512) or all ones ("ones", 2)."""
+    neg_angle = {"zero": 0, "wrap": 1, "ones": 2}.get(neg_angle, neg_angle)
+    t = np.trunc(ang.astype(np.float32) * F(1000.0)).astype(np.int64)
+    neg = (cy < 0) | (ang < 0)
+    if neg_angle == 1:
+        return (t & 0xFFFFFFFF).astype(np.uint32)
+    if neg_angle == 2:
+        return np.where(neg & (t < 0), 0xFFFFFFFF, np.where(neg, 0, t)).astype(np.uint32)
+    return np.where(neg, 0, t).astype(np.uint32)
+
+
+def fast(gray_levels_bits, threshold, oob="zero", neg_angle=0):
     """fast.wgsl compute_fast over all octaves; returns (x, y, angle, octave) rows in raster order."""
     thr = F(threshold)
     H0, W0 = gray_levels_bits[0].shape
@@ -254,7 +267,7 @@ def fast(gray_levels_bits, threshold, oob="zero"):
         corner = (_streak12(m_over) | _streak12(m_under)) > 0
         gx, gy, cx, cy = gx[corner], gy[corner], cx[corner], cy[corner]
         ang = atan2f(cy, cx)
-        code = np.where((cy < 0) | (ang < 0), F(0), np.trunc(ang * F(1000.0))).astype(np.uint32)
+        code = angle_code(cy, ang, neg_angle)
         for k in range(gx.size):
             rows.append((int(gx[k]), int(gy[k]), int(code[k]), octv))
     return np.array(rows, dtype=np.uint32).reshape(-1, 4)
@@ -302,16 +315,16 @@ CONTRACT_LUM, CONTRACT_BLUR, CONTRACT_ROT = 1, 2, 4
 
 
 def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, y8=False, oob="zero", weight_bits=0, contract=0, dot_order=0,
-            f16_round=0):
+            f16_round=0, neg_angle=0):
     """orb.rs:469-557 stage order (y8: the frame is a one-byte-per-pixel Y plane).  oob / weight_bits / contract (a bit per stage) /
-    dot_order / f16_round: the implementation-defined switches (out-of-level loads, sampler weight precision, fused multiply-adds,
-    reduction order, rounding of the R16Float stores); defaults = CRD-6 / CRD-5 / CRD-2, -5, -10 / CRD-3."""
+    dot_order / f16_round / neg_angle: the implementation-defined switches (out-of-level loads, sampler weight precision, fused
+    multiply-adds, reduction order, rounding of the R16Float stores, u32() of a negative angle); defaults = CRD-6 / CRD-5 / CRD-2, -5, -10 / CRD-3."""
     gray = [grayscale_y8(rgba, f16_round) if y8 else grayscale(rgba, contract & CONTRACT_LUM, dot_order, f16_round)]
     for _ in range(1, depth):
         gray.append(mip(gray[-1], weight_bits, f16_round))
     tmp = [blur_pass(g, weight_bits, contract & CONTRACT_BLUR, f16_round) for g in gray]
     blur = [blur_pass(t, weight_bits, contract & CONTRACT_BLUR, f16_round) for t in tmp]
-    kps = fast(gray, threshold, oob)
+    kps = fast(gray, threshold, oob, neg_angle)
     total = kps.shape[0]
     kps = kps[:max_features]
     desc = brief(blur, kps, oob, contract & CONTRACT_ROT, dot_order)
@@ -438,7 +451,7 @@ def fast_ex(gray_levels_bits, threshold, arc=12):
         ro, ru = _has_run(m_over, arc), _has_run(m_under, arc)
         corner = ro | ru
         ang = atan2f(cy, cx)
-        code = np.where((cy < 0) | (ang < 0), F(0), np.trunc(ang * F(1000.0))).astype(np.uint32)
+        code = angle_code(cy, ang)
         sc = np.where(ro, s_over, s_under)
         for k in np.nonzero(corner)[0]:
             rows.append((int(gx[k]), int(gy[k]), int(code[k]), octv))

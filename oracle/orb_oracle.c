@@ -14,7 +14,7 @@
 
 #include "orb_pattern.h"
 
-static const orc_impl_t ORC_IMPL_DEFAULT = {ORC_OOB_ZERO, 0, 0, 0, 0};
+static const orc_impl_t ORC_IMPL_DEFAULT = {ORC_OOB_ZERO, 0, 0, 0, 0, 0};
 
 /* ------------------------------------------------------------------------------------------
  * scalar helpers
@@ -127,9 +127,22 @@ float orc_atan2f(float y, float x) {
 }
 
 /* fast.wgsl:153 `u32(angle * 1000.0)`: negative angles saturate to 0. */
-uint32_t orc_angle_code(float cy, float cx) {
+uint32_t orc_angle_code(float cy, float cx) { return orc_angle_code_neg(cy, cx, ORC_NEG_ZERO); }
+
+/* Implementation-defined point (orc_impl_t::neg_angle): naga 0.20 emits `u32(f32)` as a bare OpConvertFToU, which Vulkan leaves UNDEFINED
+ * for a negative operand -- and the angle is negative for more than half of the keypoints of the test frames (Q7).  GPUs saturate to 0 (the default, ORC_NEG_ZERO).  A CPU
+ * adapter need not: LLVM's fptoui compiled for x86-64 converts through a 64-bit signed integer and keeps the low word, so -1234.5 becomes
+ * 2^32 - 1234 (ORC_NEG_WRAP -- lavapipe / llvmpipe, the kind of adapter BASELINE.json configs[0] names), and with AVX-512's unsigned
+ * conversion every out-of-range operand becomes 0xffffffff (ORC_NEG_ONES).  Such a code then reaches brief.wgsl:35 as an angle of
+ * millions of radians, whose cos / sin are the adapter's own business: tools/pin_oracle.py recognises the pattern and compares only the
+ * keypoints with non-negative angles. */
+uint32_t orc_angle_code_neg(float cy, float cx, uint32_t neg) {
     float r = orc_atan2f(cy, cx);
-    if (cy < 0.0f || r < 0.0f) return 0u;
+    if (cy < 0.0f || r < 0.0f) {
+        if (neg == ORC_NEG_WRAP) return (uint32_t)(int64_t)truncf(r * 1000.0f); /* two's complement of the truncated value; -0.x -> 0 */
+        if (neg == ORC_NEG_ONES) return truncf(r * 1000.0f) < 0.0f ? 0xffffffffu : 0u;
+        return 0u;
+    }
     return (uint32_t)truncf(r * 1000.0f);
 }
 
@@ -210,7 +223,7 @@ void orc_grayscale_fp(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gra
 
 /* contract != 0: the contracting compiler in source order (round 4's one form) */
 void orc_grayscale_impl(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray, uint32_t contract) {
-    orc_impl_t impl = {ORC_OOB_ZERO, 0, contract ? ORC_CONTRACT_ALL : 0u, 0, 0};
+    orc_impl_t impl = {ORC_OOB_ZERO, 0, contract ? ORC_CONTRACT_ALL : 0u, 0, 0, 0};
     orc_grayscale_fp(rgba, W, H, gray, &impl);
 }
 
@@ -238,7 +251,7 @@ void orc_mip(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint3
 }
 
 void orc_mip_impl(const uint16_t *src, uint32_t ws, uint32_t hs, uint16_t *dst, uint32_t wd, uint32_t hd, uint32_t wbits) {
-    orc_impl_t impl = {ORC_OOB_ZERO, wbits, 0, 0, 0};
+    orc_impl_t impl = {ORC_OOB_ZERO, wbits, 0, 0, 0, 0};
     orc_mip_fp(src, ws, hs, dst, wd, hd, &impl);
 }
 
@@ -305,7 +318,7 @@ void orc_blur_pass_impl(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *d
 /* contract (CRD-13): `result += textureSample(..) * weight` (gaussian_blur_x.wgsl:58) as one fma per tap.  The bilinear
  * filter itself is the sampler's arithmetic, not the shader's: it keeps CRD-5 (and the weight precision switch). */
 void orc_blur_pass_impl2(const uint16_t *src, uint32_t w, uint32_t h, uint16_t *dst, uint32_t wbits, uint32_t contract) {
-    orc_impl_t impl = {ORC_OOB_ZERO, wbits, contract ? ORC_CONTRACT_ALL : 0u, 0, 0};
+    orc_impl_t impl = {ORC_OOB_ZERO, wbits, contract ? ORC_CONTRACT_ALL : 0u, 0, 0, 0};
     orc_blur_pass_fp(src, w, h, dst, &impl);
 }
 
@@ -381,6 +394,11 @@ void orc_fast(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, or
 
 void orc_fast_impl(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, uint32_t oob, orc_corner_t *out,
                    uint32_t cap, uint32_t *total) {
+    orc_fast_impl2(pyr, lay, threshold, oob, ORC_NEG_ZERO, out, cap, total);
+}
+
+void orc_fast_impl2(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, uint32_t oob, uint32_t neg, orc_corner_t *out,
+                    uint32_t cap, uint32_t *total) {
     uint32_t count = 0;
     uint32_t W0 = lay->w[0], H0 = lay->h[0];
     uint32_t lim_x = W0 - 16u, lim_y = H0 - 16u; /* textureDimensions(texture) is the level-0 size; u32 wrap kept */
@@ -420,7 +438,7 @@ void orc_fast_impl(const uint16_t *pyr, const orc_pyramid_t *lay, float threshol
                     if (count < cap) {
                         out[count].x = gx;
                         out[count].y = gy;
-                        out[count].angle = orc_angle_code(cy, cx);
+                        out[count].angle = orc_angle_code_neg(cy, cx, neg);
                         out[count].octave = oct;
                     }
                     count++;
@@ -475,7 +493,7 @@ void orc_brief_rotate(uint32_t angle_code, int px, int py, uint32_t contract, ui
 
 void orc_brief_impl2(const uint16_t *blur_pyr, const orc_pyramid_t *lay, const orc_corner_t *corners, uint32_t n,
                      uint32_t oob, uint32_t contract, orc_descriptor_t *out) {
-    orc_impl_t impl = {oob, 0, contract ? ORC_CONTRACT_ALL : 0u, 0, 0};
+    orc_impl_t impl = {oob, 0, contract ? ORC_CONTRACT_ALL : 0u, 0, 0, 0};
     orc_brief_fp(blur_pyr, lay, corners, n, &impl, out);
 }
 
@@ -536,7 +554,7 @@ int orc_extract_impl(const uint8_t *frame, int y8, uint32_t W, uint32_t H, uint3
                      uint32_t max_features, const orc_impl_t *impl, orc_corner_t *corners, orc_descriptor_t *descriptors,
                      uint32_t *total, uint16_t *gray_pyr, uint16_t *blur_pyr) {
     if (impl && (impl->oob > ORC_OOB_UMIN || impl->sampler_weight_bits > 23 || impl->contract > ORC_CONTRACT_ALL || impl->dot_order > 1 ||
-                 impl->f16_round > 1))
+                 impl->f16_round > 1 || impl->neg_angle > ORC_NEG_ONES))
         return -1;
     return extract_impl(frame, y8, W, H, depth, threshold, max_features, impl ? impl : &ORC_IMPL_DEFAULT, corners, descriptors,
                         total, gray_pyr, blur_pyr);
@@ -581,7 +599,7 @@ static int extract_impl(const uint8_t *rgba, int y8, uint32_t W, uint32_t H, uin
     for (uint32_t m = 0; m < depth; m++) orc_blur_pass_fp(gray + lay.offset[m], lay.w[m], lay.h[m], tmp + lay.offset[m], impl);
     for (uint32_t m = 0; m < depth; m++) orc_blur_pass_fp(tmp + lay.offset[m], lay.w[m], lay.h[m], blur + lay.offset[m], impl);
     uint32_t count = 0;
-    orc_fast_impl(gray, &lay, threshold, oob, corners, max_features, &count);
+    orc_fast_impl2(gray, &lay, threshold, oob, impl->neg_angle, corners, max_features, &count);
     uint32_t stored = count < max_features ? count : max_features;
     if (descriptors) orc_brief_fp(blur, &lay, corners, stored, impl, descriptors);
     *total = count;

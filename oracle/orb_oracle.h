@@ -103,6 +103,8 @@ int orc_extract(const uint8_t *rgba, uint32_t W, uint32_t H, uint32_t depth, flo
  *   f16_round             the store to the R16Float targets (orb.rs:151, 228, 296, 311): 0 = round to nearest even (CRD-3, the
  *                         default), 1 = toward zero -- Vulkan leaves the rounding of a format conversion to the implementation.
  *                         Restatement and tools/pin_oracle.py only; the kernels round to nearest even.
+ *   neg_angle             what the conversion of a negative angle to u32 yields (fast.wgsl:153; half of all keypoints): 0 (default), the
+ *                         wrapped value, or all ones -- see orc_angle_code_neg.  Restatement and tool only.
  * The defaults are what every other entry of this header computes. */
 #define ORC_OOB_ZERO 0u
 #define ORC_OOB_CLAMP 1u
@@ -117,7 +119,14 @@ typedef struct {
     uint32_t contract;
     uint32_t dot_order;
     uint32_t f16_round;
+    uint32_t neg_angle; /* ORC_NEG_*: what `u32(angle * 1000.0)` (fast.wgsl:153) makes of a NEGATIVE angle -- OpConvertFToU is undefined there */
 } orc_impl_t;
+#define ORC_NEG_ZERO 0u /* saturates to 0 (GPUs; SURVEY.md Q7, the default) */
+#define ORC_NEG_WRAP 1u /* the low 32 bits of the truncated value: 2^32 - m (LLVM's fptoui on x86-64: lavapipe / llvmpipe) */
+#define ORC_NEG_ONES 2u /* 0xffffffff (AVX-512's unsigned conversion of an out-of-range operand) */
+uint32_t orc_angle_code_neg(float cy, float cx, uint32_t neg);
+void orc_fast_impl2(const uint16_t *pyr, const orc_pyramid_t *lay, float threshold, uint32_t oob, uint32_t neg, orc_corner_t *out,
+                    uint32_t cap, uint32_t *total);
 uint16_t orc_f32_to_f16_mode(float v, uint32_t rtz);
 void orc_grayscale_fp(const uint8_t *rgba, uint32_t W, uint32_t H, uint16_t *gray, const orc_impl_t *impl);
 void orc_grayscale_y8_fp(const uint8_t *y8, uint32_t W, uint32_t H, uint16_t *gray, const orc_impl_t *impl);

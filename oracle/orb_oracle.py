@@ -60,6 +60,8 @@ def lib():
         L.orc_atan2f.restype = f32
         L.orc_angle_code.argtypes = [f32, f32]
         L.orc_angle_code.restype = u32
+        L.orc_angle_code_neg.argtypes = [f32, f32, u32]
+        L.orc_angle_code_neg.restype = u32
         L.orc_detect_streak_16.argtypes = [u32]
         L.orc_detect_streak_16.restype = u32
         L.orc_unorm8.argtypes = [ctypes.c_uint8]
@@ -196,9 +198,12 @@ OOB_POLICIES = {"zero": 0, "clamp": 1, "umin": 2}
 CONTRACT_LUM, CONTRACT_BLUR, CONTRACT_ROT, CONTRACT_ALL = 1, 2, 4, 7
 
 
-def _impl(oob, weight_bits, contract=0, dot_order=0, f16_round=0):
-    return (ctypes.c_uint32 * 5)(OOB_POLICIES[oob] if isinstance(oob, str) else int(oob), int(weight_bits), int(contract), int(dot_order),
-                                 int(f16_round))
+NEG_ANGLE = {"zero": 0, "wrap": 1, "ones": 2}  # orc_impl_t::neg_angle: u32() of a negative angle (fast.wgsl:153; undefined in SPIR-V)
+
+
+def _impl(oob, weight_bits, contract=0, dot_order=0, f16_round=0, neg_angle=0):
+    return (ctypes.c_uint32 * 6)(OOB_POLICIES[oob] if isinstance(oob, str) else int(oob), int(weight_bits), int(contract), int(dot_order),
+                                 int(f16_round), NEG_ANGLE[neg_angle] if isinstance(neg_angle, str) else int(neg_angle))
 
 
 def grayscale_fp(rgba, contract=0, dot_order=0, f16_round=0):
@@ -240,9 +245,9 @@ def brief_rotate(code, px, py, contract=0, dot_order=0):
 
 
 def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=False, oob="zero", weight_bits=0, y8=False, contract=0,
-            dot_order=0, f16_round=0):
+            dot_order=0, f16_round=0, neg_angle=0):
     """Whole frame.  Returns dict(total, corners[structured], descriptors[u32 (n,8)], gray, blur).
-    oob / weight_bits / contract (bits CONTRACT_*) / dot_order / f16_round: the implementation-defined switches (orc_impl_t);
+    oob / weight_bits / contract (bits CONTRACT_*) / dot_order / f16_round / neg_angle: the implementation-defined switches (orc_impl_t);
     y8: a one-byte-per-pixel frame."""
     rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
     H, W = rgba.shape[:2]
@@ -252,7 +257,7 @@ def extract(rgba, depth=2, threshold=20.0 / 255.0, max_features=8192, planes=Fal
     _, ntex = level_dims(W, H, depth)
     gray = np.zeros(ntex, dtype=np.uint16) if planes else None
     blur = np.zeros(ntex, dtype=np.uint16) if planes else None
-    impl = _impl(oob, weight_bits, contract, dot_order, f16_round)
+    impl = _impl(oob, weight_bits, contract, dot_order, f16_round, neg_angle)
     rc = lib().orc_extract_impl(_ptr(rgba), 1 if y8 else 0, W, H, depth, ctypes.c_float(np.float32(threshold)), max_features,
                                 ctypes.cast(impl, ctypes.c_void_p), _ptr(corners), _ptr(desc), ctypes.byref(total),
                                 _ptr(gray) if planes else None, _ptr(blur) if planes else None)
@@ -356,6 +361,11 @@ def gauss_pass(src, vertical):
     out = np.empty((h, w), dtype=np.uint16)
     lib().orc_gauss_pass(_ptr(src), w, h, _ptr(out), 1 if vertical else 0)
     return out
+
+
+def angle_code_neg(cy, cx, neg_angle):
+    """fast.wgsl:153 under orc_impl_t::neg_angle ("zero" | "wrap" | "ones")."""
+    return int(lib().orc_angle_code_neg(float(np.float32(cy)), float(np.float32(cx)), NEG_ANGLE[neg_angle] if isinstance(neg_angle, str) else int(neg_angle)))
 
 
 def angle_code_signed(cy, cx):

@@ -874,6 +874,78 @@ def test_pin_tool_reports_a_truncating_store(oracle, tmp_path):
     assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 5
 
 
+def test_negative_angle_conversion_policies(oracle, numpy_ref):
+    """fast.wgsl:153 `u32(angle * 1000.0)` of a negative angle (orc_impl_t::neg_angle): 0 by default (Q7), the low 32 bits of the
+    truncated value under "wrap" (x86-64's conversion through a 64-bit integer), all ones under "ones"; angles >= 0 never change;
+    a negative angle above -0.001 truncates to 0 under every policy.  C == NumPy on a whole frame under each policy."""
+    cy, cx = np.float32(-1.0), np.float32(1.0)  # atan2 = -pi/4 = -0.785398...
+    assert oracle.angle_code_neg(cy, cx, "zero") == 0 == oracle.angle_code(cy, cx)
+    assert oracle.angle_code_neg(cy, cx, "wrap") == (1 << 32) - 785
+    assert oracle.angle_code_neg(cy, cx, "ones") == 0xFFFFFFFF
+    for pol in ("zero", "wrap", "ones"):
+        assert oracle.angle_code_neg(np.float32(1.0), np.float32(1.0), pol) == 785
+        assert oracle.angle_code_neg(np.float32(-1e-5), np.float32(1.0), pol) == 0  # -0.00001 rad * 1000 truncates to -0
+        assert oracle.angle_code_neg(np.float32(-1.0), np.float32(-1e-9), pol) == oracle.angle_code_neg(np.float32(-1.0), np.float32(0.0), pol)
+    rgba = oracle.synth_frame(200, 136, 11, 15)
+    base = oracle.extract(rgba, depth=3)
+    for pol in ("wrap", "ones"):
+        a = oracle.extract(rgba, depth=3, neg_angle=pol)
+        b = numpy_ref.extract(rgba, depth=3, neg_angle=pol)
+        assert a["total"] == b["total"] == base["total"]
+        ca = np.stack([a["corners"][k] for k in ("x", "y", "angle", "octave")], 1)
+        assert np.array_equal(ca, b["corners"]) and np.array_equal(a["descriptors"], b["descriptors"])
+        pos = base["corners"]["angle"] > 0
+        assert pos.any() and (~pos).any()
+        assert np.array_equal(a["corners"]["angle"][pos], base["corners"]["angle"][pos])
+        assert np.array_equal(a["descriptors"][pos], base["descriptors"][pos])
+        big = a["corners"]["angle"] > 3142
+        assert big.any() and not (big & pos).any()
+        if pol == "ones":
+            assert (a["corners"]["angle"][big] == 0xFFFFFFFF).all()
+        else:
+            m = (1 << 32) - a["corners"]["angle"][big].astype(np.int64)
+            assert (m >= 1).all() and (m <= 3142).all() and len(np.unique(m)) > 1
+
+
+def test_pin_tool_recognises_an_adapter_that_does_not_saturate_negative_angles(oracle, tmp_path):
+    """A dump whose negative angles wrapped modulo 2^32 (a CPU adapter; SURVEY.md Q7 assumed saturation), with whatever that
+    adapter's cos / sin made of the descriptors there: the tool reads the policy off the codes, checks the codes against the
+    restatement under it, leaves those descriptors out, pins the rest -- exit code 7.  A wrong wrapped code is still a mismatch."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pin_oracle
+    S = pin_oracle.setting
+    few = [S(), S("clamp"), S("zero", 8), S("zero", 0, 7)]
+    for pol in ("wrap", "ones"):
+        t, c, d = pin_oracle.oracle_result(S(), 2, 15, neg_angle=pol)
+        big = c[:, 2] > 3142
+        assert 0 < big.sum() < len(c)
+        d[big] ^= np.uint32(0x5A5A5A5A)  # some other cos / sin at 4e6 rad
+        _write_dump(tmp_path, t, c, d, 2, 15)
+        assert pin_oracle.neg_angle_policy(c) == pol
+        _, results, exact = pin_oracle.check(str(tmp_path), few)
+        assert S() in exact and S("zero", 8) not in exact and S("clamp") not in exact
+        assert results[S()]["descriptors_not_compared"] == int(big.sum())
+    assert pin_oracle.main(["pin_oracle.py", "check", str(tmp_path)]) == 7
+    # under the default policy the same dump is not exact (the codes differ) ...
+    ref0 = pin_oracle.oracle_result(S(), 2, 15, planes=True)
+    r = pin_oracle.compare(pin_oracle.load_dump(str(tmp_path)), ref0, blur=ref0[3], s=S())
+    assert not r["exact"] and r["angle_off_by_more"] == int(big.sum())
+    # ... a descriptor bit at a NON-negative angle still counts, and so does a wrapped code that is not the restatement's
+    t, c, d = pin_oracle.oracle_result(S(), 2, 15, neg_angle="wrap")
+    d2 = d.copy()
+    d2[np.flatnonzero(c[:, 2] <= 3142)[0], 0] ^= 1
+    _write_dump(tmp_path, t, c, d2, 2, 15)
+    assert pin_oracle.check(str(tmp_path), few)[2] == []
+    c2 = c.copy()
+    c2[np.flatnonzero(c[:, 2] > 3142)[0], 2] -= 5
+    _write_dump(tmp_path, t, c2, d, 2, 15)
+    assert pin_oracle.check(str(tmp_path), few)[2] == []
+    # codes that are neither: no policy
+    c3 = c.copy()
+    c3[0, 2] = 100000
+    assert pin_oracle.neg_angle_policy(c3) is None and pin_oracle.neg_angle_policy(pin_oracle.oracle_result(S(), 2, 15)[1]) == "zero"
+
+
 @pytest.mark.parametrize("bins", [8, 30, 1024, 6284])
 def test_intended_angle_bins(oracle, numpy_ref, bins):
     """IM-6b: bin = code * N / 6284, rotation by the bin's centre code (bin * 6284 + 3142) / N -- every code against the definition in

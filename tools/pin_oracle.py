@@ -23,6 +23,11 @@ Exit codes of `check`:
     6   pinned up to the adapter's sin / cos (and possibly its atan2): every descriptor bit that differs at an agreeing angle
         belongs to a test one of whose rotated coordinates (brief.wgsl:50-57) lies within --sincos-tol of a non-zero integer, and
         truncating that coordinate to the other side gives the dump's bit;
+    7   pinned on the keypoints with non-negative angles only: the adapter's `u32(angle * 1000.0)` (fast.wgsl:153) does not
+        saturate a NEGATIVE angle to 0 (SPIR-V leaves that conversion undefined; SURVEY.md Q7 assumed what GPUs do) but wraps it
+        modulo 2^32 or returns all ones -- a CPU adapter (lavapipe / llvmpipe on x86-64).  The codes themselves are checked
+        against the restatement under that policy (orc_impl_t::neg_angle); the descriptors of those keypoints are rotated by
+        an angle of millions of radians, whose cos / sin are the adapter's own, and are NOT compared.  The kernels saturate;
     1   not pinned.
 
 TEST INFRASTRUCTURE (it imports oracle/): never part of the product.
@@ -89,15 +94,15 @@ def load_dump(d):
 _CACHE = {}
 
 
-def oracle_result(s=DEFAULT, seed=SEED, flags=FLAGS, planes=False):
+def oracle_result(s=DEFAULT, seed=SEED, flags=FLAGS, planes=False, neg_angle="zero"):
     """(total, corners (n, 4) sorted, descriptors (n, 8)[, blur pyramid]) of the restatement under setting s (kept per process:
-    `check` asks for 192 of them, the tests for the same ones again)."""
+    `check` asks for 192 of them, the tests for the same ones again).  neg_angle: see neg_angle_policy()."""
     s = Setting(*s)
-    key = (s, seed, flags)
+    key = (s, seed, flags, neg_angle)
     if key not in _CACHE:
         rgba = orb_oracle.synth_frame(W, H, seed, flags)
         ref = orb_oracle.extract(rgba, depth=DEPTH, threshold=THR, max_features=CAP, oob=s.oob, weight_bits=s.weight_bits, planes=True,
-                                 contract=s.contract, dot_order=s.dot_order, f16_round=s.f16_round)
+                                 contract=s.contract, dot_order=s.dot_order, f16_round=s.f16_round, neg_angle=neg_angle)
         c, d = orb_oracle.sort_keypoints(ref["corners"], ref["descriptors"])
         _CACHE[key] = (ref["total"], np.stack([c[k] for k in ("x", "y", "angle", "octave")], 1).astype(np.uint32), d.astype(np.uint32),
                        ref["blur"])
@@ -113,6 +118,20 @@ def descriptors_at(blur, corners_xyao, s=DEFAULT):
     for i, k in enumerate(("x", "y", "angle", "octave")):
         c[k] = corners_xyao[:, i]
     return orb_oracle.brief(blur, W, H, DEPTH, c, oob=s.oob, contract=s.contract, dot_order=s.dot_order)
+
+
+def neg_angle_policy(corners):
+    """What the dumping adapter's `u32(angle * 1000.0)` made of NEGATIVE angles, read off the dumped codes (atan2 lies in
+    [-pi, pi]: a code above 3142 can only be a negative angle that was not saturated): "zero" (no such code: Q7, every GPU),
+    "ones" (all of them 0xffffffff) or "wrap" (2^32 - m, m <= 3142).  None: codes that are none of these."""
+    big = corners[:, 2][corners[:, 2] > 3142]
+    if big.size == 0:
+        return "zero"
+    if (big == 0xFFFFFFFF).all():
+        return "ones"
+    if (big >= np.uint32(0x100000000 - 3142 - 1)).all():
+        return "wrap"
+    return None
 
 
 _PATTERN = None
@@ -200,10 +219,12 @@ def compare(dump, ref, blur=None, s=DEFAULT, sincos_tol=SINCOS_TOL):
     only_dump, only_oracle = unkey(np.setdiff1d(k0, k1, assume_unique=True)), unkey(np.setdiff1d(k1, k0, assume_unique=True))
     da = np.abs(c0[i0, 2].astype(np.int64) - c1[i1, 2].astype(np.int64))
     xor = d0[i0] ^ d1[i1]
+    unsat = (c0[i0, 2] > 3142) | (c1[i1, 2] > 3142)  # a negative angle that u32() did not saturate (neg_angle_policy): the code is
+    xor[unsat] = 0                                   # compared, the descriptor -- rotated by millions of radians -- is not
     nb = np.unpackbits(xor.view(np.uint8), axis=1).sum(1).astype(np.int64) if len(i0) else np.zeros(0, dtype=np.int64)
     angle_off1, angle_other = int((da == 1).sum()), int((da > 1).sum())
     bits, kp_with_bits, bits_same_angle = int(nb.sum()), int((nb > 0).sum()), int(nb[da == 0].sum())
-    off1 = [int(i) for i in i0[da == 1]]  # dump rows whose angle code is the oracle's +- 1
+    off1 = [int(i) for i in i0[(da == 1) & ~unsat]]  # dump rows whose angle code is the oracle's +- 1
     left = [(int(i0[j]), xor[j]) for j in np.flatnonzero((da == 0) & (nb > 0))]  # bits differ although the angle codes agree
     bits_at_dump_angle = None
     if blur is not None and off1:
@@ -230,7 +251,7 @@ def compare(dump, ref, blur=None, s=DEFAULT, sincos_tol=SINCOS_TOL):
                     else:
                         sincos_ok = False
                         sincos_unexplained += 1
-    return {"total_dump": t0, "total_oracle": t1, "only_in_dump": only_dump, "only_in_oracle": only_oracle,
+    return {"descriptors_not_compared": int(unsat.sum()), "total_dump": t0, "total_oracle": t1, "only_in_dump": only_dump, "only_in_oracle": only_oracle,
             "angle_off_by_1": int(angle_off1), "angle_off_by_more": int(angle_other), "descriptor_bits": int(bits),
             "keypoints_with_bit_differences": int(kp_with_bits),
             "descriptor_bits_where_angles_agree": int(bits_same_angle),
@@ -244,12 +265,14 @@ def compare(dump, ref, blur=None, s=DEFAULT, sincos_tol=SINCOS_TOL):
 
 
 def check(d, settings=None, sincos_tol=SINCOS_TOL):
-    """(dump, {Setting: differences}, [settings that reproduce the dump exactly])."""
+    """(dump, {Setting: differences}, [settings that reproduce the dump exactly]).  The restatement runs under the negative-angle
+    policy the dump itself shows (neg_angle_policy; "zero" when its codes fit none)."""
     dump = load_dump(d)
     seed, flags = dump_params(d)
+    neg = neg_angle_policy(dump[1]) or "zero"
     results = {}
     for s in (settings or SETTINGS):
-        ref = oracle_result(s, seed, flags, planes=True)
+        ref = oracle_result(s, seed, flags, planes=True, neg_angle=neg)
         results[s] = compare(dump, ref, blur=ref[3], s=s, sincos_tol=sincos_tol)
     exact = [s for s in results if results[s]["exact"]]
     return dump, results, exact
@@ -275,6 +298,14 @@ def main(argv):
         return 0
     if len(argv) == 3 and argv[1] == "check":
         dump, results, exact = check(argv[2], sincos_tol=tol)
+        neg = neg_angle_policy(dump[1])
+        if neg != "zero":
+            n_big = int((dump[1][:, 2] > 3142).sum())
+            print("NEGATIVE ANGLES ARE NOT SATURATED by this adapter: %d of %d dumped angle codes exceed 3142 (%s).  SURVEY.md Q7 / CRD-9 "
+                  "assumed u32() of a negative float gives 0, as GPUs do; SPIR-V leaves it undefined.  Those codes are compared with "
+                  "the restatement under neg_angle=%s; the descriptors of those keypoints are not compared.\n"
+                  % (n_big, len(dump[1]), {"wrap": "2^32 - m: the conversion wraps", "ones": "all 0xffffffff",
+                                           None: "neither 2^32 - m nor all ones: not a policy the restatement knows"}[neg], neg or "zero"))
         # one line per setting would be 192 lines: the default arithmetic per (oob, weight bits), then whatever is exact or near
         for s, r in results.items():
             if (s.contract, s.dot_order, s.f16_round) != (0, 0, 0) and not (r["exact"] or r["exact_up_to_atan2"] or r["exact_up_to_sincos"]):
@@ -289,6 +320,13 @@ def main(argv):
             ax = _axes(carried or exact)
             print("\nPINNED on this frame: %d of %d settings of the implementation-defined switches reproduce the dump bit for bit." % (len(exact), len(results)))
             print("What this frame leaves open among them: " + "; ".join("%s in %s" % (f, v) for f, v in ax.items() if len(v) > 1) or "nothing")
+            if neg != "zero":
+                print("ON THE KEYPOINTS WITH NON-NEGATIVE ANGLES ONLY (%d of %d): the other descriptors were rotated by an angle of millions "
+                      "of radians and were not compared.  The kernels saturate negative angles (what GPUs do); to reproduce THIS adapter "
+                      "a kernel switch for the conversion and that adapter's cos / sin at 4e6 rad would be owed -- more likely the "
+                      "adapter is a CPU rasteriser (lavapipe) and not the one to pin to.  Options for the rest: %s"
+                      % (len(dump[1]) - results[exact[0]]["descriptors_not_compared"], len(dump[1]), options_for((carried or exact)[0])))
+                return 7
             if not carried:
                 print("ONLY with R16Float stores that round toward zero (f16_round = 1): the restatement follows, the kernels round to "
                       "nearest even (v_cvt_f16_f32) -- a kernel switch is owed.  Settings: %s" % [describe(s) for s in exact[:4]])
