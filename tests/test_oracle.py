@@ -7,6 +7,7 @@ restatement, and (3) the committed golden fixtures (regression pins of the build
 import glob
 import hashlib
 import os
+import re
 import sys
 
 import numpy as np
@@ -944,6 +945,33 @@ def test_pin_tool_recognises_an_adapter_that_does_not_saturate_negative_angles(o
     c3 = c.copy()
     c3[0, 2] = 100000
     assert pin_oracle.neg_angle_policy(c3) is None and pin_oracle.neg_angle_policy(pin_oracle.oracle_result(S(), 2, 15)[1]) == "zero"
+
+
+def test_green_product_in_two_operations(numpy_ref):
+    """k_front's packed luminance computes the green product fl(fl(G / 255) * 0.587f) of the non-contracted forms as fma(G, kGHi, fl(G * kGLo)):
+    the constants are read from the kernel source and the identity is checked for every byte with exact rational arithmetic (and
+    with the NumPy restatement's fma).  The same search finds no such pair for the other weights -- the kernel does not claim one."""
+    from fractions import Fraction
+    src = open(os.path.join(ROOT, "tinyslam_amd", "csrc", "orb_kernels_front.h")).read()
+    m = re.search(r"kGHi = (0x[0-9a-fA-F.]+p[-+]?\d+)f, kGLo = (0x[0-9a-fA-F.]+p[-+]?\d+)f", src)
+    assert m, "the constants of the green product are no longer where this test reads them"
+    hi, lo = np.float32(float.fromhex(m.group(1))), np.float32(float.fromhex(m.group(2)))
+    assert float(hi) == float.fromhex(m.group(1)) and float(lo) == float.fromhex(m.group(2))  # both are binary32 values
+    b = np.arange(256, dtype=np.float32)
+    want = ((b / np.float32(255.0)).astype(np.float32) * np.float32(0.587)).astype(np.float32)  # CRD-1, CRD-2
+    t = (b * lo).astype(np.float32)
+    assert np.array_equal(numpy_ref.fma32(b, np.full(256, hi, dtype=np.float32), t), want)
+
+    def rne(fr):  # a rational to the nearest binary32, ties to even
+        x = np.float32(float(fr))
+        cands = [np.nextafter(x, np.float32(-np.inf)), x, np.nextafter(x, np.float32(np.inf))]
+        d = [abs(Fraction(float(c)) - fr) for c in cands]
+        best = min(d)
+        win = [c for c, dd in zip(cands, d) if dd == best]
+        return win[0] if len(win) == 1 else [c for c in win if (int(np.float32(c).view(np.uint32)) & 1) == 0][0]
+
+    for i in range(256):
+        assert rne(Fraction(i) * Fraction(float(hi)) + Fraction(float(t[i]))) == want[i], i
 
 
 @pytest.mark.parametrize("bins", [8, 30, 1024, 6284])

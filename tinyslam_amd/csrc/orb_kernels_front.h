@@ -163,23 +163,33 @@ __device__ __forceinline__ uint32_t luminance_pair_f16(uint32_t rgba0, uint32_t 
     const float2_t R = {(float)(rgba0 & 255u), (float)(rgba1 & 255u)};
     const float2_t G = {(float)((rgba0 >> 8) & 255u), (float)((rgba1 >> 8) & 255u)};
     const float2_t B = {(float)((rgba0 >> 16) & 255u), (float)((rgba1 >> 16) & 255u)};
-    const float2_t tr = R * rc_lo, tg = G * rc_lo, tb = B * rc_lo;
+    const float2_t tr = R * rc_lo, tb = B * rc_lo;
     const float2_t r = __builtin_elementwise_fma(R, rc_hi, tr);  // exact byte/255, see unorm8_exact
-    const float2_t g = __builtin_elementwise_fma(G, rc_hi, tg);
     const float2_t b = __builtin_elementwise_fma(B, rc_hi, tb);
     constexpr float wr1 = BT601 ? 0.299f : 0.229f;
     const float2_t wr = {wr1, wr1}, wg = {0.587f, 0.587f}, wb = {0.114f, 0.114f};
     float2_t l;
-    if constexpr (LUM == 1) {
-        const float2_t t = r * wr;
-        const float2_t u = __builtin_elementwise_fma(g, wg, t);
-        l = __builtin_elementwise_fma(b, wb, u);
-    } else if constexpr (LUM == 3) {
-        const float2_t t = b * wb;
-        const float2_t u = __builtin_elementwise_fma(g, wg, t);
-        l = __builtin_elementwise_fma(r, wr, u);
+    if constexpr (LUM == 1 || LUM == 3) {
+        const float2_t tg = G * rc_lo;
+        const float2_t g = __builtin_elementwise_fma(G, rc_hi, tg);
+        if constexpr (LUM == 1) {
+            const float2_t t = r * wr;
+            const float2_t u = __builtin_elementwise_fma(g, wg, t);
+            l = __builtin_elementwise_fma(b, wb, u);
+        } else {
+            const float2_t t = b * wb;
+            const float2_t u = __builtin_elementwise_fma(g, wg, t);
+            l = __builtin_elementwise_fma(r, wr, u);
+        }
     } else {
-        const float2_t pr = r * wr1, pg = g * 0.587f, pb = b * 0.114f;
+        // The green product fl(fl(G / 255) * 0.587f) -- two roundings -- in TWO operations instead of three: fma(G, kGHi, fl(G * kGLo)) is
+        // that value for every byte G (the pair was found by search and is checked for all 256 bytes, exactly, by
+        // tests/test_oracle.py::test_green_product_in_two_operations; no such pair exists for 0.229f, 0.299f or 0.114f).
+        constexpr float kGHi = 0x1.2db8fcp-9f, kGLo = 0x1.a6bf2ep-33f;
+        const float2_t g_hi = {kGHi, kGHi}, g_lo = {kGLo, kGLo};
+        const float2_t tg = G * g_lo;
+        const float2_t pg = __builtin_elementwise_fma(G, g_hi, tg);
+        const float2_t pr = r * wr1, pb = b * 0.114f;
         if constexpr (LUM == 2) {
             const float2_t s = pb + pg;
             l = s + pr;
