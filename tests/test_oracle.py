@@ -974,6 +974,32 @@ def test_green_product_in_two_operations(numpy_ref):
         assert rne(Fraction(i) * Fraction(float(hi)) + Fraction(float(t[i]))) == want[i], i
 
 
+REFTEXT = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "reftext", "*.npz")))
+
+
+@pytest.mark.parametrize("path", REFTEXT, ids=[os.path.basename(p) for p in REFTEXT])
+def test_reference_text_fixture(oracle, numpy_ref, path):
+    """tests/golden/reftext/*.npz hold what the reference's shader text yields when tests/wgsl_interp.py executes it
+    (tests/golden/make_reftext_golden.py, on a machine with the reference checkout): both restatements reproduce every grey and blur
+    level, the counter, the keypoints with their angle codes and the descriptors, bit for bit -- also where the checkout is absent."""
+    g = np.load(path)
+    rgba, depth, thr, cap = g["rgba"], int(g["depth"]), np.float32(g["threshold"]), int(g["max_features"])
+    H, W = rgba.shape[:2]
+    ref = oracle.extract(rgba, depth=depth, threshold=thr, max_features=cap, planes=True)
+    nref = numpy_ref.extract(rgba, depth=depth, threshold=thr, max_features=cap)
+    dims, _ = oracle.level_dims(W, H, depth)
+    for m, (w, h, off) in enumerate(dims):
+        assert np.array_equal(ref["gray"][off:off + w * h].reshape(h, w), g["gray%d" % m]), "grey level %d" % m
+        assert np.array_equal(ref["blur"][off:off + w * h].reshape(h, w), g["blur%d" % m]), "blur level %d" % m
+        assert np.array_equal(nref["gray"][m], g["gray%d" % m]) and np.array_equal(nref["blur"][m], g["blur%d" % m])
+    assert ref["total"] == nref["total"] == int(g["total"]) > 0
+    rc, rd = oracle.sort_keypoints(ref["corners"], ref["descriptors"])
+    assert np.array_equal(np.stack([rc[k] for k in ("x", "y", "angle", "octave")], 1), g["corners"]) and np.array_equal(rd, g["descriptors"])
+    nc = nref["corners"]
+    order = np.lexsort((nc[:, 0], nc[:, 1], nc[:, 3]))
+    assert np.array_equal(nc[order], g["corners"]) and np.array_equal(nref["descriptors"][order], g["descriptors"])
+
+
 @pytest.mark.parametrize("bins", [8, 30, 1024, 6284])
 def test_intended_angle_bins(oracle, numpy_ref, bins):
     """IM-6b: bin = code * N / 6284, rotation by the bin's centre code (bin * 6284 + 3142) / N -- every code against the definition in
