@@ -5,9 +5,14 @@
  * fixtures for this path and cannot be built or run in this environment (Rust + wgpu/Vulkan,
  * no cargo/rustc/Vulkan ICD).  This file restates the reference's WGSL
  * shaders and the stage order of src/orb.rs in plain C, with the implementation-defined
- * points fixed by SURVEY.md's canonical restatement decisions CRD-1..CRD-12.  It is pinned
- * only by known-answer tests derived from the reference text and by a second, independently
- * written NumPy restatement (oracle/orb_numpy.py).
+ * points fixed by SURVEY.md's canonical restatement decisions CRD-1..CRD-13.  It is pinned
+ * only by known-answer tests derived from the reference text, by a second, independently
+ * written NumPy restatement (oracle/orb_numpy.py) and -- since round 5 -- by the shader text
+ * ITSELF, executed by a small WGSL interpreter (tests/wgsl_interp.py, tests/test_reference_text.py:
+ * every plane and record bit for bit; tests/golden/reftext/ holds its outputs as data).  That
+ * rules out transcription errors; it does not pin the implementation-defined points to any
+ * adapter -- the parity stays UNPINNED until a dump of the reference is held
+ * (tools/pin_oracle.py, rust/dump_config0).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything
  * under oracle/.  The product (tinyslam_amd/, include/) never includes, links or calls it.
