@@ -6,7 +6,9 @@ DATA -- the input frame, every grey and blur level as binary16 bit patterns, the
 and travel to machines that have no checkout (the GPU box), where tests/test_oracle.py and tests/test_gpu_reftext.py compare the restatement
 and the kernels with them.  Not a pin to an adapter: DESIGN.md section 2.
 
-    python tests/golden/make_reftext_golden.py
+    python tests/golden/make_reftext_golden.py            # the four small frames, one minute
+    python tests/golden/make_reftext_golden.py config0    # BASELINE.json configs[0]'s 640x480 frame as well (a quarter of an hour: the
+                                                          # interpreter runs 1.9 million fragment and 0.4 million compute invocations)
 """
 import os
 import sys
@@ -32,17 +34,29 @@ CASES = [
 ]
 
 
+# BASELINE.json configs[0]: one 640x480 frame, generator gradient + blobs + wedges, seed 1, depth 2, max_features 8192 -- the frame itself is not
+# stored (1.2 MB): the fixture holds its generator parameters and SHA-256, tests rebuild it with oracle.synth_frame
+CONFIG0 = ("t640x480_d2_config0", 640, 480, 2, 1, 7)
+
+
 def main():
     orb_oracle.build()
     os.makedirs(os.path.join(HERE, "reftext"), exist_ok=True)
-    for name, W, H, depth, seed, flags in CASES:
+    config0 = len(sys.argv) > 1 and sys.argv[1] == "config0"
+    for name, W, H, depth, seed, flags in ([CONFIG0] if config0 else CASES):
         t0 = time.time()
-        rgba = rt.frame_with_corners(orb_oracle, W, H, seed, flags)
-        gray, blur, total, c, d = rt.run_reference_text(orb_oracle, rgba, depth, THR, CAP)
-        assert total <= CAP
+        cap = 8192 if config0 else CAP
+        rgba = orb_oracle.synth_frame(W, H, seed, flags) if config0 else rt.frame_with_corners(orb_oracle, W, H, seed, flags)
+        gray, blur, total, c, d = rt.run_reference_text(orb_oracle, rgba, depth, THR, cap)
+        assert total <= cap
         order = np.lexsort((c[:, 0], c[:, 1], c[:, 3]))
-        out = dict(rgba=rgba, depth=np.uint32(depth), threshold=THR, max_features=np.uint32(CAP), total=np.uint32(total),
+        out = dict(depth=np.uint32(depth), threshold=THR, max_features=np.uint32(cap), total=np.uint32(total),
                    corners=c[order].astype(np.uint32), descriptors=d[order].astype(np.uint32))
+        if config0:
+            import hashlib
+            out.update(synth=np.array([W, H, seed, flags], dtype=np.uint32), rgba_sha256=np.array(hashlib.sha256(rgba.tobytes()).hexdigest()))
+        else:
+            out.update(rgba=rgba)
         for m in range(depth):
             out["gray%d" % m] = gray[m].a.astype(np.float16).view(np.uint16)
             out["blur%d" % m] = blur[m].a.astype(np.float16).view(np.uint16)

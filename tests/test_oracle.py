@@ -977,13 +977,23 @@ def test_green_product_in_two_operations(numpy_ref):
 REFTEXT = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "reftext", "*.npz")))
 
 
+def reftext_frame(oracle, g):
+    """A fixture's input frame: stored, or (BASELINE configs[0]'s 640x480 frame) rebuilt from its generator parameters and checked by hash."""
+    if "rgba" in g:
+        return g["rgba"]
+    W, H, seed, flags = (int(v) for v in g["synth"])
+    rgba = oracle.synth_frame(W, H, seed, flags)
+    assert hashlib.sha256(rgba.tobytes()).hexdigest() == str(g["rgba_sha256"])
+    return rgba
+
+
 @pytest.mark.parametrize("path", REFTEXT, ids=[os.path.basename(p) for p in REFTEXT])
 def test_reference_text_fixture(oracle, numpy_ref, path):
     """tests/golden/reftext/*.npz hold what the reference's shader text yields when tests/wgsl_interp.py executes it
     (tests/golden/make_reftext_golden.py, on a machine with the reference checkout): both restatements reproduce every grey and blur
     level, the counter, the keypoints with their angle codes and the descriptors, bit for bit -- also where the checkout is absent."""
     g = np.load(path)
-    rgba, depth, thr, cap = g["rgba"], int(g["depth"]), np.float32(g["threshold"]), int(g["max_features"])
+    rgba, depth, thr, cap = reftext_frame(oracle, g), int(g["depth"]), np.float32(g["threshold"]), int(g["max_features"])
     H, W = rgba.shape[:2]
     ref = oracle.extract(rgba, depth=depth, threshold=thr, max_features=cap, planes=True)
     nref = numpy_ref.extract(rgba, depth=depth, threshold=thr, max_features=cap)
