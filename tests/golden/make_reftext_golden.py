@@ -7,8 +7,9 @@ and travel to machines that have no checkout (the GPU box), where tests/test_ora
 and the kernels with them.  Not a pin to an adapter: DESIGN.md section 2.
 
     python tests/golden/make_reftext_golden.py            # the four small frames, one minute
-    python tests/golden/make_reftext_golden.py config0    # BASELINE.json configs[0]'s 640x480 frame as well (a quarter of an hour: the
-                                                          # interpreter runs 1.9 million fragment and 0.4 million compute invocations)
+    python tests/golden/make_reftext_golden.py config0    # BASELINE.json configs[0]'s 640x480 frame (nine minutes: the interpreter runs
+                                                          # 1.9 million fragment and 0.4 million compute invocations)
+    python tests/golden/make_reftext_golden.py config1    # configs[1]'s 1280x720 frame (half an hour)
 """
 import os
 import sys
@@ -37,13 +38,17 @@ CASES = [
 # BASELINE.json configs[0]: one 640x480 frame, generator gradient + blobs + wedges, seed 1, depth 2, max_features 8192 -- the frame itself is not
 # stored (1.2 MB): the fixture holds its generator parameters and SHA-256, tests rebuild it with oracle.synth_frame
 CONFIG0 = ("t640x480_d2_config0", 640, 480, 2, 1, 7)
+# BASELINE.json configs[1] / [2]: one 1280x720 frame, + noise, seed 2 -- the benchmark's frame size.  Half an hour of interpreter; the grey levels
+# (noise: incompressible) are stored as SHA-256 only.
+CONFIG1 = ("t1280x720_d2_config1", 1280, 720, 2, 2, 15)
 
 
 def main():
     orb_oracle.build()
     os.makedirs(os.path.join(HERE, "reftext"), exist_ok=True)
-    config0 = len(sys.argv) > 1 and sys.argv[1] == "config0"
-    for name, W, H, depth, seed, flags in ([CONFIG0] if config0 else CASES):
+    big = {"config0": CONFIG0, "config1": CONFIG1}.get(sys.argv[1] if len(sys.argv) > 1 else "")
+    config0 = big is not None
+    for name, W, H, depth, seed, flags in ([big] if big else CASES):
         t0 = time.time()
         cap = 8192 if config0 else CAP
         rgba = orb_oracle.synth_frame(W, H, seed, flags) if config0 else rt.frame_with_corners(orb_oracle, W, H, seed, flags)
@@ -58,7 +63,12 @@ def main():
         else:
             out.update(rgba=rgba)
         for m in range(depth):
-            out["gray%d" % m] = gray[m].a.astype(np.float16).view(np.uint16)
+            g16 = gray[m].a.astype(np.float16).view(np.uint16)
+            if W * H > 400000:
+                import hashlib
+                out["gray%d_sha256" % m] = np.array(hashlib.sha256(np.ascontiguousarray(g16).tobytes()).hexdigest())
+            else:
+                out["gray%d" % m] = g16
             out["blur%d" % m] = blur[m].a.astype(np.float16).view(np.uint16)
         np.savez_compressed(os.path.join(HERE, "reftext", name + ".npz"), **out)
         print("%s: %d keypoints (%s per octave, %d with a non-zero angle), %.0f s"

@@ -999,9 +999,15 @@ def test_reference_text_fixture(oracle, numpy_ref, path):
     nref = numpy_ref.extract(rgba, depth=depth, threshold=thr, max_features=cap)
     dims, _ = oracle.level_dims(W, H, depth)
     for m, (w, h, off) in enumerate(dims):
-        assert np.array_equal(ref["gray"][off:off + w * h].reshape(h, w), g["gray%d" % m]), "grey level %d" % m
+        if "gray%d" % m in g:
+            assert np.array_equal(ref["gray"][off:off + w * h].reshape(h, w), g["gray%d" % m]), "grey level %d" % m
+            assert np.array_equal(nref["gray"][m], g["gray%d" % m])
+        else:  # a large level of a noisy frame is held as its SHA-256
+            want = str(g["gray%d_sha256" % m])
+            assert hashlib.sha256(np.ascontiguousarray(ref["gray"][off:off + w * h]).tobytes()).hexdigest() == want, "grey level %d" % m
+            assert hashlib.sha256(np.ascontiguousarray(nref["gray"][m]).tobytes()).hexdigest() == want
         assert np.array_equal(ref["blur"][off:off + w * h].reshape(h, w), g["blur%d" % m]), "blur level %d" % m
-        assert np.array_equal(nref["gray"][m], g["gray%d" % m]) and np.array_equal(nref["blur"][m], g["blur%d" % m])
+        assert np.array_equal(nref["blur"][m], g["blur%d" % m])
     assert ref["total"] == nref["total"] == int(g["total"]) > 0
     rc, rd = oracle.sort_keypoints(ref["corners"], ref["descriptors"])
     assert np.array_equal(np.stack([rc[k] for k in ("x", "y", "angle", "octave")], 1), g["corners"]) and np.array_equal(rd, g["descriptors"])
