@@ -1016,6 +1016,28 @@ def test_reference_text_fixture(oracle, numpy_ref, path):
     assert np.array_equal(nc[order], g["corners"]) and np.array_equal(nref["descriptors"][order], g["descriptors"])
 
 
+def test_pin_tool_on_the_executed_text_of_config0(oracle, tmp_path):
+    """tools/pin_oracle.py fed with what the EXECUTED reference text yields on BASELINE configs[0]'s frame (tests/golden/reftext/, made by the
+    interpreter -- not by the restatement the tool compares with): it reports the defaults among the exact settings, as it would for a dump
+    of an adapter that follows CRD-1..13."""
+    path = os.path.join(ROOT, "tests", "golden", "reftext", "t640x480_d2_config0.npz")
+    if not os.path.exists(path):
+        pytest.skip("the configs[0] fixture of the executed text is not in the tree")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pin_oracle
+    g = np.load(path)
+    W, H, seed, flags = (int(v) for v in g["synth"])
+    assert (W, H, int(g["depth"]), int(g["max_features"])) == (640, 480, 2, 8192)
+    _write_dump(tmp_path, int(g["total"]), g["corners"], g["descriptors"], seed, flags)
+    S = pin_oracle.setting
+    few = [S(), S("clamp"), S("umin"), S("zero", 8), S("zero", 0, 7), S(f16_round=1)]
+    _, results, exact = pin_oracle.check(str(tmp_path), few)
+    # (this smooth frame tells the out-of-level policies and the store's rounding apart, not the sampler's weight bits or the contractions:
+    # the tool's own remark -- "dump the noisy frame as well")
+    assert S() in exact and S("clamp") not in exact and S("umin") not in exact and S(f16_round=1) not in exact
+    assert pin_oracle.neg_angle_policy(g["corners"]) == "zero"
+
+
 @pytest.mark.parametrize("bins", [8, 30, 1024, 6284])
 def test_intended_angle_bins(oracle, numpy_ref, bins):
     """IM-6b: bin = code * N / 6284, rotation by the bin's centre code (bin * 6284 + 3142) / N -- every code against the definition in
