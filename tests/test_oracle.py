@@ -1016,13 +1016,15 @@ def test_reference_text_fixture(oracle, numpy_ref, path):
     assert np.array_equal(nc[order], g["corners"]) and np.array_equal(nref["descriptors"][order], g["descriptors"])
 
 
-def test_pin_tool_on_the_executed_text_of_config0(oracle, tmp_path):
-    """tools/pin_oracle.py fed with what the EXECUTED reference text yields on BASELINE configs[0]'s frame (tests/golden/reftext/, made by the
-    interpreter -- not by the restatement the tool compares with): it reports the defaults among the exact settings, as it would for a dump
-    of an adapter that follows CRD-1..13."""
-    path = os.path.join(ROOT, "tests", "golden", "reftext", "t640x480_d2_config0.npz")
+@pytest.mark.parametrize("name", ["t640x480_d2_config0", "t640x480_d2_noisy"])
+def test_pin_tool_on_the_executed_text(oracle, tmp_path, name):
+    """tools/pin_oracle.py fed with what the EXECUTED reference text yields on the two frames it asks a maintainer to dump -- BASELINE
+    configs[0]'s and the noisy one (tests/golden/reftext/, made by the interpreter, not by the restatement the tool compares with): it finds
+    the defaults among the exact settings, as it would for a dump of an adapter that follows CRD-1..13, and the noisy frame rules out what
+    the smooth one cannot (the sampler's weight bits)."""
+    path = os.path.join(ROOT, "tests", "golden", "reftext", name + ".npz")
     if not os.path.exists(path):
-        pytest.skip("the configs[0] fixture of the executed text is not in the tree")
+        pytest.skip("this fixture of the executed text is not in the tree")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pin_oracle
     g = np.load(path)
@@ -1032,9 +1034,9 @@ def test_pin_tool_on_the_executed_text_of_config0(oracle, tmp_path):
     S = pin_oracle.setting
     few = [S(), S("clamp"), S("umin"), S("zero", 8), S("zero", 0, 7), S(f16_round=1)]
     _, results, exact = pin_oracle.check(str(tmp_path), few)
-    # (this smooth frame tells the out-of-level policies and the store's rounding apart, not the sampler's weight bits or the contractions:
-    # the tool's own remark -- "dump the noisy frame as well")
     assert S() in exact and S("clamp") not in exact and S("umin") not in exact and S(f16_round=1) not in exact
+    if name.endswith("noisy"):
+        assert S("zero", 8) not in exact
     assert pin_oracle.neg_angle_policy(g["corners"]) == "zero"
 
 
